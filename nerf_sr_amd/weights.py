@@ -1,0 +1,103 @@
+"""Weight interface of the render hot path.
+
+The reference hands the NeRF MLP to the path as the 24-tensor ``state_dict()``
+of ``VanillaMLP`` (reference ``models/networks.py:131-180``; checkpoint writer
+``models/base_model.py:181-196``).  nn.Linear layout: ``weight`` is
+``(out, in)`` row-major, ``y = x @ W.T + b``.
+
+This module owns
+  * the key/shape table of that state_dict (``STATE_DICT_SPEC``),
+  * a deterministic, seedable generator for synthetic weights (no checkpoints
+    can be downloaded), used by tests, the golden-vector script and
+    ``bench.py`` so that no weight blob has to be committed.
+
+Everything here is numpy; nothing touches the GPU.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+
+# Architecture constants of the path (reference defaults):
+#   D=8, W=256, skips=[4]  (models/networks.py:124-126)
+#   deg_pos=10, deg_dir=4  (models/nerf_model.py:56-57)
+D_LAYERS = 8
+WIDTH = 256
+SKIP_LAYER = 4            # 0-based index of the trunk layer whose input is cat([pe, h])
+DEG_POS = 10
+DEG_DIR = 4
+POS_CH = 3 + 3 * 2 * DEG_POS   # 63
+DIR_CH = 3 + 3 * 2 * DEG_DIR   # 27
+IN_CH = POS_CH + DIR_CH        # 90
+MACS_PER_POINT = 593_408
+FLOP_PER_POINT = 2 * MACS_PER_POINT
+
+
+def _spec():
+    spec = OrderedDict()
+    for i in range(D_LAYERS):
+        if i == 0:
+            fan_in = POS_CH
+        elif i == SKIP_LAYER:
+            fan_in = WIDTH + POS_CH
+        else:
+            fan_in = WIDTH
+        spec[f"xyz_encoding_{i + 1}.0.weight"] = (WIDTH, fan_in)
+        spec[f"xyz_encoding_{i + 1}.0.bias"] = (WIDTH,)
+    spec["xyz_encoding_final.weight"] = (WIDTH, WIDTH)
+    spec["xyz_encoding_final.bias"] = (WIDTH,)
+    spec["dir_encoding.0.weight"] = (WIDTH // 2, WIDTH + DIR_CH)
+    spec["dir_encoding.0.bias"] = (WIDTH // 2,)
+    spec["sigma.weight"] = (1, WIDTH)
+    spec["sigma.bias"] = (1,)
+    spec["rgb.0.weight"] = (3, WIDTH // 2)
+    spec["rgb.0.bias"] = (3,)
+    return spec
+
+
+#: key -> shape, in the order ``VanillaMLP.state_dict()`` yields them
+STATE_DICT_SPEC = _spec()
+N_PARAMS = sum(int(np.prod(s)) for s in STATE_DICT_SPEC.values())
+assert N_PARAMS == 595_844
+assert sum(int(np.prod(s)) for k, s in STATE_DICT_SPEC.items() if k.endswith("weight")) == MACS_PER_POINT
+
+
+def make_state_dict(seed: int = 99, structured: bool = True, bias_scale: float = 0.05):
+    """Deterministic synthetic ``VanillaMLP`` weights as ``{key: float32 ndarray}``.
+
+    ``W ~ N(0, 2/fan_in)`` mirrors ``init_type=kaiming`` of the reference
+    (``models/networks.py:31-38``: kaiming_normal_, fan_in, a=0).  The reference
+    zero-inits biases; a small non-zero bias (``bias_scale``) is used here so
+    that bias handling of the kernels is actually exercised by the parity tests.
+
+    ``structured=True`` additionally reshapes the density head
+    (``sigma.weight *= 30``, ``sigma.bias = -40``): about a quarter of the sample
+    points then carry density, so rendered opacity / depth / weights vary from
+    ray to ray instead of saturating at the first samples (probed: LLFF-like rays
+    give opacity mean 0.64, std 0.27).
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = OrderedDict()
+    for key, shape in STATE_DICT_SPEC.items():
+        if key.endswith("weight"):
+            fan_in = shape[1]
+            w = rng.standard_normal(shape, dtype=np.float64) * np.sqrt(2.0 / fan_in)
+            sd[key] = w.astype(np.float32)
+        else:
+            sd[key] = (rng.standard_normal(shape, dtype=np.float64) * bias_scale).astype(np.float32)
+    if structured:
+        sd["sigma.weight"] = (sd["sigma.weight"] * np.float32(30.0)).astype(np.float32)
+        sd["sigma.bias"] = np.full((1,), -40.0, dtype=np.float32)
+    return sd
+
+
+def check_state_dict(sd) -> None:
+    """Raise ``ValueError`` unless ``sd`` has exactly the 24 keys/shapes of the path."""
+    missing = [k for k in STATE_DICT_SPEC if k not in sd]
+    if missing:
+        raise ValueError(f"state_dict is missing keys: {missing}")
+    for k, shape in STATE_DICT_SPEC.items():
+        got = tuple(sd[k].shape)
+        if got != tuple(shape):
+            raise ValueError(f"state_dict[{k!r}] has shape {got}, expected {tuple(shape)}")

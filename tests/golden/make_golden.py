@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors that pin ``oracle/nerf_oracle.py`` to the reference.
+
+Runs ONLY in the development container (needs ``/root/reference``).  It imports the
+reference's own Python (read-only) through a ``sys.modules`` shim for the optional
+dependencies this image lacks, drives the reference functions on small
+deterministic inputs and writes inputs + outputs as ``tests/golden/*.npz``.
+Nothing of the reference's source is copied: the fixtures are data only.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Weights are NOT stored: they come from ``nerf_sr_amd.weights.make_state_dict``
+(seeds recorded in the fixtures) and are loaded into the reference nets with
+``load_state_dict``.
+"""
+import os
+import sys
+import types
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("NSR_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+
+from nerf_sr_amd.weights import make_state_dict  # noqa: E402
+from nerf_sr_amd import cameras  # noqa: E402
+
+
+def install_shim():
+    """Stub modules the reference imports but this image lacks; neutralise set_device."""
+    class _Anything:
+        """Placeholder for any attribute of a stubbed optional dependency."""
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return _Anything()
+
+        def __getattr__(self, name):
+            return _Anything()
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        m.__getattr__ = lambda attr: _Anything      # PEP 562: any other name resolves to a dummy class
+        sys.modules[name] = m
+        return m
+
+    import numpy.lib
+    stub("numpy.lib.shape_base", expand_dims=np.expand_dims)
+    tv = stub("torchvision")
+    tv.transforms = stub("torchvision.transforms")
+    tv.transforms.functional = stub("torchvision.transforms.functional")
+    tv.models = stub("torchvision.models")
+    tv.utils = stub("torchvision.utils")
+    stub("cv2")
+    stub("imageio")
+    stub("tensorboard")
+    tb = stub("torch.utils.tensorboard", SummaryWriter=object)
+    torch.utils.tensorboard = tb
+    dom = stub("dominate")
+    dom.tags = stub("dominate.tags")
+    stub("kornia")
+    torch.cuda.set_device = lambda d: None
+    sys.path.insert(0, REF)
+
+
+def np32(t):
+    return t.detach().cpu().numpy().astype(np.float32) if t.dtype.is_floating_point else t.detach().cpu().numpy()
+
+
+def build_reference_model(white_bkgd: bool, seed_c: int, seed_f: int, img_wh=(16, 12), downscale=2):
+    from options.test_options import TestOptions
+    from models import create_model
+    tmp = tempfile.mkdtemp(prefix="nsr_golden_")
+    argv = ["x", "--name", "golden", "--checkpoints_dir", tmp, "--dataset_root", tmp,
+            "--model", "nerf_downX", "--dataset_mode", "llff_downX",
+            "--img_wh", str(img_wh[0]), str(img_wh[1]), "--downscale", str(downscale),
+            "--N_coarse", "64", "--N_importance", "64"]
+    if white_bkgd:
+        argv.append("--white_bkgd")
+    old = sys.argv
+    sys.argv = argv
+    try:
+        opt = TestOptions().parse(None)
+    finally:
+        sys.argv = old
+    opt.white_bkgd = white_bkgd
+    opt.noise_std = 0.0
+    model = create_model(opt)
+    sd_c = {k: torch.from_numpy(v) for k, v in make_state_dict(seed_c).items()}
+    sd_f = {k: torch.from_numpy(v) for k, v in make_state_dict(seed_f).items()}
+    model.netCoarse.load_state_dict(sd_c)
+    model.netFine.load_state_dict(sd_f)
+    model.eval()
+    return model, opt
+
+
+def main():
+    install_shim()
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+    import models.utils as ru
+    from models.rendering import VolumetricRenderer
+    import einops
+
+    out = {}
+
+    # ------------------------------------------------------------------ R1-R4 ray grids
+    H, W, s = 12, 16, 2            # HR 16x12 <- LR 8x6
+    c2w_l = cameras.spiral_pose(0.7)
+    c2w_b = cameras.spheric_pose(40.0)
+    f_l = cameras.llff_focal(W)
+    f_b = cameras.blender_focal(W)
+    g = {}
+    for tag, c2w, focal, ndc, nf in (("llff", c2w_l, f_l, True, (0.0, 1.0)), ("blender", c2w_b, f_b, False, (2.0, 6.0))):
+        dirs = ru.get_ray_directions(H, W, focal, True)
+        ro, rd = ru.get_rays(dirs, torch.FloatTensor(c2w))
+        if ndc:
+            near, far = 0, 1
+            ro, rd = ru.get_ndc_rays(H, W, focal, 1.0, ro, rd)
+        else:
+            near, far = nf
+        rays = torch.cat([ro, rd, near * torch.ones_like(ro[:, :1]), far * torch.ones_like(ro[:, :1])], 1)
+        raysX = einops.rearrange(rays.view(H, W, -1), '(h s1) (w s2) c -> (h w) (s1 s2) c', s1=s, s2=s)
+        g[f"{tag}_c2w"] = c2w
+        g[f"{tag}_focal"] = np.float64(focal)
+        g[f"{tag}_dirs"] = np32(dirs)
+        g[f"{tag}_rays_hr"] = np32(rays)
+        g[f"{tag}_rays_lr"] = np32(raysX)
+    g["H"], g["W"], g["s"] = H, W, s
+    # s = 4 regroup of the llff grid as well
+    H4, W4 = 12, 16
+    dirs = ru.get_ray_directions(H4, W4, f_l, True)
+    ro, rd = ru.get_rays(dirs, torch.FloatTensor(c2w_l))
+    ro, rd = ru.get_ndc_rays(H4, W4, f_l, 1.0, ro, rd)
+    rays = torch.cat([ro, rd, 0 * torch.ones_like(ro[:, :1]), 1 * torch.ones_like(ro[:, :1])], 1)
+    g["llff_rays_lr_s4"] = np32(einops.rearrange(rays.view(H4, W4, -1), '(h s1) (w s2) c -> (h w) (s1 s2) c', s1=4, s2=4))
+    np.savez_compressed(os.path.join(HERE, "raygrid.npz"), **g)
+
+    # ------------------------------------------------------------------ full path, two families
+    for tag, white, c2w, focal, ndc, nf in (("llff", False, c2w_l, cameras.llff_focal(32), True, (0.0, 1.0)),
+                                            ("blender", True, c2w_b, cameras.blender_focal(32), False, (2.0, 6.0))):
+        model, opt = build_reference_model(white, seed_c=99, seed_f=100, img_wh=(32, 16), downscale=2)
+        Hh, Wh = 16, 32     # HR 32x16 -> 512 rays; use the first 256 (64 LR px x 4)
+        dirs = ru.get_ray_directions(Hh, Wh, focal, True)
+        ro, rd = ru.get_rays(dirs, torch.FloatTensor(c2w))
+        if ndc:
+            near, far = 0, 1
+            ro, rd = ru.get_ndc_rays(Hh, Wh, focal, 1.0, ro, rd)
+        else:
+            near, far = nf
+        rays = torch.cat([ro, rd, near * torch.ones_like(ro[:, :1]), far * torch.ones_like(ro[:, :1])], 1)
+        raysX = einops.rearrange(rays.view(Hh, Wh, -1), '(h s1) (w s2) c -> (h w) (s1 s2) c', s1=2, s2=2)
+        rays_in = raysX.reshape(-1, 8)[:256].contiguous()
+
+        f = {"rays": np32(rays_in), "white_bkgd": white, "seed_coarse": 99, "seed_fine": 100}
+        # stage by stage, through the reference's own functions
+        o, d, near_t, far_t = rays_in[:, 0:3], rays_in[:, 3:6], rays_in[:, 6:7], rays_in[:, 7:8]
+        dir_emb = model.embeddings['dir'](d)
+        z_c, xyz_c = ru.sample_along_rays(o, d, near_t, far_t, 64, False, False)
+        f["dir_pe"] = np32(dir_emb)
+        f["z_coarse"] = np32(z_c)
+        f["pos_pe_first8"] = np32(model.embeddings['pos'](xyz_c.view(-1, 3)[:8]))
+        x_embed = torch.cat([model.embeddings['pos'](xyz_c.view(-1, 3)), dir_emb.repeat_interleave(64, dim=0)], -1)
+        f["mlp_in_512"] = np32(x_embed[:512])
+        f["mlp_out_coarse_512"] = np32(model.netCoarse(x_embed[:512]))
+        f["mlp_out_fine_512"] = np32(model.netFine(x_embed[:512]))
+        f["mlp_sigma_only_64"] = np32(model.netCoarse(x_embed[:64], sigma_only=True))
+        c_rgbs, c_sig = model.render_rays(model.netCoarse, xyz_c, dir_emb)
+        f["coarse_point_rgb"] = np32(c_rgbs[:16])
+        f["coarse_point_sigma"] = np32(c_sig)
+        rend = VolumetricRenderer(opt)
+        comp, depth, opac, wts = rend(c_rgbs.clone(), c_sig.clone(), z_c, white)
+        z_f, xyz_f = ru.resample_along_rays(o, d, z_c, wts, 64, False)
+        f["z_fine"] = np32(z_f)
+        # the whole path in one call (chunked exactly as the reference does)
+        model.set_input({"rays": rays_in[None]})
+        model.forward()
+        for k in ("coarse_comp_rgbs", "coarse_depth", "coarse_opacity", "coarse_weights",
+                  "fine_comp_rgbs", "fine_depth", "fine_opacity", "fine_weights"):
+            f[k] = np32(getattr(model, f"out_{k}"))
+        assert np.array_equal(f["coarse_comp_rgbs"], np32(comp))
+        # A1: s^2 means and A2: unflatten, through the reference methods
+        model.data_rgbs = torch.zeros((64, 3))
+        model.comp_low_res_output()
+        f["lr_fine_rgb_s2"] = np32(model.out_fine_comp_rgbs)
+        f["lr_fine_depth_s2"] = np32(model.out_fine_depth)
+        f["lr_coarse_rgb_s2"] = np32(model.out_coarse_comp_rgbs)
+        model.data_rgbs = torch.zeros((16, 3))
+        model.out_fine_comp_rgbs = torch.from_numpy(f["fine_comp_rgbs"])
+        model.out_fine_depth = torch.from_numpy(f["fine_depth"])
+        model.out_coarse_comp_rgbs = torch.from_numpy(f["coarse_comp_rgbs"])
+        model.out_coarse_depth = torch.from_numpy(f["coarse_depth"])
+        opt.downscale = 4
+        model.comp_low_res_output()
+        f["lr_fine_rgb_s4"] = np32(model.out_fine_comp_rgbs)
+        opt.downscale = 2
+        # unflatten of a 16x8 HR image (128 rays)
+        opt.img_wh = [16, 8]
+        f["unflatten_16x8"] = np32(model.unflatten_reshape(torch.from_numpy(f["fine_comp_rgbs"][:128])))
+        # PSNR formula
+        from models.criterions import PSNR
+        a = torch.from_numpy(f["fine_comp_rgbs"])
+        b = torch.from_numpy(f["coarse_comp_rgbs"])
+        f["psnr_fine_vs_coarse"] = np.float64(PSNR(opt)(a, b).item())
+        np.savez_compressed(os.path.join(HERE, f"path_{tag}.npz"), **f)
+
+    # ------------------------------------------------------------------ edge cases for V1 / S2
+    class _O:  # minimal opt for the renderer
+        sigma_activation = 'relu'
+    rend = VolumetricRenderer(_O())
+    e = {}
+    R = 8
+    z = torch.linspace(0, 1, 64)[None].repeat(R, 1) * torch.linspace(1, 2, R)[:, None] + 2.0
+    o = torch.zeros(R, 3)
+    d = torch.tensor([[0.0, 0.0, -1.0]]).repeat(R, 1)
+    rgb = torch.rand(R, 64, 3)
+    sig = torch.zeros(R, 64)
+    sig[1, 20] = 1e4                               # one-hot density: denom < eps branch
+    sig[2] = torch.rand(64) * 5 - 1                # mixed sign (relu matters)
+    sig[3, 30:34] = 50.0                           # short slab
+    sig[4] = 1e-3                                  # nearly empty
+    sig[5] = 1e3                                   # fully saturated at the first sample
+    sig[6, 0] = 30.0; sig[6, 63] = 30.0            # mass only in the two bins dropped by weights[:, 1:-1]
+    sig[7] = torch.rand(64) * 40
+    for white in (False, True):
+        comp, depth, opac, wts = rend(rgb.clone(), sig.clone(), z, white)
+        e[f"comp_white{int(white)}"] = np32(comp)
+    e["depth"], e["opacity"], e["weights"] = np32(depth), np32(opac), np32(wts)
+    zf, _ = ru.resample_along_rays(o, d, z, wts, 64, False)
+    e["z_fine"] = np32(zf)
+    zf128, _ = ru.resample_along_rays(o, d, z, wts, 128, False)
+    e["z_fine_ni128"] = np32(zf128)
+    u = torch.rand(R, 64)
+    torch.manual_seed(1234)
+    zfr, _ = ru.resample_along_rays(o, d, z, wts, 64, True)      # randomized branch: u drawn by torch.rand
+    torch.manual_seed(1234)
+    e["u_rand"] = np32(torch.rand(R, 64))
+    e["z_fine_rand"] = np32(zfr)
+    # randomized coarse sampling (rand_like) and lindisp
+    torch.manual_seed(77)
+    near_t, far_t = 2.0 * torch.ones(R, 1), 6.0 * torch.ones(R, 1)
+    zr, _ = ru.sample_along_rays(o, d, near_t, far_t, 64, True, False)
+    torch.manual_seed(77)
+    e["u_coarse"] = np32(torch.rand(R, 64))
+    e["z_coarse_rand"] = np32(zr)
+    zl, _ = ru.sample_along_rays(o, d, near_t, far_t, 64, False, True)
+    e["z_coarse_lindisp"] = np32(zl)
+    e["rgb"], e["sigma"], e["z"] = np32(rgb), np32(sig), np32(z)
+    np.savez_compressed(os.path.join(HERE, "edge_cases.npz"), **e)
+    print("golden fixtures written to", HERE)
+    for fn in sorted(os.listdir(HERE)):
+        if fn.endswith(".npz"):
+            print(f"  {fn}: {os.path.getsize(os.path.join(HERE, fn)) / 1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()
