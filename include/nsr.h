@@ -1,0 +1,149 @@
+/*
+ * nsr.h — C ABI of libnsr: the MI355X-native (gfx950) supersampled volumetric
+ * render hot path of NeRF-SR.
+ *
+ * The reference (cwchenwang/NeRF-SR) has no FFI: the path sits behind Python
+ * functions / nn.Module.__call__ on fp32 tensors.  Each entry
+ * point below replaces one of those call sites; the reference-side binding a
+ * maintainer would add is a ctypes stub.  Citations are
+ * file:line in the reference tree.
+ *
+ * Conventions
+ *   - every pointer named *_dev / rays / z / out ... is a DEVICE pointer to
+ *     contiguous fp32 unless stated otherwise; the caller (PyTorch) owns all
+ *     buffers and pre-allocates outputs; the library allocates nothing.
+ *   - `stream` is a hipStream_t passed as void*; work is only ENQUEUED on it,
+ *     the library never synchronises the device or the host.
+ *   - every function returns NSR_OK (0) or a negative nsr_status; no exceptions,
+ *     no global mutable state: re-entrant from any number of host threads
+ *     (one per GPU under nn.DataParallel, models/networks.py:67).
+ *   - the device is the caller's current HIP device (hipSetDevice).
+ *   - fixed architecture of the path: D=8, W=256, skips=[4], deg_pos=10,
+ *     deg_dir=4, dim_pos=dim_dir=dim_rgb=3 (models/networks.py:124-126,
+ *     models/nerf_model.py:52-57) — the only one the reference's scripts use.
+ */
+#ifndef NSR_H_
+#define NSR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSR_VERSION 100 /* 0.1.0 */
+
+typedef enum nsr_status {
+  NSR_OK = 0,
+  NSR_ERR_INVALID_ARG = -1, /* null pointer, negative size, misaligned pointer */
+  NSR_ERR_UNSUPPORTED = -2, /* sample count / degree / precision outside the built path */
+  NSR_ERR_LAUNCH = -3,      /* hipGetLastError() != hipSuccess after an enqueue */
+  NSR_ERR_WORKSPACE = -4    /* workspace smaller than nsr_forward_rays_workspace_bytes() */
+} nsr_status;
+
+/* arithmetic the MLP contraction runs in (everything else is always fp32) */
+typedef enum nsr_precision {
+  NSR_FP32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (parity path) */
+  NSR_BF16 = 1,   /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate (fast path)       */
+  NSR_BF16X3 = 2  /* split-bf16: hi*hi + hi*lo + lo*hi, fp32 accumulate (~2^-16 products)       */
+} nsr_precision;
+
+/* number of tensors in VanillaMLP.state_dict(), in state_dict order:
+ * xyz_encoding_{1..8}.0.{weight,bias}, xyz_encoding_final.{weight,bias},
+ * dir_encoding.0.{weight,bias}, sigma.{weight,bias}, rgb.0.{weight,bias}
+ * (models/networks.py:131-180; SURVEY.md §5 "Checkpoint / resume") */
+#define NSR_N_STATE_TENSORS 24
+
+int nsr_version(void);
+const char* nsr_status_string(int status);
+
+/* ---- weights ------------------------------------------------------------
+ * Replaces: handing `model.netCoarse` / `model.netFine` (nn.Module holding the
+ * 24-tensor state_dict) to render_rays (models/nerf_downX_model.py:260-268).
+ * The packed blob is the MFMA-fragment-ordered weight stream the MLP kernel
+ * consumes; it is created in caller-owned device memory and must be re-packed
+ * after every optimiser step. */
+size_t nsr_packed_weights_bytes(int precision);
+/* w: HOST array of 24 DEVICE pointers (nn.Linear layout (out,in) row-major). */
+int nsr_pack_weights(const float* const* w, void* packed_dev, int precision, void* stream);
+
+/* ---- R1-R4: sub-pixel ray generation ---------------------------------------
+ * Replaces get_ray_directions + get_rays (+ get_ndc_rays) + the einops regroup
+ * '(h s1) (w s2) c -> (h w) (s1 s2) c' (models/utils.py:98-196;
+ * data/llff_downX_dataset.py:473-490; data/blender_downX_dataset.py:207-215).
+ * c2w: HOST pointer to 12 floats (3x4 row-major).  H, W, focal: HR image.
+ * ndc != 0: LLFF path (near plane 1.0, near/far columns := 0/1, `near`,`far`
+ * ignored); ndc == 0: near/far columns := near, far.
+ * rays_dev: (H/s * W/s * s*s, 8) = [o(3), d(3), near, far], LR-pixel-major,
+ * sub-pixel index dy*s+dx.  H % s == 0 and W % s == 0 required. */
+int nsr_gen_rays(const float* c2w, int H, int W, double focal, int s, int ndc, float near_, float far_,
+                 float* rays_dev, void* stream);
+
+/* ---- E1: positional encoding ------------------------------------------------
+ * Replaces PositionalEncoding.__call__ (models/embedding.py:44-62), 3 input
+ * channels: x (n,3) -> out (n, 3 + 6*deg) = [x, sin(2^0 x), cos(2^0 x), ...]. */
+int nsr_posenc(const float* x, int64_t n, int deg, float* out, void* stream);
+
+/* ---- S1: stratified sampling -------------------------------------------------
+ * Replaces sample_along_rays (models/utils.py:17-44).  rays (R,8).
+ * u == NULL: deterministic (eval) depths; u (R,n_samples): the uniform numbers
+ * the reference draws with torch.rand_like (randomized=True branch).
+ * z (R,n_samples); pts (R,n_samples,3) or NULL to skip cast_rays (utils.py:5-14). */
+int nsr_sample_along_rays(const float* rays, int64_t R, int n_samples, int lindisp, const float* u,
+                          float* z, float* pts, void* stream);
+
+/* ---- M1: the NeRF MLP --------------------------------------------------------
+ * Replaces VanillaMLP.forward(x, sigma_only) (models/networks.py:182-226):
+ * x (P,90) embedded rows -> out (P,4) = [rgb, sigma_raw], or (P,1) if sigma_only. */
+int nsr_mlp_forward(const void* packed_dev, int precision, const float* x, int64_t P, int sigma_only,
+                    float* out, void* stream);
+/* Replaces render_rays(model, xyz, dir_embedded) (models/nerf_downX_model.py:260-278)
+ * fused with cast_rays and both positional encodings: rays (R,8), z (R,N) ->
+ * out (R*N, 4) = [rgb, sigma_raw] per sample point; the (P,90) matrix is never
+ * materialised. */
+int nsr_render_rays(const void* packed_dev, int precision, const float* rays, const float* z, int64_t R,
+                    int n_samples, float* out, void* stream);
+
+/* ---- V1: volumetric compositing ------------------------------------------------
+ * Replaces VolumetricRenderer.forward (models/rendering.py:75-111).
+ * rgb: element (r,k,c) at rgb[(r*N+k)*rgb_stride + c]; sigma: (r,k) at
+ * sigma[(r*N+k)*sigma_stride]  (strides 3/1 = the reference's separate tensors,
+ * 4/4 with sigma = rgb+3 = the interleaved (P,4) MLP output).
+ * Outputs: comp_rgb (R,3), depth (R), opacity (R), weights (R,N); any may be NULL. */
+int nsr_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z,
+                  int64_t R, int n_samples, int white_bkgd, float* comp_rgb, float* depth, float* opacity,
+                  float* weights, void* stream);
+
+/* ---- S2: hierarchical inverse-CDF resampling -----------------------------------
+ * Replaces resample_along_rays (models/utils.py:47-95).  z (R,Nc), weights (R,Nc),
+ * u == NULL: linspace(0,1,Ni) (eval) else u (R,Ni) (randomized).  z_out (R,Nc+Ni)
+ * sorted; pts (R,Nc+Ni,3) or NULL (needs rays when non-NULL). */
+int nsr_resample_along_rays(const float* rays, const float* z, const float* weights, int64_t R, int n_coarse,
+                            int n_importance, const float* u, float* z_out, float* pts, void* stream);
+
+/* ---- D3: forward_rays, fused driver ----------------------------------------------
+ * Replaces NeRFDownXModel.forward_rays / forward in eval mode
+ * (models/nerf_downX_model.py:280-324) for the whole ray batch in one enqueue
+ * sequence (no ray_chunk / point_chunk slicing, no host syncs).
+ * outs[8] (HOST array of DEVICE pointers, any entry may be NULL), in this order:
+ *   0 coarse_comp_rgbs (R,3)  1 coarse_depth (R)  2 coarse_opacity (R)  3 coarse_weights (R,Nc)
+ *   4 fine_comp_rgbs  (R,3)   5 fine_depth (R)    6 fine_opacity (R)    7 fine_weights (R,Nc+Ni)
+ * n_importance == 0 skips the fine pass (outs[4..7] untouched, packed_fine may be NULL).
+ * workspace: device scratch of nsr_forward_rays_workspace_bytes() bytes. */
+size_t nsr_forward_rays_workspace_bytes(int64_t R, int n_coarse, int n_importance);
+int nsr_forward_rays(const void* packed_coarse, const void* packed_fine, int precision, const float* rays,
+                     int64_t R, int n_coarse, int n_importance, int white_bkgd, int lindisp,
+                     float* const* outs, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- A1 / A2: supersampling epilogue -----------------------------------------------
+ * nsr_sr_mean replaces reshape(N_lr, s^2, c).mean(1) (models/nerf_downX_model.py:337-348).
+ * nsr_unflatten replaces unflatten_reshape '(h1 w1) (s1 s2) c -> (h1 s1) (w1 s2) c'
+ * (models/nerf_downX_model.py:410-416): x (H/s*W/s*s*s, c) -> out (H, W, c). */
+int nsr_sr_mean(const float* hr, int64_t n_lr, int s2, int c, float* lr, void* stream);
+int nsr_unflatten(const float* x, int H, int W, int s, int c, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSR_H_ */

@@ -1,0 +1,70 @@
+"""ctypes binding of libnsr.so (the C ABI declared in include/nsr.h).
+
+This is exactly the stub a reference maintainer would add: plain
+pointers and sizes, torch only supplies device memory (``tensor.data_ptr()``) and
+the current HIP stream.  There is no fallback: a missing library or a missing
+symbol raises at import/first use, and every non-zero status becomes a RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnsr.so")
+
+NSR_FP32, NSR_BF16, NSR_BF16X3 = 0, 1, 2
+PRECISIONS = {"fp32": NSR_FP32, "bf16": NSR_BF16, "bf16x3": NSR_BF16X3}
+
+# symbol -> (restype, argtypes); must list every function of include/nsr.h
+SIGNATURES = {
+    "nsr_version": (c_int, []),
+    "nsr_status_string": (c_char_p, [c_int]),
+    "nsr_packed_weights_bytes": (c_size_t, [c_int]),
+    "nsr_pack_weights": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p]),
+    "nsr_gen_rays": (c_int, [POINTER(c_float), c_int, c_int, c_double, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
+    "nsr_posenc": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "nsr_sample_along_rays": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsr_mlp_forward": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "nsr_render_rays": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "nsr_composite": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsr_resample_along_rays": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
+                                        c_void_p, c_void_p, c_void_p]),
+    "nsr_forward_rays_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "nsr_forward_rays": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                                 POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
+    "nsr_sr_mean": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "nsr_unflatten": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class NsrError(RuntimeError):
+    """A libnsr entry point returned a non-zero nsr_status."""
+
+
+def load() -> ctypes.CDLL:
+    """dlopen libnsr.so and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m nerf_sr_amd.build` "
+            "(needs hipcc). nerf_sr_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().nsr_status_string(status).decode()
+        raise NsrError(f"{what} failed: nsr_status {status} ({msg})")

@@ -1,0 +1,70 @@
+"""Build libnsr.so (gfx950) in-tree with hipcc.  ``python -m nerf_sr_amd.build [--force]``.
+
+One shared object, plain C ABI (include/nsr.h), no torch in the link line.  The
+ray-/render-side translation units are compiled with ``-ffp-contract=off`` so the
+elementwise stages keep the reference's multiply-then-add rounding; the MLP unit
+is MFMA code where fused accumulation is inherent.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libnsr.so")
+ARCH = "gfx950"
+
+UNITS = [
+    # (source, extra flags)
+    ("nsr_rays.hip", ["-ffp-contract=off"]),
+    ("nsr_render.hip", ["-ffp-contract=off"]),
+    ("nsr_mlp.hip", ["-ffp-contract=off"]),
+    ("nsr_api.hip", []),
+]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libnsr.so cannot be built")
+    return exe
+
+
+def _newest_source_mtime() -> float:
+    m = os.path.getmtime(os.path.abspath(__file__))      # flag changes in this file rebuild too
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for fn in os.listdir(root):
+            m = max(m, os.path.getmtime(os.path.join(root, fn)))
+    return m
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile every HIP unit for gfx950 and link ``nerf_sr_amd/libnsr.so``; returns its path."""
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source_mtime():
+        return LIB
+    hipcc = _hipcc()
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    objs = []
+    for src, extra in UNITS:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        srcp = os.path.join(CSRC, src)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < _newest_source_mtime():
+            cmd = [hipcc, *common, *extra, "-c", srcp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

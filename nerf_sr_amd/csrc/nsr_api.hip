@@ -1,0 +1,72 @@
+// D3: the fused forward_rays driver (models/nerf_downX_model.py:280-324, eval
+// mode) — one enqueue sequence for the WHOLE ray batch: no ray_chunk /
+// point_chunk slicing (288 GB of HBM hold every intermediate of a full image),
+// no host synchronisation (the reference syncs twice per 4096-ray chunk,
+// nerf_downX_model.py:273,284).
+#include "nsr_common.h"
+
+extern "C" int nsr_version(void) { return NSR_VERSION; }
+
+extern "C" const char* nsr_status_string(int status) {
+  switch (status) {
+    case NSR_OK: return "ok";
+    case NSR_ERR_INVALID_ARG: return "invalid argument (null / negative size / misaligned pointer)";
+    case NSR_ERR_UNSUPPORTED: return "configuration outside the built path (sample count, degree or precision)";
+    case NSR_ERR_LAUNCH: return "HIP kernel launch failed";
+    case NSR_ERR_WORKSPACE: return "workspace too small";
+    default: return "unknown nsr status";
+  }
+}
+
+static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// workspace carve: z_coarse (R,Nc) | raw_coarse (R,Nc,4) | z_fine (R,Nf) | raw_fine (R,Nf,4) | w_coarse (R,Nc)
+extern "C" size_t nsr_forward_rays_workspace_bytes(int64_t R, int n_coarse, int n_importance) {
+  if (R < 0 || n_coarse <= 0 || n_importance < 0) return 0;
+  const size_t r = (size_t)R, nc = (size_t)n_coarse, nf = (size_t)(n_coarse + n_importance);
+  size_t total = align256(r * nc * 4) + align256(r * nc * 16) + align256(r * nc * 4);
+  if (n_importance > 0) total += align256(r * nf * 4) + align256(r * nf * 16);
+  return total;
+}
+
+extern "C" int nsr_forward_rays(const void* packed_coarse, const void* packed_fine, int precision, const float* rays,
+                                int64_t R, int n_coarse, int n_importance, int white_bkgd, int lindisp,
+                                float* const* outs, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!packed_coarse || !outs || R < 0 || n_coarse <= 0 || n_importance < 0) return NSR_ERR_INVALID_ARG;
+  if (n_importance > 0 && !packed_fine) return NSR_ERR_INVALID_ARG;
+  if (workspace_bytes < nsr_forward_rays_workspace_bytes(R, n_coarse, n_importance)) return NSR_ERR_WORKSPACE;
+  if (R == 0) return NSR_OK;
+  if (!rays || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return NSR_ERR_INVALID_ARG;
+  const size_t r = (size_t)R, nc = (size_t)n_coarse, nf = (size_t)(n_coarse + n_importance);
+  char* ws = static_cast<char*>(workspace);
+  float* z_c = reinterpret_cast<float*>(ws);   ws += align256(r * nc * 4);
+  float* raw_c = reinterpret_cast<float*>(ws); ws += align256(r * nc * 16);
+  float* w_c_ws = reinterpret_cast<float*>(ws); ws += align256(r * nc * 4);
+  float* z_f = nullptr;
+  float* raw_f = nullptr;
+  if (n_importance > 0) {
+    z_f = reinterpret_cast<float*>(ws);   ws += align256(r * nf * 4);
+    raw_f = reinterpret_cast<float*>(ws); ws += align256(r * nf * 16);
+  }
+  int rc;
+  // S1: coarse depths
+  rc = nsr_sample_along_rays(rays, R, n_coarse, lindisp, nullptr, z_c, nullptr, stream);
+  if (rc != NSR_OK) return rc;
+  // D2+M1: coarse network at every sample
+  rc = nsr_render_rays(packed_coarse, precision, rays, z_c, R, n_coarse, raw_c, stream);
+  if (rc != NSR_OK) return rc;
+  // V1: coarse compositing (weights are needed by the resampler even if the caller does not want them)
+  float* w_c = outs[3] ? outs[3] : w_c_ws;
+  rc = nsr_composite(raw_c, 4, raw_c + 3, 4, z_c, R, n_coarse, white_bkgd, outs[0], outs[1], outs[2], w_c, stream);
+  if (rc != NSR_OK) return rc;
+  if (n_importance == 0) return NSR_OK;
+  // S2: importance resampling + merge
+  rc = nsr_resample_along_rays(rays, z_c, w_c, R, n_coarse, n_importance, nullptr, z_f, nullptr, stream);
+  if (rc != NSR_OK) return rc;
+  // fine network + compositing
+  rc = nsr_render_rays(packed_fine, precision, rays, z_f, R, n_coarse + n_importance, raw_f, stream);
+  if (rc != NSR_OK) return rc;
+  rc = nsr_composite(raw_f, 4, raw_f + 3, 4, z_f, R, n_coarse + n_importance, white_bkgd, outs[4], outs[5], outs[6],
+                     outs[7], stream);
+  return rc;
+}

@@ -1,0 +1,342 @@
+// M1 / D2: the NeRF MLP (VanillaMLP.forward, models/networks.py:182-226) fused
+// with cast_rays + both positional encodings (render_rays,
+// models/nerf_downX_model.py:260-278).  fp32 parity path:
+// v_mfma_f32_32x32x2_f32, exact fp32 products, fp32 accumulation.
+//
+// Structure (see nsr_mlp_layout.h for the fragment algebra):
+//   * workgroup = 4 waves (one per SIMD), wave = 32 sample points, tile = 128 points;
+//   * activations never leave registers: the D fragment of layer L is the B
+//     operand of layer L+1 (transposed evaluation, weights as the A operand);
+//   * the 2.27 MiB weight stream of one net is DMA'd global->LDS
+//     (global_load_lds_dwordx4, 1 KiB per wave-instruction) in 32 KiB chunks
+//     through a 2-deep ring; each chunk feeds 128 MFMAs (8192 cycles) per wave,
+//     one workgroup barrier per chunk;
+//   * sigma (256->1) and rgb (128->3) heads are VALU dot products on the
+//     register-resident activations; bias enters as the accumulator init.
+#include "nsr_common.h"
+#include "nsr_mlp_layout.h"
+
+using namespace nsr;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// weight packing (device side gather into the fragment-ordered stream)
+// ---------------------------------------------------------------------------
+struct PackPtrs {
+  const float* p[NSR_N_STATE_TENSORS];
+};
+
+__device__ __forceinline__ int tensor_ld(int tensor) {
+  switch (tensor) {
+    case 0: return kPosCh;
+    case 8: return kWidth + kPosCh;
+    case 18: return kWidth + kDirCh;
+    default: return kWidth;
+  }
+}
+
+__global__ void __launch_bounds__(256) pack_fp32_kernel(PackPtrs w, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= kStreamFloats + kAuxFloats) return;
+  float v = 0.0f;
+  if (idx < kStreamPieces * 256) {
+    const int piece = idx >> 8, lane = (idx & 255) >> 2, j = idx & 3;
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < kNumSegments; ++i)
+      if (piece >= kSegmentsDev[i].piece0) s = i;
+    const Segment seg = kSegmentsDev[s];
+    const int local = piece - seg.piece0;
+    const int slab = local / seg.nb, nb = local % seg.nb;
+    const int t = 4 * slab + j, h = lane >> 5, n = 32 * nb + (lane & 31);
+    const int col = seg_col(seg.src, t, h);
+    if (col != kPad) v = w.p[seg.tensor][n * tensor_ld(seg.tensor) + seg.col0 + col];
+  } else if (idx >= kStreamFloats) {
+    const int a = idx - kStreamFloats;
+    if (a < kAuxBiasFinal) v = w.p[2 * (a >> 8) + 1][a & 255];
+    else if (a < kAuxBiasDir) v = w.p[17][a - kAuxBiasFinal];
+    else if (a < kAuxSigmaW) v = w.p[19][a - kAuxBiasDir];
+    else if (a < kAuxRgbW) v = w.p[20][a - kAuxSigmaW];
+    else if (a < kAuxSigmaB) v = w.p[22][a - kAuxRgbW];
+    else if (a < kAuxRgbB) v = w.p[21][0];
+    else if (a < kAuxRgbB + 3) v = w.p[23][a - kAuxRgbB];
+  }
+  out[idx] = v;
+}
+
+extern "C" size_t nsr_packed_weights_bytes(int precision) {
+  if (precision == NSR_FP32) return sizeof(float) * (size_t)(kStreamFloats + kAuxFloats);
+  return 0;
+}
+
+extern "C" int nsr_pack_weights(const float* const* w, void* packed_dev, int precision, void* stream) {
+  if (!w || !packed_dev) return NSR_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(packed_dev) & 15) != 0) return NSR_ERR_INVALID_ARG;
+  if (precision != NSR_FP32) return NSR_ERR_UNSUPPORTED;
+  PackPtrs pp;
+  for (int i = 0; i < NSR_N_STATE_TENSORS; ++i) {
+    if (!w[i]) return NSR_ERR_INVALID_ARG;
+    pp.p[i] = w[i];
+  }
+  const int total = kStreamFloats + kAuxFloats;
+  hipLaunchKernelGGL(pack_fp32_kernel, dim3((total + 255) / 256), dim3(256), 0, nsr_stream(stream), pp,
+                     static_cast<float*>(packed_dev));
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// fused MLP kernel, fp32 MFMA
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+// one wave-instruction: 64 lanes x 16 B, global -> LDS (dst = wave-uniform base + lane*16)
+__device__ __forceinline__ void glds16(const float* gsrc_lane, float* lds_base_wave) {
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)gsrc_lane, (lds_ptr_t)lds_base_wave, 16, 0, 0);
+}
+
+struct Stream {
+  const float* base;   // packed stream
+  int q;               // next chunk to CONSUME
+  int q_end;           // chunks in this launch's stream
+};
+
+// enqueue chunk `q` into ring slot `buf` (each wave moves 8 of the 32 pieces)
+__device__ __forceinline__ void issue_chunk(const float* stream, int q, float* ring_slot, int wave, int lane) {
+  const float* src = stream + (size_t)q * (kChunkBytes / 4) + wave * 8 * 256 + lane * 4;
+  float* dst = ring_slot + wave * 8 * 256;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) glds16(src + i * 256, dst + i * 256);
+}
+
+// Consume one segment of the stream: acc[nb] += W_seg(nb, :) * B, B = b[0..STEPS-1].
+// Segments always start on an even chunk, so the ring slot is (local chunk & 1).
+template <int NB, int STEPS, int NREG>
+__device__ __forceinline__ void run_segment(f32x16 (&acc)[NB], const float (&b)[NREG], Stream& st, float* ring,
+                                            int wave, int lane) {
+  constexpr int kSlabsPerChunk = kChunkPieces / NB;         // NB=8: 4, NB=4: 8
+  constexpr int kSlabs = STEPS / 4;
+  constexpr int kChunks = (kSlabs + kSlabsPerChunk - 1) / kSlabsPerChunk;
+  static_assert(STEPS <= NREG, "B operand registers");
+#pragma unroll
+  for (int c = 0; c < kChunks; ++c) {
+    // chunk st.q has been in flight for a whole chunk time: drain + make it visible to all waves;
+    // the same barrier proves every wave is done reading the other slot.
+    __syncthreads();
+    if (st.q + 1 < st.q_end) issue_chunk(st.base, st.q + 1, ring + ((c + 1) & 1) * (kChunkBytes / 4), wave, lane);
+    const f32x4* buf = reinterpret_cast<const f32x4*>(ring + (c & 1) * (kChunkBytes / 4));
+#pragma unroll
+    for (int sl = 0; sl < kSlabsPerChunk; ++sl) {
+      if (c * kSlabsPerChunk + sl >= kSlabs) break;   // compile-time after unrolling (short last chunk)
+      f32x4 wf[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) wf[nb] = buf[(sl * NB + nb) * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float bv = b[(c * kSlabsPerChunk + sl) * 4 + j];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nb][j], bv, acc[nb], 0, 0, 0);
+      }
+    }
+    st.q += 1;
+  }
+}
+
+// accumulator init = bias, in D-fragment order
+template <int NB>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[NB], const float* bias, int h) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 32 * nb + 8 * q + 4 * h);
+      acc[nb][4 * q + 0] = b4[0];
+      acc[nb][4 * q + 1] = b4[1];
+      acc[nb][4 * q + 2] = b4[2];
+      acc[nb][4 * q + 3] = b4[3];
+    }
+}
+
+// dot( regs[0..16*NB-1], w[feature(t, h)] ) for one lane-half; caller adds the halves
+template <int NB>
+__device__ __forceinline__ float half_dot(const float (&v)[16 * NB], const float* w, int h) {
+  float s = 0.0f;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(w + 32 * nb + 8 * q + 4 * h);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s = fmaf(v[16 * nb + 4 * q + i], w4[i], s);
+    }
+  return s;
+}
+
+// MODE 0: x is (P, 90) embedded rows.  MODE 1: x is rays (R, 8), z (R, N) given.
+template <int MODE, bool SIGMA_ONLY>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ zv,
+                int64_t P, int N, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float ring[2 * kChunkBytes / 4];   // 64 KiB
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  const float* aux = packed + kStreamFloats;
+
+  Stream st;
+  st.base = packed;
+  st.q = 0;
+  st.q_end = SIGMA_ONLY ? 60 : (kStreamPiecesPadded / kChunkPieces);
+  issue_chunk(st.base, 0, ring, wave, lane);   // overlap the first 32 KiB with the encoding prologue
+
+  const int64_t p = (int64_t)blockIdx.x * 128 + wave * 32 + m;
+  const int64_t pc = p < P ? p : P - 1;
+
+  float pe[32], de[16];
+  if (MODE == 0) {
+    const float* row = x + pc * kInCh;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+      const int col = pecol(t, h);
+      pe[t] = (col == kPad) ? 0.0f : row[col];
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int col = dircol(t, h);
+      de[t] = (col == kPad) ? 0.0f : row[kPosCh + col];
+    }
+  } else {
+    const int64_t ray = pc / N;
+    const float4 ra = reinterpret_cast<const float4*>(x + ray * 8)[0];
+    const float4 rb = reinterpret_cast<const float4*>(x + ray * 8)[1];
+    const float zk = zv[pc];
+    const float d[3] = {ra.w, rb.x, rb.y};
+    // cast_rays (models/utils.py:14): o + z*d, separate multiply and add as ATen does
+    const float v[3] = {__fadd_rn(ra.x, __fmul_rn(zk, d[0])), __fadd_rn(ra.y, __fmul_rn(zk, d[1])),
+                        __fadd_rn(ra.z, __fmul_rn(zk, d[2]))};
+    pe[0] = h ? v[2] : v[0];
+    pe[1] = h ? 0.0f : v[1];
+#pragma unroll
+    for (int f = 0; f < 5; ++f)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float sn, cs;
+        sincosf(ldexpf(v[c], 5 * h + f), &sn, &cs);   // 2^k * x is exact; full-range sin/cos
+        pe[2 + 6 * f + c] = sn;
+        pe[2 + 6 * f + 3 + c] = cs;
+      }
+    de[0] = h ? d[2] : d[0];
+    de[1] = h ? 0.0f : d[1];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float sn, cs;
+        sincosf(ldexpf(d[c], 2 * h + f), &sn, &cs);
+        de[2 + 6 * f + c] = sn;
+        de[2 + 6 * f + 3 + c] = cs;
+      }
+    de[14] = 0.0f;
+    de[15] = 0.0f;
+  }
+
+  f32x16 acc[8];
+  float act[128];
+  float sigma = 0.0f;
+
+  // ---- L1: pe(63) -> 256
+  init_bias<8>(acc, aux + kAuxBias0, h);
+  run_segment<8, 32, 32>(acc, pe, st, ring, wave, lane);
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) act[16 * nb + r] = fmaxf(acc[nb][r], 0.0f);
+
+  // ---- L2..L8 (+ xyz_encoding_final as "layer 8", no activation)
+  constexpr int kLast = SIGMA_ONLY ? 7 : 8;
+#pragma unroll 1
+  for (int L = 1; L <= kLast; ++L) {
+    init_bias<8>(acc, aux + kAuxBias0 + L * 256, h);
+    if (L == 4) run_segment<8, 32, 32>(acc, pe, st, ring, wave, lane);   // skip: cat([pe, h])
+    run_segment<8, 128, 128>(acc, act, st, ring, wave, lane);
+    if (L < 8) {
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) act[16 * nb + r] = fmaxf(acc[nb][r], 0.0f);
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) act[16 * nb + r] = acc[nb][r];
+    }
+    if (L == 7) {   // density head on h8 (raw: the renderer applies the relu)
+      float s = half_dot<8>(act, aux + kAuxSigmaW, h);
+      s += __shfl_xor(s, 32, 64);
+      sigma = s + aux[kAuxSigmaB];
+    }
+  }
+
+  if (SIGMA_ONLY) {
+    if (h == 0 && p < P) out[p] = sigma;
+    return;
+  }
+
+  // ---- dir_encoding: cat([g(256), de(27)]) -> 128, relu
+  f32x16 acc4[4];
+  init_bias<4>(acc4, aux + kAuxBiasDir, h);
+  run_segment<4, 128, 128>(acc4, act, st, ring, wave, lane);
+  run_segment<4, 16, 16>(acc4, de, st, ring, wave, lane);
+  float cfe[64];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cfe[16 * nb + r] = fmaxf(acc4[nb][r], 0.0f);
+
+  // ---- rgb head: 128 -> 3, sigmoid
+  float rgb[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float s = half_dot<4>(cfe, aux + kAuxRgbW + 128 * k, h);
+    s += __shfl_xor(s, 32, 64);
+    s += aux[kAuxRgbB + k];
+    rgb[k] = 1.0f / (1.0f + expf(-s));
+  }
+  if (h == 0 && p < P) reinterpret_cast<float4*>(out)[p] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
+}
+
+extern "C" int nsr_mlp_forward(const void* packed_dev, int precision, const float* x, int64_t P, int sigma_only,
+                               float* out, void* stream) {
+  if (P < 0 || !packed_dev) return NSR_ERR_INVALID_ARG;
+  if (precision != NSR_FP32) return NSR_ERR_UNSUPPORTED;
+  if (P == 0) return NSR_OK;   // empty batch: nothing to read or write (pointers may be null)
+  if (!x || !out) return NSR_ERR_INVALID_ARG;
+  if (!sigma_only && (reinterpret_cast<uintptr_t>(out) & 15) != 0) return NSR_ERR_INVALID_ARG;
+  const dim3 grid((unsigned)((P + 127) / 128)), block(256);
+  const float* pk = static_cast<const float*>(packed_dev);
+  if (sigma_only)
+    hipLaunchKernelGGL((mlp_fp32_kernel<0, true>), grid, block, 0, nsr_stream(stream), pk, x, nullptr, P, 1, out);
+  else
+    hipLaunchKernelGGL((mlp_fp32_kernel<0, false>), grid, block, 0, nsr_stream(stream), pk, x, nullptr, P, 1, out);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
+extern "C" int nsr_render_rays(const void* packed_dev, int precision, const float* rays, const float* z, int64_t R,
+                               int n_samples, float* out, void* stream) {
+  if (!packed_dev || R < 0 || n_samples <= 0) return NSR_ERR_INVALID_ARG;
+  if (precision != NSR_FP32) return NSR_ERR_UNSUPPORTED;
+  if (R == 0) return NSR_OK;
+  if (!rays || !z || !out) return NSR_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(out) & 15) != 0 || (reinterpret_cast<uintptr_t>(rays) & 15) != 0)
+    return NSR_ERR_INVALID_ARG;
+  const int64_t P = R * n_samples;
+  const dim3 grid((unsigned)((P + 127) / 128)), block(256);
+  hipLaunchKernelGGL((mlp_fp32_kernel<1, false>), grid, block, 0, nsr_stream(stream),
+                     static_cast<const float*>(packed_dev), rays, z, P, n_samples, out);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}

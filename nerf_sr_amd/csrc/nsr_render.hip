@@ -1,0 +1,213 @@
+// Per-ray stages of the path: alpha compositing (V1) and hierarchical
+// inverse-CDF resampling (S2).  One 64-lane wavefront owns one ray; the
+// sigma->weight chain is a wavefront scan (shuffle based), the (rgb, depth,
+// opacity) sums are wavefront reductions.  HBM-bound: each sample's 16-20 bytes
+// are read once, the weights written once.
+//
+// Numerics follow the reference's CPU path: torch.cumprod / torch.cumsum on CPU
+// accumulate fp32 inputs in double and round every output element to fp32
+// (ATen cpu_cum_base_kernel, acc_type<float,false> = double), so the scans here
+// run in double and round per element as well.
+#include "nsr_common.h"
+
+#define NSR_MAX_SAMPLES 512   // composite: N <= 512 (8 samples per lane)
+#define NSR_RS_MAX 256        // resample: Nc <= 256, Ni <= 256
+
+// ---------------------------------------------------------------------------
+// V1  (reference: models/rendering.py:75-111)
+// ---------------------------------------------------------------------------
+template <int K>   // samples per lane, lane l owns samples l*K .. l*K+K-1
+__global__ void __launch_bounds__(256) composite_kernel(const float* __restrict__ rgb, int rgb_stride,
+                                                        const float* __restrict__ sigma, int sigma_stride,
+                                                        const float* __restrict__ z, int64_t R, int N, int white,
+                                                        float* __restrict__ comp_rgb, float* __restrict__ depth,
+                                                        float* __restrict__ opacity, float* __restrict__ weights) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= R) return;   // whole wave exits together
+  const int64_t base = r * N;
+  float zk[K], sg[K], cr[K], cg[K], cb[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int k = lane * K + i;
+    const bool ok = k < N;
+    const int64_t p = base + (ok ? k : N - 1);
+    zk[i] = z[p];
+    sg[i] = sigma[p * sigma_stride];
+    cr[i] = rgb[p * rgb_stride + 0];
+    cg[i] = rgb[p * rgb_stride + 1];
+    cb[i] = rgb[p * rgb_stride + 2];
+  }
+  const float z_next_lane = __shfl_down(zk[0], 1, 64);
+  float alpha[K];
+  double pl[K];   // lane-local inclusive products of (1 - alpha + 1e-10)
+  double run = 1.0;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int k = lane * K + i;
+    const float zn = (i + 1 < K) ? zk[(i + 1 < K) ? i + 1 : i] : z_next_lane;
+    const float delta = (k >= N - 1) ? 1e10f : __fsub_rn(zn, zk[i]);
+    const float s = fmaxf(sg[i], 0.0f);
+    float a = __fsub_rn(1.0f, expf(__fmul_rn(-delta, s)));
+    if (k >= N) a = 0.0f;
+    alpha[i] = a;
+    const float f = (k < N) ? __fadd_rn(__fsub_rn(1.0f, a), 1e-10f) : 1.0f;
+    run *= (double)f;
+    pl[i] = run;
+  }
+  // exclusive prefix over lanes of the lane totals
+  const double incl = wave_scan_mul_d(run, lane);
+  double excl = __shfl_up(incl, 1, 64);
+  if (lane == 0) excl = 1.0;
+  float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_o = 0.f;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int k = lane * K + i;
+    // T_k = fp32( prod_{j<k} f_j ), T_0 = 1 exactly
+    const double t_d = (i == 0) ? excl : excl * pl[(i > 0) ? i - 1 : 0];
+    const float T = (k == 0) ? 1.0f : (float)t_d;
+    const float w = __fmul_rn(alpha[i], T);
+    if (k < N) {
+      if (weights) weights[base + k] = w;
+      acc_r = __fadd_rn(acc_r, __fmul_rn(w, cr[i]));
+      acc_g = __fadd_rn(acc_g, __fmul_rn(w, cg[i]));
+      acc_b = __fadd_rn(acc_b, __fmul_rn(w, cb[i]));
+      acc_d = __fadd_rn(acc_d, __fmul_rn(w, zk[i]));
+      acc_o = __fadd_rn(acc_o, w);
+    }
+  }
+  acc_r = wave_sum(acc_r); acc_g = wave_sum(acc_g); acc_b = wave_sum(acc_b);
+  acc_d = wave_sum(acc_d); acc_o = wave_sum(acc_o);
+  if (lane == 0) {
+    if (white) {
+      const float bg = __fsub_rn(1.0f, acc_o);
+      acc_r = __fadd_rn(acc_r, bg); acc_g = __fadd_rn(acc_g, bg); acc_b = __fadd_rn(acc_b, bg);
+    }
+    if (comp_rgb) { comp_rgb[r * 3 + 0] = acc_r; comp_rgb[r * 3 + 1] = acc_g; comp_rgb[r * 3 + 2] = acc_b; }
+    if (depth) depth[r] = acc_d;
+    if (opacity) opacity[r] = acc_o;
+  }
+}
+
+extern "C" int nsr_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z,
+                             int64_t R, int n_samples, int white_bkgd, float* comp_rgb, float* depth,
+                             float* opacity, float* weights, void* stream) {
+  if (R < 0 || n_samples <= 0 || rgb_stride < 3 || sigma_stride < 1) return NSR_ERR_INVALID_ARG;
+  if (n_samples > NSR_MAX_SAMPLES) return NSR_ERR_UNSUPPORTED;
+  if (R == 0) return NSR_OK;
+  if (!rgb || !sigma || !z) return NSR_ERR_INVALID_ARG;
+  const int K = (n_samples + 63) / 64;
+  const dim3 block(256), grid((unsigned)((R + 3) / 4));
+  hipStream_t st = nsr_stream(stream);
+#define NSR_LAUNCH_COMPOSITE(KK)                                                                              \
+  hipLaunchKernelGGL(composite_kernel<KK>, grid, block, 0, st, rgb, rgb_stride, sigma, sigma_stride, z, R, \
+                     n_samples, white_bkgd, comp_rgb, depth, opacity, weights)
+  switch (K) {
+    case 1: NSR_LAUNCH_COMPOSITE(1); break;
+    case 2: NSR_LAUNCH_COMPOSITE(2); break;
+    case 3: NSR_LAUNCH_COMPOSITE(3); break;
+    case 4: NSR_LAUNCH_COMPOSITE(4); break;
+    default: NSR_LAUNCH_COMPOSITE(8); break;
+  }
+#undef NSR_LAUNCH_COMPOSITE
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// S2  (reference: models/utils.py:47-95)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) resample_kernel(const float* __restrict__ rays, const float* __restrict__ z,
+                                                       const float* __restrict__ weights, int64_t R, int Nc, int Ni,
+                                                       const float* __restrict__ u, float* __restrict__ z_out,
+                                                       float* __restrict__ pts) {
+  __shared__ float s_z[4][NSR_RS_MAX];
+  __shared__ float s_cdf[4][NSR_RS_MAX];
+  __shared__ float s_bins[4][NSR_RS_MAX];
+  __shared__ float s_val[4][2 * NSR_RS_MAX];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wv;
+  if (r >= R) return;   // wave-uniform; no block-level barrier is used below
+  float* zs = s_z[wv];
+  float* cdf = s_cdf[wv];
+  float* bins = s_bins[wv];
+  float* val = s_val[wv];
+  const float eps = 1e-5f;
+  const int nb = Nc - 2;            // entries of the pdf (weights[:, 1:-1])
+  // stage z, and the coarse half of the merge buffer
+  for (int k = lane; k < Nc; k += 64) {
+    const float v = z[r * Nc + k];
+    zs[k] = v;
+    val[k] = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // bins = interval mid points (Nc-1 of them)
+  for (int k = lane; k < Nc - 1; k += 64) bins[k] = __fmul_rn(0.5f, __fadd_rn(zs[k], zs[k + 1]));
+  // pdf normaliser: sum of the fp32 terms, accumulated in double and rounded once (torch's
+  // fp32 sum order is build dependent; the correctly rounded sum is within 1 ulp of any of them)
+  double part = 0.0;
+  for (int j = lane; j < nb; j += 64) part += (double)__fadd_rn(weights[r * Nc + j + 1], eps);
+  const float wsum = (float)wave_sum_d(part);
+  // cdf = [0, cumsum(pdf)]  (double accumulate, fp32 per element)
+  double carry = 0.0;
+  for (int seg = 0; seg < nb; seg += 64) {
+    const int j = seg + lane;
+    const float pdf = (j < nb) ? __fdiv_rn(__fadd_rn(weights[r * Nc + j + 1], eps), wsum) : 0.0f;
+    const double incl = wave_scan_add_d((double)pdf, lane) + carry;
+    if (j < nb) cdf[j + 1] = (float)incl;
+    carry = __shfl(incl, 63, 64);
+  }
+  if (lane == 0) cdf[0] = 0.0f;
+  __builtin_amdgcn_wave_barrier();
+  // invert the cdf at u
+  for (int j = lane; j < Ni; j += 64) {
+    const float uj = u ? u[r * Ni + j] : nsr_linspace01(j, Ni);
+    int lo = 0, hi = Nc - 1;        // searchsorted(cdf[0..Nc-2], u, right=True)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] <= uj) lo = mid + 1; else hi = mid;
+    }
+    const int below = max(lo - 1, 0), above = min(lo, nb);
+    const float cb = cdf[below], ca = cdf[above];
+    const float bb = bins[below], ba = bins[above];
+    float denom = __fsub_rn(ca, cb);
+    if (denom < eps) denom = 1.0f;
+    const float zn = __fadd_rn(bb, __fmul_rn(__fdiv_rn(__fsub_rn(uj, cb), denom), __fsub_rn(ba, bb)));
+    val[Nc + j] = zn;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // sort(cat([z, z_new])) by stable rank counting: every value's output slot is the
+  // number of values that precede it (ties broken by position).
+  const int M = Nc + Ni;
+  for (int i = lane; i < M; i += 64) {
+    const float v = val[i];
+    int rank = 0;
+    for (int j = 0; j < M; ++j) {
+      const float o = val[j];
+      rank += (o < v || (o == v && j < i)) ? 1 : 0;
+    }
+    z_out[r * M + rank] = v;
+    if (pts) {
+      const float4 a = reinterpret_cast<const float4*>(rays + r * 8)[0];
+      const float4 b = reinterpret_cast<const float4*>(rays + r * 8)[1];
+      float* p = pts + (r * M + rank) * 3;
+      p[0] = __fadd_rn(a.x, __fmul_rn(v, a.w));
+      p[1] = __fadd_rn(a.y, __fmul_rn(v, b.x));
+      p[2] = __fadd_rn(a.z, __fmul_rn(v, b.y));
+    }
+  }
+}
+
+extern "C" int nsr_resample_along_rays(const float* rays, const float* z, const float* weights, int64_t R,
+                                       int n_coarse, int n_importance, const float* u, float* z_out, float* pts,
+                                       void* stream) {
+  if (R < 0 || n_coarse < 3 || n_importance <= 0) return NSR_ERR_INVALID_ARG;
+  if (n_coarse > NSR_RS_MAX || n_importance > NSR_RS_MAX) return NSR_ERR_UNSUPPORTED;
+  if (R == 0) return NSR_OK;
+  if (!z || !weights || !z_out) return NSR_ERR_INVALID_ARG;
+  if (pts && (!rays || (reinterpret_cast<uintptr_t>(rays) & 15) != 0)) return NSR_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, nsr_stream(stream), rays, z,
+                     weights, R, n_coarse, n_importance, u, z_out, pts);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}

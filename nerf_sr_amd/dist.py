@@ -1,0 +1,90 @@
+"""Multi-GPU layer of the path: contiguous ray-range sharding + ONE all-gather of pixels.
+
+Rays are independent; the only cross-ray op is the s*s mean, local to one LR pixel.
+So the LR-pixel range is cut into ``world`` contiguous blocks (an LR pixel's s*s
+sub-rays stay on one GPU), weights are replicated (4.77 MB, loaded per rank), every
+rank renders its block, and one all-gather (RCCL over xGMI when the backend is
+``nccl``; ``gloo`` in the CPU tests) assembles the image on every rank.  This replaces
+the reference's nn.DataParallel scatter/gather inside every MLP call
+(models/networks.py:54-69) — see SURVEY §2.3 / §8e.  One process per GPU.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous [lo, hi) blocks; the first ``n_items % world`` ranks take one extra item."""
+    if world <= 0 or n_items < 0:
+        raise ValueError("world must be positive and n_items non-negative")
+    q, r = divmod(n_items, world)
+    out, lo = [], 0
+    for k in range(world):
+        hi = lo + q + (1 if k < r else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def _world(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def all_gather_pixels(local: torch.Tensor, n_items: int, group=None) -> torch.Tensor:
+    """Gather per-rank pixel blocks (n_local, c) into the full (n_items, c) tensor on every rank.
+
+    Shards may differ by one row: each rank pads to the largest shard so that a single
+    fixed-size ``all_gather_into_tensor`` does the exchange, then the pad rows are dropped.
+    """
+    rank, world = _world(group)
+    if world == 1:
+        return local
+    bounds = shard_bounds(n_items, world)
+    lo, hi = bounds[rank]
+    if local.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank} holds {local.shape[0]} rows, expected {hi - lo}")
+    c = local.shape[1:]
+    cap = max(b - a for a, b in bounds)
+    send = local
+    if hi - lo < cap:
+        send = torch.zeros((cap, *c), dtype=local.dtype, device=local.device)
+        send[: hi - lo] = local
+    recv = torch.empty((world * cap, *c), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    if all(b - a == cap for a, b in bounds):
+        return recv
+    return torch.cat([recv[k * cap: k * cap + (b - a)] for k, (a, b) in enumerate(bounds)], 0)
+
+
+def render_sharded(render_block: Callable[[int, int], torch.Tensor], n_lr: int, group=None) -> torch.Tensor:
+    """Run ``render_block(lo, hi) -> (hi-lo, c)`` on this rank's LR-pixel block and all-gather.
+
+    ``render_block`` is the per-GPU hot path (rays of LR pixels [lo, hi) -> LR pixel values);
+    the result is the full (n_lr, c) image on every rank, bit-identical to a 1-GPU render
+    because no reduction crosses a shard boundary.
+    """
+    rank, world = _world(group)
+    lo, hi = shard_bounds(n_lr, world)[rank]
+    return all_gather_pixels(render_block(lo, hi), n_lr, group)
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialise the default process group from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, local_rank, world).  No-op for world == 1."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world

@@ -1,0 +1,134 @@
+"""Host-side mirror of ``NeRFDownXModel`` for the render path only.
+
+Reproduces the call protocol the reference's loops use
+(``set_input -> forward -> out_* -> comp_low_res_output``; train.py:79-80,
+test.py:52, models/nerf_downX_model.py:235-353,410-416,621-669) on top of the HIP
+path.  Losses, optimisers, checkpoints, visualisers and the GAN / refinement
+branches are out of scope.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .ops import VanillaMLP, VolumetricRenderer, PositionalEncoding
+
+
+def default_options(**kw) -> SimpleNamespace:
+    """The option values that define the path (SURVEY §5 'Config / flags')."""
+    opt = SimpleNamespace(
+        N_coarse=64, N_importance=64, lindisp=False, white_bkgd=False, randomized=True, noise_std=0.0,
+        deg_pos=10, deg_dir=4, dim_pos=3, dim_dir=3, dim_rgb=3, downscale=2, img_wh=(504, 378),
+        sigma_activation="relu", color_activation="sigmoid", gamma_correct=False,
+        ray_chunk=4096, point_chunk=262144, precision="fp32",
+    )
+    for k, v in kw.items():
+        setattr(opt, k, v)
+    return opt
+
+
+class NeRFDownXModel:
+    """``model.set_input(data); model.forward(); model.comp_low_res_output()`` as in the
+    reference; the ``out_*`` attributes carry the same tensors (same shapes, fp32)."""
+
+    def __init__(self, opt: Optional[SimpleNamespace] = None, device="cuda"):
+        self.opt = opt or default_options()
+        self.device = torch.device(device)
+        if self.opt.gamma_correct:
+            raise NotImplementedError("--gamma_correct is off in every reference script; not built")
+        self.netCoarse = VanillaMLP(self.opt, precision=self.opt.precision, device=self.device)
+        self.netFine = VanillaMLP(self.opt, precision=self.opt.precision, device=self.device)
+        self.models = {"coarse": self.netCoarse, "fine": self.netFine}
+        self.embeddings = {"pos": PositionalEncoding(3, self.opt.deg_pos), "dir": PositionalEncoding(3, self.opt.deg_dir)}
+        self.renderer = VolumetricRenderer(self.opt)
+        self.randomized = False
+        self._ws = None
+        self._outs: Dict[str, torch.Tensor] = {}
+
+    # -- weights ---------------------------------------------------------------
+    def load_networks(self, sd_coarse, sd_fine):
+        """Takes the two 24-key state_dicts the reference stores as
+        ``{epoch}_net_Coarse.pth`` / ``{epoch}_net_Fine.pth`` (models/base_model.py:181-219)."""
+        self.netCoarse.load_state_dict(sd_coarse)
+        self.netFine.load_state_dict(sd_fine)
+        return self
+
+    # -- mode toggles (nerf_downX_model.py:250-258) ------------------------------
+    def train(self):
+        self.randomized = bool(self.opt.randomized)
+        return self
+
+    def eval(self):
+        self.randomized = False
+        return self
+
+    # -- D1 ------------------------------------------------------------------------
+    def set_input(self, input: Dict[str, torch.Tensor]):
+        for name, v in input.items():
+            v = v.squeeze(0) if (v.ndim > 0 and v.shape[0] == 1) else v
+            v = v.reshape(-1, v.shape[-1]) if v.ndim in (3, 4) else v
+            setattr(self, f"data_{name}", v.to(self.device))
+
+    # -- D2 ------------------------------------------------------------------------
+    def render_rays(self, model: VanillaMLP, xyz: torch.Tensor, dir_embedded: torch.Tensor, **kwargs):
+        """Reference signature (xyz (R,N,3), dir_embedded (R,27)) -> (rgbs, sigmas): the
+        unfused route through explicit positional encoding and ``VanillaMLP.forward``."""
+        R, N = xyz.shape[:2]
+        x = torch.cat([self.embeddings["pos"](xyz.reshape(-1, 3)), dir_embedded.repeat_interleave(N, dim=0)], -1)
+        out = model(x, **kwargs).view(R, N, -1)
+        return out[..., :3], out[..., 3]
+
+    # -- D3 ------------------------------------------------------------------------
+    def forward_rays(self, rays: torch.Tensor) -> Dict[str, torch.Tensor]:
+        opt = self.opt
+        if not self.randomized:
+            self._outs = ops.forward_rays(self.netCoarse, self.netFine if opt.N_importance > 0 else None, rays,
+                                          opt.N_coarse, opt.N_importance, opt.white_bkgd, opt.lindisp)
+            return self._outs
+        # randomized (training-mode) forward: same kernels, stage by stage, jitter drawn with torch.rand
+        o, d, near, far = rays[:, 0:3], rays[:, 3:6], rays[:, 6:7], rays[:, 7:8]
+        z, _ = ops.sample_along_rays(o, d, near, far, opt.N_coarse, True, opt.lindisp)
+        rgb, sig = ops.render_rays(self.netCoarse, rays, z)
+        if opt.noise_std > 0:
+            sig = sig + torch.randn_like(sig) * opt.noise_std
+        c = self.renderer(rgb, sig, z, opt.white_bkgd)
+        out = dict(zip(ops.OUT_KEYS[:4], c))
+        if opt.N_importance > 0:
+            z2, _ = ops.resample_along_rays(o, d, z, c[3], opt.N_importance, True)
+            rgb2, sig2 = ops.render_rays(self.netFine, rays, z2)
+            if opt.noise_std > 0:
+                sig2 = sig2 + torch.randn_like(sig2) * opt.noise_std
+            out.update(zip(ops.OUT_KEYS[4:], self.renderer(rgb2, sig2, z2, opt.white_bkgd)))
+        return out
+
+    def forward(self):
+        out = self.forward_rays(self.data_rays)
+        for name, v in out.items():
+            setattr(self, f"out_{name}", v)
+
+    # -- A1 / A2 ---------------------------------------------------------------------
+    def comp_low_res_output(self):
+        s2 = self.opt.downscale ** 2
+        n_lr = self.data_rgbs.shape[0] if hasattr(self, "data_rgbs") else self.out_coarse_comp_rgbs.shape[0] // s2
+        for name in ("coarse_comp_rgbs", "coarse_depth", "fine_comp_rgbs", "fine_depth"):
+            if hasattr(self, f"out_{name}"):
+                hr = getattr(self, f"out_{name}")
+                setattr(self, f"out_{name}_ori", hr)
+                setattr(self, f"out_{name}", ops.sr_mean(hr, n_lr, s2))
+
+    def unflatten_reshape(self, input: torch.Tensor) -> torch.Tensor:
+        return ops.unflatten_reshape(input, self.opt.img_wh, self.opt.downscale)
+
+    # -- full image (test loop body, nerf_downX_model.py:621-669 without the savers) -----
+    @torch.no_grad()
+    def render_image(self, c2w, focal: float, ndc: bool, near: float = 0.0, far: float = 1.0):
+        """Rays generated on the device -> forward -> LR means + HR image of one pose."""
+        rays = ops.subpixel_rays(c2w, self.opt.img_wh, focal, self.opt.downscale, ndc, near, far, self.device)
+        self.set_input({"rays": rays})
+        self.forward()
+        hr = self.unflatten_reshape(self.out_fine_comp_rgbs)
+        self.comp_low_res_output()
+        return {"hr_rgb": hr, "lr_rgb": self.out_fine_comp_rgbs, "lr_depth": self.out_fine_depth}

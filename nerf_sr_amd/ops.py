@@ -1,0 +1,289 @@
+"""Host-side mirror of the reference's operator interface for the render hot path.
+
+Same names, argument meaning and return shapes as the reference functions they
+replace (cited per function), implemented as calls into libnsr.so through the C
+ABI.  PyTorch is plumbing only: it owns the device buffers and the stream.
+All tensors are fp32, contiguous, on the current HIP device.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_float, c_void_p
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .weights import STATE_DICT_SPEC, check_state_dict, IN_CH
+
+__all__ = [
+    "subpixel_rays", "PositionalEncoding", "sample_along_rays", "resample_along_rays", "cast_rays",
+    "VanillaMLP", "VolumetricRenderer", "render_rays", "forward_rays", "sr_mean", "unflatten_reshape",
+]
+
+
+def _stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]) -> c_void_p:
+    return c_void_p(0) if t is None else c_void_p(t.data_ptr())
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (nerf_sr_amd has no CPU path)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _pack_rays(ori, dir, near, far) -> torch.Tensor:
+    R = ori.shape[0]
+    near = near.reshape(R, 1) if isinstance(near, torch.Tensor) else torch.full((R, 1), float(near), device=ori.device)
+    far = far.reshape(R, 1) if isinstance(far, torch.Tensor) else torch.full((R, 1), float(far), device=ori.device)
+    return torch.cat([ori, dir, near, far], 1).contiguous()
+
+
+# ----------------------------------------------------------------------------- R1-R4
+def subpixel_rays(c2w, img_wh: Tuple[int, int], focal: float, downscale: int, ndc: bool,
+                  near: float = 0.0, far: float = 1.0, device="cuda") -> torch.Tensor:
+    """(H/s*W/s, s*s, 8) sub-pixel ray tensor of one pose, generated on the device.
+
+    Replaces get_ray_directions + get_rays (+ get_ndc_rays) + the einops regroup
+    (models/utils.py:98-196, data/llff_downX_dataset.py:473-490,
+    data/blender_downX_dataset.py:207-215).  ``img_wh`` is the HR size (W, H).
+    """
+    lib = _lib.load()
+    W, H = int(img_wh[0]), int(img_wh[1])
+    s = int(downscale)
+    c = np.ascontiguousarray(np.asarray(c2w, dtype=np.float32).reshape(12))
+    rays = torch.empty((H // s) * (W // s), s * s, 8, dtype=torch.float32, device=device)
+    _lib.check(lib.nsr_gen_rays(c.ctypes.data_as(ctypes.POINTER(c_float)), H, W, float(focal), s, int(bool(ndc)),
+                                float(near), float(far), _p(rays), _stream()), "nsr_gen_rays")
+    return rays
+
+
+# ----------------------------------------------------------------------------- E1
+class PositionalEncoding:
+    """``x -> [x, sin(2^k x), cos(2^k x)]_k``; mirrors models/embedding.py:14-62
+    (log-scale bands, xyz included; 3 input channels)."""
+
+    def __init__(self, in_channels: int = 3, N_freqs: int = 10, opt=None):
+        if in_channels != 3:
+            raise ValueError("the built path encodes 3-channel inputs only")
+        self.in_channels, self.N_freqs = in_channels, int(N_freqs)
+
+    @property
+    def out_channels(self) -> int:
+        return self.in_channels * (2 * self.N_freqs + 1)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        x = _f32(x, "x")
+        if x.ndim != 2 or x.shape[1] != 3:
+            raise ValueError(f"x must be (B, 3), got {tuple(x.shape)}")
+        out = torch.empty(x.shape[0], self.out_channels, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().nsr_posenc(_p(x), x.shape[0], self.N_freqs, _p(out), _stream()), "nsr_posenc")
+        return out
+
+
+# ----------------------------------------------------------------------------- S1 / S2
+def cast_rays(ori, dir, z_vals):
+    """``ori + z*dir`` (models/utils.py:5-14) — kept for API parity; torch elementwise."""
+    return ori[..., None, :] + z_vals[..., None] * dir[..., None, :]
+
+
+def sample_along_rays(ori, dir, near, far, num_samples: int, randomized: bool, lindisp: bool,
+                      u: Optional[torch.Tensor] = None):
+    """Stratified depths and points; mirrors models/utils.py:17-44.
+
+    ``randomized=True`` draws the per-bin jitter with ``torch.rand`` on the device
+    unless ``u`` (R, num_samples) is supplied (used by the parity tests).
+    Returns ``(z_vals (R,N), points (R,N,3))``.
+    """
+    rays = _pack_rays(_f32(ori, "ori"), _f32(dir, "dir"), near, far)
+    R = rays.shape[0]
+    if randomized and u is None:
+        u = torch.rand(R, num_samples, device=rays.device)
+    if u is not None:
+        u = _f32(u, "u")
+    z = torch.empty(R, num_samples, dtype=torch.float32, device=rays.device)
+    pts = torch.empty(R, num_samples, 3, dtype=torch.float32, device=rays.device)
+    _lib.check(_lib.load().nsr_sample_along_rays(_p(rays), R, num_samples, int(bool(lindisp)), _p(u), _p(z), _p(pts),
+                                                 _stream()), "nsr_sample_along_rays")
+    return z, pts
+
+
+def resample_along_rays(ori, dir, z_vals, weights, num_samples: int, randomized: bool,
+                        u: Optional[torch.Tensor] = None):
+    """Inverse-CDF importance resampling + merge; mirrors models/utils.py:47-95.
+    Returns ``(z_vals (R, N+num_samples) sorted, points)``."""
+    ori, dir = _f32(ori, "ori"), _f32(dir, "dir")
+    z_vals, weights = _f32(z_vals, "z_vals"), _f32(weights, "weights")
+    R, Nc = z_vals.shape
+    rays = _pack_rays(ori, dir, 0.0, 1.0)
+    if randomized and u is None:
+        u = torch.rand(R, num_samples, device=z_vals.device)
+    if u is not None:
+        u = _f32(u, "u")
+    z_out = torch.empty(R, Nc + num_samples, dtype=torch.float32, device=z_vals.device)
+    pts = torch.empty(R, Nc + num_samples, 3, dtype=torch.float32, device=z_vals.device)
+    _lib.check(_lib.load().nsr_resample_along_rays(_p(rays), _p(z_vals), _p(weights), R, Nc, num_samples, _p(u),
+                                                   _p(z_out), _p(pts), _stream()), "nsr_resample_along_rays")
+    return z_out, pts
+
+
+# ----------------------------------------------------------------------------- M1
+class VanillaMLP:
+    """The 8x256 NeRF MLP; mirrors models/networks.py:121-226.
+
+    Weights enter as the reference's 24-key ``state_dict`` (``load_state_dict``) and
+    are re-laid-out once into the MFMA fragment stream the kernel consumes
+    (``nsr_pack_weights``).  ``forward(x, sigma_only=False)``: x (B, 90) embedded rows
+    -> (B, 4) = [rgb, sigma] (or (B, 1)).
+    """
+
+    def __init__(self, opt=None, precision: str = "fp32", device="cuda"):
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {list(_lib.PRECISIONS)}")
+        self.precision = precision
+        self._prec = _lib.PRECISIONS[precision]
+        self.device = torch.device(device)
+        nbytes = _lib.load().nsr_packed_weights_bytes(self._prec)
+        if nbytes == 0:
+            raise _lib.NsrError(f"precision {precision!r} is not built into libnsr.so")
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self._sd = None
+
+    def load_state_dict(self, sd: Dict[str, "np.ndarray | torch.Tensor"]):
+        check_state_dict(sd)
+        dev = {}
+        for k in STATE_DICT_SPEC:
+            v = sd[k]
+            v = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v.detach()
+            dev[k] = v.to(device=self.device, dtype=torch.float32).contiguous()
+        ptrs = (c_void_p * len(dev))(*[c_void_p(t.data_ptr()) for t in dev.values()])
+        _lib.check(_lib.load().nsr_pack_weights(ptrs, _p(self.packed), self._prec, _stream()), "nsr_pack_weights")
+        self._sd = dev     # keep the fp32 originals alive (state_dict() round trip)
+        return self
+
+    def state_dict(self):
+        if self._sd is None:
+            raise RuntimeError("no weights loaded")
+        return {k: v.clone() for k, v in self._sd.items()}
+
+    def forward(self, x: torch.Tensor, sigma_only: bool = False) -> torch.Tensor:
+        if self._sd is None:
+            raise RuntimeError("VanillaMLP.forward called before load_state_dict")
+        x = _f32(x, "x")
+        if x.ndim != 2 or x.shape[1] != IN_CH:
+            raise ValueError(f"x must be (B, {IN_CH}), got {tuple(x.shape)}")
+        out = torch.empty(x.shape[0], 1 if sigma_only else 4, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().nsr_mlp_forward(_p(self.packed), self._prec, _p(x), x.shape[0], int(bool(sigma_only)),
+                                               _p(out), _stream()), "nsr_mlp_forward")
+        return out
+
+    __call__ = forward
+
+
+# ----------------------------------------------------------------------------- V1
+class VolumetricRenderer:
+    """Alpha compositing; mirrors models/rendering.py:66-111 (sigma_activation = relu)."""
+
+    def __init__(self, opt=None):
+        act = getattr(opt, "sigma_activation", "relu") if opt is not None else "relu"
+        if act != "relu":
+            raise ValueError("the built path implements sigma_activation='relu' only")
+
+    def forward(self, rgb, sigma, z_vals, white_bkgd: bool):
+        rgb, sigma, z_vals = _f32(rgb, "rgb"), _f32(sigma, "sigma"), _f32(z_vals, "z_vals")
+        R, N = z_vals.shape
+        if rgb.shape != (R, N, 3) or sigma.shape != (R, N):
+            raise ValueError("rgb must be (R,N,3) and sigma (R,N) matching z_vals (R,N)")
+        dev = z_vals.device
+        comp = torch.empty(R, 3, dtype=torch.float32, device=dev)
+        depth = torch.empty(R, dtype=torch.float32, device=dev)
+        opac = torch.empty(R, dtype=torch.float32, device=dev)
+        w = torch.empty(R, N, dtype=torch.float32, device=dev)
+        _lib.check(_lib.load().nsr_composite(_p(rgb), 3, _p(sigma), 1, _p(z_vals), R, N, int(bool(white_bkgd)),
+                                             _p(comp), _p(depth), _p(opac), _p(w), _stream()), "nsr_composite")
+        return comp, depth, opac, w
+
+    __call__ = forward
+
+
+# ----------------------------------------------------------------------------- D2 / D3
+def render_rays(model: VanillaMLP, rays: torch.Tensor, z_vals: torch.Tensor):
+    """Fused render_rays (models/nerf_downX_model.py:260-278): MLP at every sample of
+    every ray, positional encodings computed in-kernel.  rays (R,8), z (R,N) ->
+    ``(rgbs (R,N,3), sigmas (R,N))`` as views of one (R,N,4) buffer."""
+    rays, z_vals = _f32(rays, "rays"), _f32(z_vals, "z_vals")
+    R, N = z_vals.shape
+    raw = torch.empty(R, N, 4, dtype=torch.float32, device=rays.device)
+    _lib.check(_lib.load().nsr_render_rays(_p(model.packed), model._prec, _p(rays), _p(z_vals), R, N, _p(raw),
+                                           _stream()), "nsr_render_rays")
+    return raw[..., :3], raw[..., 3]
+
+
+OUT_KEYS = ("coarse_comp_rgbs", "coarse_depth", "coarse_opacity", "coarse_weights",
+            "fine_comp_rgbs", "fine_depth", "fine_opacity", "fine_weights")
+
+
+def forward_rays(coarse: VanillaMLP, fine: Optional[VanillaMLP], rays: torch.Tensor, N_coarse: int = 64,
+                 N_importance: int = 64, white_bkgd: bool = False, lindisp: bool = False,
+                 workspace: Optional[torch.Tensor] = None, outs: Optional[Dict[str, torch.Tensor]] = None,
+                 want_weights: bool = True) -> Dict[str, torch.Tensor]:
+    """Eval-mode forward_rays for the WHOLE batch in one enqueue sequence
+    (models/nerf_downX_model.py:280-324): returns the reference's 8-entry dict.
+    ``workspace`` / ``outs`` let a caller reuse buffers across frames."""
+    lib = _lib.load()
+    rays = _f32(rays, "rays").reshape(-1, 8)
+    R = rays.shape[0]
+    if N_importance > 0 and fine is None:
+        raise ValueError("N_importance > 0 needs the fine network")
+    if fine is not None and fine._prec != coarse._prec:
+        raise ValueError("coarse and fine networks must use the same precision")
+    dev = rays.device
+    need = lib.nsr_forward_rays_workspace_bytes(R, N_coarse, N_importance)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+    Nf = N_coarse + N_importance
+    shapes = {"coarse_comp_rgbs": (R, 3), "coarse_depth": (R,), "coarse_opacity": (R,), "coarse_weights": (R, N_coarse),
+              "fine_comp_rgbs": (R, 3), "fine_depth": (R,), "fine_opacity": (R,), "fine_weights": (R, Nf)}
+    if outs is None:
+        outs = {}
+    keys = OUT_KEYS if N_importance > 0 else OUT_KEYS[:4]
+    for k in keys:
+        if k.endswith("weights") and not want_weights:
+            continue
+        if k not in outs or tuple(outs[k].shape) != shapes[k]:
+            outs[k] = torch.empty(shapes[k], dtype=torch.float32, device=dev)
+    ptrs = (c_void_p * 8)(*[_p(outs.get(k)) for k in OUT_KEYS])
+    _lib.check(lib.nsr_forward_rays(_p(coarse.packed), _p(fine.packed) if fine is not None else c_void_p(0),
+                                    coarse._prec, _p(rays), R, N_coarse, N_importance, int(bool(white_bkgd)),
+                                    int(bool(lindisp)), ptrs, _p(workspace), workspace.numel(), _stream()),
+               "nsr_forward_rays")
+    return outs
+
+
+# ----------------------------------------------------------------------------- A1 / A2
+def sr_mean(hr: torch.Tensor, n_lr: int, s2: int) -> torch.Tensor:
+    """``reshape(N_lr, s^2, c).mean(1)`` (models/nerf_downX_model.py:337-348)."""
+    hr = _f32(hr, "hr")
+    c = hr.numel() // (n_lr * s2)
+    lr = torch.empty(n_lr, c, dtype=torch.float32, device=hr.device)
+    _lib.check(_lib.load().nsr_sr_mean(_p(hr), n_lr, s2, c, _p(lr), _stream()), "nsr_sr_mean")
+    return lr
+
+
+def unflatten_reshape(x: torch.Tensor, img_wh: Tuple[int, int], downscale: int) -> torch.Tensor:
+    """(N_lr*s^2, c) -> HR image (H, W, c) (models/nerf_downX_model.py:410-416)."""
+    x = _f32(x, "x")
+    W, H = int(img_wh[0]), int(img_wh[1])
+    c = x.numel() // (H * W)
+    out = torch.empty(H, W, c, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().nsr_unflatten(_p(x), H, W, int(downscale), c, _p(out), _stream()), "nsr_unflatten")
+    return out

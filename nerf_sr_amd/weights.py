@@ -63,7 +63,15 @@ assert N_PARAMS == 595_844
 assert sum(int(np.prod(s)) for k, s in STATE_DICT_SPEC.items() if k.endswith("weight")) == MACS_PER_POINT
 
 
-def make_state_dict(seed: int = 99, structured: bool = True, bias_scale: float = 0.05):
+#: synthetic density-field presets: (spectral decay of the PE input columns, sigma.weight scale, sigma.bias)
+FIELDS = {
+    "plain": (0.0, 1.0, None),     # kaiming only: fog everywhere, every ray saturates
+    "smooth": (1.0, 10.0, -3.0),   # default: 1/f spectrum, ~45 % empty samples, opacity varies ray to ray
+    "sharp": (0.0, 30.0, -40.0),   # stress: white spectrum x30 density head, chaotic under fp32 rounding
+}
+
+
+def make_state_dict(seed: int = 99, field: str = "smooth", bias_scale: float = 0.05):
     """Deterministic synthetic ``VanillaMLP`` weights as ``{key: float32 ndarray}``.
 
     ``W ~ N(0, 2/fan_in)`` mirrors ``init_type=kaiming`` of the reference
@@ -71,12 +79,26 @@ def make_state_dict(seed: int = 99, structured: bool = True, bias_scale: float =
     zero-inits biases; a small non-zero bias (``bias_scale``) is used here so
     that bias handling of the kernels is actually exercised by the parity tests.
 
-    ``structured=True`` additionally reshapes the density head
-    (``sigma.weight *= 30``, ``sigma.bias = -40``): about a quarter of the sample
-    points then carry density, so rendered opacity / depth / weights vary from
-    ray to ray instead of saturating at the first samples (probed: LLFF-like rays
-    give opacity mean 0.64, std 0.27).
+    ``field`` shapes the random density field so that renders are non-trivial
+    (no dataset or checkpoint is reachable offline):
+
+    * ``"smooth"`` (default) scales the positional-encoding columns of octave k in
+      the two layers that read them (``xyz_encoding_1``, ``xyz_encoding_5``) by
+      ``2^-k`` — a 1/f spectrum, band-limited at the sample spacing like a trained
+      scene — and sets ``sigma.weight *= 10, sigma.bias = -3``: ~45 % of the
+      samples are empty, opacity mean 0.3-0.9 with std ~0.3 across rays.  On this
+      field the reference algorithm itself is well conditioned (fp32 vs fp64
+      oracle differ by < 1e-5 RGB), so an all-rays 1e-4 parity bound is meaningful.
+    * ``"sharp"`` (white spectrum, ``sigma.weight *= 30, sigma.bias = -40``) is a
+      stress field: the reference's ``denom < 1e-5 -> 1`` snap
+      (``models/utils.py:87-88``) and the 1/pdf amplification of the inverse CDF
+      make its own fp32 and fp64 results differ by > 1e-2 on ~5 % of the rays, so
+      only statistical parity can be asked of it.
+    * ``"plain"``: kaiming weights only.
     """
+    if field not in FIELDS:
+        raise ValueError(f"field must be one of {list(FIELDS)}")
+    decay, sigma_scale, sigma_bias = FIELDS[field]
     rng = np.random.Generator(np.random.PCG64(seed))
     sd = OrderedDict()
     for key, shape in STATE_DICT_SPEC.items():
@@ -86,9 +108,15 @@ def make_state_dict(seed: int = 99, structured: bool = True, bias_scale: float =
             sd[key] = w.astype(np.float32)
         else:
             sd[key] = (rng.standard_normal(shape, dtype=np.float64) * bias_scale).astype(np.float32)
-    if structured:
-        sd["sigma.weight"] = (sd["sigma.weight"] * np.float32(30.0)).astype(np.float32)
-        sd["sigma.bias"] = np.full((1,), -40.0, dtype=np.float32)
+    if decay > 0:
+        for key in ("xyz_encoding_1.0.weight", f"xyz_encoding_{SKIP_LAYER + 1}.0.weight"):
+            w = sd[key].copy()
+            for k in range(DEG_POS):
+                w[:, 3 + 6 * k: 9 + 6 * k] *= np.float32(2.0 ** (-decay * k))
+            sd[key] = w
+    sd["sigma.weight"] = (sd["sigma.weight"] * np.float32(sigma_scale)).astype(np.float32)
+    if sigma_bias is not None:
+        sd["sigma.bias"] = np.full((1,), sigma_bias, dtype=np.float32)
     return sd
 
 

@@ -176,6 +176,47 @@ def resample_fine(o, d, z, weights, n_imp: int, u: torch.Tensor = None):
     return z_all, points_on_rays(o, d, z_all)
 
 
+def resample_conditioning(z, weights, n_imp: int, u: torch.Tensor = None):
+    """Test helper (not part of the reference): how ill-conditioned is S2 on these rays?
+
+    The inverse CDF divides by ``denom = cdf[above] - cdf[below]`` and the reference snaps
+    ``denom < 1e-5`` to 1 (``models/utils.py:87-88``).  cdf entries carry ~1e-7 of fp32
+    rounding noise (sum order of ``weights.sum``), so a new sample moves by
+    ``~1e-7 * (bins_a - bins_b) / denom`` and, when ``denom`` sits within that noise of the
+    1e-5 threshold, jumps by up to a whole bin between two correct fp32 evaluations
+    (e.g. the reference on CPU vs on a GPU).  Returns per ray, computed in float64:
+    ``amp`` = max over new samples of ``(bins_a - bins_b) / denom``, ``margin`` = min over
+    new samples of ``|denom_raw - 1e-5|``, and ``bin_width`` = max interval between bins.
+    """
+    z, weights = z.double(), weights.double()
+    eps = 1e-5
+    bins = 0.5 * (z[:, :-1] + z[:, 1:])
+    w = weights[:, 1:-1] + eps
+    R, nb = w.shape
+    cdf = torch.cumsum(w / w.sum(-1, keepdim=True), -1)
+    cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
+    if u is None:
+        u = torch.linspace(0, 1, n_imp, dtype=torch.float64).expand(R, n_imp)
+    u = u.double().contiguous()
+    # per-bin slope of the inverse CDF and distance of its denom from the snap threshold
+    denom_raw = cdf[:, 1:] - cdf[:, :-1]                       # (R, nb)
+    width = bins[:, 1:] - bins[:, :-1]
+    slope = width / torch.where(denom_raw < eps, torch.ones_like(denom_raw), denom_raw)
+    dist = (denom_raw - eps).abs()
+    # bin each sample falls in; a sample within 1e-6 of a bin edge may be evaluated in the
+    # neighbouring bin by another correct fp32 implementation (incl. u = 1 at the clamped end)
+    j = torch.clamp(torch.searchsorted(cdf, u, right=True) - 1, 0, nb - 1)
+    amp = torch.gather(slope, 1, j)
+    margin = torch.gather(dist, 1, j)
+    for dj in (-1, 1):
+        jn = torch.clamp(j + dj, 0, nb - 1)
+        edge = torch.gather(cdf, 1, j + (1 if dj == 1 else 0))
+        near = (u - edge).abs() < 1e-6
+        amp = torch.where(near, torch.maximum(amp, torch.gather(slope, 1, jn)), amp)
+        margin = torch.where(near, torch.minimum(margin, torch.gather(dist, 1, jn)), margin)
+    return amp.max(-1)[0], margin.min(-1)[0], width.max(-1)[0]
+
+
 # ----------------------------------------------------------------------------
 # M1: the NeRF MLP
 # ----------------------------------------------------------------------------

@@ -1,0 +1,81 @@
+"""CPU-side checks of the drop-in boundary: libnsr.so builds/loads, exports every symbol
+include/nsr.h declares, and rejects bad arguments without touching a GPU."""
+import ctypes
+import os
+import re
+from ctypes import c_void_p
+
+import pytest
+
+from nerf_sr_amd import _lib, build as nsr_build
+from nerf_sr_amd.weights import N_PARAMS
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        nsr_build.build(verbose=False)       # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "nsr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nsr_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound(lib):
+    names = _declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/nsr.h but not exported by libnsr.so"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in nerf_sr_amd/_lib.py"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_version_and_status_strings(lib):
+    assert lib.nsr_version() == 100
+    assert lib.nsr_status_string(0) == b"ok"
+    for code in (-1, -2, -3, -4, -99):
+        assert len(lib.nsr_status_string(code)) > 0
+
+
+def test_sizes(lib):
+    nbytes = lib.nsr_packed_weights_bytes(_lib.NSR_FP32)
+    # fragment stream (zero padded K) + aux block: a bit more than the raw parameters
+    assert N_PARAMS * 4 <= nbytes <= int(N_PARAMS * 4 * 1.05)
+    R, nc, ni = 190512, 64, 64
+    ws = lib.nsr_forward_rays_workspace_bytes(R, nc, ni)
+    assert ws >= R * (nc * 4 + nc * 16 + nc * 4 + (nc + ni) * 4 + (nc + ni) * 16)
+    assert lib.nsr_forward_rays_workspace_bytes(-1, nc, ni) == 0
+
+
+def test_invalid_arguments_are_rejected_before_any_launch(lib):
+    null = c_void_p(0)
+    one = c_void_p(16)     # non-null, never dereferenced: validation happens first
+    assert lib.nsr_posenc(null, 10, 10, one, null) == -1
+    assert lib.nsr_posenc(one, -1, 10, one, null) == -1
+    assert lib.nsr_sample_along_rays(one, 4, 0, 0, null, one, null, null) == -1
+    assert lib.nsr_composite(one, 2, one, 1, one, 4, 64, 0, null, null, null, null, null) == -1
+    assert lib.nsr_composite(one, 3, one, 1, one, 4, 4096, 0, null, null, null, null, null) == -2
+    assert lib.nsr_resample_along_rays(null, one, one, 4, 2, 64, null, one, null, null) == -1
+    assert lib.nsr_resample_along_rays(null, one, one, 4, 64, 1024, null, one, null, null) == -2
+    assert lib.nsr_mlp_forward(null, 0, one, 4, 0, one, null) == -1
+    assert lib.nsr_mlp_forward(one, 7, one, 4, 0, one, null) == -2
+    assert lib.nsr_render_rays(one, 0, one, one, 4, 0, one, null) == -1
+    assert lib.nsr_sr_mean(one, 4, 0, 3, one, null) == -1
+    assert lib.nsr_unflatten(one, 12, 16, 5, 3, one, null) == -1
+    outs = (c_void_p * 8)()
+    assert lib.nsr_forward_rays(one, one, 0, one, 4, 64, 64, 0, 0, outs, c_void_p(256), 16, null) == -4
+    # zero-sized work is a no-op success
+    assert lib.nsr_posenc(one, 0, 10, one, null) == 0
+    assert lib.nsr_composite(one, 3, one, 1, one, 0, 64, 0, null, null, null, null, null) == 0
+
+
+def test_product_has_no_cpu_fallback():
+    import torch
+    from nerf_sr_amd import ops
+    with pytest.raises(ValueError, match="no CPU path"):
+        ops.PositionalEncoding(3, 10)(torch.zeros(4, 3))

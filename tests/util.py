@@ -1,0 +1,41 @@
+"""Shared assertions of the parity tests."""
+import numpy as np
+import torch
+
+from oracle import nerf_oracle as oc
+
+
+def to_np(a):
+    return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+
+
+def assert_close(got, want, atol):
+    got, want = to_np(got), to_np(want)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    err = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max()) if got.size else 0.0
+    assert err <= atol, f"max abs err {err:.3e} > {atol:.1e}"
+    return err
+
+
+def assert_resample_close(got, want, z, weights, n_imp, u=None, base_tol=2e-6):
+    """z_fine parity with a conditioning-aware bound (see oracle.resample_conditioning).
+
+    Well-conditioned rays: |err| <= base_tol + 5e-7 * amp (fp32 rounding noise of the cdf times
+    the inverse-CDF slope).  Rays whose ``denom`` lies within 5e-7 of the reference's 1e-5 snap
+    threshold are genuinely two-valued in fp32: there a new sample may sit anywhere in its bin.
+    """
+    got, want = to_np(got).astype(np.float64), to_np(want).astype(np.float64)
+    assert got.shape == want.shape
+    zc = torch.as_tensor(to_np(z))
+    wc = torch.as_tensor(to_np(weights))
+    uc = None if u is None else torch.as_tensor(to_np(u))
+    amp, margin, width = [t.numpy() for t in oc.resample_conditioning(zc, wc, n_imp, uc)]
+    err = np.abs(got - want).max(-1)
+    tol = base_tol + 5e-7 * amp
+    chaotic = margin < 5e-7
+    tol = np.where(chaotic, np.maximum(tol, width * 1.0001), tol)
+    bad = np.nonzero(err > tol)[0]
+    assert bad.size == 0, (f"{bad.size} rays outside the conditioning bound; worst ray {bad[0]}: err {err[bad[0]]:.3e} "
+                           f"tol {tol[bad[0]]:.3e} amp {amp[bad[0]]:.3e} margin {margin[bad[0]]:.3e}")
+    assert (np.diff(got, axis=-1) >= 0).all(), "z_fine not sorted"
+    return float(err.max()), int(chaotic.sum())
