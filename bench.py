@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the render hot path: rendered rays/s on BASELINE.json config #2.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path over one synthetic frame per GPU:
+sub-pixel ray generation (504x378 <- 252x189, 2x supersampling, NDC, 190,512 rays) ->
+coarse MLP @64 samples -> compositing -> inverse-CDF resampling -> fine MLP @128 samples ->
+compositing -> s^2 mean; with N > 1 every rank renders its own frame (contiguous ray
+shard of an N-frame batch; N = 4 is exactly config #4's 762,048 rays) and ONE all-gather
+of the rendered LR pixels closes the step (weak scaling).  Weights are synthetic
+(nerf_sr_amd.weights, "smooth" field), inputs are generated on the device: nothing
+crosses PCIe inside the timed region.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+``roofline`` (fine-MLP launch, algorithmic FLOPs / HIP-event duration vs the dense MFMA
+peak of the dtype) and ``cpu_baseline`` (the torch-CPU oracle port timed on this host).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from nerf_sr_amd import cameras, ops  # noqa: E402
+from nerf_sr_amd import dist as nsr_dist  # noqa: E402
+from nerf_sr_amd.weights import FLOP_PER_POINT, make_state_dict  # noqa: E402
+
+IMG_WH = (504, 378)
+DOWNSCALE = 2
+N_COARSE, N_IMPORTANCE = 64, 64
+RAYS_PER_FRAME = IMG_WH[0] * IMG_WH[1]                      # 190,512
+N_LR = RAYS_PER_FRAME // DOWNSCALE ** 2                     # 47,628
+FLOP_PER_RAY = FLOP_PER_POINT * (N_COARSE + N_COARSE + N_IMPORTANCE)   # 227,868,672
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}
+DTYPE_NAME = {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3"}
+
+
+def cpu_baseline(sd_c, sd_f, rays_cpu: torch.Tensor, target_s: float = 15.0):
+    """Time the oracle port on a bounded ray sample (rank 0, N=1 only)."""
+    from oracle import nerf_oracle as oc     # checker/baseline only; never on the product path
+    sdc, sdf = oc.to_torch_sd(sd_c), oc.to_torch_sd(sd_f)
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        n0 = 2048
+        t0 = time.perf_counter()
+        oc.forward_rays(sdc, sdf, rays_cpu[:n0], N_COARSE, N_IMPORTANCE, False)      # also the warm-up
+        t_probe = time.perf_counter() - t0
+        n = int(min(max(n0, n0 * target_s / max(t_probe, 1e-3)), 32768, rays_cpu.shape[0]))
+        n -= n % 4
+        t0 = time.perf_counter()
+        out = oc.forward_rays(sdc, sdf, rays_cpu[:n], N_COARSE, N_IMPORTANCE, False)
+        dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{n} rays of the same frame (middle rows), torch-CPU oracle, fp32, {dt:.1f} s"}, out, n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--precision", default=os.environ.get("NSR_PRECISION", "fp32"), choices=list(PEAK_TFLOPS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, local, world = nsr_dist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    sd_c, sd_f = make_state_dict(99), make_state_dict(100)
+    net_c = ops.VanillaMLP(precision=args.precision, device=dev).load_state_dict(sd_c)
+    net_f = ops.VanillaMLP(precision=args.precision, device=dev).load_state_dict(sd_f)
+    c2w = cameras.spiral_pose(0.4 + 0.35 * rank)             # frame `rank` of the N-frame batch
+    focal = cameras.llff_focal(IMG_WH[0])
+    ws = torch.empty(ops._lib.load().nsr_forward_rays_workspace_bytes(RAYS_PER_FRAME, N_COARSE, N_IMPORTANCE),
+                     dtype=torch.uint8, device=dev)
+    outs = {}
+    n_ev = args.steps + args.warmup
+    events = [ops.HipEvents(4) for _ in range(n_ev)]
+
+    def step(i):
+        rays = ops.subpixel_rays(c2w, IMG_WH, focal, DOWNSCALE, True, device=dev).view(-1, 8)
+        o = ops.forward_rays(net_c, net_f, rays, N_COARSE, N_IMPORTANCE, False, workspace=ws, outs=outs,
+                             events=events[i].handles)
+        lr = ops.sr_mean(o["fine_comp_rgbs"], N_LR, DOWNSCALE ** 2)
+        frames = nsr_dist.all_gather_pixels(lr, N_LR * world) if world > 1 else lr
+        return rays, o, frames
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        rays, o, frames = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_rays = RAYS_PER_FRAME * world * args.steps
+        value = total_rays / dt
+        fine_ms = [events[args.warmup + i].elapsed_ms(2, 3) for i in range(args.steps)]
+        coarse_ms = [events[args.warmup + i].elapsed_ms(0, 1) for i in range(args.steps)]
+        fine_avg = sum(fine_ms) / len(fine_ms)
+        fine_flop = RAYS_PER_FRAME * (N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT
+        achieved = fine_flop / (fine_avg * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.precision]
+        res = {
+            "metric": "rays/sec (64+128 samples, 2x SS)", "value": value, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
+            "config": {"workload": "BASELINE config #2: LLFF-like 504x378 <- 252x189, 2x supersampling, "
+                                   "64 coarse + 128 fine samples/ray, 190,512 rays per GPU per step"
+                                   + ("" if world == 1 else f"; {world}-frame batch, contiguous ray shards, "
+                                      "one all-gather of LR pixels per step"),
+                       "rays_per_step": RAYS_PER_FRAME * world, "n_coarse": N_COARSE, "n_importance": N_IMPORTANCE,
+                       "precision": args.precision, "parallelism": f"ray-shard x{world}"},
+            "achieved_tflops_whole_path": value * FLOP_PER_RAY / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "mlp kernel, fine pass (190,512 rays x 128 samples)",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None, "launch_ms": fine_avg, "coarse_launch_ms": sum(coarse_ms) / len(coarse_ms),
+                         "flop_per_launch": fine_flop},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            lo = (RAYS_PER_FRAME // 2) - (RAYS_PER_FRAME // 2) % 4
+            base, ref, n = cpu_baseline(sd_c, sd_f, rays[lo:lo + 32768].cpu())
+            res["cpu_baseline"] = base
+            from oracle import nerf_oracle as oc
+            got = o["fine_comp_rgbs"][lo:lo + n].cpu()
+            res["parity"] = {
+                "max_abs_rgb_vs_oracle": float((got - ref["fine_comp_rgbs"]).abs().max()),
+                "psnr_build_vs_oracle_db": oc.psnr(got, ref["fine_comp_rgbs"]),
+                "psnr_delta_db_vs_common_target": abs(oc.psnr(got, ref["coarse_comp_rgbs"]) -
+                                                      oc.psnr(ref["fine_comp_rgbs"], ref["coarse_comp_rgbs"])),
+                "rays_checked": n}
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -136,6 +136,20 @@ int nsr_forward_rays(const void* packed_coarse, const void* packed_fine, int pre
                      int64_t R, int n_coarse, int n_importance, int white_bkgd, int lindisp,
                      float* const* outs, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same as nsr_forward_rays, plus HIP-event instrumentation for benchmarks: `events` is a HOST
+ * array of 4 hipEvent_t (or NULL) recorded on `stream` immediately before / after the coarse
+ * MLP launch ([0],[1]) and the fine MLP launch ([2],[3]) — the kernels that carry >99 % of the
+ * path's FLOPs — so that a harness can read per-launch durations without a profiler. */
+int nsr_forward_rays_profiled(const void* packed_coarse, const void* packed_fine, int precision, const float* rays,
+                              int64_t R, int n_coarse, int n_importance, int white_bkgd, int lindisp,
+                              float* const* outs, void* workspace, size_t workspace_bytes, void* stream,
+                              void* const* events);
+/* Thin wrappers over hipEventCreate / hipEventDestroy / hipEventSynchronize+hipEventElapsedTime so a
+ * ctypes harness uses the same HIP runtime instance libnsr is linked to.  elapsed: milliseconds. */
+int nsr_event_create(void** event_out);
+int nsr_event_destroy(void* event);
+int nsr_event_elapsed_ms(void* start, void* stop, float* ms_out);
+
 /* ---- A1 / A2: supersampling epilogue -----------------------------------------------
  * nsr_sr_mean replaces reshape(N_lr, s^2, c).mean(1) (models/nerf_downX_model.py:337-348).
  * nsr_unflatten replaces unflatten_reshape '(h1 w1) (s1 s2) c -> (h1 s1) (w1 s2) c'

@@ -35,6 +35,11 @@ SIGNATURES = {
     "nsr_forward_rays_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "nsr_forward_rays": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                  POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
+    "nsr_forward_rays_profiled": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                                          POINTER(c_void_p), c_void_p, c_size_t, c_void_p, POINTER(c_void_p)]),
+    "nsr_event_create": (c_int, [POINTER(c_void_p)]),
+    "nsr_event_destroy": (c_int, [c_void_p]),
+    "nsr_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     "nsr_sr_mean": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "nsr_unflatten": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }

@@ -29,9 +29,39 @@ extern "C" size_t nsr_forward_rays_workspace_bytes(int64_t R, int n_coarse, int 
   return total;
 }
 
+extern "C" int nsr_event_create(void** event_out) {
+  if (!event_out) return NSR_ERR_INVALID_ARG;
+  hipEvent_t ev;
+  if (hipEventCreate(&ev) != hipSuccess) return NSR_ERR_LAUNCH;
+  *event_out = ev;
+  return NSR_OK;
+}
+extern "C" int nsr_event_destroy(void* event) {
+  if (!event) return NSR_ERR_INVALID_ARG;
+  return hipEventDestroy(static_cast<hipEvent_t>(event)) == hipSuccess ? NSR_OK : NSR_ERR_LAUNCH;
+}
+extern "C" int nsr_event_elapsed_ms(void* start, void* stop, float* ms_out) {
+  if (!start || !stop || !ms_out) return NSR_ERR_INVALID_ARG;
+  if (hipEventSynchronize(static_cast<hipEvent_t>(stop)) != hipSuccess) return NSR_ERR_LAUNCH;
+  return hipEventElapsedTime(ms_out, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)) == hipSuccess
+             ? NSR_OK : NSR_ERR_LAUNCH;
+}
+
 extern "C" int nsr_forward_rays(const void* packed_coarse, const void* packed_fine, int precision, const float* rays,
                                 int64_t R, int n_coarse, int n_importance, int white_bkgd, int lindisp,
                                 float* const* outs, void* workspace, size_t workspace_bytes, void* stream) {
+  return nsr_forward_rays_profiled(packed_coarse, packed_fine, precision, rays, R, n_coarse, n_importance, white_bkgd,
+                                   lindisp, outs, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int nsr_forward_rays_profiled(const void* packed_coarse, const void* packed_fine, int precision,
+                                         const float* rays, int64_t R, int n_coarse, int n_importance, int white_bkgd,
+                                         int lindisp, float* const* outs, void* workspace, size_t workspace_bytes,
+                                         void* stream, void* const* events) {
+  hipStream_t st = nsr_stream(stream);
+  auto mark = [&](int i) {
+    if (events && events[i]) (void)hipEventRecord(static_cast<hipEvent_t>(events[i]), st);
+  };
   if (!packed_coarse || !outs || R < 0 || n_coarse <= 0 || n_importance < 0) return NSR_ERR_INVALID_ARG;
   if (n_importance > 0 && !packed_fine) return NSR_ERR_INVALID_ARG;
   if (workspace_bytes < nsr_forward_rays_workspace_bytes(R, n_coarse, n_importance)) return NSR_ERR_WORKSPACE;
@@ -53,7 +83,9 @@ extern "C" int nsr_forward_rays(const void* packed_coarse, const void* packed_fi
   rc = nsr_sample_along_rays(rays, R, n_coarse, lindisp, nullptr, z_c, nullptr, stream);
   if (rc != NSR_OK) return rc;
   // D2+M1: coarse network at every sample
+  mark(0);
   rc = nsr_render_rays(packed_coarse, precision, rays, z_c, R, n_coarse, raw_c, stream);
+  mark(1);
   if (rc != NSR_OK) return rc;
   // V1: coarse compositing (weights are needed by the resampler even if the caller does not want them)
   float* w_c = outs[3] ? outs[3] : w_c_ws;
@@ -64,7 +96,9 @@ extern "C" int nsr_forward_rays(const void* packed_coarse, const void* packed_fi
   rc = nsr_resample_along_rays(rays, z_c, w_c, R, n_coarse, n_importance, nullptr, z_f, nullptr, stream);
   if (rc != NSR_OK) return rc;
   // fine network + compositing
+  mark(2);
   rc = nsr_render_rays(packed_fine, precision, rays, z_f, R, n_coarse + n_importance, raw_f, stream);
+  mark(3);
   if (rc != NSR_OK) return rc;
   rc = nsr_composite(raw_f, 4, raw_f + 3, 4, z_f, R, n_coarse + n_importance, white_bkgd, outs[4], outs[5], outs[6],
                      outs[7], stream);

@@ -8,7 +8,7 @@ All tensors are fp32, contiguous, on the current HIP device.
 from __future__ import annotations
 
 import ctypes
-from ctypes import c_float, c_void_p
+from ctypes import c_float, c_void_p  # noqa: F401
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -235,10 +235,11 @@ OUT_KEYS = ("coarse_comp_rgbs", "coarse_depth", "coarse_opacity", "coarse_weight
 def forward_rays(coarse: VanillaMLP, fine: Optional[VanillaMLP], rays: torch.Tensor, N_coarse: int = 64,
                  N_importance: int = 64, white_bkgd: bool = False, lindisp: bool = False,
                  workspace: Optional[torch.Tensor] = None, outs: Optional[Dict[str, torch.Tensor]] = None,
-                 want_weights: bool = True) -> Dict[str, torch.Tensor]:
+                 want_weights: bool = True, events=None) -> Dict[str, torch.Tensor]:
     """Eval-mode forward_rays for the WHOLE batch in one enqueue sequence
     (models/nerf_downX_model.py:280-324): returns the reference's 8-entry dict.
-    ``workspace`` / ``outs`` let a caller reuse buffers across frames."""
+    ``workspace`` / ``outs`` let a caller reuse buffers across frames; ``events`` (4 raw
+    hipEvent_t handles from ``HipEvents``) brackets the coarse / fine MLP launches."""
     lib = _lib.load()
     rays = _f32(rays, "rays").reshape(-1, 8)
     R = rays.shape[0]
@@ -262,11 +263,38 @@ def forward_rays(coarse: VanillaMLP, fine: Optional[VanillaMLP], rays: torch.Ten
         if k not in outs or tuple(outs[k].shape) != shapes[k]:
             outs[k] = torch.empty(shapes[k], dtype=torch.float32, device=dev)
     ptrs = (c_void_p * 8)(*[_p(outs.get(k)) for k in OUT_KEYS])
-    _lib.check(lib.nsr_forward_rays(_p(coarse.packed), _p(fine.packed) if fine is not None else c_void_p(0),
-                                    coarse._prec, _p(rays), R, N_coarse, N_importance, int(bool(white_bkgd)),
-                                    int(bool(lindisp)), ptrs, _p(workspace), workspace.numel(), _stream()),
+    ev = (c_void_p * 4)(*events) if events is not None else None
+    _lib.check(lib.nsr_forward_rays_profiled(_p(coarse.packed), _p(fine.packed) if fine is not None else c_void_p(0),
+                                             coarse._prec, _p(rays), R, N_coarse, N_importance, int(bool(white_bkgd)),
+                                             int(bool(lindisp)), ptrs, _p(workspace), workspace.numel(), _stream(), ev),
                "nsr_forward_rays")
     return outs
+
+
+class HipEvents:
+    """n raw hipEvent_t handles (created through libnsr so they belong to its HIP runtime)."""
+
+    def __init__(self, n: int):
+        lib = _lib.load()
+        self.handles = []
+        for _ in range(n):
+            h = c_void_p()
+            _lib.check(lib.nsr_event_create(ctypes.byref(h)), "nsr_event_create")
+            self.handles.append(h)
+
+    def elapsed_ms(self, i: int, j: int) -> float:
+        ms = c_float()
+        _lib.check(_lib.load().nsr_event_elapsed_ms(self.handles[i], self.handles[j], ctypes.byref(ms)),
+                   "nsr_event_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            lib = _lib.load()
+            for h in self.handles:
+                lib.nsr_event_destroy(h)
+        except Exception:
+            pass
 
 
 # ----------------------------------------------------------------------------- A1 / A2

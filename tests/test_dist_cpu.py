@@ -1,0 +1,71 @@
+"""Multi-GPU layer on CPU: world_size-2 gloo processes exercise the sharding + all-gather logic
+of nerf_sr_amd.dist (the per-GPU render itself needs a GPU and is covered by -m gpu tests)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nerf_sr_amd.dist import all_gather_pixels, render_sharded, shard_bounds
+
+
+def test_shard_bounds_cover_and_balance():
+    for n, w in ((47628, 8), (47628, 1), (7, 3), (0, 4), (5, 8), (40000, 7)):
+        b = shard_bounds(n, w)
+        assert len(b) == w and b[0][0] == 0 and b[-1][1] == n
+        assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in b]
+        assert max(sizes) - min(sizes) <= 1
+    # config #4: 47,628 LR px over 8 GPUs -> 5,954/5,953 px per GPU
+    assert sorted({hi - lo for lo, hi in shard_bounds(47628, 8)}) == [5953, 5954]
+    with pytest.raises(ValueError):
+        shard_bounds(10, 0)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_lr, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # stand-in for the per-GPU hot path: "pixel value" = f(LR pixel index), so the gathered
+        # image is checkable and must be identical on every rank and to a 1-process render
+        def render_block(lo, hi):
+            idx = torch.arange(lo, hi, dtype=torch.float32)
+            return torch.stack([idx, idx * 0.5, idx * idx % 7], -1)
+        img = render_sharded(render_block, n_lr)
+        want = render_block(0, n_lr)
+        ok = img.shape == want.shape and torch.equal(img, want)
+        # direct API with an uneven last shard and a wrong-sized block
+        lo, hi = shard_bounds(n_lr, world)[rank]
+        again = all_gather_pixels(want[lo:hi].clone(), n_lr)
+        ok = ok and torch.equal(again, want)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_lr", [47628, 47629, 3])
+def test_world2_gloo_sharded_render_matches_single_process(n_lr):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_lr, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        if p.is_alive():
+            p.kill()
+            pytest.fail("gloo worker hung")
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert [r for r, _ in res] == [0, 1]
+    assert all(ok for _, ok in res)
