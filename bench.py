@@ -43,8 +43,8 @@ RAYS_PER_FRAME = IMG_WH[0] * IMG_WH[1]                      # 190,512
 N_LR = RAYS_PER_FRAME // DOWNSCALE ** 2                     # 47,628
 FLOP_PER_RAY = FLOP_PER_POINT * (N_COARSE + N_COARSE + N_IMPORTANCE)   # 227,868,672
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}
-DTYPE_NAME = {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3"}
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "f16x3": 2500.0}
+DTYPE_NAME = {"fp32": "f32", "bf16": "bf16", "f16x3": "f16x3"}
 
 
 def cpu_baseline(sd_c, sd_f, rays_cpu: torch.Tensor, target_s: float = 15.0):

@@ -46,7 +46,8 @@ typedef enum nsr_status {
 typedef enum nsr_precision {
   NSR_FP32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (parity path) */
   NSR_BF16 = 1,   /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate (fast path)       */
-  NSR_BF16X3 = 2  /* split-bf16: hi*hi + hi*lo + lo*hi, fp32 accumulate (~2^-16 products)       */
+  NSR_F16X3 = 2   /* split-fp16 on v_mfma_f32_32x32x16_f16: hi*hi + hi*lo + lo*hi, fp32 accumulate;
+                     products exact to ~2^-21 -> fp32-grade results at 3/16 of the fp32-MFMA cost  */
 } nsr_precision;
 
 /* number of tensors in VanillaMLP.state_dict(), in state_dict order:

@@ -22,6 +22,7 @@ UNITS = [
     ("nsr_rays.hip", ["-ffp-contract=off"]),
     ("nsr_render.hip", ["-ffp-contract=off"]),
     ("nsr_mlp.hip", ["-ffp-contract=off"]),
+    ("nsr_mlp_f16.hip", ["-ffp-contract=off"]),
     ("nsr_api.hip", []),
 ]
 

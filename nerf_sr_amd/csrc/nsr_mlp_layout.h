@@ -107,3 +107,76 @@ NSR_HD int seg_col(int src, int t, int h) {
 }
 
 }  // namespace nsr
+
+// ===========================================================================
+// Split-fp16 ("f16x3") stream.  v_mfma_f32_32x32x16_f16: A / B fragments are 8
+// halves per lane, lane (i, h) holds k = 8h..8h+7 of a 16-deep k-step.  The same
+// register algebra as above holds with k-step s covering registers t = 8s..8s+7:
+// the D fragment of an output block nb becomes k-steps 2nb, 2nb+1 of the next layer.
+// Every fp32 weight w is stored as hi = RN_f16(w), lo = RN_f16(w - hi); the kernel
+// forms  a_hi*b_hi + (a_hi*b_lo + a_lo*b_hi)  with fp32 accumulation (products
+// exact to ~2^-21 relative).
+//
+// The stream is consumed block-row by block-row ("chunk" = all k-steps of one
+// 32-feature output block, so the block's result can be re-split into the next
+// layer's operands while the following block is on the matrix pipe):
+//   chunk = [ A_hi(s=0), A_lo(s=0), A_hi(1), A_lo(1), ..., bias piece ]
+// L1 (K=64) packs four output blocks per chunk.
+// ===========================================================================
+namespace nsr {
+namespace hx {
+
+constexpr int kChunks = 70;          // 2 (L1) + 24 (L2-4) + 8 (L5) + 24 (L6-8) + 8 (final) + 4 (dir)
+constexpr int kChunksSigmaOnly = 58; // through L8
+constexpr int kSlotPieces = 41;      // largest chunk: L5, 20 k-steps * 2 + bias
+constexpr int kSlotFloats = kSlotPieces * 256;
+
+struct Chunk {
+  int tensor;   // weight tensor (state_dict index); bias = tensor + 1
+  int nb0;      // first output block
+  int nnb;      // output blocks in the chunk (4 for L1, else 1)
+  int steps;    // 16-deep k-steps per output block
+  int piece0;   // first piece of the chunk in the stream
+};
+
+NSR_HD int chunk_pieces(int steps, int nnb) { return 2 * steps * nnb + 1; }
+
+NSR_HD Chunk chunk_info(int q) {
+  Chunk c{};
+  if (q < 2) {                       // L1: 63(+1) -> 256, 4 k-steps
+    c.tensor = 0; c.nb0 = 4 * q; c.nnb = 4; c.steps = 4; c.piece0 = 33 * q;
+  } else if (q < 26) {               // L2..L4
+    const int l = (q - 2) >> 3;
+    c.tensor = 2 * (l + 1); c.nb0 = (q - 2) & 7; c.nnb = 1; c.steps = 16; c.piece0 = 66 + 33 * (q - 2);
+  } else if (q < 34) {               // L5: cat([pe, h]) -> 4 + 16 k-steps
+    c.tensor = 8; c.nb0 = q - 26; c.nnb = 1; c.steps = 20; c.piece0 = 858 + 41 * (q - 26);
+  } else if (q < 66) {               // L6..L8, xyz_encoding_final
+    const int l = (q - 34) >> 3;
+    c.tensor = 2 * (l + 5); c.nb0 = (q - 34) & 7; c.nnb = 1; c.steps = 16; c.piece0 = 1186 + 33 * (q - 34);
+  } else {                           // dir_encoding: cat([g, de]) -> 16 + 2 k-steps, 4 output blocks
+    c.tensor = 18; c.nb0 = q - 66; c.nnb = 1; c.steps = 18; c.piece0 = 2242 + 37 * (q - 66);
+  }
+  return c;
+}
+constexpr int kPiecesTotal = 2242 + 37 * 4;             // 2390 pieces of 1 KiB
+// aux (fp32): sigma_w 256 | rgb_w 384 | sigma_b 1 | rgb_b 3
+constexpr int kAuxSigmaW = 0, kAuxRgbW = 256, kAuxSigmaB = 640, kAuxRgbB = 641, kAuxFloats = 704;
+
+// weight column (or kPad) that register t of lane-half h multiplies in k-step space of `tensor`
+NSR_HD int column_of(int tensor, int s, int j, int h) {
+  const int t = 8 * s + j;
+  if (tensor == 0) return pecol(t, h);
+  if (tensor == 8) {
+    if (s < 4) return pecol(t, h);
+    return kPosCh + act_feature(t - 32, h);
+  }
+  if (tensor == 18) {
+    if (s < 16) return act_feature(t, h);
+    const int c = dircol(t - 128, h);
+    return c == kPad ? kPad : kWidth + c;
+  }
+  return act_feature(t, h);
+}
+
+}  // namespace hx
+}  // namespace nsr

@@ -1,0 +1,32 @@
+"""Development aid: accuracy + speed of one MLP precision mode vs the fp32 oracle."""
+import sys, time, numpy as np, torch
+sys.path.insert(0, '.')
+from nerf_sr_amd import ops, cameras
+from nerf_sr_amd.weights import make_state_dict, FLOP_PER_POINT
+from oracle import nerf_oracle as oc
+prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
+def cu(a): return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+for tag in ("llff", "blender"):
+    g = np.load(f'tests/golden/path_{tag}.npz')
+    net_c = ops.VanillaMLP(precision=prec).load_state_dict(make_state_dict(99)); net_f = ops.VanillaMLP(precision=prec).load_state_dict(make_state_dict(100))
+    x = cu(g["mlp_in_512"]); out = net_c(x)
+    print(tag, "mlp512 rgb err %.2e sigma err %.2e" % ((out[:, :3].cpu() - torch.from_numpy(g["mlp_out_coarse_512"][:, :3])).abs().max(), (out[:, 3].cpu() - torch.from_numpy(g["mlp_out_coarse_512"][:, 3])).abs().max()))
+    so = net_c(x[:64], sigma_only=True)
+    print(tag, "sigma_only err %.2e" % (so.cpu() - torch.from_numpy(g["mlp_sigma_only_64"])).abs().max())
+    rays = cu(g["rays"]); zc = cu(g["z_coarse"])
+    rgb, sig = ops.render_rays(net_c, rays, zc)
+    print(tag, "fused sigma err %.2e rgb16 err %.2e" % ((sig.cpu() - torch.from_numpy(g["coarse_point_sigma"])).abs().max(), (rgb[:16].cpu() - torch.from_numpy(g["coarse_point_rgb"])).abs().max()))
+    o = ops.forward_rays(net_c, net_f, rays, 64, 64, bool(g["white_bkgd"]))
+    for k in ("coarse_comp_rgbs", "fine_comp_rgbs", "fine_depth", "fine_opacity"):
+        d = (o[k].cpu() - torch.from_numpy(g[k])).abs()
+        print(tag, k, "max %.2e median %.2e" % (d.max(), d.median()))
+    print(tag, "psnr(build, ref) %.1f dB" % oc.psnr(o["fine_comp_rgbs"].cpu(), torch.from_numpy(g["fine_comp_rgbs"])))
+net_c = ops.VanillaMLP(precision=prec).load_state_dict(make_state_dict(99)); net_f = ops.VanillaMLP(precision=prec).load_state_dict(make_state_dict(100))
+rays = ops.subpixel_rays(cameras.spiral_pose(0.4), (504, 378), cameras.llff_focal(504), 2, True).reshape(-1, 8)
+R = rays.shape[0]
+ws = torch.empty(ops._lib.load().nsr_forward_rays_workspace_bytes(R, 64, 64), dtype=torch.uint8, device='cuda'); outs = {}
+for i in range(2): ops.forward_rays(net_c, net_f, rays, 64, 64, False, workspace=ws, outs=outs)
+torch.cuda.synchronize(); t0 = time.time(); n = 5
+for i in range(n): ops.forward_rays(net_c, net_f, rays, 64, 64, False, workspace=ws, outs=outs)
+torch.cuda.synchronize(); dt = (time.time() - t0) / n
+print(f"{prec}: {dt*1e3:.1f} ms/image  {R/dt:.0f} rays/s  {R/dt*192*FLOP_PER_POINT/1e12:.1f} TFLOP/s (algorithmic)")
