@@ -22,7 +22,7 @@ UNITS = [
     ("nsr_rays.hip", ["-ffp-contract=off"]),
     ("nsr_render.hip", ["-ffp-contract=off"]),
     ("nsr_mlp.hip", ["-ffp-contract=off"]),
-    ("nsr_mlp_f16.hip", ["-ffp-contract=off"]),
+    ("nsr_mlp_f16.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("nsr_api.hip", []),
 ]
 
@@ -42,14 +42,20 @@ def _newest_source_mtime() -> float:
     return m
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    """Compile every HIP unit for gfx950 and link ``nerf_sr_amd/libnsr.so``; returns its path."""
+def build(force: bool = False, verbose: bool = True, variant: str = "", defines=()) -> str:
+    """Compile every HIP unit for gfx950 and link ``nerf_sr_amd/libnsr.so``; returns its path.
+
+    ``variant`` / ``defines`` build an ablation library ``libnsr_<variant>.so`` with extra ``-D`` flags
+    (development aid; select it at run time with ``NSR_LIB_PATH``)."""
+    LIB = os.path.join(HERE, f"libnsr_{variant}.so") if variant else globals()["LIB"]
+    if variant:
+        force = True
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source_mtime():
         return LIB
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build", variant) if variant else os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", *defines]
     objs = []
     for src, extra in UNITS:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -68,4 +74,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build(variant=sys.argv[i + 1], defines=[a for a in sys.argv[i + 2:] if a.startswith("-D")]))
+    else:
+        print(build(force="--force" in sys.argv))

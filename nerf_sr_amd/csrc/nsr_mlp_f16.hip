@@ -12,9 +12,16 @@
 // matrix pipe; two register sets alternate roles layer by layer.
 #include "nsr_common.h"
 #include "nsr_mlp_layout.h"
+#include <utility>
 
 using namespace nsr;
 using namespace nsr::hx;
+
+#ifdef NSR_ABL_NO_BARRIER
+#define NSR_SYNC() ((void)0)
+#else
+#define NSR_SYNC() __syncthreads()
+#endif
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -62,7 +69,8 @@ __global__ void __launch_bounds__(256) pack_f16x3_kernel(PackPtrsH w, unsigned* 
     const int npieces = chunk_pieces(c.steps, c.nnb);
     if (local == npieces - 1) {
       // bias piece: fp32 bias of the chunk's output blocks, 32 per block
-      if (word < 32 * c.nnb) v = __float_as_uint(w.p[c.tensor + 1][32 * c.nb0 + word]);
+      const int n_rows = (c.tensor == 20) ? 1 : 32 * c.nnb;     // sigma head: one real output row
+      if (word < n_rows) v = __float_as_uint(w.p[c.tensor + 1][32 * c.nb0 + word]);
     } else {
       const int g = local / (2 * c.steps), rem = local % (2 * c.steps);
       const int s = rem >> 1, part = rem & 1;
@@ -73,16 +81,15 @@ __global__ void __launch_bounds__(256) pack_f16x3_kernel(PackPtrsH w, unsigned* 
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int col = column_of(c.tensor, s, 2 * jj + e, h);
-        f[e] = (col == kPad) ? 0.0f : w.p[c.tensor][n * ld + col];
+        const bool real_row = (c.tensor != 20) || n == 0;
+        f[e] = (col == kPad || !real_row) ? 0.0f : w.p[c.tensor][n * ld + col];
       }
       v = pack_hl(f[0], f[1], part);
     }
   } else {
     const int a = idx - stream_words;
     float f = 0.0f;
-    if (a < hx::kAuxRgbW) f = w.p[20][a];
-    else if (a < hx::kAuxSigmaB) f = w.p[22][a - hx::kAuxRgbW];
-    else if (a < hx::kAuxRgbB) f = w.p[21][0];
+    if (a < hx::kAuxRgbB) f = w.p[22][a];
     else if (a < hx::kAuxRgbB + 3) f = w.p[23][a - hx::kAuxRgbB];
     v = __float_as_uint(f);
   }
@@ -118,59 +125,125 @@ struct Loader {
   const float* stream;   // packed blob viewed as 32-bit words
   int q;                 // chunk being CONSUMED
   int q_end;
+  bool skip_final;       // sigma_only launches jump from L8 straight to the density-head chunk
   int wave, lane;
-  // descriptor of chunk q+1 (what the current chunk's body is prefetching)
-  const float* next_src;
+  // descriptor of chunk q+1 (what the current chunk's body is prefetching): wave-uniform byte address of
+  // this wave's first piece (scalar registers) + the lane's 16-byte offset (one 32-bit VGPR)
+  const char* next_base;
+  unsigned lane_off;
   int next_pieces;
 };
 
 __device__ __forceinline__ void loader_prepare_next(Loader& ld) {
-  const int qn = ld.q + 1;
+  int qn = ld.q + 1;
+  if (ld.skip_final && qn == kChunkFinal0) qn = kChunkSigma;
   if (qn < ld.q_end) {
     const Chunk c = chunk_info(qn);
     ld.next_pieces = chunk_pieces(c.steps, c.nnb);
-    ld.next_src = ld.stream + (size_t)c.piece0 * 256 + ld.lane * 4;
+    ld.next_base = reinterpret_cast<const char*>(ld.stream) + ((size_t)c.piece0 + ld.wave) * 1024;
   } else {
     ld.next_pieces = 0;
-    ld.next_src = ld.stream;
+    ld.next_base = reinterpret_cast<const char*>(ld.stream);
   }
 }
 
 // issue DMA piece number 4*i + wave of the next chunk into `slot` (no-op past its end)
 __device__ __forceinline__ void loader_issue(const Loader& ld, float* slot, int i) {
+#ifdef NSR_ABL_NO_DMA
+  return;
+#endif
   const int p = 4 * i + ld.wave;
-  if (p < ld.next_pieces) glds16(ld.next_src + p * 256, slot + p * 256);
+  if (p < ld.next_pieces)
+    glds16(reinterpret_cast<const float*>(ld.next_base + i * 4096 + ld.lane_off), slot + p * 256);
 }
 
 __device__ __forceinline__ h8 as_h8(const u32x4& v) { return __builtin_bit_cast(h8, v); }
 
-// NSTEP k-steps of one output block: am += A_hi*B_hi, ac += A_hi*B_lo + A_lo*B_hi.
-// Prefetches two DMA pieces of the next chunk per k-step for steps < 6 (ISSUE).
-template <int NSTEP, int B0, bool ISSUE, int NB>
-__device__ __forceinline__ void mma_steps(f32x16& am, f32x16& ac, const u32x4 (&bh)[NB], const u32x4 (&bl)[NB],
-                                          const u32x4* a_pieces, const Loader& ld, float* next_slot, int issue0) {
+struct Acc {
+  f32x16 m;   // bias + sum a_hi*b_hi
+  f32x16 c;   // sum (a_hi*b_lo + a_lo*b_hi)
+};
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>)
+template <int... S, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, S...>, F&& f) {
+  (f(std::integral_constant<int, S>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+// LDS byte address (32-bit) of a __shared__ object
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)((const __attribute__((address_space(3))) char*)p);
+}
+// A-fragment load the compiler does not track: hipcc's own waitcnt insertion drains lgkmcnt(0) every
+// PF steps (stalling on loads issued two instructions earlier); these are waited for by COUNT below.
+template <int OFF>
+__device__ __forceinline__ void lds_read16_async(u32x4& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+// wait until at most N younger LDS operations are outstanding; names the registers so that every
+// consumer is ordered behind the wait (cdna_hip_programming.md §5.7, form ii)
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N));
+}
+
+// NSTEP k-steps of one output block.  A fragments are software-pipelined PF steps ahead of the
+// MFMAs that consume them; sched_barrier pins the order.  a_addr is the lane's LDS byte address of
+// the block's first piece; b_of(s, part) yields the step's activation operands, hook(s) runs in the
+// MFMA shadow of step s.
+template <int NSTEP, class BOf, class Hook>
+__device__ __forceinline__ void block_mma(Acc& acc, const float* a_ptr, BOf&& b_of, Hook&& hook) {
+  constexpr int PF = 3;
+  u32x4 ah[NSTEP], al[NSTEP];
+  const u32x4* a_pieces = reinterpret_cast<const u32x4*>(a_ptr);
+#ifdef NSR_ABL_NO_LDSREAD
+  u32x4 fake = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+  asm volatile("" : "+v"(fake));
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) { ah[s] = fake; al[s] = fake; }
+  (void)a_pieces;
+#else
+#pragma unroll
+  for (int s = 0; s < PF && s < NSTEP; ++s) {
+    ah[s] = a_pieces[(2 * s) * 64];
+    al[s] = a_pieces[(2 * s + 1) * 64];
+  }
+#endif
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
-    const u32x4 ah = a_pieces[(2 * s) * 64];
-    const u32x4 al = a_pieces[(2 * s + 1) * 64];
-    am = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah), as_h8(bh[B0 + s]), am, 0, 0, 0);
-    ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah), as_h8(bl[B0 + s]), ac, 0, 0, 0);
-    ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(al), as_h8(bh[B0 + s]), ac, 0, 0, 0);
-    if (ISSUE && issue0 + s < 6) {
-      loader_issue(ld, next_slot, 2 * (issue0 + s));
-      loader_issue(ld, next_slot, 2 * (issue0 + s) + 1);
+#ifndef NSR_ABL_NO_LDSREAD
+    if (s + PF < NSTEP) {
+      ah[s + PF] = a_pieces[(2 * (s + PF)) * 64];
+      al[s + PF] = a_pieces[(2 * (s + PF) + 1) * 64];
     }
+#endif
+    const u32x4 bh = b_of(s, 0), bl = b_of(s, 1);
+#ifndef NSR_ABL_NO_MFMA
+    acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bh), acc.m, 0, 0, 0);
+    acc.c = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bl), acc.c, 0, 0, 0);
+    acc.c = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(al[s]), as_h8(bh), acc.c, 0, 0, 0);
+#else
+    acc.m[0] += __builtin_bit_cast(float, ah[s][0] ^ bh[0] ^ al[s][1] ^ bl[1]);
+#endif
+    hook(s);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 // accumulator init from the chunk's bias piece (fp32, D-fragment order)
-__device__ __forceinline__ void init_bias(f32x16& am, const float* bias32, int h) {
+__device__ __forceinline__ void init_acc(Acc& a, const float* bias32, int h) {
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias32 + 8 * qd + 4 * h);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) am[4 * qd + i] = b4[i];
+    for (int i = 0; i < 4; ++i) a.m[4 * qd + i] = b4[i];
   }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a.c[r] = 0.0f;
 }
 
 // v -> (hi, lo) fp16 pairs packed two per 32-bit register (round toward zero for hi; lo takes the rest)
@@ -181,55 +254,103 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
   lo = __builtin_bit_cast(unsigned, pl);
 }
 
-// finished block (am + ac), optional relu -> k-steps 2nb, 2nb+1 of the next layer's operands
-__device__ __forceinline__ void split_block(const f32x16& v, u32x4& h0, u32x4& l0, u32x4& h1, u32x4& l1) {
-  unsigned a[4], b[4], c[4], d[4];
+// Pair P (accumulator registers 2P, 2P+1) of the pending block -> operand registers of the consuming
+// layer: block nb becomes k-steps 2nb (P < 4 -> h0/l0) and 2nb+1 (P >= 4 -> h1/l1), element P & 3.
+template <int P>
+__device__ __forceinline__ void pair_convert(const Acc& p, float lower, u32x4& h0, u32x4& l0, u32x4& h1, u32x4& l1) {
+#ifdef NSR_ABL_NO_CONVERT
+  unsigned a = __float_as_uint(p.m[2 * P] + p.c[2 * P]), b = __float_as_uint(p.m[2 * P + 1] + p.c[2 * P + 1]);
+#else
+  const float x0 = fmaxf(p.m[2 * P] + p.c[2 * P], lower);
+  const float x1 = fmaxf(p.m[2 * P + 1] + p.c[2 * P + 1], lower);
+  unsigned a, b;
+  split2(x0, x1, a, b);
+#endif
+  // pin the conversion HERE (in the MFMA shadow of the current k-step): without it LLVM sinks the
+  // pure VALU work to its first use, i.e. serialises all eight blocks' conversions at the layer end
+  asm volatile("" : "+v"(a), "+v"(b));
+  if (P < 4) { h0[P & 3] = a; l0[P & 3] = b; } else { h1[P & 3] = a; l1[P & 3] = b; }
+}
+// one pair per k-step, k-steps S0 .. S0+7
+template <int S0>
+__device__ __forceinline__ void pending_step(int s, const Acc& p, float lower, u32x4& h0, u32x4& l0, u32x4& h1,
+                                             u32x4& l1) {
+  if (s == S0 + 0) pair_convert<0>(p, lower, h0, l0, h1, l1);
+  if (s == S0 + 1) pair_convert<1>(p, lower, h0, l0, h1, l1);
+  if (s == S0 + 2) pair_convert<2>(p, lower, h0, l0, h1, l1);
+  if (s == S0 + 3) pair_convert<3>(p, lower, h0, l0, h1, l1);
+  if (s == S0 + 4) pair_convert<4>(p, lower, h0, l0, h1, l1);
+  if (s == S0 + 5) pair_convert<5>(p, lower, h0, l0, h1, l1);
+  if (s == S0 + 6) pair_convert<6>(p, lower, h0, l0, h1, l1);
+  if (s == S0 + 7) pair_convert<7>(p, lower, h0, l0, h1, l1);
+}
+// colour head: pair P of a finished dir_encoding block (relu) dotted with the three rgb rows
+template <int P>
+__device__ __forceinline__ void pair_rgb(const Acc& p, const float* w32, int h, float (&rgb)[3]) {
+  const float x0 = fmaxf(p.m[2 * P] + p.c[2 * P], 0.0f);
+  const float x1 = fmaxf(p.m[2 * P + 1] + p.c[2 * P + 1], 0.0f);
+  constexpr int r = 2 * P;                       // registers r, r+1 <-> features 8*(r>>2) + 4h + (r&3), +1
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    split2(v[2 * p], v[2 * p + 1], a[p], b[p]);
-    split2(v[8 + 2 * p], v[8 + 2 * p + 1], c[p], d[p]);
+  for (int k = 0; k < 3; ++k) {
+    const float2 w2 = *reinterpret_cast<const float2*>(w32 + 128 * k + 8 * (r >> 2) + 4 * h + (r & 3));
+    rgb[k] = fmaf(x1, w2.y, fmaf(x0, w2.x, rgb[k]));
   }
-  h0 = u32x4{a[0], a[1], a[2], a[3]};
-  l0 = u32x4{b[0], b[1], b[2], b[3]};
-  h1 = u32x4{c[0], c[1], c[2], c[3]};
-  l1 = u32x4{d[0], d[1], d[2], d[3]};
+}
+template <int S0>
+__device__ __forceinline__ void rgb_step(int s, const Acc& p, const float* w32, int h, float (&rgb)[3]) {
+  if (s == S0 + 0) pair_rgb<0>(p, w32, h, rgb);
+  if (s == S0 + 1) pair_rgb<1>(p, w32, h, rgb);
+  if (s == S0 + 2) pair_rgb<2>(p, w32, h, rgb);
+  if (s == S0 + 3) pair_rgb<3>(p, w32, h, rgb);
+  if (s == S0 + 4) pair_rgb<4>(p, w32, h, rgb);
+  if (s == S0 + 5) pair_rgb<5>(p, w32, h, rgb);
+  if (s == S0 + 6) pair_rgb<6>(p, w32, h, rgb);
+  if (s == S0 + 7) pair_rgb<7>(p, w32, h, rgb);
 }
 
-// sum_r v[r] * w[feature(r, h)] over one block (features 8q + 4h + i)
-__device__ __forceinline__ float block_dot(const f32x16& v, const float* w32, int h, float s) {
-#pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
-    const f32x4 w4 = *reinterpret_cast<const f32x4*>(w32 + 8 * qd + 4 * h);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s = fmaf(v[4 * qd + i], w4[i], s);
-  }
-  return s;
+// weight DMA of the next chunk: one piece per k-step over the first 11 k-steps of the chunk
+__device__ __forceinline__ void dma_step(const Loader& ld, float* next_slot, int s) {
+  if (s < 11) loader_issue(ld, next_slot, s);
 }
+
+constexpr int kConvStep0 = 6;   // pending block is converted in k-steps 6..13 (one register pair each)
 
 // One 256 -> 256 trunk layer L (1..8; 8 = xyz_encoding_final): in (bh, bl) -> out (oh, ol).
-// L == 4 prepends the 4 positional-encoding k-steps (skip connection); L == 7 also feeds the
-// density head from the fp32 block results.
-__device__ __forceinline__ void trunk_layer(int L, const u32x4 (&bh)[16], const u32x4 (&bl)[16], u32x4 (&oh)[16],
-                                            u32x4 (&ol)[16], const u32x4 (&peh)[4], const u32x4 (&pel)[4],
-                                            Loader& ld, float* ring, const float* aux, int h, float& sigma_acc) {
+// L == 4 prepends the 4 positional-encoding k-steps (skip connection).  `pend` is the block that
+// finished last (block 7 of the previous layer on entry; block 7 of this layer on exit): it is
+// summed, activated and re-split in the MFMA shadow of the FOLLOWING block's k-steps 1..4.
+__device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[16], u32x4 (&oh)[16], u32x4 (&ol)[16],
+                                            const u32x4* stash, Loader& ld, float* ring, int h, Acc& pend) {
   const float lower = (L < 8) ? 0.0f : -__builtin_inff();   // relu on L1..L8, none on xyz_encoding_final
   const int skip = (L == 4) ? 8 : 0;                        // pieces taken by the pe k-steps
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) {
     float* slot = ring + (nb & 1) * kSlotFloats;
     float* next_slot = ring + ((nb + 1) & 1) * kSlotFloats;
-    __syncthreads();                       // chunk ld.q landed (vmcnt(0)) and the other slot is free
+    NSR_SYNC();                            // chunk ld.q landed (vmcnt(0)) and the other slot is free
     loader_prepare_next(ld);
-    const u32x4* a0 = reinterpret_cast<const u32x4*>(slot) + ld.lane;
-    f32x16 am, ac = {};
-    init_bias(am, slot + (32 + skip) * 256, h);   // bias piece follows the 2*steps weight pieces
-    if (L == 4) mma_steps<4, 0, false, 4>(am, ac, peh, pel, a0, ld, next_slot, 0);
-    mma_steps<16, 0, true, 16>(am, ac, bh, bl, a0 + skip * 64, ld, next_slot, 0);
-    f32x16 v;
+    const float* a0 = slot + ld.lane * 4;
+    Acc cur;
+    init_acc(cur, slot + (32 + skip) * 256, h);   // bias piece follows the 2*steps weight pieces
+    if (L == 4) {
+      // skip connection: the encoded position was parked in LDS by the prologue (8 fragments per lane)
+      u32x4 pe8[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = fmaxf(am[r] + ac[r], lower);
-    if (L == 7) sigma_acc = block_dot(v, aux + hx::kAuxSigmaW + 32 * nb, h, sigma_acc);
-    split_block(v, oh[2 * nb], ol[2 * nb], oh[2 * nb + 1], ol[2 * nb + 1]);
+      for (int i = 0; i < 8; ++i) pe8[i] = stash[i * 64];
+      block_mma<4>(cur, a0, [&](int s, int part) -> u32x4 { return pe8[4 * part + s]; }, [&](int) {});
+    }
+    block_mma<16>(
+        cur, a0 + skip * 256, [&](int s, int part) -> u32x4 { return part ? bl[s] : bh[s]; },
+        [&](int s) {
+          dma_step(ld, next_slot, s);
+          if (nb == 0)
+            // block 7 of the previous layer (always relu'd: the previous layer is L1..L7) -> k-steps 14, 15
+            // of THIS layer's input, needed only at the end of this chunk
+            pending_step<kConvStep0>(s, pend, 0.0f, bh[14], bl[14], bh[15], bl[15]);
+          else
+            pending_step<kConvStep0>(s, pend, lower, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1]);
+        });
+    pend = cur;
     ld.q += 1;
   }
 }
@@ -238,18 +359,24 @@ template <int MODE, bool SIGMA_ONLY, int NS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ zv,
                  int64_t P, int N, float* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float ring[2 * kSlotFloats];   // 2 x 41 KiB
+  // 2 x 41 KiB weight ring + per-wave stash of the encoded inputs (12 fragments x 64 lanes x 16 B = 12 KiB)
+  // + the colour-head block (rgb weights and bias, 448 floats), so the loop issues no global loads
+  __shared__ __attribute__((aligned(16))) float ring[2 * kSlotFloats + 4 * 12 * 256 + hx::kAuxFloats];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 31, h = lane >> 5;
-  const float* aux = packed + kPiecesTotal * 256;
+  const float* aux = ring + 2 * kSlotFloats + 4 * 12 * 256;   // LDS copy, visible after the first barrier
+  for (int i = threadIdx.x; i < hx::kAuxFloats; i += 256)
+    ring[2 * kSlotFloats + 4 * 12 * 256 + i] = packed[kPiecesTotal * 256 + i];
 
   Loader ld;
   ld.stream = packed;
   ld.q = -1;
-  ld.q_end = SIGMA_ONLY ? kChunksSigmaOnly : kChunks;
+  ld.q_end = SIGMA_ONLY ? kChunkSigma + 1 : kChunks;
+  ld.skip_final = SIGMA_ONLY;
   ld.wave = wave;
   ld.lane = lane;
+  ld.lane_off = (unsigned)lane * 16u;
   loader_prepare_next(ld);                 // chunk 0
 #pragma unroll
   for (int i = 0; i < 11; ++i) loader_issue(ld, ring, i);
@@ -322,42 +449,86 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     del[s] = u32x4{b[0], b[1], b[2], b[3]};
   }
 
-  u32x4 bh[16], bl[16], oh[16], ol[16];
+  // park the split encodings in LDS: L5 (skip) and dir_encoding re-read them, which frees 48 registers
+  u32x4* stash = reinterpret_cast<u32x4*>(ring + 2 * kSlotFloats) + wave * 12 * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    stash[s * 64] = peh[s];
+    stash[(4 + s) * 64] = pel[s];
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    stash[(8 + s) * 64] = deh[s];
+    stash[(10 + s) * 64] = del[s];
+  }
 
-  // ---- L1: two chunks of four output blocks, 4 k-steps each
+  u32x4 bh[16], bl[16], oh[16], ol[16];
+  Acc pend;
+
+  // ---- L1: two chunks of four output blocks, 4 k-steps each; block b is re-split during block b+1
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     float* slot = ring + (c & 1) * kSlotFloats;
     float* next_slot = ring + ((c + 1) & 1) * kSlotFloats;
-    __syncthreads();
+    NSR_SYNC();
     loader_prepare_next(ld);
-    const u32x4* a0 = reinterpret_cast<const u32x4*>(slot) + lane;
+    const float* a0 = slot + lane * 4;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int nb = 4 * c + g;
-      f32x16 am, ac = {};
-      init_bias(am, slot + 32 * 256 + 32 * g, h);
-      mma_steps<4, 0, true, 4>(am, ac, peh, pel, a0 + g * 8 * 64, ld, next_slot, (g == 0) ? 0 : (g == 1 ? 4 : 6));
-      f32x16 v;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = fmaxf(am[r] + ac[r], 0.0f);
-      split_block(v, bh[2 * nb], bl[2 * nb], bh[2 * nb + 1], bl[2 * nb + 1]);
+      Acc cur;
+      init_acc(cur, slot + 32 * 256 + 32 * g, h);
+      block_mma<4>(
+          cur, a0 + g * 8 * 256, [&](int s, int part) -> u32x4 { return part ? pel[s] : peh[s]; },
+          [&](int s) {
+            dma_step(ld, next_slot, 4 * g + s);
+            if (nb > 0) {   // two register pairs per k-step: the block has only four
+              pending_step<0>(2 * s, pend, 0.0f, bh[2 * nb - 2], bl[2 * nb - 2], bh[2 * nb - 1], bl[2 * nb - 1]);
+              pending_step<0>(2 * s + 1, pend, 0.0f, bh[2 * nb - 2], bl[2 * nb - 2], bh[2 * nb - 1], bl[2 * nb - 1]);
+            }
+          });
+      pend = cur;
     }
     ld.q += 1;
   }
 
   // ---- L2..L8 (+ xyz_encoding_final), two layers per trip so the register sets swap roles
-  float sigma = 0.0f;
   constexpr int kPairs = SIGMA_ONLY ? 3 : 4;
 #pragma unroll 1
   for (int pair = 0; pair < kPairs; ++pair) {
     const int L = 1 + 2 * pair;
-    trunk_layer(L, bh, bl, oh, ol, peh, pel, ld, ring, aux, h, sigma);
-    trunk_layer(L + 1, oh, ol, bh, bl, peh, pel, ld, ring, aux, h, sigma);
+    trunk_layer(L, bh, bl, oh, ol, stash, ld, ring, h, pend);
+    trunk_layer(L + 1, oh, ol, bh, bl, stash, ld, ring, h, pend);
   }
-  if (SIGMA_ONLY) trunk_layer(7, bh, bl, oh, ol, peh, pel, ld, ring, aux, h, sigma);
-  sigma += __shfl_xor(sigma, 32, 64);
-  sigma += aux[hx::kAuxSigmaB];
+  if (SIGMA_ONLY) {
+    trunk_layer(7, bh, bl, oh, ol, stash, ld, ring, h, pend);
+    ld.q = kChunkSigma;      // xyz_encoding_final is not evaluated
+  }
+
+  // ---- density head: sigma.weight as row 0 of one more 32-row block over h8 (= oh/ol: the input of
+  // xyz_encoding_final, still intact).  The pending block is xyz_encoding_final's last one (-> bh, no
+  // activation), or L8's last one in a sigma_only launch (-> oh, relu).
+  float sigma;
+  {
+    float* slot = ring;                      // 58 / 66 chunks so far: slot parity 0
+    float* next_slot = ring + kSlotFloats;
+    NSR_SYNC();
+    loader_prepare_next(ld);
+    const float* a0 = slot + lane * 4;
+    Acc cur;
+    init_acc(cur, slot + 32 * 256, h);
+    block_mma<16>(
+        cur, a0, [&](int s, int part) -> u32x4 { return part ? ol[s] : oh[s]; },
+        [&](int s) {
+          dma_step(ld, next_slot, s);
+          if (SIGMA_ONLY)
+            pending_step<kConvStep0>(s, pend, 0.0f, oh[14], ol[14], oh[15], ol[15]);
+          else
+            pending_step<kConvStep0>(s, pend, -__builtin_inff(), bh[14], bl[14], bh[15], bl[15]);
+        });
+    sigma = cur.m[0] + cur.c[0];             // row 0 of the block lives in register 0 of the h == 0 lanes
+    ld.q += 1;
+  }
   if (SIGMA_ONLY) {
     if (h == 0 && p < P) out[p] = sigma;
     return;
@@ -367,22 +538,28 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   float rgb[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
-    float* slot = ring + (nb & 1) * kSlotFloats;
-    float* next_slot = ring + ((nb + 1) & 1) * kSlotFloats;
-    __syncthreads();
+    float* slot = ring + ((nb + 1) & 1) * kSlotFloats;     // 67 chunks precede dir_encoding
+    float* next_slot = ring + (nb & 1) * kSlotFloats;
+    NSR_SYNC();
     loader_prepare_next(ld);
-    const u32x4* a0 = reinterpret_cast<const u32x4*>(slot) + lane;
-    f32x16 am, ac = {};
-    init_bias(am, slot + 36 * 256, h);
-    mma_steps<16, 0, true, 16>(am, ac, bh, bl, a0, ld, next_slot, 0);
-    mma_steps<2, 0, false, 2>(am, ac, deh, del, a0 + 32 * 64, ld, next_slot, 0);
-    f32x16 v;
+    const float* a0 = slot + lane * 4;
+    Acc cur;
+    init_acc(cur, slot + 36 * 256, h);
+    u32x4 de4[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = fmaxf(am[r] + ac[r], 0.0f);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) rgb[k] = block_dot(v, aux + hx::kAuxRgbW + 128 * k + 32 * nb, h, rgb[k]);
+    for (int i = 0; i < 4; ++i) de4[i] = stash[(8 + i) * 64];
+    block_mma<18>(
+        cur, a0,
+        [&](int s, int part) -> u32x4 { return (s < 16) ? (part ? bl[s & 15] : bh[s & 15]) : de4[2 * part + (s & 1)]; },
+        [&](int s) {
+          dma_step(ld, next_slot, s);
+          if (nb > 0) rgb_step<kConvStep0>(s, pend, aux + hx::kAuxRgbW + 32 * (nb - 1), h, rgb);
+        });
+    pend = cur;
     ld.q += 1;
   }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) rgb_step<0>(s, pend, aux + hx::kAuxRgbW + 32 * 3, h, rgb);
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     float s = rgb[k];

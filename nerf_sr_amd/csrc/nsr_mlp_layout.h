@@ -126,8 +126,9 @@ NSR_HD int seg_col(int src, int t, int h) {
 namespace nsr {
 namespace hx {
 
-constexpr int kChunks = 70;          // 2 (L1) + 24 (L2-4) + 8 (L5) + 24 (L6-8) + 8 (final) + 4 (dir)
-constexpr int kChunksSigmaOnly = 58; // through L8
+constexpr int kChunks = 71;          // 2 (L1) + 24 (L2-4) + 8 (L5) + 24 (L6-8) + 8 (final) + 1 (sigma) + 4 (dir)
+constexpr int kChunkFinal0 = 58;     // first chunk of xyz_encoding_final (skipped by sigma_only launches)
+constexpr int kChunkSigma = 66;      // density head: sigma.weight as row 0 of a 32-row block over h8
 constexpr int kSlotPieces = 41;      // largest chunk: L5, 20 k-steps * 2 + bias
 constexpr int kSlotFloats = kSlotPieces * 256;
 
@@ -153,14 +154,16 @@ NSR_HD Chunk chunk_info(int q) {
   } else if (q < 66) {               // L6..L8, xyz_encoding_final
     const int l = (q - 34) >> 3;
     c.tensor = 2 * (l + 5); c.nb0 = (q - 34) & 7; c.nnb = 1; c.steps = 16; c.piece0 = 1186 + 33 * (q - 34);
+  } else if (q == 66) {              // sigma head on h8 (same input registers as xyz_encoding_final)
+    c.tensor = 20; c.nb0 = 0; c.nnb = 1; c.steps = 16; c.piece0 = 2242;
   } else {                           // dir_encoding: cat([g, de]) -> 16 + 2 k-steps, 4 output blocks
-    c.tensor = 18; c.nb0 = q - 66; c.nnb = 1; c.steps = 18; c.piece0 = 2242 + 37 * (q - 66);
+    c.tensor = 18; c.nb0 = q - 67; c.nnb = 1; c.steps = 18; c.piece0 = 2275 + 37 * (q - 67);
   }
   return c;
 }
-constexpr int kPiecesTotal = 2242 + 37 * 4;             // 2390 pieces of 1 KiB
-// aux (fp32): sigma_w 256 | rgb_w 384 | sigma_b 1 | rgb_b 3
-constexpr int kAuxSigmaW = 0, kAuxRgbW = 256, kAuxSigmaB = 640, kAuxRgbB = 641, kAuxFloats = 704;
+constexpr int kPiecesTotal = 2275 + 37 * 4;             // 2423 pieces of 1 KiB
+// aux (fp32): rgb_w 384 | rgb_b 3
+constexpr int kAuxRgbW = 0, kAuxRgbB = 384, kAuxFloats = 448;
 
 // weight column (or kPad) that register t of lane-half h multiplies in k-step space of `tensor`
 NSR_HD int column_of(int tensor, int s, int j, int h) {

@@ -1,6 +1,6 @@
 """Development aid: accuracy + speed of one MLP precision mode vs the fp32 oracle."""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_sr_amd import ops, cameras
 from nerf_sr_amd.weights import make_state_dict, FLOP_PER_POINT
 from oracle import nerf_oracle as oc

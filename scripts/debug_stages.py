@@ -1,6 +1,6 @@
 """Development aid: per-stage max error of the HIP path vs oracle/golden, with locations."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_sr_amd import ops, cameras
 from nerf_sr_amd.weights import make_state_dict
 from oracle import nerf_oracle as oc

@@ -1,6 +1,6 @@
 """Scratch timing of forward_rays on config #2 (development aid; bench.py is the contract)."""
 import sys, time, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_sr_amd import ops, cameras
 from nerf_sr_amd.weights import make_state_dict, FLOP_PER_POINT
 prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
