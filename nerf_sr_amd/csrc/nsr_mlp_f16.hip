@@ -20,7 +20,7 @@ using namespace nsr::hx;
 #ifdef NSR_ABL_NO_BARRIER
 #define NSR_SYNC() ((void)0)
 #else
-#define NSR_SYNC() __syncthreads()
+#define NSR_SYNC() do { dma_drain(); __syncthreads(); } while (0)
 #endif
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -117,9 +117,30 @@ extern "C" int nsr_f16x3_pack(const float* const* w, void* packed_dev, void* str
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-__device__ __forceinline__ void glds16(const float* gsrc_lane, float* lds_base_wave) {
-  __builtin_amdgcn_global_load_lds((glb_ptr_t)gsrc_lane, (lds_ptr_t)lds_base_wave, 16, 0, 0);
+// LDS byte address (32-bit) of a __shared__ object
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)((const __attribute__((address_space(3))) char*)p);
 }
+
+// Weight DMA (global -> LDS, 64 lanes x 16 B) issued from inline asm: wave-uniform 64-bit base in SGPRs
+// + one 32-bit lane offset.  Why not __builtin_amdgcn_global_load_lds: hipcc's waitcnt insertion treats
+// an in-flight LDS-DMA as a FLAT-like event and from then on waits lgkmcnt(0) — i.e. for the fragment
+// loads issued two instructions earlier — before every MFMA group.  The asm form is invisible to that
+// pass; its completion is waited for by hand (dma_drain) right before the barrier that publishes the
+// chunk.  OFF (0..3072) is added to BOTH the global and the LDS address, so one (base, M0) pair serves
+// four consecutive 1 KiB pieces.  M0 is written in the same statement that consumes it (hipcc reserves
+// M0 and uses it nowhere else in this kernel).
+template <int OFF>
+__device__ __forceinline__ void glds16_asm(const char* base_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1 offset:%3"
+      :
+      : "v"(lane_off), "s"(base_uniform), "s"(lds_dst_uniform), "i"(OFF)
+      : "memory");
+}
+__device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 struct Loader {
   const float* stream;   // packed blob viewed as 32-bit words
@@ -127,41 +148,56 @@ struct Loader {
   int q_end;
   bool skip_final;       // sigma_only launches jump from L8 straight to the density-head chunk
   int wave, lane;
-  // descriptor of chunk q+1 (what the current chunk's body is prefetching): wave-uniform byte address of
-  // this wave's first piece (scalar registers) + the lane's 16-byte offset (one 32-bit VGPR)
+  // descriptor of chunk q+1 (what the current chunk's body is prefetching).  Each wave moves a contiguous
+  // quarter of the chunk (8..11 pieces): wave-uniform byte address of its first piece (scalar registers),
+  // the matching LDS byte address, its piece count, + the lane's 16-byte offset (one 32-bit VGPR)
   const char* next_base;
+  unsigned next_lds;
+  int next_count;
   unsigned lane_off;
-  int next_pieces;
 };
 
-__device__ __forceinline__ void loader_prepare_next(Loader& ld) {
+__device__ __forceinline__ void loader_prepare_next(Loader& ld, const float* next_slot) {
   int qn = ld.q + 1;
   if (ld.skip_final && qn == kChunkFinal0) qn = kChunkSigma;
+  // nothing follows the last chunk: re-fetch chunk 0 into the idle slot so that the first eight DMA issues
+  // of every chunk stay unconditional (branch-free k-steps; 32 KiB of dead traffic per tile)
+  int pieces = 32, piece0 = 0;
   if (qn < ld.q_end) {
     const Chunk c = chunk_info(qn);
-    ld.next_pieces = chunk_pieces(c.steps, c.nnb);
-    ld.next_base = reinterpret_cast<const char*>(ld.stream) + ((size_t)c.piece0 + ld.wave) * 1024;
-  } else {
-    ld.next_pieces = 0;
-    ld.next_base = reinterpret_cast<const char*>(ld.stream);
+    pieces = chunk_pieces(c.steps, c.nnb);
+    piece0 = c.piece0;
   }
+  const int first = (ld.wave * pieces) >> 2;
+  ld.next_count = (((ld.wave + 1) * pieces) >> 2) - first;
+  ld.next_base = reinterpret_cast<const char*>(ld.stream) + (size_t)(piece0 + first) * 1024;
+  ld.next_lds = lds_addr(next_slot) + (unsigned)first * 1024u;
 }
 
-// issue DMA piece number 4*i + wave of the next chunk into `slot` (no-op past its end)
-__device__ __forceinline__ void loader_issue(const Loader& ld, float* slot, int i) {
+// issue this wave's DMA piece number i of the next chunk (no-op past its end)
+__device__ __forceinline__ void loader_issue(const Loader& ld, int i) {
 #ifdef NSR_ABL_NO_DMA
   return;
 #endif
-  const int p = 4 * i + ld.wave;
-  if (p < ld.next_pieces)
-    glds16(reinterpret_cast<const float*>(ld.next_base + i * 4096 + ld.lane_off), slot + p * 256);
+  // every wave owns at least 8 pieces of every chunk: the first eight issues need no bounds test
+  if (i < 8 || i < ld.next_count) {
+    const char* base = ld.next_base + (i >> 2) * 4096;
+    const unsigned dst = ld.next_lds + (unsigned)(i >> 2) * 4096u;
+    switch (i & 3) {
+      case 0: glds16_asm<0>(base, ld.lane_off, dst); break;
+      case 1: glds16_asm<1024>(base, ld.lane_off, dst); break;
+      case 2: glds16_asm<2048>(base, ld.lane_off, dst); break;
+      default: glds16_asm<3072>(base, ld.lane_off, dst); break;
+    }
+  }
 }
 
 __device__ __forceinline__ h8 as_h8(const u32x4& v) { return __builtin_bit_cast(h8, v); }
 
 struct Acc {
-  f32x16 m;   // bias + sum a_hi*b_hi
-  f32x16 c;   // sum (a_hi*b_lo + a_lo*b_hi)
+  f32x16 m;   // bias + sum (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi), fp32.  (A separate accumulator for the
+              // two correction terms was measured: it removes the dependent MFMA issue (-5 % on a bare
+              // MFMA+LDS loop) but its 16 extra adds per block cost more in the full kernel.)
 };
 
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>)
@@ -174,10 +210,6 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-// LDS byte address (32-bit) of a __shared__ object
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-  return (unsigned)(size_t)((const __attribute__((address_space(3))) char*)p);
-}
 // A-fragment load the compiler does not track: hipcc's own waitcnt insertion drains lgkmcnt(0) every
 // PF steps (stalling on loads issued two instructions earlier); these are waited for by COUNT below.
 template <int OFF>
@@ -223,9 +255,10 @@ __device__ __forceinline__ void block_mma(Acc& acc, const float* a_ptr, BOf&& b_
 #endif
     const u32x4 bh = b_of(s, 0), bl = b_of(s, 1);
 #ifndef NSR_ABL_NO_MFMA
+    // a_lo first: it is the younger of the step's two fragment loads, so ONE lgkmcnt wait serves all three
+    acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(al[s]), as_h8(bh), acc.m, 0, 0, 0);
+    acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bl), acc.m, 0, 0, 0);
     acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bh), acc.m, 0, 0, 0);
-    acc.c = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bl), acc.c, 0, 0, 0);
-    acc.c = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(al[s]), as_h8(bh), acc.c, 0, 0, 0);
 #else
     acc.m[0] += __builtin_bit_cast(float, ah[s][0] ^ bh[0] ^ al[s][1] ^ bl[1]);
 #endif
@@ -242,8 +275,6 @@ __device__ __forceinline__ void init_acc(Acc& a, const float* bias32, int h) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) a.m[4 * qd + i] = b4[i];
   }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) a.c[r] = 0.0f;
 }
 
 // v -> (hi, lo) fp16 pairs packed two per 32-bit register (round toward zero for hi; lo takes the rest)
@@ -256,39 +287,74 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
 
 // Pair P (accumulator registers 2P, 2P+1) of the pending block -> operand registers of the consuming
 // layer: block nb becomes k-steps 2nb (P < 4 -> h0/l0) and 2nb+1 (P >= 4 -> h1/l1), element P & 3.
+// Done in two halves so that no k-step carries more than ~5 extra VALU issues (a wave has ~5 free
+// issue slots per MFMA): A = activation + hi, B = lo.
+struct PairTmp {
+  float x0, x1;
+  unsigned hi;
+};
 template <int P>
-__device__ __forceinline__ void pair_convert(const Acc& p, float lower, u32x4& h0, u32x4& l0, u32x4& h1, u32x4& l1) {
+__device__ __forceinline__ void pair_half_a(const Acc& p, float lower, PairTmp& t, u32x4& h0, u32x4& h1) {
+  t.x0 = fmaxf(p.m[2 * P], lower);
+  t.x1 = fmaxf(p.m[2 * P + 1], lower);
 #ifdef NSR_ABL_NO_CONVERT
-  unsigned a = __float_as_uint(p.m[2 * P] + p.c[2 * P]), b = __float_as_uint(p.m[2 * P + 1] + p.c[2 * P + 1]);
+  t.hi = __float_as_uint(t.x0);
 #else
-  const float x0 = fmaxf(p.m[2 * P] + p.c[2 * P], lower);
-  const float x1 = fmaxf(p.m[2 * P + 1] + p.c[2 * P + 1], lower);
-  unsigned a, b;
-  split2(x0, x1, a, b);
+  t.hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(t.x0, t.x1));
 #endif
-  // pin the conversion HERE (in the MFMA shadow of the current k-step): without it LLVM sinks the
-  // pure VALU work to its first use, i.e. serialises all eight blocks' conversions at the layer end
-  asm volatile("" : "+v"(a), "+v"(b));
-  if (P < 4) { h0[P & 3] = a; l0[P & 3] = b; } else { h1[P & 3] = a; l1[P & 3] = b; }
+  // pin the work HERE (MFMA shadow of the current k-step); LLVM would otherwise sink it to its first use,
+  // i.e. serialise all eight blocks' conversions at the layer end
+  asm volatile("" : "+v"(t.hi), "+v"(t.x0), "+v"(t.x1));
+  if (P < 4) h0[P & 3] = t.hi; else h1[P & 3] = t.hi;
 }
-// one pair per k-step, k-steps S0 .. S0+7
-template <int S0>
-__device__ __forceinline__ void pending_step(int s, const Acc& p, float lower, u32x4& h0, u32x4& l0, u32x4& h1,
-                                             u32x4& l1) {
-  if (s == S0 + 0) pair_convert<0>(p, lower, h0, l0, h1, l1);
-  if (s == S0 + 1) pair_convert<1>(p, lower, h0, l0, h1, l1);
-  if (s == S0 + 2) pair_convert<2>(p, lower, h0, l0, h1, l1);
-  if (s == S0 + 3) pair_convert<3>(p, lower, h0, l0, h1, l1);
-  if (s == S0 + 4) pair_convert<4>(p, lower, h0, l0, h1, l1);
-  if (s == S0 + 5) pair_convert<5>(p, lower, h0, l0, h1, l1);
-  if (s == S0 + 6) pair_convert<6>(p, lower, h0, l0, h1, l1);
-  if (s == S0 + 7) pair_convert<7>(p, lower, h0, l0, h1, l1);
+template <int P>
+__device__ __forceinline__ void pair_half_b(const PairTmp& t, u32x4& l0, u32x4& l1) {
+#ifdef NSR_ABL_NO_CONVERT
+  unsigned lo = __float_as_uint(t.x1);
+#else
+  const auto ph = __builtin_bit_cast(decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)), t.hi);
+  unsigned lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(t.x0 - (float)ph[0], t.x1 - (float)ph[1]));
+#endif
+  asm volatile("" : "+v"(lo));
+  if (P < 4) l0[P & 3] = lo; else l1[P & 3] = lo;
+}
+// half-pair number hp (0..15) of the pending block
+__device__ __forceinline__ void pending_half(int hp, const Acc& p, float lower, PairTmp& t, u32x4& h0, u32x4& l0,
+                                             u32x4& h1, u32x4& l1) {
+  switch (hp) {
+    case 0: pair_half_a<0>(p, lower, t, h0, h1); break;
+    case 1: pair_half_b<0>(t, l0, l1); break;
+    case 2: pair_half_a<1>(p, lower, t, h0, h1); break;
+    case 3: pair_half_b<1>(t, l0, l1); break;
+    case 4: pair_half_a<2>(p, lower, t, h0, h1); break;
+    case 5: pair_half_b<2>(t, l0, l1); break;
+    case 6: pair_half_a<3>(p, lower, t, h0, h1); break;
+    case 7: pair_half_b<3>(t, l0, l1); break;
+    case 8: pair_half_a<4>(p, lower, t, h0, h1); break;
+    case 9: pair_half_b<4>(t, l0, l1); break;
+    case 10: pair_half_a<5>(p, lower, t, h0, h1); break;
+    case 11: pair_half_b<5>(t, l0, l1); break;
+    case 12: pair_half_a<6>(p, lower, t, h0, h1); break;
+    case 13: pair_half_b<6>(t, l0, l1); break;
+    case 14: pair_half_a<7>(p, lower, t, h0, h1); break;
+    case 15: pair_half_b<7>(t, l0, l1); break;
+    default: break;
+  }
+}
+// Schedule over the k-steps of a 16-step chunk: 16 halves in k-steps 0..13 (k-steps 0 and 7 take two), so
+// that even the operands of k-steps 14, 15 (block 7 of the previous layer) are ready before they are used.
+__device__ __forceinline__ void pending_step(int s, const Acc& p, float lower, PairTmp& t, u32x4& h0, u32x4& l0,
+                                             u32x4& h1, u32x4& l1) {
+  if (s == 0) { pending_half(0, p, lower, t, h0, l0, h1, l1); pending_half(1, p, lower, t, h0, l0, h1, l1); }
+  else if (s < 7) pending_half(s + 1, p, lower, t, h0, l0, h1, l1);
+  else if (s == 7) { pending_half(8, p, lower, t, h0, l0, h1, l1); pending_half(9, p, lower, t, h0, l0, h1, l1); }
+  else if (s < 14) pending_half(s + 2, p, lower, t, h0, l0, h1, l1);
 }
 // colour head: pair P of a finished dir_encoding block (relu) dotted with the three rgb rows
 template <int P>
 __device__ __forceinline__ void pair_rgb(const Acc& p, const float* w32, int h, float (&rgb)[3]) {
-  const float x0 = fmaxf(p.m[2 * P] + p.c[2 * P], 0.0f);
-  const float x1 = fmaxf(p.m[2 * P + 1] + p.c[2 * P + 1], 0.0f);
+  const float x0 = fmaxf(p.m[2 * P], 0.0f);
+  const float x1 = fmaxf(p.m[2 * P + 1], 0.0f);
   constexpr int r = 2 * P;                       // registers r, r+1 <-> features 8*(r>>2) + 4h + (r&3), +1
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -309,8 +375,8 @@ __device__ __forceinline__ void rgb_step(int s, const Acc& p, const float* w32, 
 }
 
 // weight DMA of the next chunk: one piece per k-step over the first 11 k-steps of the chunk
-__device__ __forceinline__ void dma_step(const Loader& ld, float* next_slot, int s) {
-  if (s < 11) loader_issue(ld, next_slot, s);
+__device__ __forceinline__ void dma_step(const Loader& ld, int s) {
+  if (s < 11) loader_issue(ld, s);
 }
 
 constexpr int kConvStep0 = 6;   // pending block is converted in k-steps 6..13 (one register pair each)
@@ -328,9 +394,10 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
     float* slot = ring + (nb & 1) * kSlotFloats;
     float* next_slot = ring + ((nb + 1) & 1) * kSlotFloats;
     NSR_SYNC();                            // chunk ld.q landed (vmcnt(0)) and the other slot is free
-    loader_prepare_next(ld);
+    loader_prepare_next(ld, next_slot);
     const float* a0 = slot + ld.lane * 4;
     Acc cur;
+    PairTmp ptmp;
     init_acc(cur, slot + (32 + skip) * 256, h);   // bias piece follows the 2*steps weight pieces
     if (L == 4) {
       // skip connection: the encoded position was parked in LDS by the prologue (8 fragments per lane)
@@ -342,13 +409,13 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
     block_mma<16>(
         cur, a0 + skip * 256, [&](int s, int part) -> u32x4 { return part ? bl[s] : bh[s]; },
         [&](int s) {
-          dma_step(ld, next_slot, s);
+          dma_step(ld, s);
           if (nb == 0)
             // block 7 of the previous layer (always relu'd: the previous layer is L1..L7) -> k-steps 14, 15
             // of THIS layer's input, needed only at the end of this chunk
-            pending_step<kConvStep0>(s, pend, 0.0f, bh[14], bl[14], bh[15], bl[15]);
+            pending_step(s, pend, 0.0f, ptmp, bh[14], bl[14], bh[15], bl[15]);
           else
-            pending_step<kConvStep0>(s, pend, lower, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1]);
+            pending_step(s, pend, lower, ptmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1]);
         });
     pend = cur;
     ld.q += 1;
@@ -377,9 +444,9 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   ld.wave = wave;
   ld.lane = lane;
   ld.lane_off = (unsigned)lane * 16u;
-  loader_prepare_next(ld);                 // chunk 0
+  loader_prepare_next(ld, ring);           // chunk 0
 #pragma unroll
-  for (int i = 0; i < 11; ++i) loader_issue(ld, ring, i);
+  for (int i = 0; i < 11; ++i) loader_issue(ld, i);
   ld.q = 0;
 
   const int64_t p = (int64_t)blockIdx.x * 128 + wave * 32 + m;
@@ -399,7 +466,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
       de[t] = (col == kPad) ? 0.0f : row[kPosCh + col];
     }
   } else {
-    const int64_t ray = (NS > 0) ? pc / NS : pc / N;
+    const int64_t ray = pc / ((NS > 0) ? NS : N);
     const float4 ra = reinterpret_cast<const float4*>(x + ray * 8)[0];
     const float4 rb = reinterpret_cast<const float4*>(x + ray * 8)[1];
     const float zk = zv[pc];
@@ -471,20 +538,22 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     float* slot = ring + (c & 1) * kSlotFloats;
     float* next_slot = ring + ((c + 1) & 1) * kSlotFloats;
     NSR_SYNC();
-    loader_prepare_next(ld);
+    loader_prepare_next(ld, next_slot);
     const float* a0 = slot + lane * 4;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int nb = 4 * c + g;
       Acc cur;
+      PairTmp ptmp;
       init_acc(cur, slot + 32 * 256 + 32 * g, h);
       block_mma<4>(
           cur, a0 + g * 8 * 256, [&](int s, int part) -> u32x4 { return part ? pel[s] : peh[s]; },
           [&](int s) {
-            dma_step(ld, next_slot, 4 * g + s);
-            if (nb > 0) {   // two register pairs per k-step: the block has only four
-              pending_step<0>(2 * s, pend, 0.0f, bh[2 * nb - 2], bl[2 * nb - 2], bh[2 * nb - 1], bl[2 * nb - 1]);
-              pending_step<0>(2 * s + 1, pend, 0.0f, bh[2 * nb - 2], bl[2 * nb - 2], bh[2 * nb - 1], bl[2 * nb - 1]);
+            dma_step(ld, 4 * g + s);
+            if (nb > 0) {   // four halves per k-step: the block has only four k-steps
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4)
+                pending_half(4 * s + q4, pend, 0.0f, ptmp, bh[2 * nb - 2], bl[2 * nb - 2], bh[2 * nb - 1], bl[2 * nb - 1]);
             }
           });
       pend = cur;
@@ -513,20 +582,21 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     float* slot = ring;                      // 58 / 66 chunks so far: slot parity 0
     float* next_slot = ring + kSlotFloats;
     NSR_SYNC();
-    loader_prepare_next(ld);
+    loader_prepare_next(ld, next_slot);
     const float* a0 = slot + lane * 4;
     Acc cur;
+    PairTmp ptmp;
     init_acc(cur, slot + 32 * 256, h);
     block_mma<16>(
         cur, a0, [&](int s, int part) -> u32x4 { return part ? ol[s] : oh[s]; },
         [&](int s) {
-          dma_step(ld, next_slot, s);
+          dma_step(ld, s);
           if (SIGMA_ONLY)
-            pending_step<kConvStep0>(s, pend, 0.0f, oh[14], ol[14], oh[15], ol[15]);
+            pending_step(s, pend, 0.0f, ptmp, oh[14], ol[14], oh[15], ol[15]);
           else
-            pending_step<kConvStep0>(s, pend, -__builtin_inff(), bh[14], bl[14], bh[15], bl[15]);
+            pending_step(s, pend, -__builtin_inff(), ptmp, bh[14], bl[14], bh[15], bl[15]);
         });
-    sigma = cur.m[0] + cur.c[0];             // row 0 of the block lives in register 0 of the h == 0 lanes
+    sigma = cur.m[0];                        // row 0 of the block lives in register 0 of the h == 0 lanes
     ld.q += 1;
   }
   if (SIGMA_ONLY) {
@@ -541,7 +611,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     float* slot = ring + ((nb + 1) & 1) * kSlotFloats;     // 67 chunks precede dir_encoding
     float* next_slot = ring + (nb & 1) * kSlotFloats;
     NSR_SYNC();
-    loader_prepare_next(ld);
+    loader_prepare_next(ld, next_slot);
     const float* a0 = slot + lane * 4;
     Acc cur;
     init_acc(cur, slot + 36 * 256, h);
@@ -552,7 +622,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
         cur, a0,
         [&](int s, int part) -> u32x4 { return (s < 16) ? (part ? bl[s & 15] : bh[s & 15]) : de4[2 * part + (s & 1)]; },
         [&](int s) {
-          dma_step(ld, next_slot, s);
+          dma_step(ld, s);
           if (nb > 0) rgb_step<kConvStep0>(s, pend, aux + hx::kAuxRgbW + 32 * (nb - 1), h, rgb);
         });
     pend = cur;
