@@ -307,6 +307,72 @@ def test_sharp_field_statistical_parity(ops, fam):
     assert float(e_hip.max()) <= max(3.0 * float(e_ref.max()), 1e-3)
 
 
+# ------------------------------------------------------------------------------- split-fp16 MLP path
+@pytest.fixture(scope="module")
+def fam_x3(fam, ops):
+    g, _, _, sd_c, sd_f = fam
+    return g, ops.VanillaMLP(precision="f16x3").load_state_dict(sd_c), ops.VanillaMLP(precision="f16x3").load_state_dict(sd_f)
+
+
+def test_f16x3_mlp_vs_golden(ops, fam_x3):
+    """NSR_F16X3: fp16 MFMA with split operands must be indistinguishable from fp32 at the contract's scale:
+    colours to 2e-6, raw density (|sigma| ~ 5) to 1e-4 (products carry ~2^-21 relative error)."""
+    g, net_c, net_f = fam_x3
+    x = _cu(g["mlp_in_512"])
+    for net, key in ((net_c, "mlp_out_coarse_512"), (net_f, "mlp_out_fine_512")):
+        out = net(x)
+        _close(out[:, :3], g[key][:, :3], 3e-6)
+        _close(out[:, 3], g[key][:, 3], 1e-4)
+    _close(net_c(x[:64], sigma_only=True), g["mlp_sigma_only_64"], 1e-4)
+    # ragged tail + position independence, as for the fp32 kernel
+    out = net_c(x[:333 - 77])
+    out2 = net_c(x[5:200].contiguous())
+    assert torch.equal(out[5:200], out2)
+    rgb, sig = ops.render_rays(net_c, _cu(g["rays"]), _cu(g["z_coarse"]))
+    _close(sig, g["coarse_point_sigma"], 1e-4)
+    _close(rgb[:16], g["coarse_point_rgb"], 3e-6)
+
+
+def test_f16x3_forward_rays_vs_golden(ops, fam_x3):
+    g, net_c, net_f = fam_x3
+    white = bool(g["white_bkgd"])
+    far = float(g["rays"][0, 7])
+    out = ops.forward_rays(net_c, net_f, _cu(g["rays"]), 64, 64, white)
+    for k in ("coarse_comp_rgbs", "fine_comp_rgbs"):
+        _close(out[k], g[k], RGB_TOL)
+        assert float(np.median(np.abs(out[k].cpu().numpy() - g[k]))) < 2e-6
+    for k in ("coarse_opacity", "fine_opacity"):
+        _close(out[k], g[k], 1e-4)
+    for k in ("coarse_depth", "fine_depth"):
+        _close(out[k], g[k], 1e-4 * far)
+    tgt = torch.from_numpy(g["coarse_comp_rgbs"])
+    assert abs(oc.psnr(torch.from_numpy(g["fine_comp_rgbs"]), tgt) - oc.psnr(out["fine_comp_rgbs"].cpu(), tgt)) < PSNR_TOL
+    # bit-identical under any split of the batch (no cross-ray state in the kernel)
+    a = {k: v.clone() for k, v in ops.forward_rays(net_c, net_f, _cu(g["rays"])[:77].contiguous(), 64, 64, white).items()}
+    b = ops.forward_rays(net_c, net_f, _cu(g["rays"])[77:].contiguous(), 64, 64, white)
+    full = ops.forward_rays(net_c, net_f, _cu(g["rays"]), 64, 64, white)
+    for k in full:
+        assert torch.equal(full[k], torch.cat([a[k], b[k]], 0)), k
+
+
+def test_f16x3_agrees_with_fp32_kernel_full_frame(ops):
+    """Config #2 at full size: the two MLP precisions must render the same image (<= 1e-4 RGB on >= 99.9 % of
+    the rays; the rest sit on the reference's own resampling discontinuities, see test_sharp_field...)."""
+    sd_c, sd_f = make_state_dict(99), make_state_dict(100)
+    rays = ops.subpixel_rays(cameras.spiral_pose(0.4), (504, 378), cameras.llff_focal(504), 2, True).reshape(-1, 8)
+    outs = {}
+    for prec in ("fp32", "f16x3"):
+        net_c = ops.VanillaMLP(precision=prec).load_state_dict(sd_c)
+        net_f = ops.VanillaMLP(precision=prec).load_state_dict(sd_f)
+        outs[prec] = {k: v.clone() for k, v in ops.forward_rays(net_c, net_f, rays, 64, 64, False).items()}
+    d = (outs["fp32"]["fine_comp_rgbs"] - outs["f16x3"]["fine_comp_rgbs"]).abs().max(-1)[0]
+    dc = (outs["fp32"]["coarse_comp_rgbs"] - outs["f16x3"]["coarse_comp_rgbs"]).abs().max()
+    assert float(dc) < 1e-5
+    assert float(d.median()) < 2e-6
+    assert float((d > RGB_TOL).float().mean()) < 1e-3
+    assert oc.psnr(outs["fp32"]["fine_comp_rgbs"].cpu(), outs["f16x3"]["fine_comp_rgbs"].cpu()) > 90.0
+
+
 # ------------------------------------------------------------------------------- full-size properties
 def test_full_size_properties_config2(ops):
     """BASELINE config #2 at full size (504x378 <- 252x189, 190,512 rays, 64+128 samples):
