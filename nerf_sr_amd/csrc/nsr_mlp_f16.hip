@@ -142,47 +142,72 @@ __device__ __forceinline__ void glds16_asm(const char* base_uniform, unsigned la
 }
 __device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// ---------------------------------------------------------------------------
+// weight-stream loader: 3-slot LDS ring, the chunk at sequence position j lives in slot j % 3.
+//
+// Protocol (per wave, chunk j being consumed):
+//   * entering chunk j: its data is PUBLISHED (every wave's DMA landed and a barrier passed), chunk
+//     j+1's DMA has been issued by every wave, and the first k-steps' fragments + bias of chunk j are
+//     already in registers (prefetched at the end of chunk j-1) — no bubble at the chunk boundary;
+//   * at k-step kBar of chunk j: wait for the own DMA of chunk j+1 (issued half a chunk ago), barrier
+//     => chunk j+1 is published and every wave has left chunk j-1, whose slot is therefore free;
+//   * k-steps kBar..kBar+5: issue the DMA of chunk j+2 into that slot (two pieces per k-step);
+//   * last three k-steps: prefetch chunk j+1's first fragments and bias.
+// ---------------------------------------------------------------------------
+constexpr int kSlotBytes = kSlotFloats * 4;
+constexpr int kBar = 8;
+
 struct Loader {
   const float* stream;   // packed blob viewed as 32-bit words
-  int q;                 // chunk being CONSUMED
-  int q_end;
+  int j;                 // sequence position of the chunk being CONSUMED
+  int n_seq;             // chunks in this launch's sequence
   bool skip_final;       // sigma_only launches jump from L8 straight to the density-head chunk
-  int wave, lane;
-  // descriptor of chunk q+1 (what the current chunk's body is prefetching).  Each wave moves a contiguous
-  // quarter of the chunk (8..11 pieces): wave-uniform byte address of its first piece (scalar registers),
-  // the matching LDS byte address, its piece count, + the lane's 16-byte offset (one 32-bit VGPR)
-  const char* next_base;
-  unsigned next_lds;
-  int next_count;
-  unsigned lane_off;
+  int wave;
+  unsigned lane_off;     // lane * 16
+  unsigned slot_cur, slot_next, slot_free;   // LDS byte addresses of the slots of chunks j, j+1, j+2
+  // DMA descriptor of the chunk being fetched.  Each wave moves a contiguous quarter of it (8..11 pieces):
+  // wave-uniform byte address of its first piece, the matching LDS byte address, its piece count
+  const char* dma_base;
+  unsigned dma_lds;
+  int dma_count;
 };
 
-__device__ __forceinline__ void loader_prepare_next(Loader& ld, const float* next_slot) {
-  int qn = ld.q + 1;
-  if (ld.skip_final && qn == kChunkFinal0) qn = kChunkSigma;
-  // nothing follows the last chunk: re-fetch chunk 0 into the idle slot so that the first eight DMA issues
-  // of every chunk stay unconditional (branch-free k-steps; 32 KiB of dead traffic per tile)
-  int pieces = 32, piece0 = 0;
-  if (qn < ld.q_end) {
-    const Chunk c = chunk_info(qn);
+// sequence position -> chunk id (-1 past the end)
+__device__ __forceinline__ int seq_chunk(const Loader& ld, int j) {
+  if (j >= ld.n_seq) return -1;
+  return (ld.skip_final && j >= kChunkFinal0) ? j + (kChunkSigma - kChunkFinal0) : j;
+}
+
+__device__ __forceinline__ void loader_prepare_dma(Loader& ld, int j, unsigned slot_lds) {
+  const int q = seq_chunk(ld, j);
+  int pieces = 0, piece0 = 0;
+  if (q >= 0) {
+    const Chunk c = chunk_info(q);
     pieces = chunk_pieces(c.steps, c.nnb);
     piece0 = c.piece0;
   }
   const int first = (ld.wave * pieces) >> 2;
-  ld.next_count = (((ld.wave + 1) * pieces) >> 2) - first;
-  ld.next_base = reinterpret_cast<const char*>(ld.stream) + (size_t)(piece0 + first) * 1024;
-  ld.next_lds = lds_addr(next_slot) + (unsigned)first * 1024u;
+  ld.dma_count = (((ld.wave + 1) * pieces) >> 2) - first;
+  ld.dma_base = reinterpret_cast<const char*>(ld.stream) + (size_t)(piece0 + first) * 1024;
+  ld.dma_lds = slot_lds + (unsigned)first * 1024u;
 }
 
-// issue this wave's DMA piece number i of the next chunk (no-op past its end)
+// byte offset of the bias piece inside the slot of the chunk at sequence position j
+__device__ __forceinline__ unsigned seq_bias_off(const Loader& ld, int j) {
+  const int q = seq_chunk(ld, j);
+  if (q < 0) return 0u;
+  const Chunk c = chunk_info(q);
+  return (unsigned)(chunk_pieces(c.steps, c.nnb) - 1) * 1024u;
+}
+
+// issue this wave's DMA piece number i of the chunk being fetched (no-op past its end)
 __device__ __forceinline__ void loader_issue(const Loader& ld, int i) {
 #ifdef NSR_ABL_NO_DMA
   return;
 #endif
-  // every wave owns at least 8 pieces of every chunk: the first eight issues need no bounds test
-  if (i < 8 || i < ld.next_count) {
-    const char* base = ld.next_base + (i >> 2) * 4096;
-    const unsigned dst = ld.next_lds + (unsigned)(i >> 2) * 4096u;
+  if (i < ld.dma_count) {
+    const char* base = ld.dma_base + (i >> 2) * 4096;
+    const unsigned dst = ld.dma_lds + (unsigned)(i >> 2) * 4096u;
     switch (i & 3) {
       case 0: glds16_asm<0>(base, ld.lane_off, dst); break;
       case 1: glds16_asm<1024>(base, ld.lane_off, dst); break;
@@ -192,7 +217,30 @@ __device__ __forceinline__ void loader_issue(const Loader& ld, int i) {
   }
 }
 
+__device__ __forceinline__ void loader_advance(Loader& ld) {
+  const unsigned t = ld.slot_cur;
+  ld.slot_cur = ld.slot_next;
+  ld.slot_next = ld.slot_free;
+  ld.slot_free = t;
+  ld.j += 1;
+}
+
+// the publish point of chunk j+1 (see protocol above), then start fetching chunk j+2
+__device__ __forceinline__ void loader_publish(Loader& ld) {
+  dma_drain();
+  __syncthreads();
+  loader_prepare_dma(ld, ld.j + 2, ld.slot_free);
+}
+
 __device__ __forceinline__ h8 as_h8(const u32x4& v) { return __builtin_bit_cast(h8, v); }
+__device__ __forceinline__ const u32x4* lds_vec(unsigned byte_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (const u32x4*)(const __attribute__((address_space(3))) u32x4*)(size_t)byte_addr;
+#else
+  (void)byte_addr;
+  return nullptr;   // host pass of the single-source compile; never executed
+#endif
+}
 
 struct Acc {
   f32x16 m;   // bias + sum (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi), fp32.  (A separate accumulator for the
@@ -200,80 +248,67 @@ struct Acc {
               // MFMA+LDS loop) but its 16 extra adds per block cost more in the full kernel.)
 };
 
-// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>)
-template <int... S, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, S...>, F&& f) {
-  (f(std::integral_constant<int, S>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
+// what a k-step sequence needs before its first MFMA: the A fragments of its first kPF k-steps (and, for
+// a new chunk, the accumulator init = bias).  Filled during the last k-steps of the preceding sequence.
+constexpr int kPF = 3;
+struct Pre {
+  u32x4 ah[kPF], al[kPF];
+  f32x16 bias;
+};
 
-// A-fragment load the compiler does not track: hipcc's own waitcnt insertion drains lgkmcnt(0) every
-// PF steps (stalling on loads issued two instructions earlier); these are waited for by COUNT below.
-template <int OFF>
-__device__ __forceinline__ void lds_read16_async(u32x4& dst, unsigned addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+// fragments of k-step k (< kPF) of the sequence whose pieces start at LDS byte address `seq_addr` (+ lane*16)
+__device__ __forceinline__ void prefetch_frag(Pre& pre, int k, unsigned seq_addr) {
+  const u32x4* a = lds_vec(seq_addr);
+  pre.ah[k] = a[(2 * k) * 64];
+  pre.al[k] = a[(2 * k + 1) * 64];
 }
-// wait until at most N younger LDS operations are outstanding; names the registers so that every
-// consumer is ordered behind the wait (cdna_hip_programming.md §5.7, form ii)
-template <int N>
-__device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b) {
-  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N));
-}
-
-// NSTEP k-steps of one output block.  A fragments are software-pipelined PF steps ahead of the
-// MFMAs that consume them; sched_barrier pins the order.  a_addr is the lane's LDS byte address of
-// the block's first piece; b_of(s, part) yields the step's activation operands, hook(s) runs in the
-// MFMA shadow of step s.
-template <int NSTEP, class BOf, class Hook>
-__device__ __forceinline__ void block_mma(Acc& acc, const float* a_ptr, BOf&& b_of, Hook&& hook) {
-  constexpr int PF = 3;
-  u32x4 ah[NSTEP], al[NSTEP];
-  const u32x4* a_pieces = reinterpret_cast<const u32x4*>(a_ptr);
-#ifdef NSR_ABL_NO_LDSREAD
-  u32x4 fake = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-  asm volatile("" : "+v"(fake));
+// accumulator init of a chunk from its bias piece (fp32, D-fragment order; broadcast reads)
+__device__ __forceinline__ void prefetch_bias(Pre& pre, unsigned bias_addr, int h) {
+  const f32x4* b = reinterpret_cast<const f32x4*>(lds_vec(bias_addr + 16u * (unsigned)h));
 #pragma unroll
-  for (int s = 0; s < NSTEP; ++s) { ah[s] = fake; al[s] = fake; }
-  (void)a_pieces;
-#else
+  for (int qd = 0; qd < 4; ++qd) {
+    const f32x4 b4 = b[2 * qd];                    // floats 8*qd + 4*h .. +3
 #pragma unroll
-  for (int s = 0; s < PF && s < NSTEP; ++s) {
-    ah[s] = a_pieces[(2 * s) * 64];
-    al[s] = a_pieces[(2 * s + 1) * 64];
+    for (int i = 0; i < 4; ++i) pre.bias[4 * qd + i] = b4[i];
   }
-#endif
+}
+
+// NSTEP k-steps of one output block, fragments software-pipelined kPF k-steps ahead (the first kPF come
+// in through `pre`), order pinned by sched_barrier.  a_addr: LDS byte address (+ lane*16) of the
+// sequence's first piece.  b_of(s, part) yields the k-step's activation operands; hook(s) runs in the MFMA
+// shadow of k-step s; BAR >= 0 places the chunk's publish point + DMA issue (k-steps BAR..BAR+5);
+// next(k), k = 0..2, runs in the last three k-steps and prefetches the following sequence into `nxt`.
+template <int NSTEP, int BAR, class BOf, class Hook, class Next>
+__device__ __forceinline__ void block_mma(Acc& acc, const Pre& pre, unsigned a_addr, Loader& ld, BOf&& b_of,
+                                          Hook&& hook, Next&& next) {
+  static_assert(NSTEP >= kPF, "sequence shorter than the prefetch depth");
+  const u32x4* a_pieces = lds_vec(a_addr);
+  u32x4 ah[NSTEP], al[NSTEP];
+#pragma unroll
+  for (int s = 0; s < kPF; ++s) {
+    ah[s] = pre.ah[s];
+    al[s] = pre.al[s];
+  }
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
-#ifndef NSR_ABL_NO_LDSREAD
-    if (s + PF < NSTEP) {
-      ah[s + PF] = a_pieces[(2 * (s + PF)) * 64];
-      al[s + PF] = a_pieces[(2 * (s + PF) + 1) * 64];
+    if (s == BAR) loader_publish(ld);
+    if (s + kPF < NSTEP) {
+      ah[s + kPF] = a_pieces[(2 * (s + kPF)) * 64];
+      al[s + kPF] = a_pieces[(2 * (s + kPF) + 1) * 64];
+    } else {
+      next(s + kPF - NSTEP);
     }
-#endif
     const u32x4 bh = b_of(s, 0), bl = b_of(s, 1);
-#ifndef NSR_ABL_NO_MFMA
     // a_lo first: it is the younger of the step's two fragment loads, so ONE lgkmcnt wait serves all three
     acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(al[s]), as_h8(bh), acc.m, 0, 0, 0);
     acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bl), acc.m, 0, 0, 0);
     acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bh), acc.m, 0, 0, 0);
-#else
-    acc.m[0] += __builtin_bit_cast(float, ah[s][0] ^ bh[0] ^ al[s][1] ^ bl[1]);
-#endif
     hook(s);
+    if (BAR >= 0 && s >= BAR && s < BAR + 6) {
+      loader_issue(ld, 2 * (s - BAR));
+      loader_issue(ld, 2 * (s - BAR) + 1);
+    }
     __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// accumulator init from the chunk's bias piece (fp32, D-fragment order)
-__device__ __forceinline__ void init_acc(Acc& a, const float* bias32, int h) {
-#pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
-    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias32 + 8 * qd + 4 * h);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a.m[4 * qd + i] = b4[i];
   }
 }
 
@@ -374,51 +409,59 @@ __device__ __forceinline__ void rgb_step(int s, const Acc& p, const float* w32, 
   if (s == S0 + 7) pair_rgb<7>(p, w32, h, rgb);
 }
 
-// weight DMA of the next chunk: one piece per k-step over the first 11 k-steps of the chunk
-__device__ __forceinline__ void dma_step(const Loader& ld, int s) {
-  if (s < 11) loader_issue(ld, s);
-}
 
-constexpr int kConvStep0 = 6;   // pending block is converted in k-steps 6..13 (one register pair each)
+constexpr int kConvStep0 = 6;   // colour head: pending dir block is consumed in k-steps 6..13 (one pair each)
+
+// prefetch of the NEXT chunk (sequence position j+1) during the last three k-steps of chunk j
+__device__ __forceinline__ void prefetch_next_chunk(Pre& nxt, int k, const Loader& ld, unsigned bias_off, int h) {
+  prefetch_frag(nxt, k, ld.slot_next + ld.lane_off);
+  if (k == 1) prefetch_bias(nxt, ld.slot_next + bias_off, h);
+}
 
 // One 256 -> 256 trunk layer L (1..8; 8 = xyz_encoding_final): in (bh, bl) -> out (oh, ol).
 // L == 4 prepends the 4 positional-encoding k-steps (skip connection).  `pend` is the block that
 // finished last (block 7 of the previous layer on entry; block 7 of this layer on exit): it is
-// summed, activated and re-split in the MFMA shadow of the FOLLOWING block's k-steps 1..4.
+// activated and re-split in the MFMA shadow of the FOLLOWING block's k-steps 0..13.  `pre` carries the
+// prefetched head of the next chunk across chunk (and layer) boundaries.
 __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[16], u32x4 (&oh)[16], u32x4 (&ol)[16],
-                                            const u32x4* stash, Loader& ld, float* ring, int h, Acc& pend) {
+                                            const u32x4* stash, Loader& ld, int h, Acc& pend, Pre& pre) {
   const float lower = (L < 8) ? 0.0f : -__builtin_inff();   // relu on L1..L8, none on xyz_encoding_final
-  const int skip = (L == 4) ? 8 : 0;                        // pieces taken by the pe k-steps
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) {
-    float* slot = ring + (nb & 1) * kSlotFloats;
-    float* next_slot = ring + ((nb + 1) & 1) * kSlotFloats;
-    NSR_SYNC();                            // chunk ld.q landed (vmcnt(0)) and the other slot is free
-    loader_prepare_next(ld, next_slot);
-    const float* a0 = slot + ld.lane * 4;
     Acc cur;
+    cur.m = pre.bias;
     PairTmp ptmp;
-    init_acc(cur, slot + (32 + skip) * 256, h);   // bias piece follows the 2*steps weight pieces
+    unsigned a_addr = ld.slot_cur + ld.lane_off;
+    const unsigned next_bias = seq_bias_off(ld, ld.j + 1);
+    Pre nxt;
     if (L == 4) {
-      // skip connection: the encoded position was parked in LDS by the prologue (8 fragments per lane)
+      // skip connection: the encoded position was parked in LDS by the prologue (8 fragments per lane);
+      // its 4 k-steps run first and hand the act part's first fragments over through `mid`
       u32x4 pe8[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) pe8[i] = stash[i * 64];
-      block_mma<4>(cur, a0, [&](int s, int part) -> u32x4 { return pe8[4 * part + s]; }, [&](int) {});
+      Pre mid;
+      block_mma<4, -1>(
+          cur, pre, a_addr, ld, [&](int s, int part) -> u32x4 { return pe8[4 * part + s]; }, [&](int) {},
+          [&](int k) { prefetch_frag(mid, k, a_addr + 8 * 1024); });
+      pre.ah[0] = mid.ah[0]; pre.ah[1] = mid.ah[1]; pre.ah[2] = mid.ah[2];
+      pre.al[0] = mid.al[0]; pre.al[1] = mid.al[1]; pre.al[2] = mid.al[2];
+      a_addr += 8 * 1024;
     }
-    block_mma<16>(
-        cur, a0 + skip * 256, [&](int s, int part) -> u32x4 { return part ? bl[s] : bh[s]; },
+    block_mma<16, kBar>(
+        cur, pre, a_addr, ld, [&](int s, int part) -> u32x4 { return part ? bl[s] : bh[s]; },
         [&](int s) {
-          dma_step(ld, s);
           if (nb == 0)
             // block 7 of the previous layer (always relu'd: the previous layer is L1..L7) -> k-steps 14, 15
             // of THIS layer's input, needed only at the end of this chunk
             pending_step(s, pend, 0.0f, ptmp, bh[14], bl[14], bh[15], bl[15]);
           else
             pending_step(s, pend, lower, ptmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1]);
-        });
+        },
+        [&](int k) { prefetch_next_chunk(nxt, k, ld, next_bias, h); });
     pend = cur;
-    ld.q += 1;
+    pre = nxt;
+    loader_advance(ld);
   }
 }
 
@@ -426,28 +469,33 @@ template <int MODE, bool SIGMA_ONLY, int NS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ zv,
                  int64_t P, int N, float* __restrict__ out) {
-  // 2 x 41 KiB weight ring + per-wave stash of the encoded inputs (12 fragments x 64 lanes x 16 B = 12 KiB)
-  // + the colour-head block (rgb weights and bias, 448 floats), so the loop issues no global loads
-  __shared__ __attribute__((aligned(16))) float ring[2 * kSlotFloats + 4 * 12 * 256 + hx::kAuxFloats];
+  // 3 x 41 KiB weight ring + per-wave stash of the encoded position (8 fragments x 64 lanes x 16 B = 8 KiB
+  // per wave) + the colour-head block (rgb weights and bias, 448 floats): 160,512 B of the CU's 160 KiB
+  constexpr int kStash0 = 3 * kSlotFloats, kAux0 = kStash0 + 4 * 8 * 256;
+  __shared__ __attribute__((aligned(16))) float ring[kAux0 + hx::kAuxFloats];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 31, h = lane >> 5;
-  const float* aux = ring + 2 * kSlotFloats + 4 * 12 * 256;   // LDS copy, visible after the first barrier
-  for (int i = threadIdx.x; i < hx::kAuxFloats; i += 256)
-    ring[2 * kSlotFloats + 4 * 12 * 256 + i] = packed[kPiecesTotal * 256 + i];
+  const float* aux = ring + kAux0;          // LDS copy, visible after the first barrier
+  for (int i = threadIdx.x; i < hx::kAuxFloats; i += 256) ring[kAux0 + i] = packed[kPiecesTotal * 256 + i];
 
   Loader ld;
   ld.stream = packed;
-  ld.q = -1;
-  ld.q_end = SIGMA_ONLY ? kChunkSigma + 1 : kChunks;
+  ld.j = 0;
+  ld.n_seq = SIGMA_ONLY ? kChunkFinal0 + 1 : kChunks;
   ld.skip_final = SIGMA_ONLY;
   ld.wave = wave;
-  ld.lane = lane;
   ld.lane_off = (unsigned)lane * 16u;
-  loader_prepare_next(ld, ring);           // chunk 0
+  ld.slot_cur = lds_addr(ring);
+  ld.slot_next = ld.slot_cur + kSlotBytes;
+  ld.slot_free = ld.slot_cur + 2 * kSlotBytes;
+  // chunks 0 and 1 stream in behind the encoding prologue
+  loader_prepare_dma(ld, 0, ld.slot_cur);
 #pragma unroll
   for (int i = 0; i < 11; ++i) loader_issue(ld, i);
-  ld.q = 0;
+  loader_prepare_dma(ld, 1, ld.slot_next);
+#pragma unroll
+  for (int i = 0; i < 11; ++i) loader_issue(ld, i);
 
   const int64_t p = (int64_t)blockIdx.x * 128 + wave * 32 + m;
   const int64_t pc = p < P ? p : P - 1;
@@ -516,49 +564,56 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     del[s] = u32x4{b[0], b[1], b[2], b[3]};
   }
 
-  // park the split encodings in LDS: L5 (skip) and dir_encoding re-read them, which frees 48 registers
-  u32x4* stash = reinterpret_cast<u32x4*>(ring + 2 * kSlotFloats) + wave * 12 * 64 + lane;
+
+  // park the split position encoding in LDS: L5 (skip) re-reads it, which frees 32 registers in the loop
+  u32x4* stash = reinterpret_cast<u32x4*>(ring + kStash0) + wave * 8 * 64 + lane;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     stash[s * 64] = peh[s];
     stash[(4 + s) * 64] = pel[s];
   }
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    stash[(8 + s) * 64] = deh[s];
-    stash[(10 + s) * 64] = del[s];
-  }
 
   u32x4 bh[16], bl[16], oh[16], ol[16];
   Acc pend;
+  Pre pre;
 
-  // ---- L1: two chunks of four output blocks, 4 k-steps each; block b is re-split during block b+1
+  // ---- L1: two chunks of four output blocks, 4 k-steps each; block b is re-split during block b+1.
+  // Publish point at the chunk start (chunk 0 / 1 were issued above; chunk j+2 is fetched here).
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    float* slot = ring + (c & 1) * kSlotFloats;
-    float* next_slot = ring + ((c + 1) & 1) * kSlotFloats;
-    NSR_SYNC();
-    loader_prepare_next(ld, next_slot);
-    const float* a0 = slot + lane * 4;
+    loader_publish(ld);
+    const unsigned a_chunk = ld.slot_cur + ld.lane_off;
+    const unsigned next_bias = seq_bias_off(ld, ld.j + 1);
+    Pre nxt;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int nb = 4 * c + g;
+      const unsigned a_addr = a_chunk + g * 8 * 1024;
+      Pre mine;
+#pragma unroll
+      for (int k = 0; k < kPF; ++k) prefetch_frag(mine, k, a_addr);
+      prefetch_bias(mine, ld.slot_cur + 32 * 1024 + 128 * g, h);
       Acc cur;
+      cur.m = mine.bias;
       PairTmp ptmp;
-      init_acc(cur, slot + 32 * 256 + 32 * g, h);
-      block_mma<4>(
-          cur, a0 + g * 8 * 256, [&](int s, int part) -> u32x4 { return part ? pel[s] : peh[s]; },
+      block_mma<4, -1>(
+          cur, mine, a_addr, ld, [&](int s, int part) -> u32x4 { return part ? pel[s] : peh[s]; },
           [&](int s) {
-            dma_step(ld, 4 * g + s);
+            const int i = 4 * g + s;        // DMA of chunk j+2: one piece per k-step over the chunk's 16 k-steps
+            if (i < 11) loader_issue(ld, i);
             if (nb > 0) {   // four halves per k-step: the block has only four k-steps
 #pragma unroll
               for (int q4 = 0; q4 < 4; ++q4)
                 pending_half(4 * s + q4, pend, 0.0f, ptmp, bh[2 * nb - 2], bl[2 * nb - 2], bh[2 * nb - 1], bl[2 * nb - 1]);
             }
+          },
+          [&](int k) {
+            if (c == 1 && g == 3) prefetch_next_chunk(nxt, k, ld, next_bias, h);   // head of the first trunk chunk
           });
       pend = cur;
     }
-    ld.q += 1;
+    if (c == 1) pre = nxt;
+    loader_advance(ld);
   }
 
   // ---- L2..L8 (+ xyz_encoding_final), two layers per trip so the register sets swap roles
@@ -566,38 +621,35 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
 #pragma unroll 1
   for (int pair = 0; pair < kPairs; ++pair) {
     const int L = 1 + 2 * pair;
-    trunk_layer(L, bh, bl, oh, ol, stash, ld, ring, h, pend);
-    trunk_layer(L + 1, oh, ol, bh, bl, stash, ld, ring, h, pend);
+    trunk_layer(L, bh, bl, oh, ol, stash, ld, h, pend, pre);
+    trunk_layer(L + 1, oh, ol, bh, bl, stash, ld, h, pend, pre);
   }
-  if (SIGMA_ONLY) {
-    trunk_layer(7, bh, bl, oh, ol, stash, ld, ring, h, pend);
-    ld.q = kChunkSigma;      // xyz_encoding_final is not evaluated
-  }
+  if (SIGMA_ONLY) trunk_layer(7, bh, bl, oh, ol, stash, ld, h, pend, pre);   // xyz_encoding_final is not evaluated
 
   // ---- density head: sigma.weight as row 0 of one more 32-row block over h8 (= oh/ol: the input of
   // xyz_encoding_final, still intact).  The pending block is xyz_encoding_final's last one (-> bh, no
   // activation), or L8's last one in a sigma_only launch (-> oh, relu).
   float sigma;
   {
-    float* slot = ring;                      // 58 / 66 chunks so far: slot parity 0
-    float* next_slot = ring + kSlotFloats;
-    NSR_SYNC();
-    loader_prepare_next(ld, next_slot);
-    const float* a0 = slot + lane * 4;
     Acc cur;
+    cur.m = pre.bias;
     PairTmp ptmp;
-    init_acc(cur, slot + 32 * 256, h);
-    block_mma<16>(
-        cur, a0, [&](int s, int part) -> u32x4 { return part ? ol[s] : oh[s]; },
+    const unsigned next_bias = seq_bias_off(ld, ld.j + 1);
+    Pre nxt;
+    block_mma<16, kBar>(
+        cur, pre, ld.slot_cur + ld.lane_off, ld, [&](int s, int part) -> u32x4 { return part ? ol[s] : oh[s]; },
         [&](int s) {
-          dma_step(ld, s);
           if (SIGMA_ONLY)
             pending_step(s, pend, 0.0f, ptmp, oh[14], ol[14], oh[15], ol[15]);
           else
             pending_step(s, pend, -__builtin_inff(), ptmp, bh[14], bl[14], bh[15], bl[15]);
+        },
+        [&](int k) {
+          if (!SIGMA_ONLY) prefetch_next_chunk(nxt, k, ld, next_bias, h);
         });
     sigma = cur.m[0];                        // row 0 of the block lives in register 0 of the h == 0 lanes
-    ld.q += 1;
+    pre = nxt;
+    loader_advance(ld);
   }
   if (SIGMA_ONLY) {
     if (h == 0 && p < P) out[p] = sigma;
@@ -608,25 +660,24 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   float rgb[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
-    float* slot = ring + ((nb + 1) & 1) * kSlotFloats;     // 67 chunks precede dir_encoding
-    float* next_slot = ring + (nb & 1) * kSlotFloats;
-    NSR_SYNC();
-    loader_prepare_next(ld, next_slot);
-    const float* a0 = slot + lane * 4;
     Acc cur;
-    init_acc(cur, slot + 36 * 256, h);
-    u32x4 de4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) de4[i] = stash[(8 + i) * 64];
-    block_mma<18>(
-        cur, a0,
-        [&](int s, int part) -> u32x4 { return (s < 16) ? (part ? bl[s & 15] : bh[s & 15]) : de4[2 * part + (s & 1)]; },
+    cur.m = pre.bias;
+    const unsigned next_bias = seq_bias_off(ld, ld.j + 1);
+    Pre nxt;
+    block_mma<18, kBar>(
+        cur, pre, ld.slot_cur + ld.lane_off, ld,
+        [&](int s, int part) -> u32x4 {
+          return (s < 16) ? (part ? bl[s & 15] : bh[s & 15]) : (part ? del[s & 1] : deh[s & 1]);
+        },
         [&](int s) {
-          dma_step(ld, s);
           if (nb > 0) rgb_step<kConvStep0>(s, pend, aux + hx::kAuxRgbW + 32 * (nb - 1), h, rgb);
+        },
+        [&](int k) {
+          if (nb < 3) prefetch_next_chunk(nxt, k, ld, next_bias, h);
         });
     pend = cur;
-    ld.q += 1;
+    pre = nxt;
+    loader_advance(ld);
   }
 #pragma unroll
   for (int s = 0; s < 8; ++s) rgb_step<0>(s, pend, aux + hx::kAuxRgbW + 32 * 3, h, rgb);
