@@ -66,6 +66,16 @@ def cpu_baseline(sd_c, sd_f, rays_cpu: torch.Tensor, target_s: float = 15.0):
             "sample": f"{n} rays of the same frame (middle rows), torch-CPU oracle, fp32, {dt:.1f} s"}, out, n
 
 
+def measured_traffic(precision: str):
+    """HBM bytes per fine-pass MLP launch from the committed PMC passes (profiles/r1_traffic.json:
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024, gfx950 correction); None if the file is absent."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r1_traffic.json")) as f:
+            return json.load(f)[precision]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,7 +155,8 @@ def main():
             "achieved_tflops_whole_path": value * FLOP_PER_RAY / 1e12,
             "roofline": {"bound": "mfma", "kernel": "mlp kernel, fine pass (190,512 rays x 128 samples)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "launch_ms": fine_avg, "coarse_launch_ms": sum(coarse_ms) / len(coarse_ms),
+                         "traffic": measured_traffic(args.precision), "traffic_unit": "bytes/launch (PMC, profiles/r1_traffic.json)",
+                         "launch_ms": fine_avg, "coarse_launch_ms": sum(coarse_ms) / len(coarse_ms),
                          "flop_per_launch": fine_flop,
                          "note": ("achieved counts ALGORITHMIC flops (2 x 593,408 MAC per point); f16x3 issues 3 MFMAs "
                                   "per product, so its matrix pipe is busy for 3x this figure"

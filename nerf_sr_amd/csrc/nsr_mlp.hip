@@ -107,10 +107,27 @@ extern "C" int nsr_pack_weights(const float* const* w, void* packed_dev, int pre
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-// one wave-instruction: 64 lanes x 16 B, global -> LDS (dst = wave-uniform base + lane*16)
-__device__ __forceinline__ void glds16(const float* gsrc_lane, float* lds_base_wave) {
-  __builtin_amdgcn_global_load_lds((glb_ptr_t)gsrc_lane, (lds_ptr_t)lds_base_wave, 16, 0, 0);
+// LDS byte address (32-bit) of a __shared__ object
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)((const __attribute__((address_space(3))) char*)p);
 }
+
+// One wave-instruction: 64 lanes x 16 B, global -> LDS (dst = wave-uniform M0 + OFF + lane*16), issued from
+// inline asm with a wave-uniform 64-bit base + one 32-bit lane offset.  Why not
+// __builtin_amdgcn_global_load_lds: with an LDS-DMA in flight hipcc's waitcnt pass waits lgkmcnt(0) before
+// every MFMA group (see nsr_mlp_f16.hip); the asm form is invisible to it and is drained by hand
+// (dma_drain) right before the barrier that publishes the chunk.
+template <int OFF>
+__device__ __forceinline__ void glds16_asm(const char* base_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1 offset:%3"
+      :
+      : "v"(lane_off), "s"(base_uniform), "s"(lds_dst_uniform), "i"(OFF)
+      : "memory");
+}
+__device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 struct Stream {
   const float* base;   // packed stream
@@ -118,12 +135,19 @@ struct Stream {
   int q_end;           // chunks in this launch's stream
 };
 
-// enqueue chunk `q` into ring slot `buf` (each wave moves 8 of the 32 pieces)
+// enqueue chunk `q` into ring slot `ring_slot`: each wave moves a contiguous quarter (8 pieces = 8 KiB)
 __device__ __forceinline__ void issue_chunk(const float* stream, int q, float* ring_slot, int wave, int lane) {
-  const float* src = stream + (size_t)q * (kChunkBytes / 4) + wave * 8 * 256 + lane * 4;
-  float* dst = ring_slot + wave * 8 * 256;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) glds16(src + i * 256, dst + i * 256);
+  const char* src = reinterpret_cast<const char*>(stream) + (size_t)q * kChunkBytes + wave * 8192;
+  const unsigned dst = lds_addr(ring_slot) + (unsigned)wave * 8192u;
+  const unsigned lane_off = (unsigned)lane * 16u;
+  glds16_asm<0>(src, lane_off, dst);
+  glds16_asm<1024>(src, lane_off, dst);
+  glds16_asm<2048>(src, lane_off, dst);
+  glds16_asm<3072>(src, lane_off, dst);
+  glds16_asm<0>(src + 4096, lane_off, dst + 4096u);
+  glds16_asm<1024>(src + 4096, lane_off, dst + 4096u);
+  glds16_asm<2048>(src + 4096, lane_off, dst + 4096u);
+  glds16_asm<3072>(src + 4096, lane_off, dst + 4096u);
 }
 
 // Consume one segment of the stream: acc[nb] += W_seg(nb, :) * B, B = b[0..STEPS-1].
@@ -139,6 +163,7 @@ __device__ __forceinline__ void run_segment(f32x16 (&acc)[NB], const float (&b)[
   for (int c = 0; c < kChunks; ++c) {
     // chunk st.q has been in flight for a whole chunk time: drain + make it visible to all waves;
     // the same barrier proves every wave is done reading the other slot.
+    dma_drain();
     __syncthreads();
     if (st.q + 1 < st.q_end) issue_chunk(st.base, st.q + 1, ring + ((c + 1) & 1) * (kChunkBytes / 4), wave, lane);
     const f32x4* buf = reinterpret_cast<const f32x4*>(ring + (c & 1) * (kChunkBytes / 4));

@@ -227,8 +227,12 @@ __device__ __forceinline__ void loader_advance(Loader& ld) {
 
 // the publish point of chunk j+1 (see protocol above), then start fetching chunk j+2
 __device__ __forceinline__ void loader_publish(Loader& ld) {
+#ifndef NSR_ABL_NO_DRAIN
   dma_drain();
+#endif
+#ifndef NSR_ABL_NO_BARRIER
   __syncthreads();
+#endif
   loader_prepare_dma(ld, ld.j + 2, ld.slot_free);
 }
 

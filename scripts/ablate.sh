@@ -1,7 +1,7 @@
 #!/bin/bash
 # time the fine-pass MLP for each ablation library (development aid)
 R=${GRAFT_REPO_ROOT:-$PWD}
-for v in "" _B _C _D _F; do
+for v in "" _nodrain _nobar _nodrainbar _nodma _noconv; do
   NSR_LIB_PATH=$R/nerf_sr_amd/libnsr$v.so python - <<PY
 import sys, time, torch
 sys.path.insert(0, "$R")
