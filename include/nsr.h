@@ -18,6 +18,10 @@
  *     no global mutable state: re-entrant from any number of host threads
  *     (one per GPU under nn.DataParallel, models/networks.py:67).
  *   - the device is the caller's current HIP device (hipSetDevice).
+ *   - ray records: `rays` is (R, ray_stride) fp32 with ray_stride = 8: [o(3), d(3), near, far], the encoded
+ *     view direction is d (nerf_downX, models/nerf_downX_model.py:282-286); or ray_stride = 11: the vanilla
+ *     model's rows with the view direction in columns 8:11 (models/nerf_model.py:209-213).  8-wide rows
+ *     must be 16-byte aligned.
  *   - fixed architecture of the path: D=8, W=256, skips=[4], deg_pos=10,
  *     deg_dir=4, dim_pos=dim_dir=dim_rgb=3 (models/networks.py:124-126,
  *     models/nerf_model.py:52-57) — the only one the reference's scripts use.
@@ -91,7 +95,7 @@ int nsr_posenc(const float* x, int64_t n, int deg, float* out, void* stream);
  * u == NULL: deterministic (eval) depths; u (R,n_samples): the uniform numbers
  * the reference draws with torch.rand_like (randomized=True branch).
  * z (R,n_samples); pts (R,n_samples,3) or NULL to skip cast_rays (utils.py:5-14). */
-int nsr_sample_along_rays(const float* rays, int64_t R, int n_samples, int lindisp, const float* u,
+int nsr_sample_along_rays(const float* rays, int ray_stride, int64_t R, int n_samples, int lindisp, const float* u,
                           float* z, float* pts, void* stream);
 
 /* ---- M1: the NeRF MLP --------------------------------------------------------
@@ -103,8 +107,8 @@ int nsr_mlp_forward(const void* packed_dev, int precision, const float* x, int64
  * fused with cast_rays and both positional encodings: rays (R,8), z (R,N) ->
  * out (R*N, 4) = [rgb, sigma_raw] per sample point; the (P,90) matrix is never
  * materialised. */
-int nsr_render_rays(const void* packed_dev, int precision, const float* rays, const float* z, int64_t R,
-                    int n_samples, float* out, void* stream);
+int nsr_render_rays(const void* packed_dev, int precision, const float* rays, int ray_stride, const float* z,
+                    int64_t R, int n_samples, float* out, void* stream);
 
 /* ---- V1: volumetric compositing ------------------------------------------------
  * Replaces VolumetricRenderer.forward (models/rendering.py:75-111).
@@ -120,8 +124,8 @@ int nsr_composite(const float* rgb, int rgb_stride, const float* sigma, int sigm
  * Replaces resample_along_rays (models/utils.py:47-95).  z (R,Nc), weights (R,Nc),
  * u == NULL: linspace(0,1,Ni) (eval) else u (R,Ni) (randomized).  z_out (R,Nc+Ni)
  * sorted; pts (R,Nc+Ni,3) or NULL (needs rays when non-NULL). */
-int nsr_resample_along_rays(const float* rays, const float* z, const float* weights, int64_t R, int n_coarse,
-                            int n_importance, const float* u, float* z_out, float* pts, void* stream);
+int nsr_resample_along_rays(const float* rays, int ray_stride, const float* z, const float* weights, int64_t R,
+                            int n_coarse, int n_importance, const float* u, float* z_out, float* pts, void* stream);
 
 /* ---- D3: forward_rays, fused driver ----------------------------------------------
  * Replaces NeRFDownXModel.forward_rays / forward in eval mode
@@ -134,7 +138,7 @@ int nsr_resample_along_rays(const float* rays, const float* z, const float* weig
  * workspace: device scratch of nsr_forward_rays_workspace_bytes() bytes. */
 size_t nsr_forward_rays_workspace_bytes(int64_t R, int n_coarse, int n_importance);
 int nsr_forward_rays(const void* packed_coarse, const void* packed_fine, int precision, const float* rays,
-                     int64_t R, int n_coarse, int n_importance, int white_bkgd, int lindisp,
+                     int ray_stride, int64_t R, int n_coarse, int n_importance, int white_bkgd, int lindisp,
                      float* const* outs, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Same as nsr_forward_rays, plus HIP-event instrumentation for benchmarks: `events` is a HOST
@@ -142,7 +146,7 @@ int nsr_forward_rays(const void* packed_coarse, const void* packed_fine, int pre
  * MLP launch ([0],[1]) and the fine MLP launch ([2],[3]) — the kernels that carry >99 % of the
  * path's FLOPs — so that a harness can read per-launch durations without a profiler. */
 int nsr_forward_rays_profiled(const void* packed_coarse, const void* packed_fine, int precision, const float* rays,
-                              int64_t R, int n_coarse, int n_importance, int white_bkgd, int lindisp,
+                              int ray_stride, int64_t R, int n_coarse, int n_importance, int white_bkgd, int lindisp,
                               float* const* outs, void* workspace, size_t workspace_bytes, void* stream,
                               void* const* events);
 /* Thin wrappers over hipEventCreate / hipEventDestroy / hipEventSynchronize+hipEventElapsedTime so a

@@ -25,17 +25,17 @@ SIGNATURES = {
     "nsr_pack_weights": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p]),
     "nsr_gen_rays": (c_int, [POINTER(c_float), c_int, c_int, c_double, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
     "nsr_posenc": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
-    "nsr_sample_along_rays": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nsr_sample_along_rays": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsr_mlp_forward": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
-    "nsr_render_rays": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "nsr_render_rays": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "nsr_composite": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "nsr_resample_along_rays": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
+    "nsr_resample_along_rays": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_void_p]),
     "nsr_forward_rays_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
-    "nsr_forward_rays": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+    "nsr_forward_rays": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int,
                                  POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
-    "nsr_forward_rays_profiled": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+    "nsr_forward_rays_profiled": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int,
                                           POINTER(c_void_p), c_void_p, c_size_t, c_void_p, POINTER(c_void_p)]),
     "nsr_event_create": (c_int, [POINTER(c_void_p)]),
     "nsr_event_destroy": (c_int, [c_void_p]),

@@ -48,16 +48,16 @@ extern "C" int nsr_event_elapsed_ms(void* start, void* stop, float* ms_out) {
 }
 
 extern "C" int nsr_forward_rays(const void* packed_coarse, const void* packed_fine, int precision, const float* rays,
-                                int64_t R, int n_coarse, int n_importance, int white_bkgd, int lindisp,
+                                int ray_stride, int64_t R, int n_coarse, int n_importance, int white_bkgd, int lindisp,
                                 float* const* outs, void* workspace, size_t workspace_bytes, void* stream) {
-  return nsr_forward_rays_profiled(packed_coarse, packed_fine, precision, rays, R, n_coarse, n_importance, white_bkgd,
-                                   lindisp, outs, workspace, workspace_bytes, stream, nullptr);
+  return nsr_forward_rays_profiled(packed_coarse, packed_fine, precision, rays, ray_stride, R, n_coarse, n_importance,
+                                   white_bkgd, lindisp, outs, workspace, workspace_bytes, stream, nullptr);
 }
 
 extern "C" int nsr_forward_rays_profiled(const void* packed_coarse, const void* packed_fine, int precision,
-                                         const float* rays, int64_t R, int n_coarse, int n_importance, int white_bkgd,
-                                         int lindisp, float* const* outs, void* workspace, size_t workspace_bytes,
-                                         void* stream, void* const* events) {
+                                         const float* rays, int ray_stride, int64_t R, int n_coarse, int n_importance,
+                                         int white_bkgd, int lindisp, float* const* outs, void* workspace,
+                                         size_t workspace_bytes, void* stream, void* const* events) {
   hipStream_t st = nsr_stream(stream);
   auto mark = [&](int i) {
     if (events && events[i]) (void)hipEventRecord(static_cast<hipEvent_t>(events[i]), st);
@@ -80,11 +80,11 @@ extern "C" int nsr_forward_rays_profiled(const void* packed_coarse, const void* 
   }
   int rc;
   // S1: coarse depths
-  rc = nsr_sample_along_rays(rays, R, n_coarse, lindisp, nullptr, z_c, nullptr, stream);
+  rc = nsr_sample_along_rays(rays, ray_stride, R, n_coarse, lindisp, nullptr, z_c, nullptr, stream);
   if (rc != NSR_OK) return rc;
   // D2+M1: coarse network at every sample
   mark(0);
-  rc = nsr_render_rays(packed_coarse, precision, rays, z_c, R, n_coarse, raw_c, stream);
+  rc = nsr_render_rays(packed_coarse, precision, rays, ray_stride, z_c, R, n_coarse, raw_c, stream);
   mark(1);
   if (rc != NSR_OK) return rc;
   // V1: coarse compositing (weights are needed by the resampler even if the caller does not want them)
@@ -93,11 +93,11 @@ extern "C" int nsr_forward_rays_profiled(const void* packed_coarse, const void* 
   if (rc != NSR_OK) return rc;
   if (n_importance == 0) return NSR_OK;
   // S2: importance resampling + merge
-  rc = nsr_resample_along_rays(rays, z_c, w_c, R, n_coarse, n_importance, nullptr, z_f, nullptr, stream);
+  rc = nsr_resample_along_rays(rays, ray_stride, z_c, w_c, R, n_coarse, n_importance, nullptr, z_f, nullptr, stream);
   if (rc != NSR_OK) return rc;
   // fine network + compositing
   mark(2);
-  rc = nsr_render_rays(packed_fine, precision, rays, z_f, R, n_coarse + n_importance, raw_f, stream);
+  rc = nsr_render_rays(packed_fine, precision, rays, ray_stride, z_f, R, n_coarse + n_importance, raw_f, stream);
   mark(3);
   if (rc != NSR_OK) return rc;
   rc = nsr_composite(raw_f, 4, raw_f + 3, 4, z_f, R, n_coarse + n_importance, white_bkgd, outs[4], outs[5], outs[6],

@@ -31,6 +31,28 @@ __device__ __forceinline__ float nsr_coarse_z(float near_, float far_, float t, 
   return __fadd_rn(__fmul_rn(near_, __fsub_rn(1.0f, t)), __fmul_rn(far_, t));
 }
 
+// ---- ray records.  stride 8: [o(3), d(3), near, far] (nerf_downX: the view direction that is encoded IS d,
+// models/nerf_downX_model.py:282-286); stride 11: the vanilla model's rows with a separate view direction in
+// columns 8:11 (models/nerf_model.py:209-213, data/llff_dataset.py:337-341).
+struct NsrRay {
+  float o[3], d[3], near_, far_, v[3];
+};
+__device__ __forceinline__ NsrRay nsr_load_ray(const float* __restrict__ rays, int64_t r, int stride) {
+  NsrRay q;
+  const float* p = rays + r * stride;
+  if (stride == 8) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0];
+    const float4 b = reinterpret_cast<const float4*>(p)[1];
+    q.o[0] = a.x; q.o[1] = a.y; q.o[2] = a.z; q.d[0] = a.w; q.d[1] = b.x; q.d[2] = b.y; q.near_ = b.z; q.far_ = b.w;
+    q.v[0] = q.d[0]; q.v[1] = q.d[1]; q.v[2] = q.d[2];
+  } else {
+    q.o[0] = p[0]; q.o[1] = p[1]; q.o[2] = p[2]; q.d[0] = p[3]; q.d[1] = p[4]; q.d[2] = p[5];
+    q.near_ = p[6]; q.far_ = p[7]; q.v[0] = p[8]; q.v[1] = p[9]; q.v[2] = p[10];
+  }
+  return q;
+}
+static inline bool nsr_ray_stride_ok(int stride) { return stride == 8 || stride == 11; }
+
 // ---- wave64 reductions / scans (DPP-free, shuffle based) -------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -71,8 +71,8 @@ extern "C" size_t nsr_f16x3_packed_bytes(void);
 extern "C" int nsr_f16x3_pack(const float* const* w, void* packed_dev, void* stream);
 extern "C" int nsr_f16x3_mlp_forward(const void* packed, const float* x, int64_t P, int sigma_only, float* out,
                                      void* stream);
-extern "C" int nsr_f16x3_render_rays(const void* packed, const float* rays, const float* z, int64_t R, int N,
-                                     float* out, void* stream);
+extern "C" int nsr_f16x3_render_rays(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
+                                     int N, float* out, void* stream);
 
 extern "C" size_t nsr_packed_weights_bytes(int precision) {
   if (precision == NSR_FP32) return sizeof(float) * (size_t)(kStreamFloats + kAuxFloats);
@@ -218,7 +218,7 @@ __device__ __forceinline__ float half_dot(const float (&v)[16 * NB], const float
 template <int MODE, bool SIGMA_ONLY>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ zv,
-                int64_t P, int N, float* __restrict__ out) {
+                int64_t P, int N, int stride, float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) float ring[2 * kChunkBytes / 4];   // 64 KiB
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -249,13 +249,12 @@ mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, c
     }
   } else {
     const int64_t ray = pc / N;
-    const float4 ra = reinterpret_cast<const float4*>(x + ray * 8)[0];
-    const float4 rb = reinterpret_cast<const float4*>(x + ray * 8)[1];
+    const NsrRay rq = nsr_load_ray(x, ray, stride);
     const float zk = zv[pc];
-    const float d[3] = {ra.w, rb.x, rb.y};
+    const float d[3] = {rq.v[0], rq.v[1], rq.v[2]};           // the direction that is ENCODED
     // cast_rays (models/utils.py:14): o + z*d, separate multiply and add as ATen does
-    const float v[3] = {__fadd_rn(ra.x, __fmul_rn(zk, d[0])), __fadd_rn(ra.y, __fmul_rn(zk, d[1])),
-                        __fadd_rn(ra.z, __fmul_rn(zk, d[2]))};
+    const float v[3] = {__fadd_rn(rq.o[0], __fmul_rn(zk, rq.d[0])), __fadd_rn(rq.o[1], __fmul_rn(zk, rq.d[1])),
+                        __fadd_rn(rq.o[2], __fmul_rn(zk, rq.d[2]))};
     pe[0] = h ? v[2] : v[0];
     pe[1] = h ? 0.0f : v[1];
 #pragma unroll
@@ -358,26 +357,26 @@ extern "C" int nsr_mlp_forward(const void* packed_dev, int precision, const floa
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   const float* pk = static_cast<const float*>(packed_dev);
   if (sigma_only)
-    hipLaunchKernelGGL((mlp_fp32_kernel<0, true>), grid, block, 0, nsr_stream(stream), pk, x, nullptr, P, 1, out);
+    hipLaunchKernelGGL((mlp_fp32_kernel<0, true>), grid, block, 0, nsr_stream(stream), pk, x, nullptr, P, 1, 8, out);
   else
-    hipLaunchKernelGGL((mlp_fp32_kernel<0, false>), grid, block, 0, nsr_stream(stream), pk, x, nullptr, P, 1, out);
+    hipLaunchKernelGGL((mlp_fp32_kernel<0, false>), grid, block, 0, nsr_stream(stream), pk, x, nullptr, P, 1, 8, out);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
 
-extern "C" int nsr_render_rays(const void* packed_dev, int precision, const float* rays, const float* z, int64_t R,
-                               int n_samples, float* out, void* stream) {
-  if (!packed_dev || R < 0 || n_samples <= 0) return NSR_ERR_INVALID_ARG;
+extern "C" int nsr_render_rays(const void* packed_dev, int precision, const float* rays, int ray_stride, const float* z,
+                               int64_t R, int n_samples, float* out, void* stream) {
+  if (!packed_dev || R < 0 || n_samples <= 0 || !nsr_ray_stride_ok(ray_stride)) return NSR_ERR_INVALID_ARG;
   if (precision != NSR_FP32 && precision != NSR_F16X3) return NSR_ERR_UNSUPPORTED;
   if (R == 0) return NSR_OK;
   if (!rays || !z || !out) return NSR_ERR_INVALID_ARG;
-  if ((reinterpret_cast<uintptr_t>(out) & 15) != 0 || (reinterpret_cast<uintptr_t>(rays) & 15) != 0)
+  if ((reinterpret_cast<uintptr_t>(out) & 15) != 0 || (ray_stride == 8 && (reinterpret_cast<uintptr_t>(rays) & 15) != 0))
     return NSR_ERR_INVALID_ARG;
-  if (precision == NSR_F16X3) return nsr_f16x3_render_rays(packed_dev, rays, z, R, n_samples, out, stream);
+  if (precision == NSR_F16X3) return nsr_f16x3_render_rays(packed_dev, rays, ray_stride, z, R, n_samples, out, stream);
   const int64_t P = R * n_samples;
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   hipLaunchKernelGGL((mlp_fp32_kernel<1, false>), grid, block, 0, nsr_stream(stream),
-                     static_cast<const float*>(packed_dev), rays, z, P, n_samples, out);
+                     static_cast<const float*>(packed_dev), rays, z, P, n_samples, ray_stride, out);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }

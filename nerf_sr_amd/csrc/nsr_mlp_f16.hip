@@ -472,7 +472,7 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
 template <int MODE, bool SIGMA_ONLY, int NS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ zv,
-                 int64_t P, int N, float* __restrict__ out) {
+                 int64_t P, int N, int stride, float* __restrict__ out) {
   // 3 x 41 KiB weight ring + per-wave stash of the encoded position (8 fragments x 64 lanes x 16 B = 8 KiB
   // per wave) + the colour-head block (rgb weights and bias, 448 floats): 160,512 B of the CU's 160 KiB
   constexpr int kStash0 = 3 * kSlotFloats, kAux0 = kStash0 + 4 * 8 * 256;
@@ -519,12 +519,11 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     }
   } else {
     const int64_t ray = pc / ((NS > 0) ? NS : N);
-    const float4 ra = reinterpret_cast<const float4*>(x + ray * 8)[0];
-    const float4 rb = reinterpret_cast<const float4*>(x + ray * 8)[1];
+    const NsrRay rq = nsr_load_ray(x, ray, stride);
     const float zk = zv[pc];
-    const float d[3] = {ra.w, rb.x, rb.y};
-    const float v[3] = {__fadd_rn(ra.x, __fmul_rn(zk, d[0])), __fadd_rn(ra.y, __fmul_rn(zk, d[1])),
-                        __fadd_rn(ra.z, __fmul_rn(zk, d[2]))};
+    const float d[3] = {rq.v[0], rq.v[1], rq.v[2]};           // the direction that is ENCODED
+    const float v[3] = {__fadd_rn(rq.o[0], __fmul_rn(zk, rq.d[0])), __fadd_rn(rq.o[1], __fmul_rn(zk, rq.d[1])),
+                        __fadd_rn(rq.o[2], __fmul_rn(zk, rq.d[2]))};
     pe[0] = h ? v[2] : v[0];
     pe[1] = h ? 0.0f : v[1];
 #pragma unroll
@@ -696,27 +695,27 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
 }
 
 template <int MODE, bool SIGMA_ONLY>
-static int launch_f16x3(const void* packed, const float* x, const float* z, int64_t P, int N, float* out,
+static int launch_f16x3(const void* packed, const float* x, const float* z, int64_t P, int N, int stride, float* out,
                         hipStream_t st) {
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   const float* pk = static_cast<const float*>(packed);
   if (MODE == 1 && N == 64)
-    hipLaunchKernelGGL((mlp_f16x3_kernel<MODE, SIGMA_ONLY, 64>), grid, block, 0, st, pk, x, z, P, N, out);
+    hipLaunchKernelGGL((mlp_f16x3_kernel<MODE, SIGMA_ONLY, 64>), grid, block, 0, st, pk, x, z, P, N, stride, out);
   else if (MODE == 1 && N == 128)
-    hipLaunchKernelGGL((mlp_f16x3_kernel<MODE, SIGMA_ONLY, 128>), grid, block, 0, st, pk, x, z, P, N, out);
+    hipLaunchKernelGGL((mlp_f16x3_kernel<MODE, SIGMA_ONLY, 128>), grid, block, 0, st, pk, x, z, P, N, stride, out);
   else
-    hipLaunchKernelGGL((mlp_f16x3_kernel<MODE, SIGMA_ONLY, 0>), grid, block, 0, st, pk, x, z, P, N, out);
+    hipLaunchKernelGGL((mlp_f16x3_kernel<MODE, SIGMA_ONLY, 0>), grid, block, 0, st, pk, x, z, P, N, stride, out);
   if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
   return NSR_OK;
 }
 
 extern "C" int nsr_f16x3_mlp_forward(const void* packed, const float* x, int64_t P, int sigma_only, float* out,
                                      void* stream) {
-  return sigma_only ? launch_f16x3<0, true>(packed, x, nullptr, P, 1, out, nsr_stream(stream))
-                    : launch_f16x3<0, false>(packed, x, nullptr, P, 1, out, nsr_stream(stream));
+  return sigma_only ? launch_f16x3<0, true>(packed, x, nullptr, P, 1, 8, out, nsr_stream(stream))
+                    : launch_f16x3<0, false>(packed, x, nullptr, P, 1, 8, out, nsr_stream(stream));
 }
 
-extern "C" int nsr_f16x3_render_rays(const void* packed, const float* rays, const float* z, int64_t R, int N,
-                                     float* out, void* stream) {
-  return launch_f16x3<1, false>(packed, rays, z, R * N, N, out, nsr_stream(stream));
+extern "C" int nsr_f16x3_render_rays(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
+                                     int N, float* out, void* stream) {
+  return launch_f16x3<1, false>(packed, rays, z, R * N, N, ray_stride, out, nsr_stream(stream));
 }

@@ -118,16 +118,15 @@ extern "C" int nsr_posenc(const float* x, int64_t n, int deg, float* out, void* 
 // ---------------------------------------------------------------------------
 // S1  (reference: models/utils.py:5-44)
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) sample_kernel(const float* __restrict__ rays, int64_t R, int N, int lindisp,
+__global__ void __launch_bounds__(256) sample_kernel(const float* __restrict__ rays, int stride, int64_t R, int N, int lindisp,
                                                      const float* __restrict__ u, float* __restrict__ z,
                                                      float* __restrict__ pts) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= R * N) return;
   const int64_t r = idx / N;
   const int k = (int)(idx - r * N);
-  const float4 a = reinterpret_cast<const float4*>(rays + r * 8)[0];
-  const float4 b = reinterpret_cast<const float4*>(rays + r * 8)[1];
-  const float near_ = b.z, far_ = b.w;
+  const NsrRay q = nsr_load_ray(rays, r, stride);
+  const float near_ = q.near_, far_ = q.far_;
   float zk = nsr_coarse_z(near_, far_, nsr_linspace01(k, N), lindisp);
   if (u != nullptr) {
     // per-bin jitter: lower + u * (upper - lower)   (utils.py:37-41)
@@ -139,21 +138,21 @@ __global__ void __launch_bounds__(256) sample_kernel(const float* __restrict__ r
   }
   z[idx] = zk;
   if (pts != nullptr) {
-    pts[idx * 3 + 0] = __fadd_rn(a.x, __fmul_rn(zk, a.w));
-    pts[idx * 3 + 1] = __fadd_rn(a.y, __fmul_rn(zk, b.x));
-    pts[idx * 3 + 2] = __fadd_rn(a.z, __fmul_rn(zk, b.y));
+    pts[idx * 3 + 0] = __fadd_rn(q.o[0], __fmul_rn(zk, q.d[0]));
+    pts[idx * 3 + 1] = __fadd_rn(q.o[1], __fmul_rn(zk, q.d[1]));
+    pts[idx * 3 + 2] = __fadd_rn(q.o[2], __fmul_rn(zk, q.d[2]));
   }
 }
 
-extern "C" int nsr_sample_along_rays(const float* rays, int64_t R, int n_samples, int lindisp, const float* u,
-                                     float* z, float* pts, void* stream) {
-  if (R < 0 || n_samples <= 0) return NSR_ERR_INVALID_ARG;
+extern "C" int nsr_sample_along_rays(const float* rays, int ray_stride, int64_t R, int n_samples, int lindisp,
+                                     const float* u, float* z, float* pts, void* stream) {
+  if (R < 0 || n_samples <= 0 || !nsr_ray_stride_ok(ray_stride)) return NSR_ERR_INVALID_ARG;
   if (R == 0) return NSR_OK;
-  if (!rays || !z || (reinterpret_cast<uintptr_t>(rays) & 15) != 0) return NSR_ERR_INVALID_ARG;
+  if (!rays || !z || (ray_stride == 8 && (reinterpret_cast<uintptr_t>(rays) & 15) != 0)) return NSR_ERR_INVALID_ARG;
   const int64_t total = R * n_samples;
   const int threads = 256;
   hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0,
-                     nsr_stream(stream), rays, R, n_samples, lindisp, u, z, pts);
+                     nsr_stream(stream), rays, ray_stride, R, n_samples, lindisp, u, z, pts);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }

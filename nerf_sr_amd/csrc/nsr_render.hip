@@ -117,7 +117,8 @@ extern "C" int nsr_composite(const float* rgb, int rgb_stride, const float* sigm
 // ---------------------------------------------------------------------------
 // S2  (reference: models/utils.py:47-95)
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) resample_kernel(const float* __restrict__ rays, const float* __restrict__ z,
+__global__ void __launch_bounds__(256) resample_kernel(const float* __restrict__ rays, int stride,
+                                                       const float* __restrict__ z,
                                                        const float* __restrict__ weights, int64_t R, int Nc, int Ni,
                                                        const float* __restrict__ u, float* __restrict__ z_out,
                                                        float* __restrict__ pts) {
@@ -188,26 +189,25 @@ __global__ void __launch_bounds__(256) resample_kernel(const float* __restrict__
     }
     z_out[r * M + rank] = v;
     if (pts) {
-      const float4 a = reinterpret_cast<const float4*>(rays + r * 8)[0];
-      const float4 b = reinterpret_cast<const float4*>(rays + r * 8)[1];
+      const NsrRay q = nsr_load_ray(rays, r, stride);
       float* p = pts + (r * M + rank) * 3;
-      p[0] = __fadd_rn(a.x, __fmul_rn(v, a.w));
-      p[1] = __fadd_rn(a.y, __fmul_rn(v, b.x));
-      p[2] = __fadd_rn(a.z, __fmul_rn(v, b.y));
+      p[0] = __fadd_rn(q.o[0], __fmul_rn(v, q.d[0]));
+      p[1] = __fadd_rn(q.o[1], __fmul_rn(v, q.d[1]));
+      p[2] = __fadd_rn(q.o[2], __fmul_rn(v, q.d[2]));
     }
   }
 }
 
-extern "C" int nsr_resample_along_rays(const float* rays, const float* z, const float* weights, int64_t R,
-                                       int n_coarse, int n_importance, const float* u, float* z_out, float* pts,
-                                       void* stream) {
-  if (R < 0 || n_coarse < 3 || n_importance <= 0) return NSR_ERR_INVALID_ARG;
+extern "C" int nsr_resample_along_rays(const float* rays, int ray_stride, const float* z, const float* weights,
+                                       int64_t R, int n_coarse, int n_importance, const float* u, float* z_out,
+                                       float* pts, void* stream) {
+  if (R < 0 || n_coarse < 3 || n_importance <= 0 || !nsr_ray_stride_ok(ray_stride)) return NSR_ERR_INVALID_ARG;
   if (n_coarse > NSR_RS_MAX || n_importance > NSR_RS_MAX) return NSR_ERR_UNSUPPORTED;
   if (R == 0) return NSR_OK;
   if (!z || !weights || !z_out) return NSR_ERR_INVALID_ARG;
-  if (pts && (!rays || (reinterpret_cast<uintptr_t>(rays) & 15) != 0)) return NSR_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, nsr_stream(stream), rays, z,
-                     weights, R, n_coarse, n_importance, u, z_out, pts);
+  if (pts && (!rays || (ray_stride == 8 && (reinterpret_cast<uintptr_t>(rays) & 15) != 0))) return NSR_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, nsr_stream(stream), rays,
+                     ray_stride, z, weights, R, n_coarse, n_importance, u, z_out, pts);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }

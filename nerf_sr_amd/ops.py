@@ -41,6 +41,13 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+def _ray_stride(rays: torch.Tensor) -> int:
+    """8: nerf_downX rows [o, d, near, far]; 11: vanilla rows with the view direction in columns 8:11."""
+    if rays.ndim != 2 or rays.shape[1] not in (8, 11):
+        raise ValueError(f"rays must be (R, 8) or (R, 11), got {tuple(rays.shape)}")
+    return int(rays.shape[1])
+
+
 def _pack_rays(ori, dir, near, far) -> torch.Tensor:
     R = ori.shape[0]
     near = near.reshape(R, 1) if isinstance(near, torch.Tensor) else torch.full((R, 1), float(near), device=ori.device)
@@ -112,7 +119,7 @@ def sample_along_rays(ori, dir, near, far, num_samples: int, randomized: bool, l
         u = _f32(u, "u")
     z = torch.empty(R, num_samples, dtype=torch.float32, device=rays.device)
     pts = torch.empty(R, num_samples, 3, dtype=torch.float32, device=rays.device)
-    _lib.check(_lib.load().nsr_sample_along_rays(_p(rays), R, num_samples, int(bool(lindisp)), _p(u), _p(z), _p(pts),
+    _lib.check(_lib.load().nsr_sample_along_rays(_p(rays), 8, R, num_samples, int(bool(lindisp)), _p(u), _p(z), _p(pts),
                                                  _stream()), "nsr_sample_along_rays")
     return z, pts
 
@@ -131,7 +138,7 @@ def resample_along_rays(ori, dir, z_vals, weights, num_samples: int, randomized:
         u = _f32(u, "u")
     z_out = torch.empty(R, Nc + num_samples, dtype=torch.float32, device=z_vals.device)
     pts = torch.empty(R, Nc + num_samples, 3, dtype=torch.float32, device=z_vals.device)
-    _lib.check(_lib.load().nsr_resample_along_rays(_p(rays), _p(z_vals), _p(weights), R, Nc, num_samples, _p(u),
+    _lib.check(_lib.load().nsr_resample_along_rays(_p(rays), 8, _p(z_vals), _p(weights), R, Nc, num_samples, _p(u),
                                                    _p(z_out), _p(pts), _stream()), "nsr_resample_along_rays")
     return z_out, pts
 
@@ -222,8 +229,9 @@ def render_rays(model: VanillaMLP, rays: torch.Tensor, z_vals: torch.Tensor):
     ``(rgbs (R,N,3), sigmas (R,N))`` as views of one (R,N,4) buffer."""
     rays, z_vals = _f32(rays, "rays"), _f32(z_vals, "z_vals")
     R, N = z_vals.shape
+    stride = _ray_stride(rays)
     raw = torch.empty(R, N, 4, dtype=torch.float32, device=rays.device)
-    _lib.check(_lib.load().nsr_render_rays(_p(model.packed), model._prec, _p(rays), _p(z_vals), R, N, _p(raw),
+    _lib.check(_lib.load().nsr_render_rays(_p(model.packed), model._prec, _p(rays), stride, _p(z_vals), R, N, _p(raw),
                                            _stream()), "nsr_render_rays")
     return raw[..., :3], raw[..., 3]
 
@@ -237,11 +245,14 @@ def forward_rays(coarse: VanillaMLP, fine: Optional[VanillaMLP], rays: torch.Ten
                  workspace: Optional[torch.Tensor] = None, outs: Optional[Dict[str, torch.Tensor]] = None,
                  want_weights: bool = True, events=None) -> Dict[str, torch.Tensor]:
     """Eval-mode forward_rays for the WHOLE batch in one enqueue sequence
-    (models/nerf_downX_model.py:280-324): returns the reference's 8-entry dict.
+    (models/nerf_downX_model.py:280-324; with 11-wide rays: the vanilla model's models/nerf_model.py:207-242):
+    returns the reference's 8-entry dict.
     ``workspace`` / ``outs`` let a caller reuse buffers across frames; ``events`` (4 raw
     hipEvent_t handles from ``HipEvents``) brackets the coarse / fine MLP launches."""
     lib = _lib.load()
-    rays = _f32(rays, "rays").reshape(-1, 8)
+    rays = _f32(rays, "rays")
+    rays = rays.reshape(-1, rays.shape[-1])
+    stride = _ray_stride(rays)
     R = rays.shape[0]
     if N_importance > 0 and fine is None:
         raise ValueError("N_importance > 0 needs the fine network")
@@ -265,7 +276,7 @@ def forward_rays(coarse: VanillaMLP, fine: Optional[VanillaMLP], rays: torch.Ten
     ptrs = (c_void_p * 8)(*[_p(outs.get(k)) for k in OUT_KEYS])
     ev = (c_void_p * 4)(*events) if events is not None else None
     _lib.check(lib.nsr_forward_rays_profiled(_p(coarse.packed), _p(fine.packed) if fine is not None else c_void_p(0),
-                                             coarse._prec, _p(rays), R, N_coarse, N_importance, int(bool(white_bkgd)),
+                                             coarse._prec, _p(rays), stride, R, N_coarse, N_importance, int(bool(white_bkgd)),
                                              int(bool(lindisp)), ptrs, _p(workspace), workspace.numel(), _stream(), ev),
                "nsr_forward_rays")
     return outs

@@ -294,13 +294,14 @@ def forward_rays(sd_coarse, sd_fine, rays: torch.Tensor, n_coarse: int = 64, n_i
 
     Restates ``models/nerf_downX_model.py:280-313`` chunked as ``:316-324``
     (``ray_chunk`` = 4096, ``options/base_options.py:69``).  Ray columns:
-    ``[o(0:3), d(3:6), near(6), far(7)]``.
+    ``[o(0:3), d(3:6), near(6), far(7)]``; 11-wide rows are the vanilla model's
+    (``models/nerf_model.py:207-242``): the encoded view direction is columns 8:11.
     """
     outs = []
     for i in range(0, rays.shape[0], ray_chunk):
         r = rays[i:i + ray_chunk]
         o, d, near, far = r[:, 0:3], r[:, 3:6], r[:, 6:7], r[:, 7:8]
-        de = posenc(d, 4)
+        de = posenc(r[:, 8:11] if r.shape[1] == 11 else d, 4)
         z, xyz = sample_coarse(o, d, near, far, n_coarse, lindisp)
         rgb, sig = render_points(sd_coarse, xyz, de)
         c_rgb, c_depth, c_op, c_w = composite(rgb, sig, z, white_bkgd)

@@ -73,12 +73,13 @@ def np32(t):
     return t.detach().cpu().numpy().astype(np.float32) if t.dtype.is_floating_point else t.detach().cpu().numpy()
 
 
-def build_reference_model(white_bkgd: bool, seed_c: int, seed_f: int, img_wh=(16, 12), downscale=2):
+def build_reference_model(white_bkgd: bool, seed_c: int, seed_f: int, img_wh=(16, 12), downscale=2,
+                          model_name="nerf_downX", dataset_mode="llff_downX"):
     from options.test_options import TestOptions
     from models import create_model
     tmp = tempfile.mkdtemp(prefix="nsr_golden_")
     argv = ["x", "--name", "golden", "--checkpoints_dir", tmp, "--dataset_root", tmp,
-            "--model", "nerf_downX", "--dataset_mode", "llff_downX",
+            "--model", model_name, "--dataset_mode", dataset_mode,
             "--img_wh", str(img_wh[0]), str(img_wh[1]), "--downscale", str(downscale),
             "--N_coarse", "64", "--N_importance", "64"]
     if white_bkgd:
@@ -209,6 +210,23 @@ def main():
         b = torch.from_numpy(f["coarse_comp_rgbs"])
         f["psnr_fine_vs_coarse"] = np.float64(PSNR(opt)(a, b).item())
         np.savez_compressed(os.path.join(HERE, f"path_{tag}.npz"), **f)
+
+    # ------------------------------------------------------------------ vanilla model (config #1 family): 11-wide
+    # rays whose encoded view direction (cols 8:11) differs from the marching direction (cols 3:6)
+    model, opt = build_reference_model(False, seed_c=99, seed_f=100, img_wh=(32, 16), downscale=1,
+                                       model_name="nerf", dataset_mode="llff")
+    gl = np.load(os.path.join(HERE, "path_llff.npz"))
+    r8 = torch.from_numpy(gl["rays"])[:128]
+    gen = torch.Generator().manual_seed(5)
+    vd = torch.nn.functional.normalize(torch.randn(128, 3, generator=gen), dim=-1)
+    r11 = torch.cat([r8, vd], 1).contiguous()
+    model.set_input({"rays": r11[None]})
+    model.forward()
+    v = {"rays": np32(r11), "white_bkgd": False, "seed_coarse": 99, "seed_fine": 100}
+    for k in ("coarse_comp_rgbs", "coarse_depth", "coarse_opacity", "coarse_weights",
+              "fine_comp_rgbs", "fine_depth", "fine_opacity", "fine_weights"):
+        v[k] = np32(getattr(model, f"out_{k}"))
+    np.savez_compressed(os.path.join(HERE, "path_vanilla.npz"), **v)
 
     # ------------------------------------------------------------------ edge cases for V1 / S2
     class _O:  # minimal opt for the renderer

@@ -57,18 +57,19 @@ def test_invalid_arguments_are_rejected_before_any_launch(lib):
     one = c_void_p(16)     # non-null, never dereferenced: validation happens first
     assert lib.nsr_posenc(null, 10, 10, one, null) == -1
     assert lib.nsr_posenc(one, -1, 10, one, null) == -1
-    assert lib.nsr_sample_along_rays(one, 4, 0, 0, null, one, null, null) == -1
+    assert lib.nsr_sample_along_rays(one, 8, 4, 0, 0, null, one, null, null) == -1
+    assert lib.nsr_sample_along_rays(one, 9, 4, 64, 0, null, one, null, null) == -1      # ray_stride must be 8 or 11
     assert lib.nsr_composite(one, 2, one, 1, one, 4, 64, 0, null, null, null, null, null) == -1
     assert lib.nsr_composite(one, 3, one, 1, one, 4, 4096, 0, null, null, null, null, null) == -2
-    assert lib.nsr_resample_along_rays(null, one, one, 4, 2, 64, null, one, null, null) == -1
-    assert lib.nsr_resample_along_rays(null, one, one, 4, 64, 1024, null, one, null, null) == -2
+    assert lib.nsr_resample_along_rays(null, 8, one, one, 4, 2, 64, null, one, null, null) == -1
+    assert lib.nsr_resample_along_rays(null, 8, one, one, 4, 64, 1024, null, one, null, null) == -2
     assert lib.nsr_mlp_forward(null, 0, one, 4, 0, one, null) == -1
     assert lib.nsr_mlp_forward(one, 7, one, 4, 0, one, null) == -2
-    assert lib.nsr_render_rays(one, 0, one, one, 4, 0, one, null) == -1
+    assert lib.nsr_render_rays(one, 0, one, 8, one, 4, 0, one, null) == -1
     assert lib.nsr_sr_mean(one, 4, 0, 3, one, null) == -1
     assert lib.nsr_unflatten(one, 12, 16, 5, 3, one, null) == -1
     outs = (c_void_p * 8)()
-    assert lib.nsr_forward_rays(one, one, 0, one, 4, 64, 64, 0, 0, outs, c_void_p(256), 16, null) == -4
+    assert lib.nsr_forward_rays(one, one, 0, one, 8, 4, 64, 64, 0, 0, outs, c_void_p(256), 16, null) == -4
     # zero-sized work is a no-op success
     assert lib.nsr_posenc(one, 0, 10, one, null) == 0
     assert lib.nsr_composite(one, 3, one, 1, one, 0, 64, 0, null, null, null, null, null) == 0

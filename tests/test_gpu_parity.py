@@ -307,6 +307,20 @@ def test_sharp_field_statistical_parity(ops, fam):
     assert float(e_hip.max()) <= max(3.0 * float(e_ref.max()), 1e-3)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
+def test_vanilla_model_11_wide_rays(ops, golden_dir, prec):
+    """Config #1 family (models/nerf_model.py:207-242): 11-wide rays, view direction in columns 8:11."""
+    g = np.load(os.path.join(golden_dir, "path_vanilla.npz"))
+    net_c = ops.VanillaMLP(precision=prec).load_state_dict(make_state_dict(int(g["seed_coarse"])))
+    net_f = ops.VanillaMLP(precision=prec).load_state_dict(make_state_dict(int(g["seed_fine"])))
+    out = ops.forward_rays(net_c, net_f, _cu(g["rays"]), 64, 64, False)
+    for k in ("coarse_comp_rgbs", "fine_comp_rgbs", "coarse_opacity", "fine_opacity"):
+        _close(out[k], g[k], RGB_TOL)
+    _close(out["fine_depth"], g["fine_depth"], 1e-4)
+    with pytest.raises(ValueError):
+        ops.forward_rays(net_c, net_f, _cu(g["rays"][:, :9]), 64, 64, False)
+
+
 # ------------------------------------------------------------------------------- split-fp16 MLP path
 @pytest.fixture(scope="module")
 def fam_x3(fam, ops):

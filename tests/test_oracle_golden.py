@@ -83,6 +83,19 @@ def test_forward_rays_and_means(path):
     assert abs(oc.psnr(_t(g["fine_comp_rgbs"]), _t(g["coarse_comp_rgbs"])) - float(g["psnr_fine_vs_coarse"])) < 1e-3
 
 
+def test_vanilla_model_11_wide_rays(golden_dir):
+    """Config #1 family: models/nerf_model.py rows carry the encoded view direction in columns 8:11."""
+    g = np.load(os.path.join(golden_dir, "path_vanilla.npz"))
+    sd_c = oc.to_torch_sd(make_state_dict(int(g["seed_coarse"])))
+    sd_f = oc.to_torch_sd(make_state_dict(int(g["seed_fine"])))
+    out = oc.forward_rays(sd_c, sd_f, _t(g["rays"]), 64, 64, False)
+    for k in ("coarse_comp_rgbs", "coarse_opacity", "fine_comp_rgbs", "fine_depth", "fine_opacity"):
+        _close(out[k], g[k], 5e-6)
+    # the fixture is only meaningful if the view direction matters
+    out8 = oc.forward_rays(sd_c, sd_f, _t(g["rays"][:, :8]), 64, 64, False)
+    assert float((out8["fine_comp_rgbs"] - out["fine_comp_rgbs"]).abs().max()) > 1e-3
+
+
 def test_resample_stage(path):
     g, sd_c, sd_f = path
     rays = _t(g["rays"])
