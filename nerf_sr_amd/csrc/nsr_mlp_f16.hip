@@ -180,7 +180,9 @@ __device__ __forceinline__ int seq_chunk(const Loader& ld, int j) {
 
 __device__ __forceinline__ void loader_prepare_dma(Loader& ld, int j, unsigned slot_lds) {
   const int q = seq_chunk(ld, j);
-  int pieces = 0, piece0 = 0;
+  // past the end of the sequence chunk 0 is re-fetched into the idle slot (32 KiB of dead traffic, twice per
+  // tile) so that the first eight DMA issues of every chunk need no bounds test; the kernel drains before exit
+  int pieces = 32, piece0 = 0;
   if (q >= 0) {
     const Chunk c = chunk_info(q);
     pieces = chunk_pieces(c.steps, c.nnb);
@@ -205,7 +207,7 @@ __device__ __forceinline__ void loader_issue(const Loader& ld, int i) {
 #ifdef NSR_ABL_NO_DMA
   return;
 #endif
-  if (i < ld.dma_count) {
+  if (i < 8 || i < ld.dma_count) {   // every wave owns at least 8 pieces of every chunk
     const char* base = ld.dma_base + (i >> 2) * 4096;
     const unsigned dst = ld.dma_lds + (unsigned)(i >> 2) * 4096u;
     switch (i & 3) {
@@ -334,8 +336,10 @@ struct PairTmp {
 };
 template <int P>
 __device__ __forceinline__ void pair_half_a(const Acc& p, float lower, PairTmp& t, u32x4& h0, u32x4& h1) {
-  t.x0 = fmaxf(p.m[2 * P], lower);
-  t.x1 = fmaxf(p.m[2 * P + 1], lower);
+  // activation = max(x, lower); raw v_max: fmaxf() would add a canonicalising v_max per operand
+  asm volatile("v_max_f32 %0, %2, %4\n\tv_max_f32 %1, %3, %4"
+               : "=&v"(t.x0), "=&v"(t.x1)
+               : "v"(p.m[2 * P]), "v"(p.m[2 * P + 1]), "v"(lower));
 #ifdef NSR_ABL_NO_CONVERT
   t.hi = __float_as_uint(t.x0);
 #else
@@ -351,10 +355,15 @@ __device__ __forceinline__ void pair_half_b(const PairTmp& t, u32x4& l0, u32x4& 
 #ifdef NSR_ABL_NO_CONVERT
   unsigned lo = __float_as_uint(t.x1);
 #else
-  const auto ph = __builtin_bit_cast(decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)), t.hi);
-  unsigned lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(t.x0 - (float)ph[0], t.x1 - (float)ph[1]));
+  // lo = f16(x - hi) for both halves with two mixed-precision FMAs (f16 source half * -1.0 + f32 -> f16 half):
+  // 2 issues instead of unpack x2, subtract x2, pack
+  unsigned lo;
+  asm volatile(
+      "v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(lo)
+      : "v"(t.hi), "v"(t.x0), "v"(t.x1));
 #endif
-  asm volatile("" : "+v"(lo));
   if (P < 4) l0[P & 3] = lo; else l1[P & 3] = lo;
 }
 // half-pair number hp (0..15) of the pending block
@@ -656,6 +665,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   }
   if (SIGMA_ONLY) {
     if (h == 0 && p < P) out[p] = sigma;
+    dma_drain();   // no LDS-DMA may be in flight when the workgroup's LDS is released
     return;
   }
 
@@ -692,6 +702,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     rgb[k] = 1.0f / (1.0f + expf(-s));
   }
   if (h == 0 && p < P) reinterpret_cast<float4*>(out)[p] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
+  dma_drain();     // no LDS-DMA may be in flight when the workgroup's LDS is released
 }
 
 template <int MODE, bool SIGMA_ONLY>
