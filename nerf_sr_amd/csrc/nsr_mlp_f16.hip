@@ -140,6 +140,19 @@ __device__ __forceinline__ void glds16_asm(const char* base_uniform, unsigned la
       : "v"(lane_off), "s"(base_uniform), "s"(lds_dst_uniform), "i"(OFF)
       : "memory");
 }
+// four consecutive pieces with ONE M0 write (6 issue slots instead of 12)
+__device__ __forceinline__ void glds16x4_asm(const char* base_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1\n\t"
+      "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+      "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+      "global_load_lds_dwordx4 %0, %1 offset:3072"
+      :
+      : "v"(lane_off), "s"(base_uniform), "s"(lds_dst_uniform)
+      : "memory");
+}
 __device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---------------------------------------------------------------------------
@@ -157,49 +170,48 @@ __device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" 
 constexpr int kSlotBytes = kSlotFloats * 4;
 constexpr int kBar = 8;
 
+// a chunk of the stream as this wave sees it: where it starts, how many 1 KiB pieces it has, and the
+// contiguous quarter of it this wave moves (all wave-uniform, SGPRs)
+struct ChunkRef {
+  int piece0, pieces;
+  int first, count;
+};
+__device__ __forceinline__ ChunkRef make_ref(int piece0, int pieces, int wave) {
+  ChunkRef c;
+  c.piece0 = piece0;
+  c.pieces = pieces;
+  c.first = (wave * pieces) >> 2;
+  c.count = (((wave + 1) * pieces) >> 2) - c.first;
+  return c;
+}
+// trunk layer L (1..8: L2..L8, xyz_encoding_final), output block nb: chunk ids 2 + 8(L-1) + nb (see chunk_info)
+__device__ __forceinline__ ChunkRef layer_ref(int L, int nb, int wave) {
+  const int pieces = (L == 4) ? 41 : 33;
+  const int base = (L <= 3) ? 66 + 264 * (L - 1) : (L == 4 ? 858 : 1186 + 264 * (L - 5));
+  return make_ref(base + pieces * nb, pieces, wave);
+}
+__device__ __forceinline__ ChunkRef sigma_ref(int wave) { return make_ref(2242, 33, wave); }
+__device__ __forceinline__ ChunkRef dir_ref(int nb, int wave) { return make_ref(2275 + 37 * nb, 37, wave); }
+// past the end of the sequence chunk 0 is re-fetched into the idle slot (32 KiB of dead traffic, twice per
+// tile) so that the first eight DMA issues of every chunk need no bounds test; the kernel drains before exit
+__device__ __forceinline__ ChunkRef end_ref(int wave) { return make_ref(0, 32, wave); }
+
 struct Loader {
   const float* stream;   // packed blob viewed as 32-bit words
-  int j;                 // sequence position of the chunk being CONSUMED
-  int n_seq;             // chunks in this launch's sequence
-  bool skip_final;       // sigma_only launches jump from L8 straight to the density-head chunk
   int wave;
   unsigned lane_off;     // lane * 16
   unsigned slot_cur, slot_next, slot_free;   // LDS byte addresses of the slots of chunks j, j+1, j+2
-  // DMA descriptor of the chunk being fetched.  Each wave moves a contiguous quarter of it (8..11 pieces):
-  // wave-uniform byte address of its first piece, the matching LDS byte address, its piece count
+  // DMA descriptor of the chunk being fetched: wave-uniform byte address of this wave's first piece, the
+  // matching LDS byte address, its piece count
   const char* dma_base;
   unsigned dma_lds;
   int dma_count;
 };
 
-// sequence position -> chunk id (-1 past the end)
-__device__ __forceinline__ int seq_chunk(const Loader& ld, int j) {
-  if (j >= ld.n_seq) return -1;
-  return (ld.skip_final && j >= kChunkFinal0) ? j + (kChunkSigma - kChunkFinal0) : j;
-}
-
-__device__ __forceinline__ void loader_prepare_dma(Loader& ld, int j, unsigned slot_lds) {
-  const int q = seq_chunk(ld, j);
-  // past the end of the sequence chunk 0 is re-fetched into the idle slot (32 KiB of dead traffic, twice per
-  // tile) so that the first eight DMA issues of every chunk need no bounds test; the kernel drains before exit
-  int pieces = 32, piece0 = 0;
-  if (q >= 0) {
-    const Chunk c = chunk_info(q);
-    pieces = chunk_pieces(c.steps, c.nnb);
-    piece0 = c.piece0;
-  }
-  const int first = (ld.wave * pieces) >> 2;
-  ld.dma_count = (((ld.wave + 1) * pieces) >> 2) - first;
-  ld.dma_base = reinterpret_cast<const char*>(ld.stream) + (size_t)(piece0 + first) * 1024;
-  ld.dma_lds = slot_lds + (unsigned)first * 1024u;
-}
-
-// byte offset of the bias piece inside the slot of the chunk at sequence position j
-__device__ __forceinline__ unsigned seq_bias_off(const Loader& ld, int j) {
-  const int q = seq_chunk(ld, j);
-  if (q < 0) return 0u;
-  const Chunk c = chunk_info(q);
-  return (unsigned)(chunk_pieces(c.steps, c.nnb) - 1) * 1024u;
+__device__ __forceinline__ void loader_prepare_dma(Loader& ld, const ChunkRef& c, unsigned slot_lds) {
+  ld.dma_count = c.count;
+  ld.dma_base = reinterpret_cast<const char*>(ld.stream) + (size_t)(c.piece0 + c.first) * 1024;
+  ld.dma_lds = slot_lds + (unsigned)c.first * 1024u;
 }
 
 // issue this wave's DMA piece number i of the chunk being fetched (no-op past its end)
@@ -219,23 +231,30 @@ __device__ __forceinline__ void loader_issue(const Loader& ld, int i) {
   }
 }
 
+// pieces 4g .. 4g+3 of the chunk being fetched, g = 0, 1 (always present)
+__device__ __forceinline__ void loader_issue4(const Loader& ld, int g) {
+#ifdef NSR_ABL_NO_DMA
+  return;
+#endif
+  glds16x4_asm(ld.dma_base + g * 4096, ld.lane_off, ld.dma_lds + (unsigned)g * 4096u);
+}
+
 __device__ __forceinline__ void loader_advance(Loader& ld) {
   const unsigned t = ld.slot_cur;
   ld.slot_cur = ld.slot_next;
   ld.slot_next = ld.slot_free;
   ld.slot_free = t;
-  ld.j += 1;
 }
 
 // the publish point of chunk j+1 (see protocol above), then start fetching chunk j+2
-__device__ __forceinline__ void loader_publish(Loader& ld) {
+__device__ __forceinline__ void loader_publish(Loader& ld, const ChunkRef& c2) {
 #ifndef NSR_ABL_NO_DRAIN
   dma_drain();
 #endif
 #ifndef NSR_ABL_NO_BARRIER
   __syncthreads();
 #endif
-  loader_prepare_dma(ld, ld.j + 2, ld.slot_free);
+  loader_prepare_dma(ld, c2, ld.slot_free);
 }
 
 __device__ __forceinline__ h8 as_h8(const u32x4& v) { return __builtin_bit_cast(h8, v); }
@@ -285,8 +304,8 @@ __device__ __forceinline__ void prefetch_bias(Pre& pre, unsigned bias_addr, int 
 // shadow of k-step s; BAR >= 0 places the chunk's publish point + DMA issue (k-steps BAR..BAR+5);
 // next(k), k = 0..2, runs in the last three k-steps and prefetches the following sequence into `nxt`.
 template <int NSTEP, int BAR, class BOf, class Hook, class Next>
-__device__ __forceinline__ void block_mma(Acc& acc, const Pre& pre, unsigned a_addr, Loader& ld, BOf&& b_of,
-                                          Hook&& hook, Next&& next) {
+__device__ __forceinline__ void block_mma(Acc& acc, const Pre& pre, unsigned a_addr, Loader& ld, const ChunkRef& c2,
+                                          BOf&& b_of, Hook&& hook, Next&& next) {
   static_assert(NSTEP >= kPF, "sequence shorter than the prefetch depth");
   const u32x4* a_pieces = lds_vec(a_addr);
   u32x4 ah[NSTEP], al[NSTEP];
@@ -297,7 +316,7 @@ __device__ __forceinline__ void block_mma(Acc& acc, const Pre& pre, unsigned a_a
   }
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
-    if (s == BAR) loader_publish(ld);
+    if (s == BAR) loader_publish(ld, c2);
     if (s + kPF < NSTEP) {
       ah[s + kPF] = a_pieces[(2 * (s + kPF)) * 64];
       al[s + kPF] = a_pieces[(2 * (s + kPF) + 1) * 64];
@@ -310,6 +329,9 @@ __device__ __forceinline__ void block_mma(Acc& acc, const Pre& pre, unsigned a_a
     acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bl), acc.m, 0, 0, 0);
     acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bh), acc.m, 0, 0, 0);
     hook(s);
+    // DMA of chunk j+2: two pieces per k-step over six k-steps.  (Measured alternatives: bursts of four pieces
+    // sharing one M0 write -7 %: back-to-back LDS-DMA issues hold the wave longer than one MFMA; one piece per
+    // k-step from an earlier publish point (k-step 5) -3 %.)
     if (BAR >= 0 && s >= BAR && s < BAR + 6) {
       loader_issue(ld, 2 * (s - BAR));
       loader_issue(ld, 2 * (s - BAR) + 1);
@@ -437,15 +459,24 @@ __device__ __forceinline__ void prefetch_next_chunk(Pre& nxt, int k, const Loade
 // activated and re-split in the MFMA shadow of the FOLLOWING block's k-steps 0..13.  `pre` carries the
 // prefetched head of the next chunk across chunk (and layer) boundaries.
 __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[16], u32x4 (&oh)[16], u32x4 (&ol)[16],
-                                            const u32x4* stash, Loader& ld, int h, Acc& pend, Pre& pre) {
+                                            const u32x4* stash, Loader& ld, int h, Acc& pend, Pre& pre,
+                                            const ChunkRef& after0, const ChunkRef& after1) {
   const float lower = (L < 8) ? 0.0f : -__builtin_inff();   // relu on L1..L8, none on xyz_encoding_final
+  const ChunkRef ref0 = layer_ref(L, 0, ld.wave);           // this layer's chunks: piece0 advances by `pieces`
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) {
+    // chunks j+1 (prefetched from at the end of this one) and j+2 (DMA'd during this one)
+    ChunkRef c1 = ref0, c2 = ref0;
+    c1.piece0 += ref0.pieces * (nb + 1);
+    c2.piece0 += ref0.pieces * (nb + 2);
+    if (nb == 7) c1 = after0;
+    if (nb == 6) c2 = after0;
+    if (nb == 7) c2 = after1;
     Acc cur;
     cur.m = pre.bias;
     PairTmp ptmp;
     unsigned a_addr = ld.slot_cur + ld.lane_off;
-    const unsigned next_bias = seq_bias_off(ld, ld.j + 1);
+    const unsigned next_bias = (unsigned)(c1.pieces - 1) * 1024u;
     Pre nxt;
     if (L == 4) {
       // skip connection: the encoded position was parked in LDS by the prologue (8 fragments per lane);
@@ -455,14 +486,14 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
       for (int i = 0; i < 8; ++i) pe8[i] = stash[i * 64];
       Pre mid;
       block_mma<4, -1>(
-          cur, pre, a_addr, ld, [&](int s, int part) -> u32x4 { return pe8[4 * part + s]; }, [&](int) {},
+          cur, pre, a_addr, ld, c2, [&](int s, int part) -> u32x4 { return pe8[4 * part + s]; }, [&](int) {},
           [&](int k) { prefetch_frag(mid, k, a_addr + 8 * 1024); });
       pre.ah[0] = mid.ah[0]; pre.ah[1] = mid.ah[1]; pre.ah[2] = mid.ah[2];
       pre.al[0] = mid.al[0]; pre.al[1] = mid.al[1]; pre.al[2] = mid.al[2];
       a_addr += 8 * 1024;
     }
     block_mma<16, kBar>(
-        cur, pre, a_addr, ld, [&](int s, int part) -> u32x4 { return part ? bl[s] : bh[s]; },
+        cur, pre, a_addr, ld, c2, [&](int s, int part) -> u32x4 { return part ? bl[s] : bh[s]; },
         [&](int s) {
           if (nb == 0)
             // block 7 of the previous layer (always relu'd: the previous layer is L1..L7) -> k-steps 14, 15
@@ -494,19 +525,16 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
 
   Loader ld;
   ld.stream = packed;
-  ld.j = 0;
-  ld.n_seq = SIGMA_ONLY ? kChunkFinal0 + 1 : kChunks;
-  ld.skip_final = SIGMA_ONLY;
   ld.wave = wave;
   ld.lane_off = (unsigned)lane * 16u;
   ld.slot_cur = lds_addr(ring);
   ld.slot_next = ld.slot_cur + kSlotBytes;
   ld.slot_free = ld.slot_cur + 2 * kSlotBytes;
   // chunks 0 and 1 stream in behind the encoding prologue
-  loader_prepare_dma(ld, 0, ld.slot_cur);
+  loader_prepare_dma(ld, make_ref(0, 33, wave), ld.slot_cur);
 #pragma unroll
   for (int i = 0; i < 11; ++i) loader_issue(ld, i);
-  loader_prepare_dma(ld, 1, ld.slot_next);
+  loader_prepare_dma(ld, make_ref(33, 33, wave), ld.slot_next);
 #pragma unroll
   for (int i = 0; i < 11; ++i) loader_issue(ld, i);
 
@@ -593,9 +621,9 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   // Publish point at the chunk start (chunk 0 / 1 were issued above; chunk j+2 is fetched here).
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    loader_publish(ld);
+    loader_publish(ld, layer_ref(1, c, wave));    // chunk j+2 = first / second chunk of L2
     const unsigned a_chunk = ld.slot_cur + ld.lane_off;
-    const unsigned next_bias = seq_bias_off(ld, ld.j + 1);
+    const unsigned next_bias = 32u * 1024u;       // L1 chunk 1 and L2's chunks: 32 weight pieces, then the bias
     Pre nxt;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -609,7 +637,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
       cur.m = mine.bias;
       PairTmp ptmp;
       block_mma<4, -1>(
-          cur, mine, a_addr, ld, [&](int s, int part) -> u32x4 { return part ? pel[s] : peh[s]; },
+          cur, mine, a_addr, ld, end_ref(wave), [&](int s, int part) -> u32x4 { return part ? pel[s] : peh[s]; },
           [&](int s) {
             const int i = 4 * g + s;        // DMA of chunk j+2: one piece per k-step over the chunk's 16 k-steps
             if (i < 11) loader_issue(ld, i);
@@ -633,10 +661,15 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
 #pragma unroll 1
   for (int pair = 0; pair < kPairs; ++pair) {
     const int L = 1 + 2 * pair;
-    trunk_layer(L, bh, bl, oh, ol, stash, ld, h, pend, pre);
-    trunk_layer(L + 1, oh, ol, bh, bl, stash, ld, h, pend, pre);
+    trunk_layer(L, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(L + 1, 0, wave), layer_ref(L + 1, 1, wave));
+    // what follows layer L+1: the next trunk layer, or (after xyz_encoding_final) the density head + dir_encoding
+    const bool last = !SIGMA_ONLY && pair == kPairs - 1;
+    const ChunkRef a0 = last ? sigma_ref(wave) : layer_ref(L + 2, 0, wave);
+    const ChunkRef a1 = last ? dir_ref(0, wave) : layer_ref(L + 2, 1, wave);
+    trunk_layer(L + 1, oh, ol, bh, bl, stash, ld, h, pend, pre, a0, a1);
   }
-  if (SIGMA_ONLY) trunk_layer(7, bh, bl, oh, ol, stash, ld, h, pend, pre);   // xyz_encoding_final is not evaluated
+  if (SIGMA_ONLY)   // xyz_encoding_final is not evaluated: L8 is followed by the density head, then nothing
+    trunk_layer(7, bh, bl, oh, ol, stash, ld, h, pend, pre, sigma_ref(wave), end_ref(wave));
 
   // ---- density head: sigma.weight as row 0 of one more 32-row block over h8 (= oh/ol: the input of
   // xyz_encoding_final, still intact).  The pending block is xyz_encoding_final's last one (-> bh, no
@@ -646,10 +679,11 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     Acc cur;
     cur.m = pre.bias;
     PairTmp ptmp;
-    const unsigned next_bias = seq_bias_off(ld, ld.j + 1);
+    const unsigned next_bias = 36u * 1024u;       // dir_encoding chunks: 36 weight pieces, then the bias
     Pre nxt;
     block_mma<16, kBar>(
-        cur, pre, ld.slot_cur + ld.lane_off, ld, [&](int s, int part) -> u32x4 { return part ? ol[s] : oh[s]; },
+        cur, pre, ld.slot_cur + ld.lane_off, ld, SIGMA_ONLY ? end_ref(wave) : dir_ref(1, wave),
+        [&](int s, int part) -> u32x4 { return part ? ol[s] : oh[s]; },
         [&](int s) {
           if (SIGMA_ONLY)
             pending_step(s, pend, 0.0f, ptmp, oh[14], ol[14], oh[15], ol[15]);
@@ -675,10 +709,10 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   for (int nb = 0; nb < 4; ++nb) {
     Acc cur;
     cur.m = pre.bias;
-    const unsigned next_bias = seq_bias_off(ld, ld.j + 1);
+    const unsigned next_bias = 36u * 1024u;
     Pre nxt;
     block_mma<18, kBar>(
-        cur, pre, ld.slot_cur + ld.lane_off, ld,
+        cur, pre, ld.slot_cur + ld.lane_off, ld, nb < 2 ? dir_ref(nb + 2, wave) : end_ref(wave),
         [&](int s, int part) -> u32x4 {
           return (s < 16) ? (part ? bl[s & 15] : bh[s & 15]) : (part ? del[s & 1] : deh[s & 1]);
         },
