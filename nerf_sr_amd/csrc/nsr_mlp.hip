@@ -262,7 +262,7 @@ mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, c
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         float sn, cs;
-        sincosf(ldexpf(v[c], 5 * h + f), &sn, &cs);   // 2^k * x is exact; full-range sin/cos
+        nsr_sincos(ldexpf(v[c], 5 * h + f), sn, cs);   // 2^k * x is exact; full-range sin/cos
         pe[2 + 6 * f + c] = sn;
         pe[2 + 6 * f + 3 + c] = cs;
       }
@@ -273,7 +273,7 @@ mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, c
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         float sn, cs;
-        sincosf(ldexpf(d[c], 2 * h + f), &sn, &cs);
+        nsr_sincos(ldexpf(d[c], 2 * h + f), sn, cs);
         de[2 + 6 * f + c] = sn;
         de[2 + 6 * f + 3 + c] = cs;
       }
