@@ -5,6 +5,8 @@
 #include "../../include/nsr.h"
 
 #define NSR_WAVE 64
+// cross-TU helpers that are not part of the C ABI (include/nsr.h) stay out of the dynamic symbol table
+#define NSR_INTERNAL __attribute__((visibility("hidden")))
 
 #define NSR_CHECK_LAUNCH()                                   \
   do {                                                       \

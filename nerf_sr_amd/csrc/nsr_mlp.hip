@@ -67,11 +67,11 @@ __global__ void __launch_bounds__(256) pack_fp32_kernel(PackPtrs w, float* __res
 }
 
 // split-fp16 path (nsr_mlp_f16.hip)
-extern "C" size_t nsr_f16x3_packed_bytes(void);
-extern "C" int nsr_f16x3_pack(const float* const* w, void* packed_dev, void* stream);
-extern "C" int nsr_f16x3_mlp_forward(const void* packed, const float* x, int64_t P, int sigma_only, float* out,
+extern "C" NSR_INTERNAL size_t nsr_f16x3_packed_bytes(void);
+extern "C" NSR_INTERNAL int nsr_f16x3_pack(const float* const* w, void* packed_dev, void* stream);
+extern "C" NSR_INTERNAL int nsr_f16x3_mlp_forward(const void* packed, const float* x, int64_t P, int sigma_only, float* out,
                                      void* stream);
-extern "C" int nsr_f16x3_render_rays(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
+extern "C" NSR_INTERNAL int nsr_f16x3_render_rays(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
                                      int N, float* out, void* stream);
 
 extern "C" size_t nsr_packed_weights_bytes(int precision) {
