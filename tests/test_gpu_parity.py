@@ -387,6 +387,29 @@ def test_f16x3_agrees_with_fp32_kernel_full_frame(ops):
     assert oc.psnr(outs["fp32"]["fine_comp_rgbs"].cpu(), outs["f16x3"]["fine_comp_rgbs"].cpu()) > 90.0
 
 
+def test_rccl_allgather_path_single_rank(ops):
+    """The multi-GPU exchange step through the real RCCL backend (world size 1 is all one GPU box allows):
+    process-group init from torchrun-style env, barrier, all_gather_into_tensor of rendered LR pixels."""
+    import torch.distributed as dist
+    from nerf_sr_amd import dist as nsr_dist
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        lr = torch.rand(47628, 3, device="cuda")
+        dist.barrier()
+        out = nsr_dist.all_gather_pixels(lr, 47628)
+        torch.cuda.synchronize()
+        assert out.shape == lr.shape and torch.equal(out, lr)
+        img = nsr_dist.render_sharded(lambda lo, hi: lr[lo:hi], 47628)
+        assert torch.equal(img, lr)
+    finally:
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------- full-size properties
 def test_full_size_properties_config2(ops):
     """BASELINE config #2 at full size (504x378 <- 252x189, 190,512 rays, 64+128 samples):
