@@ -43,8 +43,10 @@ RAYS_PER_FRAME = IMG_WH[0] * IMG_WH[1]                      # 190,512
 N_LR = RAYS_PER_FRAME // DOWNSCALE ** 2                     # 47,628
 FLOP_PER_RAY = FLOP_PER_POINT * (N_COARSE + N_COARSE + N_IMPORTANCE)   # 227,868,672
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
-PEAK_TFLOPS = {"fp32": 157.3, "f16x3": 2500.0}
-DTYPE_NAME = {"fp32": "f32", "f16x3": "f16x3 (fp16 MFMA, hi+lo split operands, fp32 accumulate)"}
+PEAK_TFLOPS = {"fp32": 157.3, "f16x3": 2500.0, "f16": 2500.0, "bf16": 2500.0}
+DTYPE_NAME = {"fp32": "f32", "f16x3": "f16x3 (fp16 MFMA, hi+lo split operands, fp32 accumulate)",
+              "f16": "f16 (fp16 MFMA operands, fp32 accumulate; fast path, not a parity path)",
+              "bf16": "bf16 (bf16 MFMA operands, fp32 accumulate; fast path, not a parity path)"}
 
 
 def cpu_baseline(sd_c, sd_f, rays_cpu: torch.Tensor, target_s: float = 12.0):
@@ -96,7 +98,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default=os.environ.get("NSR_PRECISION", "f16x3"), choices=list(PEAK_TFLOPS),
                     help="MLP arithmetic: f16x3 (default; split-fp16 MFMA, fp32-grade: passes the 1e-4 RGB contract) "
-                         "or fp32 (fp32 MFMA)")
+                         "or fp32 (fp32 MFMA); f16 / bf16 = single 16-bit operands, fast but outside the parity contract")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -173,7 +175,10 @@ def main():
                          "flop_per_launch": fine_flop,
                          "note": ("achieved counts ALGORITHMIC flops (2 x 593,408 MAC per point); f16x3 issues 3 MFMAs "
                                   "per product, so its matrix pipe is busy for 3x this figure"
-                                  if args.precision == "f16x3" else "algorithmic flops, exact fp32 MFMA")},
+                                  if args.precision == "f16x3" else
+                                  "algorithmic flops, exact fp32 MFMA" if args.precision == "fp32" else
+                                  "algorithmic flops, one 16-bit MFMA per product; fast path outside the 1e-4 "
+                                  "RGB contract (see the parity block)")},
         }
         if world == 1 and not args.no_cpu_baseline:
             lo = (RAYS_PER_FRAME // 2) - (RAYS_PER_FRAME // 2) % 4

@@ -49,9 +49,12 @@ typedef enum nsr_status {
 /* arithmetic the MLP contraction runs in (everything else is always fp32) */
 typedef enum nsr_precision {
   NSR_FP32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (parity path) */
-  NSR_BF16 = 1,   /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate (fast path)       */
-  NSR_F16X3 = 2   /* split-fp16 on v_mfma_f32_32x32x16_f16: hi*hi + hi*lo + lo*hi, fp32 accumulate;
+  NSR_BF16 = 1,   /* v_mfma_f32_32x32x16_bf16: bf16 operands (RNE), fp32 accumulate.  FAST path, NOT a
+                     parity path: colours move by ~5e-3 (PSNR vs the reference ~45 dB)             */
+  NSR_F16X3 = 2,  /* split-fp16 on v_mfma_f32_32x32x16_f16: hi*hi + hi*lo + lo*hi, fp32 accumulate;
                      products exact to ~2^-21 -> fp32-grade results at 3/16 of the fp32-MFMA cost  */
+  NSR_F16 = 3     /* v_mfma_f32_32x32x16_f16: fp16 operands (RNE), fp32 accumulate.  FAST path, NOT a
+                     parity path: colours move by ~6e-4 (PSNR vs the reference ~60 dB)             */
 } nsr_precision;
 
 /* number of tensors in VanillaMLP.state_dict(), in state_dict order:

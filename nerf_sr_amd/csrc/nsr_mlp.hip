@@ -74,9 +74,22 @@ extern "C" NSR_INTERNAL int nsr_f16x3_mlp_forward(const void* packed, const floa
 extern "C" NSR_INTERNAL int nsr_f16x3_render_rays(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
                                      int N, float* out, void* stream);
 
+// single 16-bit operand paths (nsr_mlp_h1.hip); bf = 1: bf16, 0: fp16
+extern "C" NSR_INTERNAL size_t nsr_h1_packed_bytes(void);
+extern "C" NSR_INTERNAL int nsr_h1_pack(int bf, const float* const* w, void* packed_dev, void* stream);
+extern "C" NSR_INTERNAL int nsr_h1_mlp_forward(int bf, const void* packed, const float* x, int64_t P, int sigma_only,
+                                               float* out, void* stream);
+extern "C" NSR_INTERNAL int nsr_h1_render_rays(int bf, const void* packed, const float* rays, int ray_stride,
+                                               const float* z, int64_t R, int N, float* out, void* stream);
+static inline bool precision_built(int precision) {
+  return precision == NSR_FP32 || precision == NSR_F16X3 || precision == NSR_BF16 || precision == NSR_F16;
+}
+static inline bool precision_h1(int precision) { return precision == NSR_BF16 || precision == NSR_F16; }
+
 extern "C" size_t nsr_packed_weights_bytes(int precision) {
   if (precision == NSR_FP32) return sizeof(float) * (size_t)(kStreamFloats + kAuxFloats);
   if (precision == NSR_F16X3) return nsr_f16x3_packed_bytes();
+  if (precision_h1(precision)) return nsr_h1_packed_bytes();
   return 0;
 }
 
@@ -88,6 +101,7 @@ extern "C" int nsr_pack_weights(const float* const* w, void* packed_dev, int pre
       if (!w[i]) return NSR_ERR_INVALID_ARG;
     return nsr_f16x3_pack(w, packed_dev, stream);
   }
+  if (precision_h1(precision)) return nsr_h1_pack(precision == NSR_BF16, w, packed_dev, stream);
   if (precision != NSR_FP32) return NSR_ERR_UNSUPPORTED;
   PackPtrs pp;
   for (int i = 0; i < NSR_N_STATE_TENSORS; ++i) {
@@ -349,11 +363,12 @@ mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, c
 extern "C" int nsr_mlp_forward(const void* packed_dev, int precision, const float* x, int64_t P, int sigma_only,
                                float* out, void* stream) {
   if (P < 0 || !packed_dev) return NSR_ERR_INVALID_ARG;
-  if (precision != NSR_FP32 && precision != NSR_F16X3) return NSR_ERR_UNSUPPORTED;
+  if (!precision_built(precision)) return NSR_ERR_UNSUPPORTED;
   if (P == 0) return NSR_OK;   // empty batch: nothing to read or write (pointers may be null)
   if (!x || !out) return NSR_ERR_INVALID_ARG;
   if (!sigma_only && (reinterpret_cast<uintptr_t>(out) & 15) != 0) return NSR_ERR_INVALID_ARG;
   if (precision == NSR_F16X3) return nsr_f16x3_mlp_forward(packed_dev, x, P, sigma_only, out, stream);
+  if (precision_h1(precision)) return nsr_h1_mlp_forward(precision == NSR_BF16, packed_dev, x, P, sigma_only, out, stream);
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   const float* pk = static_cast<const float*>(packed_dev);
   if (sigma_only)
@@ -367,12 +382,14 @@ extern "C" int nsr_mlp_forward(const void* packed_dev, int precision, const floa
 extern "C" int nsr_render_rays(const void* packed_dev, int precision, const float* rays, int ray_stride, const float* z,
                                int64_t R, int n_samples, float* out, void* stream) {
   if (!packed_dev || R < 0 || n_samples <= 0 || !nsr_ray_stride_ok(ray_stride)) return NSR_ERR_INVALID_ARG;
-  if (precision != NSR_FP32 && precision != NSR_F16X3) return NSR_ERR_UNSUPPORTED;
+  if (!precision_built(precision)) return NSR_ERR_UNSUPPORTED;
   if (R == 0) return NSR_OK;
   if (!rays || !z || !out) return NSR_ERR_INVALID_ARG;
   if ((reinterpret_cast<uintptr_t>(out) & 15) != 0 || (ray_stride == 8 && (reinterpret_cast<uintptr_t>(rays) & 15) != 0))
     return NSR_ERR_INVALID_ARG;
   if (precision == NSR_F16X3) return nsr_f16x3_render_rays(packed_dev, rays, ray_stride, z, R, n_samples, out, stream);
+  if (precision_h1(precision))
+    return nsr_h1_render_rays(precision == NSR_BF16, packed_dev, rays, ray_stride, z, R, n_samples, out, stream);
   const int64_t P = R * n_samples;
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   hipLaunchKernelGGL((mlp_fp32_kernel<1, false>), grid, block, 0, nsr_stream(stream),
