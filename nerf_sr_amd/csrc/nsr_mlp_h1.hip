@@ -19,8 +19,13 @@ using namespace nsr::stream;
 namespace h1 {
 
 // ---- stream layout ----------------------------------------------------------------------------------------
-// chunk = [ A(nb0, s=0), A(nb1, s=0), A(nb0, 1), A(nb1, 1), ..., bias piece (fp32: 32 x nb0 | 32 x nb1) ]
-//   0        : L1, four block pairs of 4 k-steps each, bias piece = 256 floats
+// chunk = [ A(nb0, s=0), A(nb1, s=0), A(nb0, 1), A(nb1, 1), ..., bias piece ]
+// The bias piece is itself an A fragment: lane (row i, half 0) carries (hi, lo) of bias[nb0][i] in k-slots 0, 1
+// and of bias[nb1][i] in k-slots 2, 3, zero elsewhere; one MFMA against a constant B (ones in k-slots 0, 1 resp.
+// 2, 3) initialises the accumulator with the bias, exact to 2^-22 (fp16) / 2^-17 (bf16) -- ONE LDS read per
+// chunk instead of eight broadcast reads (this kernel is LDS-bandwidth-bound: every MFMA needs a 1 KiB
+// fragment and the LDS moves 128 B/clk).
+//   0        : L1, four block pairs of 4 k-steps each + one bias piece per pair
 //   1 .. 32  : trunk layer L = 1..8 (L2..L8, xyz_encoding_final), block pair pb = 0..3 ; L == 4: 4 + 16 k-steps
 //   33       : density head paired with an all-zero block
 //   34, 35   : dir_encoding block pairs, 16 + 2 k-steps
@@ -28,7 +33,9 @@ constexpr int kChunks = 36;
 constexpr int kSlotPieces = 41;
 constexpr int kSlotFloats = kSlotPieces * 256;
 constexpr int kSlotBytes = kSlotFloats * 4;
-constexpr int kPiecesTotal = 1228;
+constexpr int kL1Pieces = 36;
+constexpr int kSigmaPiece0 = 1124, kDirPiece0 = 1157;
+constexpr int kPiecesTotal = 1231;
 constexpr int kAuxRgbW = 0, kAuxRgbB = 384, kAuxFloats = 448;
 constexpr int kBar = 8;
 constexpr int kPF = 3;
@@ -48,19 +55,19 @@ struct Chunk {
   bool l1, sigma;
 };
 NSR_HD int trunk_pieces(int L) { return (L == 4) ? 41 : 33; }
-NSR_HD int trunk_base(int L) { return (L <= 3) ? 33 + 132 * (L - 1) : (L == 4 ? 429 : 593 + 132 * (L - 5)); }
+NSR_HD int trunk_base(int L) { return (L <= 3) ? 36 + 132 * (L - 1) : (L == 4 ? 432 : 596 + 132 * (L - 5)); }
 NSR_HD Chunk chunk_info(int q) {
   Chunk c{};
   if (q == 0) {
-    c.tensor = 0; c.nb0 = 0; c.steps = 4; c.piece0 = 0; c.pieces = 33; c.l1 = true;
+    c.tensor = 0; c.nb0 = 0; c.steps = 4; c.piece0 = 0; c.pieces = kL1Pieces; c.l1 = true;
   } else if (q <= 32) {
     const int L = 1 + (q - 1) / 4, pb = (q - 1) % 4;
     c.tensor = 2 * L; c.nb0 = 2 * pb; c.steps = (L == 4) ? 20 : 16;
     c.pieces = trunk_pieces(L); c.piece0 = trunk_base(L) + c.pieces * pb;
   } else if (q == 33) {
-    c.tensor = 20; c.nb0 = 0; c.steps = 16; c.piece0 = 1121; c.pieces = 33; c.sigma = true;
+    c.tensor = 20; c.nb0 = 0; c.steps = 16; c.piece0 = kSigmaPiece0; c.pieces = 33; c.sigma = true;
   } else {
-    c.tensor = 18; c.nb0 = 2 * (q - 34); c.steps = 18; c.piece0 = 1154 + 37 * (q - 34); c.pieces = 37;
+    c.tensor = 18; c.nb0 = 2 * (q - 34); c.steps = 18; c.piece0 = kDirPiece0 + 37 * (q - 34); c.pieces = 37;
   }
   return c;
 }
@@ -70,8 +77,8 @@ __device__ __forceinline__ void issue(const Loader& ld, int i) { loader_issue<kM
 __device__ __forceinline__ ChunkRef layer_ref(int L, int pb, int wave) {
   return mkref(trunk_base(L) + trunk_pieces(L) * pb, trunk_pieces(L), wave);
 }
-__device__ __forceinline__ ChunkRef sigma_ref(int wave) { return mkref(1121, 33, wave); }
-__device__ __forceinline__ ChunkRef dir_ref(int pb, int wave) { return mkref(1154 + 37 * pb, 37, wave); }
+__device__ __forceinline__ ChunkRef sigma_ref(int wave) { return mkref(kSigmaPiece0, 33, wave); }
+__device__ __forceinline__ ChunkRef dir_ref(int pb, int wave) { return mkref(kDirPiece0 + 37 * pb, 37, wave); }
 // past the end: chunk 0 again into the idle slot (first eight DMA issues stay branch-free; drained at exit)
 __device__ __forceinline__ ChunkRef end_ref(int wave) { return mkref(0, 32, wave); }
 
@@ -115,14 +122,18 @@ __global__ void __launch_bounds__(256) pack_kernel(PackPtrs w, unsigned* __restr
       if (piece >= chunk_info(i).piece0) q = i;
     const Chunk c = chunk_info(q);
     const int local = piece - c.piece0;
-    const int nnb = c.l1 ? 8 : 2;
-    if (local == c.pieces - 1) {
-      // bias piece: fp32, 32 per output block; the density head has one real row, its partner block none
-      const int g = word >> 5, i = word & 31;
-      if (c.sigma) {
-        if (word == 0) v = __float_as_uint(w.p[21][0]);
-      } else if (g < nnb) {
-        v = __float_as_uint(w.p[c.tensor + 1][32 * (c.nb0 + g) + i]);
+    const int n_bias = c.l1 ? 4 : 1;                      // bias pieces at the end of the chunk
+    if (local >= c.pieces - n_bias) {
+      // bias fragment: lane (i, half 0), word jj < 2 = (hi, lo) of the bias of row i of block 2 * pair + jj
+      const int pair = local - (c.pieces - n_bias);
+      const int lane = word >> 2, jj = word & 3;
+      if (lane < 32 && jj < 2) {
+        float bv = 0.0f;
+        if (c.sigma) bv = (lane == 0 && jj == 0) ? w.p[21][0] : 0.0f;      // one real row, partner block none
+        else bv = w.p[c.tensor + 1][32 * (c.nb0 + 2 * pair + jj) + lane];
+        const unsigned hi2 = pack2<BF>(bv, 0.0f);
+        const float hi = BF ? __uint_as_float(hi2 << 16) : (float)__builtin_bit_cast(_Float16, (unsigned short)(hi2 & 0xffffu));
+        v = pack2<BF>(hi, bv - hi);
       }
     } else {
       int g, s;
@@ -162,23 +173,27 @@ __device__ __forceinline__ f32x16 mma(const u32x4& a, const u32x4& b, const f32x
 struct Acc2 {
   f32x16 a0, a1;   // the chunk's two output blocks
 };
-struct Pre2 {      // head of a k-step sequence: fragments of its first kPF k-steps (+ accumulator init = bias)
+struct Pre2 {      // head of a k-step sequence: fragments of its first kPF k-steps (+ the chunk's bias fragment)
   u32x4 f0[kPF], f1[kPF];
-  f32x16 bias0, bias1;
+  u32x4 bias;
 };
 __device__ __forceinline__ void prefetch_frag(Pre2& pre, int k, unsigned seq_addr) {
   const u32x4* a = lds_vec(seq_addr);
   pre.f0[k] = a[(2 * k) * 64];
   pre.f1[k] = a[(2 * k + 1) * 64];
 }
-__device__ __forceinline__ void load_bias(f32x16& dst, unsigned bias_addr, int h) {   // 32 floats at bias_addr
-  const f32x4* b = reinterpret_cast<const f32x4*>(lds_vec(bias_addr + 16u * (unsigned)h));
-#pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
-    const f32x4 b4 = b[2 * qd];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dst[4 * qd + i] = b4[i];
-  }
+// constant B operands of the bias MFMA: ones in k-slots (0, 1) resp. (2, 3) of the lanes of half 0
+template <bool BF>
+__device__ __forceinline__ void bias_operands(int h, u32x4& b0, u32x4& b1) {
+  const unsigned ones = h == 0 ? (BF ? 0x3f803f80u : 0x3c003c00u) : 0u;
+  b0 = u32x4{ones, 0u, 0u, 0u};
+  b1 = u32x4{0u, ones, 0u, 0u};
+}
+template <bool BF>
+__device__ __forceinline__ void init_acc(Acc2& acc, const u32x4& bias_frag, const u32x4& b0, const u32x4& b1) {
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  acc.a1 = mma<BF>(bias_frag, b1, zero);
+  acc.a0 = mma<BF>(bias_frag, b0, zero);
 }
 
 // NSTEP k-steps of a block pair; same pipeline discipline as block_mma in nsr_mlp_f16.hip
@@ -286,21 +301,18 @@ __device__ __forceinline__ void rgb_q(int q, const Acc2& p, const float* w64, in
   }
 }
 
-// head of the NEXT chunk (its first fragments + the two blocks' bias), prefetched in the last three k-steps
-__device__ __forceinline__ void prefetch_next_chunk(Pre2& nxt, int k, const Loader& ld, unsigned bias_off, int h) {
+// head of the NEXT chunk (its first fragments + its bias fragment), prefetched in the last three k-steps
+__device__ __forceinline__ void prefetch_next_chunk(Pre2& nxt, int k, const Loader& ld, unsigned bias_off) {
   prefetch_frag(nxt, k, ld.slot_next + ld.lane_off);
-  if (k == 1) {
-    load_bias(nxt.bias0, ld.slot_next + bias_off, h);
-    load_bias(nxt.bias1, ld.slot_next + bias_off + 128u, h);
-  }
+  if (k == 1) nxt.bias = lds_vec(ld.slot_next + bias_off + ld.lane_off)[0];
 }
 
 // One 256 -> 256 trunk layer L (1..8; 8 = xyz_encoding_final): in (bin) -> out (bout), four block-pair chunks.
 // `pend` = the pair that finished last (blocks 6, 7 of the previous layer on entry).
 template <bool BF>
 __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bin)[16], u32x4 (&bout)[16], const u32x4* stash, Loader& ld,
-                                            int h, Acc2& pend, Pre2& pre, const ChunkRef& after0,
-                                            const ChunkRef& after1) {
+                                            const u32x4& bc0, const u32x4& bc1, Acc2& pend, Pre2& pre,
+                                            const ChunkRef& after0, const ChunkRef& after1) {
   const unsigned lower = (L < 8) ? kRelu : kNoAct;
   const ChunkRef ref0 = layer_ref(L, 0, ld.wave);
 #pragma unroll
@@ -312,8 +324,7 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bin)[16], u32x4 (&bou
     if (pb == 2) c2 = after0;
     if (pb == 3) c2 = after1;
     Acc2 cur;
-    cur.a0 = pre.bias0;
-    cur.a1 = pre.bias1;
+    init_acc<BF>(cur, pre.bias, bc0, bc1);
     unsigned a_addr = ld.slot_cur + ld.lane_off;
     const unsigned next_bias = (unsigned)(c1.pieces - 1) * 1024u;
     Pre2 nxt;
@@ -338,7 +349,7 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bin)[16], u32x4 (&bou
           else
             pending_step<BF>(s, pend, lower, bout[4 * pb - 4], bout[4 * pb - 3], bout[4 * pb - 2], bout[4 * pb - 1]);
         },
-        [&](int k) { prefetch_next_chunk(nxt, k, ld, next_bias, h); });
+        [&](int k) { prefetch_next_chunk(nxt, k, ld, next_bias); });
     pend = cur;
     pre = nxt;
     loader_advance(ld);
@@ -366,7 +377,7 @@ mlp_h1_kernel(const float* __restrict__ packed, const float* __restrict__ x, con
   ld.slot_cur = lds_addr(ring);
   ld.slot_next = ld.slot_cur + kSlotBytes;
   ld.slot_free = ld.slot_cur + 2 * kSlotBytes;
-  loader_prepare_dma(ld, mkref(0, 33, wave), ld.slot_cur);             // L1
+  loader_prepare_dma(ld, mkref(0, kL1Pieces, wave), ld.slot_cur);      // L1
 #pragma unroll
   for (int i = 0; i < kMaxIssue; ++i) issue(ld, i);
   loader_prepare_dma(ld, layer_ref(1, 0, wave), ld.slot_next);         // first chunk of L2
@@ -391,6 +402,8 @@ mlp_h1_kernel(const float* __restrict__ packed, const float* __restrict__ x, con
   for (int s = 0; s < 4; ++s) stash[s * 64] = pe4[s];
 
   u32x4 ba[16], bb[16];
+  u32x4 bc0, bc1;
+  bias_operands<BF>(h, bc0, bc1);
   Acc2 pend;
   Pre2 pre;
 
@@ -405,11 +418,9 @@ mlp_h1_kernel(const float* __restrict__ packed, const float* __restrict__ x, con
       Pre2 mine;
 #pragma unroll
       for (int k = 0; k < kPF; ++k) prefetch_frag(mine, k, a_addr);
-      load_bias(mine.bias0, ld.slot_cur + 32 * 1024 + 256 * g, h);
-      load_bias(mine.bias1, ld.slot_cur + 32 * 1024 + 256 * g + 128, h);
+      mine.bias = lds_vec(ld.slot_cur + (32 + g) * 1024 + ld.lane_off)[0];
       Acc2 cur;
-      cur.a0 = mine.bias0;
-      cur.a1 = mine.bias1;
+      init_acc<BF>(cur, mine.bias, bc0, bc1);
       pair_mma<BF, 4, -1>(
           cur, mine, a_addr, ld, end_ref(wave), [&](int s) -> u32x4 { return pe4[s]; },
           [&](int s) {
@@ -422,7 +433,7 @@ mlp_h1_kernel(const float* __restrict__ packed, const float* __restrict__ x, con
             }
           },
           [&](int k) {
-            if (g == 3) prefetch_next_chunk(nxt, k, ld, 32u * 1024u, h);   // head of the first trunk chunk
+            if (g == 3) prefetch_next_chunk(nxt, k, ld, 32u * 1024u);   // head of the first trunk chunk
           });
       pend = cur;
     }
@@ -435,21 +446,20 @@ mlp_h1_kernel(const float* __restrict__ packed, const float* __restrict__ x, con
 #pragma unroll 1
   for (int pair = 0; pair < kPairs; ++pair) {
     const int L = 1 + 2 * pair;
-    trunk_layer<BF>(L, ba, bb, stash, ld, h, pend, pre, layer_ref(L + 1, 0, wave), layer_ref(L + 1, 1, wave));
+    trunk_layer<BF>(L, ba, bb, stash, ld, bc0, bc1, pend, pre, layer_ref(L + 1, 0, wave), layer_ref(L + 1, 1, wave));
     const bool last = !SIGMA_ONLY && pair == kPairs - 1;
     const ChunkRef a0 = last ? sigma_ref(wave) : layer_ref(L + 2, 0, wave);
     const ChunkRef a1 = last ? dir_ref(0, wave) : layer_ref(L + 2, 1, wave);
-    trunk_layer<BF>(L + 1, bb, ba, stash, ld, h, pend, pre, a0, a1);
+    trunk_layer<BF>(L + 1, bb, ba, stash, ld, bc0, bc1, pend, pre, a0, a1);
   }
-  if (SIGMA_ONLY) trunk_layer<BF>(7, ba, bb, stash, ld, h, pend, pre, sigma_ref(wave), end_ref(wave));
+  if (SIGMA_ONLY) trunk_layer<BF>(7, ba, bb, stash, ld, bc0, bc1, pend, pre, sigma_ref(wave), end_ref(wave));
 
   // ---- density head over h8 (= bb: the input of xyz_encoding_final, still intact), paired with a zero block.
   // Pending: xyz_encoding_final's blocks 6, 7 (-> ba, no activation) or, sigma_only, L8's (-> bb, relu).
   float sigma;
   {
     Acc2 cur;
-    cur.a0 = pre.bias0;
-    cur.a1 = pre.bias1;
+    init_acc<BF>(cur, pre.bias, bc0, bc1);
     Pre2 nxt;
     pair_mma<BF, 16, kBar>(
         cur, pre, ld.slot_cur + ld.lane_off, ld, SIGMA_ONLY ? end_ref(wave) : dir_ref(1, wave),
@@ -459,7 +469,7 @@ mlp_h1_kernel(const float* __restrict__ packed, const float* __restrict__ x, con
           else pending_step<BF>(s, pend, kNoAct, ba[12], ba[13], ba[14], ba[15]);
         },
         [&](int k) {
-          if (!SIGMA_ONLY) prefetch_next_chunk(nxt, k, ld, 36u * 1024u, h);
+          if (!SIGMA_ONLY) prefetch_next_chunk(nxt, k, ld, 36u * 1024u);
         });
     sigma = cur.a0[0];
     pre = nxt;
@@ -476,8 +486,7 @@ mlp_h1_kernel(const float* __restrict__ packed, const float* __restrict__ x, con
 #pragma unroll
   for (int pb = 0; pb < 2; ++pb) {
     Acc2 cur;
-    cur.a0 = pre.bias0;
-    cur.a1 = pre.bias1;
+    init_acc<BF>(cur, pre.bias, bc0, bc1);
     Pre2 nxt;
     pair_mma<BF, 18, kBar>(
         cur, pre, ld.slot_cur + ld.lane_off, ld, end_ref(wave),
@@ -486,7 +495,7 @@ mlp_h1_kernel(const float* __restrict__ packed, const float* __restrict__ x, con
           if (pb > 0) rgb_q(s, pend, aux + kAuxRgbW, h, rgb);     // blocks 0, 1: one pair per k-step 0..15
         },
         [&](int k) {
-          if (pb == 0) prefetch_next_chunk(nxt, k, ld, 36u * 1024u, h);
+          if (pb == 0) prefetch_next_chunk(nxt, k, ld, 36u * 1024u);
         });
     pend = cur;
     pre = nxt;
