@@ -46,7 +46,11 @@ def install_shim():
     def stub(name, **attrs):
         m = types.ModuleType(name)
         m.__dict__.update(attrs)
-        m.__getattr__ = lambda attr: _Anything      # PEP 562: any other name resolves to a dummy class
+        def _missing(attr):                         # PEP 562: any other public name resolves to a dummy class
+            if attr.startswith("__"):
+                raise AttributeError(attr)          # keep inspect / importlib probing (__file__, __path__) honest
+            return _Anything
+        m.__getattr__ = _missing
         sys.modules[name] = m
         return m
 

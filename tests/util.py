@@ -39,3 +39,21 @@ def assert_resample_close(got, want, z, weights, n_imp, u=None, base_tol=2e-6):
                            f"tol {tol[bad[0]]:.3e} amp {amp[bad[0]]:.3e} margin {margin[bad[0]]:.3e}")
     assert (np.diff(got, axis=-1) >= 0).all(), "z_fine not sorted"
     return float(err.max()), int(chaotic.sum())
+
+
+def sample_idx(numel: int, cap: int = 512):
+    """Subsample of a flattened tensor used by the training fixtures (must match
+    tests/golden/make_golden_train.py::sample_idx)."""
+    if numel <= cap:
+        return np.arange(numel)
+    stride = (numel // cap) | 1
+    return np.arange(0, numel, stride)[:cap]
+
+
+def train_draws(g):
+    """The random draws recorded in a training fixture as keyword arguments of the oracle / HIP step."""
+    d = {"noise_std": float(g["noise_std"])}
+    for k in ("u_coarse", "noise_coarse", "u_fine", "noise_fine"):
+        if k in g:
+            d[k] = g[k]
+    return d
