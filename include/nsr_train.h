@@ -1,0 +1,66 @@
+/* nsr_train.h — C ABI of the TRAINING step through the NeRF-SR render path.
+ *
+ * Same conventions as nsr.h: raw DEVICE pointers, caller-owned memory, work enqueued on the caller's HIP
+ * stream, int status returns, no global mutable state.  The reference interface replaced here is
+ * NeRFDownXModel.optimize_parameters (models/nerf_downX_model.py:398-408):
+ *     forward()  [train mode: randomized sampling, density noise]   -> nsr_train_loss_and_grads
+ *     comp_low_res_output() + calculate_losses() + loss_tot.backward()  -> nsr_train_loss_and_grads
+ *     optimizer.step()  [torch.optim.Adam, :201-204]                 -> nsr_adam_step
+ * Weights, gradients and Adam moments are the 24 tensors of VanillaMLP.state_dict() in nn.Linear layout
+ * (see NSR_N_STATE_TENSORS in nsr.h), handed over as HOST arrays of 24 DEVICE pointers, so a binding can
+ * pass `p.data_ptr()` / `p.grad.data_ptr()` of the reference's own parameters.
+ *
+ * Arithmetic: fp32 throughout (v_mfma_f32_32x32x2_f32 for the contractions), like the reference.
+ */
+#ifndef NSR_TRAIN_H_
+#define NSR_TRAIN_H_
+
+#include "nsr.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Workspace for one pass over `ray_chunk` rays (activations of one network in both orientations, gradient
+ * ping-pong buffers, padded / transposed weight copies, split-K partials).  0 on invalid arguments. */
+size_t nsr_train_workspace_bytes(int64_t ray_chunk, int n_coarse, int n_importance);
+
+/* Losses and d(loss_tot)/d(weights) of one batch.
+ *   loss_tot = lambda_coarse * mse(mean_s2(coarse rgb), target) + lambda_fine * mse(mean_s2(fine rgb), target)
+ *   (calculate_losses, nerf_downX_model.py:355-362; nn.MSELoss(reduction='mean'), criterions.py:7-15).
+ * rays (R, ray_stride) LR-pixel-major with s2 sub-rays per LR pixel (s2 = 1: the vanilla `nerf` model);
+ * target_lr (R / s2, 3).
+ * Random draws are INPUTS (the reference draws them with torch.rand_like / torch.randn_like / torch.rand,
+ * models/utils.py:37-41, 72-73, 199-212): u_coarse (R, Nc), u_fine (R, Ni) uniform in [0, 1); noise_coarse
+ * (R, Nc), noise_fine (R, Nc + Ni) standard normal, scaled by noise_std.  NULL selects the deterministic
+ * branch of the corresponding stage (randomized = False / noise off).
+ * g_coarse / g_fine: 24 gradient tensors each, OVERWRITTEN.
+ * ray_chunk: rays per pass (bounds the workspace; multiple of s2; 0 = R); gradients and losses of the passes
+ * are accumulated, the result does not depend on the chunking beyond fp32 summation order.
+ * outs: the 8 forward outputs in nsr_forward_rays order (entries may be NULL except the two comp_rgbs).
+ * lr_coarse / lr_fine: (R / s2, 3) s2-means (comp_low_res_output, :326-348); losses: DEVICE float[2] =
+ * { lambda_coarse * mse_coarse, lambda_fine * mse_fine }. */
+int nsr_train_loss_and_grads(const float* const* w_coarse, const float* const* w_fine, float* const* g_coarse,
+                             float* const* g_fine, const float* rays, int ray_stride, int64_t R, int s2,
+                             const float* target_lr, int n_coarse, int n_importance, int white_bkgd, int lindisp,
+                             const float* u_coarse, const float* u_fine, const float* noise_coarse,
+                             const float* noise_fine, float noise_std, float lambda_coarse, float lambda_fine,
+                             int64_t ray_chunk, float* const* outs, float* lr_coarse, float* lr_fine, float* losses,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* torch.optim.Adam (no weight decay, no amsgrad) on the 24 tensors of one network, in place:
+ *   m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g^2;
+ *   w -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)        (step counts from 1). */
+int nsr_adam_step(float* const* w, const float* const* g, float* const* m, float* const* v, int step, float lr,
+                  float beta1, float beta2, float eps, void* stream);
+
+/* One nn.Linear (+ activation) on the training GEMM, exposed for testing the kernel on its own:
+ *   y (P, N) = act(x (P, K) · w (N, K)^T + b),  act: 0 none, 1 relu, 2 sigmoid;  y_t (N, P) optional transpose.
+ * K % 32 == 0, ldx % 4 == 0, ldw % 4 == 0, 16-byte aligned pointers (the training step pads its operands). */
+int nsr_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* b, int act, float* y,
+               int64_t ldy, float* y_t, int64_t ldyt, int64_t P, int K, int N, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSR_TRAIN_H_ */

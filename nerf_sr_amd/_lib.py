@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("NSR_LIB_PATH", os.path.join(_HERE, "libnsr.so"))   # 
 NSR_FP32, NSR_BF16, NSR_F16X3, NSR_F16 = 0, 1, 2, 3
 PRECISIONS = {"fp32": NSR_FP32, "bf16": NSR_BF16, "f16x3": NSR_F16X3, "f16": NSR_F16}
 
-# symbol -> (restype, argtypes); must list every function of include/nsr.h
+# symbol -> (restype, argtypes); must list every function of include/nsr.h and include/nsr_train.h
 SIGNATURES = {
     "nsr_version": (c_int, []),
     "nsr_status_string": (c_char_p, [c_int]),
@@ -42,6 +42,16 @@ SIGNATURES = {
     "nsr_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     "nsr_sr_mean": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "nsr_unflatten": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    # ---- include/nsr_train.h
+    "nsr_train_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "nsr_train_loss_and_grads": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                         c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_int64,
+                                         POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nsr_adam_step": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int,
+                              c_float, c_float, c_float, c_float, c_void_p]),
+    "nsr_linear": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64,
+                           c_int64, c_int, c_int, c_void_p]),
 }
 
 _lib = None

@@ -24,6 +24,8 @@ UNITS = [
     ("nsr_mlp.hip", ["-ffp-contract=off"]),
     ("nsr_mlp_f16.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("nsr_mlp_h1.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("nsr_gemm.hip", ["-ffp-contract=off"]),
+    ("nsr_train.hip", ["-ffp-contract=off"]),
     ("nsr_api.hip", []),
 ]
 

@@ -1,0 +1,648 @@
+// Training step through the render path: include/nsr_train.h.
+//
+// Replaces NeRFDownXModel.optimize_parameters (models/nerf_downX_model.py:398-408): train-mode forward_rays
+// (:280-313), the s^2 means (:326-348), the two MSE losses (:355-362), autograd's backward through the
+// compositing and both MLPs, and torch.optim.Adam (:201-204).
+//
+// Shape of the computation on MI355X.  A training batch is small next to a rendered frame (thousands of rays), and
+// its activations have to be kept for the backward pass anyway, so the MLP runs layer by layer on one fp32-MFMA GEMM
+// kernel (nsr_gemm.hip) whose epilogue fuses bias / ReLU / sigmoid / the ReLU mask of the backward pass and writes
+// every activation and activation gradient in BOTH orientations (row-major (P, C) and transposed (C, P)).  With
+// that, all three products of a linear layer (forward, input gradient, weight gradient) are K-contiguous "NT"
+// GEMMs and nothing is ever transposed on the fly; the weight gradient is a split-K GEMM over the sample points
+// with a deterministic second-pass reduction (no atomics: results are run-to-run identical).
+// Layers are padded to MFMA-friendly shapes once per step (63 -> 64 input channels, the skip concat as
+// [pe64 | h4], the density head stacked under xyz_encoding_final as one 288-row layer, the colour head as 32 rows);
+// the gradients are scattered back to the nn.Linear shapes by the reduction kernel.
+// Per-ray stages (sampling, compositing, resampling) are the inference kernels (nsr_rays.hip / nsr_render.hip);
+// the compositing backward is a one-wave-per-ray kernel like its forward.
+#include "nsr_common.h"
+#include "nsr_gemm.h"
+#include "../../include/nsr_train.h"
+
+using namespace nsr;
+
+namespace {
+
+constexpr int kW = 256, kPe = 64, kX5 = 320, kGs = 288, kDirOut = 128, kRgbPad = 32;
+constexpr int kSigmaCol = 256, kDeCol = 260;     // columns of the [g | sigma | 0 0 0 | de27 | 0] buffer
+constexpr int kMaxSplits = 128;
+constexpr int64_t kPartialFloats = (int64_t)kGs * kX5;   // >= every padded weight-gradient shape
+
+// state_dict indices (nsr.h): layer i (1..8) weight = 2 (i - 1), bias = 2 (i - 1) + 1
+constexpr int kFinalW = 16, kFinalB = 17, kDirW = 18, kDirB = 19, kSigmaW = 20, kSigmaB = 21, kRgbW = 22, kRgbB = 23;
+__host__ __device__ constexpr int64_t tensor_numel(int t) {
+  switch (t) {
+    case 0: return 256 * 63;
+    case 8: return 256 * 319;
+    case kFinalW: return 256 * 256;
+    case kDirW: return 128 * 283;
+    case kDirB: return 128;
+    case kSigmaW: return 256;
+    case kSigmaB: return 1;
+    case kRgbW: return 3 * 128;
+    case kRgbB: return 3;
+    default: return (t & 1) ? 256 : 256 * 256;
+  }
+}
+
+inline int64_t align64(int64_t n) { return (n + 63) & ~(int64_t)63; }   // floats -> 256-byte granules
+
+// ---------------------------------------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------------------------------------
+// dst[(r0 + i) * ld + c0 + j] = src[i][col0 + j]  (or the transpose: dst[(r0 + j) * ld + c0 + i])
+__global__ void place_kernel(float* __restrict__ dst, int dst_ld, int r0, int c0, const float* __restrict__ src,
+                             int src_ld, int rows, int cols, int col0, int transpose) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  const int i = idx / cols, j = idx % cols;
+  const float v = src[(int64_t)i * src_ld + col0 + j];
+  if (transpose) dst[(int64_t)(r0 + j) * dst_ld + c0 + i] = v;
+  else dst[(int64_t)(r0 + i) * dst_ld + c0 + j] = v;
+}
+
+// E1 + cast_rays for the training layout: one thread per sample point.
+//   x5 (P, 320) columns 0..63  = [pe63, 0]          x5t (320, P) rows 0..63
+//   gs (P, 288) columns 257..287 = [0 0 0, de27, 0]  gst (288, P) rows 257..287
+__global__ void __launch_bounds__(256) encode_train_kernel(const float* __restrict__ rays, int stride,
+                                                           const float* __restrict__ z, int64_t P, int N,
+                                                           float* __restrict__ x5, float* __restrict__ x5t,
+                                                           float* __restrict__ gs, float* __restrict__ gst) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const NsrRay q = nsr_load_ray(rays, p / N, stride);
+  const float zk = z[p];
+  float pe[64];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) pe[c] = __fadd_rn(q.o[c], __fmul_rn(zk, q.d[c]));   // cast_rays, models/utils.py:5-14
+#pragma unroll
+  for (int f = 0; f < 10; ++f)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nsr_sincos(ldexpf(pe[c], f), pe[3 + 6 * f + c], pe[3 + 6 * f + 3 + c]);
+  pe[63] = 0.0f;
+  float4* row = reinterpret_cast<float4*>(x5 + p * kX5);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) row[i] = make_float4(pe[4 * i], pe[4 * i + 1], pe[4 * i + 2], pe[4 * i + 3]);
+#pragma unroll
+  for (int c = 0; c < 64; ++c) x5t[(int64_t)c * P + p] = pe[c];
+  float de[31];   // columns 257..287
+  de[0] = de[1] = de[2] = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) de[3 + c] = q.v[c];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nsr_sincos(ldexpf(q.v[c], f), de[6 + 6 * f + c], de[6 + 6 * f + 3 + c]);
+  de[30] = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 31; ++c) {
+    gs[p * kGs + 257 + c] = de[c];
+    gst[(int64_t)(257 + c) * P + p] = de[c];
+  }
+}
+
+// N1: sigma + noise * std (models/utils.py:199-212); noise == nullptr copies
+__global__ void sigma_noise_kernel(const float* __restrict__ gs, const float* __restrict__ noise, float std_,
+                                   int64_t P, float* __restrict__ out) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const float s = gs[p * kGs + kSigmaCol];
+  out[p] = noise ? __fadd_rn(s, __fmul_rn(noise[p], std_)) : s;
+}
+
+// A1 + MSE: one thread per LR pixel.  lr = mean over the s2 sub-rays; loss partial per block; gC = dL/d(comp rgb)
+// of every sub-ray = 2 lambda (lr - target) / (3 N_lr_total) / s2.
+__global__ void __launch_bounds__(256) lr_loss_kernel(const float* __restrict__ comp, const float* __restrict__ target,
+                                                      int64_t n_lr, int s2, double scale, float lambda,
+                                                      float* __restrict__ lr_out, float* __restrict__ g_comp,
+                                                      double* __restrict__ block_sums) {
+  __shared__ double red[256];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double sq = 0.0;
+  if (i < n_lr) {
+    for (int c = 0; c < 3; ++c) {
+      float acc = 0.0f;
+      for (int k = 0; k < s2; ++k) acc = __fadd_rn(acc, comp[(i * s2 + k) * 3 + c]);
+      const float lr = __fdiv_rn(acc, (float)s2);
+      lr_out[i * 3 + c] = lr;
+      const float d = __fsub_rn(lr, target[i * 3 + c]);
+      sq += (double)d * (double)d;
+      const float gc = (float)(2.0 * (double)lambda * (double)d * scale / (double)s2);
+      for (int k = 0; k < s2; ++k) g_comp[(i * s2 + k) * 3 + c] = gc;
+    }
+  }
+  red[threadIdx.x] = sq;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = red[0];
+}
+// losses[slot] += lambda * scale * sum(block_sums)   (single thread block: deterministic order)
+__global__ void __launch_bounds__(256) loss_finish_kernel(const double* __restrict__ block_sums, int n, double scale,
+                                                          float lambda, float* __restrict__ losses, int slot,
+                                                          double* __restrict__ carry) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += block_sums[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    carry[slot] += red[0];                                       // sum of squared errors over the passes so far
+    losses[slot] = (float)((double)lambda * carry[slot] * scale);   // scale = 1 / (3 N_lr)
+  }
+}
+
+// Backward of V1 (models/rendering.py:75-111) w.r.t. the point colours and densities, given dL/d(comp rgb).
+//   w_k = alpha_k T_k, T_k = prod_{j<k} f_j, f_j = 1 - alpha_j + 1e-10, alpha_k = 1 - exp(-delta_k relu(sigma_k))
+//   gw_k = gC . rgb_k (- sum(gC) with a white background: comp += 1 - sum_k w_k)
+//   dL/dalpha_k = gw_k T_k - (sum_{i>k} gw_i w_i) / f_k
+//   dL/dsigma_k = dL/dalpha_k * delta_k exp(-delta_k relu(sigma_k)) * [sigma_k > 0];   dL/drgb_k = gC w_k
+// and through the sigmoid of the colour head: d(rgb_pre) = d(rgb) * rgb (1 - rgb).
+// Outputs in the training layout: d_rgb (P, 32) columns 0..2 (3..31 zeroed), d_rgb_t (32, P) rows 0..2;
+// d_sigma into column 256 of g1 (P, 288) (257..287 zeroed) and row 256 of g1t (288, P).
+template <int K>
+__global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restrict__ rgb4, const float* __restrict__ sigma,
+                                                            const float* __restrict__ z, const float* __restrict__ g_comp,
+                                                            int64_t R, int N, int white, int64_t P,
+                                                            float* __restrict__ d_rgb, float* __restrict__ d_rgb_t,
+                                                            float* __restrict__ g1, float* __restrict__ g1t) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int64_t base = r * N;
+  const float gc0 = g_comp[r * 3 + 0], gc1 = g_comp[r * 3 + 1], gc2 = g_comp[r * 3 + 2];
+  float zk[K], sg[K], c0[K], c1[K], c2[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int k = lane * K + i;
+    const int64_t p = base + (k < N ? k : N - 1);
+    zk[i] = z[p];
+    sg[i] = sigma[p];
+    c0[i] = rgb4[p * 4 + 0];
+    c1[i] = rgb4[p * 4 + 1];
+    c2[i] = rgb4[p * 4 + 2];
+  }
+  const float z_next_lane = __shfl_down(zk[0], 1, 64);
+  float alpha[K], ex[K], dl[K], ff[K];
+  double pl[K];
+  double run = 1.0;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int k = lane * K + i;
+    const float zn = (i + 1 < K) ? zk[(i + 1 < K) ? i + 1 : i] : z_next_lane;
+    const float delta = (k >= N - 1) ? 1e10f : __fsub_rn(zn, zk[i]);
+    const float e = expf(__fmul_rn(-delta, fmaxf(sg[i], 0.0f)));
+    float a = __fsub_rn(1.0f, e);
+    if (k >= N) a = 0.0f;
+    alpha[i] = a;
+    ex[i] = e;
+    dl[i] = delta;
+    const float f = (k < N) ? __fadd_rn(__fsub_rn(1.0f, a), 1e-10f) : 1.0f;
+    ff[i] = f;
+    run *= (double)f;
+    pl[i] = run;
+  }
+  const double incl = wave_scan_mul_d(run, lane);
+  double excl = __shfl_up(incl, 1, 64);
+  if (lane == 0) excl = 1.0;
+  // weights, gw, and the inclusive prefix of gw_i w_i (suffix = total - prefix)
+  float T[K], w[K], gw[K];
+  double pre[K];
+  double acc = 0.0;
+  const float white_term = white ? __fadd_rn(__fadd_rn(gc0, gc1), gc2) : 0.0f;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int k = lane * K + i;
+    const double t_d = (i == 0) ? excl : excl * pl[(i > 0) ? i - 1 : 0];
+    T[i] = (k == 0) ? 1.0f : (float)t_d;
+    w[i] = __fmul_rn(alpha[i], T[i]);
+    gw[i] = gc0 * c0[i] + gc1 * c1[i] + gc2 * c2[i] - white_term;
+    if (k < N) acc += (double)gw[i] * (double)w[i];
+    pre[i] = acc;
+  }
+  const double lane_incl = wave_scan_add_d(acc, lane);
+  const double total = __shfl(lane_incl, 63, 64);
+  const double lane_excl = lane_incl - acc;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int k = lane * K + i;
+    if (k >= N) continue;
+    const int64_t p = base + k;
+    const double suffix = total - (lane_excl + pre[i]);             // sum_{i' > k} gw w
+    const float d_alpha = (float)((double)gw[i] * (double)T[i] - suffix / (double)ff[i]);
+    const float d_sigma = (sg[i] > 0.0f) ? d_alpha * dl[i] * ex[i] : 0.0f;
+    const float dr0 = gc0 * w[i] * c0[i] * (1.0f - c0[i]);
+    const float dr1 = gc1 * w[i] * c1[i] * (1.0f - c1[i]);
+    const float dr2 = gc2 * w[i] * c2[i] * (1.0f - c2[i]);
+    float4* dr = reinterpret_cast<float4*>(d_rgb + p * kRgbPad);
+    dr[0] = make_float4(dr0, dr1, dr2, 0.0f);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) dr[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    d_rgb_t[p] = dr0;
+    d_rgb_t[P + p] = dr1;
+    d_rgb_t[2 * P + p] = dr2;
+    float* gp = g1 + p * kGs + kSigmaCol;
+    gp[0] = d_sigma;
+#pragma unroll
+    for (int j = 1; j < 32; ++j) gp[j] = 0.0f;
+    g1t[(int64_t)kSigmaCol * P + p] = d_sigma;
+  }
+}
+
+// bias gradients: dst[i] (+)= sum over the P entries of row (row0 + i) of a transposed gradient buffer
+__global__ void __launch_bounds__(256) rowsum_kernel(const float* __restrict__ src_t, int64_t P, int row0,
+                                                     float* __restrict__ dst, int accumulate) {
+  __shared__ double red[256];
+  const float* row = src_t + (int64_t)(row0 + blockIdx.x) * P;
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < P; i += 256) s += (double)row[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dst[blockIdx.x] = (accumulate ? dst[blockIdx.x] : 0.0f) + (float)red[0];
+}
+
+// second pass of the split-K weight gradient + scatter into the nn.Linear shape:
+// dst[i * dst_ld + dc0 + j] (+)= sum_z partial[z * stride + (pr0 + i) * p_ld + pc0 + j]
+__global__ void __launch_bounds__(256) reduce_place_kernel(float* __restrict__ dst, int dst_ld, int dc0, int rows, int cols,
+                                                           const float* __restrict__ partial, int splits, int64_t stride,
+                                                           int p_ld, int pr0, int pc0, int accumulate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  const int i = idx / cols, j = idx % cols;
+  const float* src = partial + (int64_t)(pr0 + i) * p_ld + pc0 + j;
+  double s = 0.0;
+  for (int zc = 0; zc < splits; ++zc) s += (double)src[zc * stride];
+  float* d = dst + (int64_t)i * dst_ld + dc0 + j;
+  *d = (accumulate ? *d : 0.0f) + (float)s;
+}
+
+struct AdamPtrs {
+  float* w[NSR_N_STATE_TENSORS];
+  const float* g[NSR_N_STATE_TENSORS];
+  float* m[NSR_N_STATE_TENSORS];
+  float* v[NSR_N_STATE_TENSORS];
+};
+// torch/optim/adam.py (_single_tensor_adam) operation order, fp32
+__global__ void __launch_bounds__(256) adam_kernel(AdamPtrs a, float beta1, float beta2, float eps, float step_size,
+                                                   float bc2_sqrt) {
+  const int t = blockIdx.y;
+  const int64_t n = tensor_numel(t);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float g = a.g[t][i];
+    const float m = __fadd_rn(__fmul_rn(a.m[t][i], beta1), __fmul_rn(g, 1.0f - beta1));
+    const float v = __fadd_rn(__fmul_rn(a.v[t][i], beta2), __fmul_rn(__fmul_rn(g, g), 1.0f - beta2));   // addcmul: (g*g)*value
+    a.m[t][i] = m;
+    a.v[t][i] = v;
+    const float denom = __fadd_rn(__fdiv_rn(sqrtf(v), bc2_sqrt), eps);
+    a.w[t][i] = __fsub_rn(a.w[t][i], __fmul_rn(step_size, __fdiv_rn(m, denom)));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+struct WeightPack {   // padded / transposed copies of one network's weights (floats, all in one block)
+  float *w1p, *w5p, *w9p, *wdirp, *wrgbp, *b9p, *brgbp;
+  float* wt[9];       // wt[L], L = 2..8: transposes for the input gradients (wt[5] = W5[:, 63:]^T)
+  float *w9pt, *wdirpt, *wrgbpt;
+};
+struct Work {   // per-pass buffers, sized for P_max = chunk * (Nc + Ni) sample points
+  float *x5, *x5t, *h[9], *ht[9], *gs, *gst, *cc, *cct, *rgb, *sig;
+  float *g0, *g0t, *g1, *g1t, *drgb, *drgbt;
+  float *z_c, *z_f, *w_c, *comp, *g_comp, *partial, *scratch_out;
+  double *block_sums, *carry;
+  WeightPack pack[2];
+};
+
+int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base) {
+  const int64_t nf = nc + ni, P = chunk * nf;
+  int64_t off = 0;
+  auto take = [&](int64_t n) {
+    float* p = base ? base + off : nullptr;
+    off += align64(n);
+    return p;
+  };
+  Work tmp;
+  Work& k = w ? *w : tmp;
+  k.x5 = take(P * kX5);   k.x5t = take(P * kX5);
+  for (int L = 1; L <= 8; ++L) {
+    if (L == 4) { k.h[L] = nullptr; k.ht[L] = nullptr; continue; }   // h4 lives in x5[:, 64:]
+    k.h[L] = take(P * kW);
+    k.ht[L] = take(P * kW);
+  }
+  k.gs = take(P * kGs);   k.gst = take(P * kGs);
+  k.cc = take(P * kDirOut);   k.cct = take(P * kDirOut);
+  k.rgb = take(P * 4);   k.sig = take(P);
+  k.g0 = take(P * kGs);   k.g0t = take(P * kGs);
+  k.g1 = take(P * kGs);   k.g1t = take(P * kGs);
+  k.drgb = take(P * kRgbPad);   k.drgbt = take(P * kRgbPad);
+  k.z_c = take(chunk * nc);   k.z_f = take(chunk * nf);   k.w_c = take(chunk * nc);
+  k.comp = take(chunk * 3);   k.g_comp = take(chunk * 3);
+  k.scratch_out = take(chunk * (nf + 8));
+  k.partial = take(kMaxSplits * kPartialFloats);
+  k.block_sums = reinterpret_cast<double*>(take(2 * (chunk / 256 + 2)));
+  k.carry = reinterpret_cast<double*>(take(8));
+  for (int n = 0; n < 2; ++n) {
+    WeightPack& q = k.pack[n];
+    q.w1p = take(256 * 64);   q.w5p = take(256 * 320);   q.w9p = take(288 * 256);   q.wdirp = take(128 * 288);
+    q.wrgbp = take(32 * 128);   q.b9p = take(320);   q.brgbp = take(64);
+    for (int L = 2; L <= 8; ++L) q.wt[L] = take(65536);
+    q.w9pt = take(256 * 288);   q.wdirpt = take(256 * 128);   q.wrgbpt = take(128 * 32);
+  }
+  return off;
+}
+
+#define NSR_TRY(expr)            \
+  do {                           \
+    const int rc_ = (expr);      \
+    if (rc_ != NSR_OK) return rc_; \
+  } while (0)
+
+int place(hipStream_t st, float* dst, int dst_ld, int r0, int c0, const float* src, int src_ld, int rows, int cols,
+          int col0, int transpose) {
+  const int n = rows * cols;
+  hipLaunchKernelGGL(place_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dst, dst_ld, r0, c0, src, src_ld, rows, cols,
+                     col0, transpose);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
+int prepare_weights(hipStream_t st, const float* const* w, const WeightPack& q) {
+  // zero the whole pack first (padding rows / columns), it is one contiguous block starting at w1p
+  if (hipMemsetAsync(q.w1p, 0, (size_t)((q.wrgbpt + align64(128 * 32)) - q.w1p) * sizeof(float), st) != hipSuccess)
+    return NSR_ERR_LAUNCH;
+  NSR_TRY(place(st, q.w1p, 64, 0, 0, w[0], 63, 256, 63, 0, 0));
+  NSR_TRY(place(st, q.w5p, 320, 0, 0, w[8], 319, 256, 63, 0, 0));
+  NSR_TRY(place(st, q.w5p, 320, 0, 64, w[8], 319, 256, 256, 63, 0));
+  NSR_TRY(place(st, q.w9p, 256, 0, 0, w[kFinalW], 256, 256, 256, 0, 0));
+  NSR_TRY(place(st, q.w9p, 256, 256, 0, w[kSigmaW], 256, 1, 256, 0, 0));
+  NSR_TRY(place(st, q.wdirp, 288, 0, 0, w[kDirW], 283, 128, 256, 0, 0));
+  NSR_TRY(place(st, q.wdirp, 288, 0, kDeCol, w[kDirW], 283, 128, 27, 256, 0));
+  NSR_TRY(place(st, q.wrgbp, 128, 0, 0, w[kRgbW], 128, 3, 128, 0, 0));
+  NSR_TRY(place(st, q.b9p, 320, 0, 0, w[kFinalB], 256, 1, 256, 0, 0));
+  NSR_TRY(place(st, q.b9p, 320, 0, 256, w[kSigmaB], 1, 1, 1, 0, 0));
+  NSR_TRY(place(st, q.brgbp, 64, 0, 0, w[kRgbB], 3, 1, 3, 0, 0));
+  for (int L = 2; L <= 8; ++L) {
+    if (L == 5) NSR_TRY(place(st, q.wt[5], 256, 0, 0, w[8], 319, 256, 256, 63, 1));
+    else NSR_TRY(place(st, q.wt[L], 256, 0, 0, w[2 * (L - 1)], 256, 256, 256, 0, 1));
+  }
+  NSR_TRY(place(st, q.w9pt, 288, 0, 0, w[kFinalW], 256, 256, 256, 0, 1));
+  NSR_TRY(place(st, q.w9pt, 288, 0, 256, w[kSigmaW], 256, 1, 256, 0, 1));
+  NSR_TRY(place(st, q.wdirpt, 128, 0, 0, w[kDirW], 283, 128, 256, 0, 1));
+  NSR_TRY(place(st, q.wrgbpt, 32, 0, 0, w[kRgbW], 128, 3, 128, 0, 1));
+  return NSR_OK;
+}
+
+// y = act(x w^T + b) in both orientations
+int lin_fwd(hipStream_t st, const float* x, int64_t ldx, int K, const float* w, int ldw, const float* b, int act,
+            float* y, int64_t ldy, float* yt, int64_t P, int N, int n_valid) {
+  GemmArgs g{};
+  g.A = x; g.lda = ldx; g.B = w; g.ldb = ldw; g.C = y; g.ldc = ldy; g.Ct = yt; g.ldct = P; g.bias = b;
+  g.M = P; g.N = N; g.K = K; g.n_valid = n_valid; g.act = act; g.splits = 1;
+  return gemm_nt(g, st);
+}
+// dx = (dy w) * [x > 0] in both orientations (mask may be null)
+int lin_dgrad(hipStream_t st, const float* dy, int64_t lddy, int K, const float* wt, int ldwt, const float* mask,
+              int64_t ldm, float* dx, int64_t lddx, float* dxt, int64_t P, int N) {
+  GemmArgs g{};
+  g.A = dy; g.lda = lddy; g.B = wt; g.ldb = ldwt; g.C = dx; g.ldc = lddx; g.Ct = dxt; g.ldct = P;
+  g.mask = mask; g.ldm = ldm; g.M = P; g.N = N; g.K = K; g.n_valid = N; g.act = kActNone; g.splits = 1;
+  return gemm_nt(g, st);
+}
+int n_splits(int64_t P) {
+  int64_t s = P / 2048;
+  return (int)(s < 1 ? 1 : (s > kMaxSplits ? kMaxSplits : s));
+}
+// partial[z] (M x N) = dy_t (M x P) x_t (N x P)^T over the z-th slice of the points
+int lin_wgrad(hipStream_t st, const float* dyt, int M, const float* xt, int N, int64_t P, float* partial, int splits) {
+  GemmArgs g{};
+  g.A = dyt; g.lda = P; g.B = xt; g.ldb = P; g.C = partial; g.ldc = N; g.M = M; g.N = N; g.K = P; g.n_valid = N;
+  g.act = kActNone; g.splits = splits; g.split_stride = kPartialFloats;
+  return gemm_nt(g, st);
+}
+int reduce_place(hipStream_t st, float* dst, int dst_ld, int dc0, int rows, int cols, const float* partial, int splits,
+                 int p_ld, int pr0, int pc0, int accumulate) {
+  const int n = rows * cols;
+  hipLaunchKernelGGL(reduce_place_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dst, dst_ld, dc0, rows, cols, partial,
+                     splits, kPartialFloats, p_ld, pr0, pc0, accumulate);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+int rowsum(hipStream_t st, const float* src_t, int64_t P, int row0, int rows, float* dst, int accumulate) {
+  hipLaunchKernelGGL(rowsum_kernel, dim3(rows), dim3(256), 0, st, src_t, P, row0, dst, accumulate);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
+// M1 forward with everything kept for the backward pass
+int net_forward(hipStream_t st, const float* const* w, const WeightPack& q, const Work& k, int64_t P) {
+  NSR_TRY(lin_fwd(st, k.x5, kX5, kPe, q.w1p, 64, w[1], kActRelu, k.h[1], kW, k.ht[1], P, kW, kW));
+  NSR_TRY(lin_fwd(st, k.h[1], kW, kW, w[2], 256, w[3], kActRelu, k.h[2], kW, k.ht[2], P, kW, kW));
+  NSR_TRY(lin_fwd(st, k.h[2], kW, kW, w[4], 256, w[5], kActRelu, k.h[3], kW, k.ht[3], P, kW, kW));
+  NSR_TRY(lin_fwd(st, k.h[3], kW, kW, w[6], 256, w[7], kActRelu, k.x5 + kPe, kX5, k.x5t + kPe * P, P, kW, kW));
+  NSR_TRY(lin_fwd(st, k.x5, kX5, kX5, q.w5p, 320, w[9], kActRelu, k.h[5], kW, k.ht[5], P, kW, kW));
+  NSR_TRY(lin_fwd(st, k.h[5], kW, kW, w[10], 256, w[11], kActRelu, k.h[6], kW, k.ht[6], P, kW, kW));
+  NSR_TRY(lin_fwd(st, k.h[6], kW, kW, w[12], 256, w[13], kActRelu, k.h[7], kW, k.ht[7], P, kW, kW));
+  NSR_TRY(lin_fwd(st, k.h[7], kW, kW, w[14], 256, w[15], kActRelu, k.h[8], kW, k.ht[8], P, kW, kW));
+  // xyz_encoding_final stacked over the density head: [g | sigma] into columns 0..256 of the dir layer's input
+  NSR_TRY(lin_fwd(st, k.h[8], kW, kW, q.w9p, 256, q.b9p, kActNone, k.gs, kGs, k.gst, P, kGs, 257));
+  NSR_TRY(lin_fwd(st, k.gs, kGs, kGs, q.wdirp, 288, w[kDirB], kActRelu, k.cc, kDirOut, k.cct, P, kDirOut, kDirOut));
+  NSR_TRY(lin_fwd(st, k.cc, kDirOut, kDirOut, q.wrgbp, 128, q.brgbp, kActSigmoid, k.rgb, 4, nullptr, P, kRgbPad, 3));
+  return NSR_OK;
+}
+
+// backward of M1: d_rgb_pre in k.drgb / k.drgbt, d_sigma in column / row 256 of k.g1 / k.g1t
+int net_backward(hipStream_t st, const WeightPack& q, const Work& k, int64_t P, float* const* g, int acc) {
+  const int sp = n_splits(P);
+  float* part = k.partial;
+  // rgb head
+  NSR_TRY(lin_wgrad(st, k.drgbt, kRgbPad, k.cct, kDirOut, P, part, sp));
+  NSR_TRY(reduce_place(st, g[kRgbW], 128, 0, 3, 128, part, sp, kDirOut, 0, 0, acc));
+  NSR_TRY(rowsum(st, k.drgbt, P, 0, 3, g[kRgbB], acc));
+  NSR_TRY(lin_dgrad(st, k.drgb, kRgbPad, kRgbPad, q.wrgbpt, 32, k.cc, kDirOut, k.g0, kDirOut, k.g0t, P, kDirOut));
+  // dir_encoding
+  NSR_TRY(lin_wgrad(st, k.g0t, kDirOut, k.gst, kGs, P, part, sp));
+  NSR_TRY(reduce_place(st, g[kDirW], 283, 0, 128, 256, part, sp, kGs, 0, 0, acc));
+  NSR_TRY(reduce_place(st, g[kDirW], 283, 256, 128, 27, part, sp, kGs, 0, kDeCol, acc));
+  NSR_TRY(rowsum(st, k.g0t, P, 0, 128, g[kDirB], acc));
+  NSR_TRY(lin_dgrad(st, k.g0, kDirOut, kDirOut, q.wdirpt, 128, nullptr, 0, k.g1, kGs, k.g1t, P, kW));   // d g; column 256 keeps d sigma
+  // xyz_encoding_final + sigma (288-row layer over h8)
+  NSR_TRY(lin_wgrad(st, k.g1t, kGs, k.ht[8], kW, P, part, sp));
+  NSR_TRY(reduce_place(st, g[kFinalW], 256, 0, 256, 256, part, sp, kW, 0, 0, acc));
+  NSR_TRY(reduce_place(st, g[kSigmaW], 256, 0, 1, 256, part, sp, kW, 256, 0, acc));
+  NSR_TRY(rowsum(st, k.g1t, P, 0, 256, g[kFinalB], acc));
+  NSR_TRY(rowsum(st, k.g1t, P, 256, 1, g[kSigmaB], acc));
+  NSR_TRY(lin_dgrad(st, k.g1, kGs, kGs, q.w9pt, 288, k.h[8], kW, k.g0, kW, k.g0t, P, kW));
+  // xyz_encoding_8 .. 1; the gradient of layer L's pre-activation alternates between the two buffer pairs
+  const float* dy = k.g0;
+  const float* dyt = k.g0t;
+  float* nx = k.g1;
+  float* nxt = k.g1t;
+  for (int L = 8; L >= 1; --L) {
+    const float* xin_t = (L == 1 || L == 5) ? k.x5t : k.ht[L - 1];
+    const int kin = (L == 1) ? kPe : (L == 5 ? kX5 : kW);
+    NSR_TRY(lin_wgrad(st, dyt, kW, xin_t, kin, P, part, sp));
+    float* gw = g[2 * (L - 1)];
+    if (L == 1) NSR_TRY(reduce_place(st, gw, 63, 0, 256, 63, part, sp, kPe, 0, 0, acc));
+    else if (L == 5) {
+      NSR_TRY(reduce_place(st, gw, 319, 0, 256, 63, part, sp, kX5, 0, 0, acc));
+      NSR_TRY(reduce_place(st, gw, 319, 63, 256, 256, part, sp, kX5, 0, kPe, acc));
+    } else NSR_TRY(reduce_place(st, gw, 256, 0, 256, 256, part, sp, kW, 0, 0, acc));
+    NSR_TRY(rowsum(st, dyt, P, 0, 256, g[2 * (L - 1) + 1], acc));
+    if (L == 1) break;
+    // input of layer L is the output of layer L - 1 (relu'd): h4 sits in x5[:, 64:]
+    const float* mask = (L - 1 == 4) ? k.x5 + kPe : k.h[L - 1];
+    const int64_t ldm = (L - 1 == 4) ? kX5 : kW;
+    NSR_TRY(lin_dgrad(st, dy, kW, kW, q.wt[L], 256, mask, ldm, nx, kW, nxt, P, kW));
+    const float* t0 = dy; dy = nx; nx = const_cast<float*>(t0);
+    const float* t1 = dyt; dyt = nxt; nxt = const_cast<float*>(t1);
+  }
+  return NSR_OK;
+}
+
+int composite_bwd(hipStream_t st, const Work& k, const float* z, int64_t R, int N, int white, int64_t P) {
+  // rows 3..31 of d_rgb_t and 257..287 of g1t are never written by anyone else
+  if (hipMemsetAsync(k.drgbt + 3 * P, 0, (size_t)(29 * P) * sizeof(float), st) != hipSuccess) return NSR_ERR_LAUNCH;
+  if (hipMemsetAsync(k.g1t + 257 * P, 0, (size_t)(31 * P) * sizeof(float), st) != hipSuccess) return NSR_ERR_LAUNCH;
+  const dim3 block(256), grid((unsigned)((R + 3) / 4));
+  const int K = (N + 63) / 64;
+#define NSR_LAUNCH_CB(KK)                                                                                          \
+  hipLaunchKernelGGL(composite_bwd_kernel<KK>, grid, block, 0, st, k.rgb, k.sig, z, k.g_comp, R, N, white, P, k.drgb, \
+                     k.drgbt, k.g1, k.g1t)
+  switch (K) {
+    case 1: NSR_LAUNCH_CB(1); break;
+    case 2: NSR_LAUNCH_CB(2); break;
+    case 3: NSR_LAUNCH_CB(3); break;
+    case 4: NSR_LAUNCH_CB(4); break;
+    default: return NSR_ERR_UNSUPPORTED;
+  }
+#undef NSR_LAUNCH_CB
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
+}  // namespace
+
+extern "C" size_t nsr_train_workspace_bytes(int64_t ray_chunk, int n_coarse, int n_importance) {
+  if (ray_chunk <= 0 || n_coarse < 2 || n_importance < 1 || n_coarse + n_importance > 256) return 0;
+  return (size_t)work_floats(ray_chunk, n_coarse, n_importance, nullptr, nullptr) * sizeof(float);
+}
+
+extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const float* const* w_fine, float* const* g_coarse,
+                                        float* const* g_fine, const float* rays, int ray_stride, int64_t R, int s2,
+                                        const float* target_lr, int n_coarse, int n_importance, int white_bkgd,
+                                        int lindisp, const float* u_coarse, const float* u_fine,
+                                        const float* noise_coarse, const float* noise_fine, float noise_std,
+                                        float lambda_coarse, float lambda_fine, int64_t ray_chunk, float* const* outs,
+                                        float* lr_coarse, float* lr_fine, float* losses, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  if (!w_coarse || !w_fine || !g_coarse || !g_fine || !outs || R < 0 || s2 <= 0 || !nsr_ray_stride_ok(ray_stride))
+    return NSR_ERR_INVALID_ARG;
+  if (n_coarse < 2 || n_importance < 1 || n_coarse + n_importance > 256) return NSR_ERR_UNSUPPORTED;
+  if (R % s2 != 0) return NSR_ERR_INVALID_ARG;
+  if (ray_chunk <= 0 || ray_chunk > R) ray_chunk = R;
+  if (ray_chunk % s2 != 0) return NSR_ERR_INVALID_ARG;
+  for (int i = 0; i < NSR_N_STATE_TENSORS; ++i)
+    if (!w_coarse[i] || !w_fine[i] || !g_coarse[i] || !g_fine[i]) return NSR_ERR_INVALID_ARG;
+  if (R == 0) return NSR_OK;
+  if (!rays || !target_lr || !outs[0] || !outs[4] || !lr_coarse || !lr_fine || !losses || !workspace)
+    return NSR_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return NSR_ERR_INVALID_ARG;
+  if (workspace_bytes < nsr_train_workspace_bytes(ray_chunk, n_coarse, n_importance)) return NSR_ERR_WORKSPACE;
+  const bool noisy = noise_std > 0.0f;
+  hipStream_t st = nsr_stream(stream);
+  Work k;
+  work_floats(ray_chunk, n_coarse, n_importance, &k, static_cast<float*>(workspace));
+  const int nc = n_coarse, nf = n_coarse + n_importance;
+  const int64_t n_lr_total = R / s2;
+  const double mse_scale = 1.0 / (3.0 * (double)n_lr_total);
+
+  NSR_TRY(prepare_weights(st, w_coarse, k.pack[0]));
+  NSR_TRY(prepare_weights(st, w_fine, k.pack[1]));
+  if (hipMemsetAsync(k.carry, 0, 4 * sizeof(double), st) != hipSuccess) return NSR_ERR_LAUNCH;
+
+  for (int64_t r0 = 0; r0 < R; r0 += ray_chunk) {
+    const int64_t rc = (R - r0 < ray_chunk) ? R - r0 : ray_chunk;
+    const int acc = r0 > 0;
+    const float* rays_c = rays + r0 * ray_stride;
+    const int64_t lr0 = r0 / s2, n_lr = rc / s2;
+    for (int net = 0; net < 2; ++net) {
+      const int N = net ? nf : nc;
+      const int64_t P = rc * N;
+      const float* const* w = net ? w_fine : w_coarse;
+      float* const* g = net ? g_fine : g_coarse;
+      float* z = net ? k.z_f : k.z_c;
+      if (net == 0) {
+        NSR_TRY(nsr_sample_along_rays(rays_c, ray_stride, rc, nc, lindisp, u_coarse ? u_coarse + r0 * nc : nullptr, z,
+                                      nullptr, stream));
+      } else {
+        const float* wc = outs[3] ? outs[3] + r0 * nc : k.w_c;
+        NSR_TRY(nsr_resample_along_rays(rays_c, ray_stride, k.z_c, wc, rc, nc, n_importance,
+                                        u_fine ? u_fine + r0 * n_importance : nullptr, z, nullptr, stream));
+      }
+      hipLaunchKernelGGL(encode_train_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, rays_c, ray_stride, z,
+                         P, N, k.x5, k.x5t, k.gs, k.gst);
+      NSR_CHECK_LAUNCH();
+      NSR_TRY(net_forward(st, w, k.pack[net], k, P));
+      const float* noise = net ? noise_fine : noise_coarse;
+      hipLaunchKernelGGL(sigma_noise_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, k.gs,
+                         (noisy && noise) ? noise + r0 * N : nullptr, noise_std, P, k.sig);
+      NSR_CHECK_LAUNCH();
+      float* comp = outs[4 * net + 0] + r0 * 3;
+      float* depth = outs[4 * net + 1] ? outs[4 * net + 1] + r0 : nullptr;
+      float* opac = outs[4 * net + 2] ? outs[4 * net + 2] + r0 : nullptr;
+      float* wts = outs[4 * net + 3] ? outs[4 * net + 3] + r0 * N : (net ? nullptr : k.w_c);
+      NSR_TRY(nsr_composite(k.rgb, 4, k.sig, 1, z, rc, N, white_bkgd, comp, depth, opac, wts, stream));
+      // s^2 mean, loss, dL/d(comp)
+      const float lambda = net ? lambda_fine : lambda_coarse;
+      const int nblk = (int)((n_lr + 255) / 256);
+      hipLaunchKernelGGL(lr_loss_kernel, dim3(nblk), dim3(256), 0, st, comp, target_lr + lr0 * 3, n_lr, s2, mse_scale,
+                         lambda, (net ? lr_fine : lr_coarse) + lr0 * 3, k.g_comp, k.block_sums);
+      NSR_CHECK_LAUNCH();
+      hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, k.block_sums, nblk, mse_scale, lambda, losses, net,
+                         k.carry);
+      NSR_CHECK_LAUNCH();
+      NSR_TRY(composite_bwd(st, k, z, rc, N, white_bkgd, P));
+      NSR_TRY(net_backward(st, k.pack[net], k, P, g, acc));
+    }
+  }
+  return NSR_OK;
+}
+
+extern "C" int nsr_adam_step(float* const* w, const float* const* g, float* const* m, float* const* v, int step, float lr,
+                             float beta1, float beta2, float eps, void* stream) {
+  if (!w || !g || !m || !v || step < 1) return NSR_ERR_INVALID_ARG;
+  AdamPtrs a;
+  for (int i = 0; i < NSR_N_STATE_TENSORS; ++i) {
+    if (!w[i] || !g[i] || !m[i] || !v[i]) return NSR_ERR_INVALID_ARG;
+    a.w[i] = w[i]; a.g[i] = g[i]; a.m[i] = m[i]; a.v[i] = v[i];
+  }
+  // bias corrections in double like Python's floats, then one rounding to fp32
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  hipLaunchKernelGGL(adam_kernel, dim3(64, NSR_N_STATE_TENSORS), dim3(256), 0, nsr_stream(stream), a, beta1, beta2, eps,
+                     step_size, bc2_sqrt);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
+extern "C" int nsr_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* b, int act, float* y,
+                          int64_t ldy, float* y_t, int64_t ldyt, int64_t P, int K, int N, void* stream) {
+  if (P < 0 || K <= 0 || N <= 0 || act < 0 || act > 2) return NSR_ERR_INVALID_ARG;
+  if (P == 0) return NSR_OK;
+  GemmArgs g{};
+  g.A = x; g.lda = ldx; g.B = w; g.ldb = ldw; g.C = y; g.ldc = ldy; g.Ct = y_t; g.ldct = ldyt; g.bias = b;
+  g.M = P; g.N = N; g.K = K; g.n_valid = N; g.act = act; g.splits = 1;
+  return gemm_nt(g, nsr_stream(stream));
+}

@@ -1,0 +1,155 @@
+"""Host mirror of the reference's training iteration over ``include/nsr_train.h``.
+
+``Trainer`` holds what ``NeRFDownXModel`` holds in train mode (``models/nerf_downX_model.py:133-205``): the two
+networks' 24-tensor state dicts as fp32 device tensors, their gradients, and the Adam moments; its methods follow
+the reference's call protocol:
+
+    set_input(rays, rgbs)  ->  optimize_parameters()            (:235-248, :398-408)
+        = forward (train mode) + comp_low_res_output + calculate_losses + backward + optimizer.step
+
+All arithmetic runs in libnsr.so (``nsr_train_loss_and_grads``, ``nsr_adam_step``); torch supplies device memory,
+the stream and the random draws (``torch.rand`` / ``torch.randn`` on the device, exactly the four tensors the
+reference draws).  There is no CPU path.
+"""
+from __future__ import annotations
+
+from ctypes import c_void_p
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import _f32, _p, _ray_stride, _stream
+from .weights import STATE_DICT_SPEC, check_state_dict
+
+OUT_KEYS = ("coarse_comp_rgbs", "coarse_depth", "coarse_opacity", "coarse_weights",
+            "fine_comp_rgbs", "fine_depth", "fine_opacity", "fine_weights")
+
+
+def _ptr_array(tensors):
+    return (c_void_p * len(tensors))(*[c_void_p(t.data_ptr()) for t in tensors])
+
+
+def _to_dev(sd, device) -> Dict[str, torch.Tensor]:
+    check_state_dict(sd)
+    out = {}
+    for k in STATE_DICT_SPEC:
+        v = sd[k]
+        v = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v.detach()
+        out[k] = v.to(device=device, dtype=torch.float32).contiguous().clone()
+    return out
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, act: int = 0, transposed: bool = False):
+    """One ``nn.Linear`` (+ activation) on the training GEMM (``nsr_linear``): y = act(x w^T + b).
+    K must be a multiple of 32; returns y (P, N) and, if asked, also y^T (N, P)."""
+    x, w = _f32(x, "x"), _f32(w, "w")
+    P, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(P, N, dtype=torch.float32, device=x.device)
+    yt = torch.empty(N, P, dtype=torch.float32, device=x.device) if transposed else None
+    _lib.check(_lib.load().nsr_linear(_p(x), K, _p(w), K, _p(None if b is None else _f32(b, "b")), act, _p(y), N,
+                                      _p(yt), P, P, K, N, _stream()), "nsr_linear")
+    return (y, yt) if transposed else y
+
+
+class Trainer:
+    """Coarse + fine networks, gradients, Adam state and one-call training iterations."""
+
+    def __init__(self, sd_coarse, sd_fine, N_coarse: int = 64, N_importance: int = 64, white_bkgd: bool = False,
+                 lindisp: bool = False, downscale: int = 2, randomized: bool = True, noise_std: float = 0.0,
+                 lr: float = 5e-4, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                 lambda_coarse_mse: float = 1.0, lambda_fine_mse: float = 1.0, ray_chunk: int = 4096, device="cuda"):
+        self.device = torch.device(device)
+        self.params = [_to_dev(sd_coarse, self.device), _to_dev(sd_fine, self.device)]
+        self.grads = [{k: torch.zeros_like(v) for k, v in p.items()} for p in self.params]
+        self.exp_avg = [{k: torch.zeros_like(v) for k, v in p.items()} for p in self.params]
+        self.exp_avg_sq = [{k: torch.zeros_like(v) for k, v in p.items()} for p in self.params]
+        self.N_coarse, self.N_importance = int(N_coarse), int(N_importance)
+        self.white_bkgd, self.lindisp = bool(white_bkgd), bool(lindisp)
+        self.s2 = int(downscale) ** 2
+        self.randomized, self.noise_std = bool(randomized), float(noise_std)
+        self.lr, self.beta1, self.beta2, self.eps = float(lr), float(beta1), float(beta2), float(eps)
+        self.lambda_coarse, self.lambda_fine = float(lambda_coarse_mse), float(lambda_fine_mse)
+        self.ray_chunk = int(ray_chunk) - int(ray_chunk) % self.s2
+        self.step = 0
+        self._ws = None
+        self.losses = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self.out: Dict[str, torch.Tensor] = {}
+
+    # -- reference protocol ------------------------------------------------------------------------------
+    def set_input(self, rays: torch.Tensor, rgbs: torch.Tensor):
+        """rays (N_lr, s2, 8 | 11) or (N_lr * s2, 8 | 11); rgbs (N_lr, 3) LR targets (set_input, :235-248)."""
+        rays = _f32(rays.reshape(-1, rays.shape[-1]), "rays")
+        self.data_rays, self.data_rgbs = rays, _f32(rgbs.reshape(-1, 3), "rgbs")
+        if rays.shape[0] != self.data_rgbs.shape[0] * self.s2:
+            raise ValueError("rays must hold s^2 sub-rays per LR target pixel")
+
+    def draw(self, R: int) -> Dict[str, Optional[torch.Tensor]]:
+        """The random tensors of one train-mode forward, in the reference's order (models/utils.py:40, 210, 73)."""
+        d = {"u_coarse": None, "noise_coarse": None, "u_fine": None, "noise_fine": None}
+        if self.randomized:
+            nc, nf = self.N_coarse, self.N_coarse + self.N_importance
+            d["u_coarse"] = torch.rand(R, nc, device=self.device)
+            if self.noise_std > 0:
+                d["noise_coarse"] = torch.randn(R, nc, device=self.device)
+            d["u_fine"] = torch.rand(R, self.N_importance, device=self.device)
+            if self.noise_std > 0:
+                d["noise_fine"] = torch.randn(R, nf, device=self.device)
+        return d
+
+    def loss_and_grads(self, draws: Optional[Dict[str, Optional[torch.Tensor]]] = None):
+        """forward + comp_low_res_output + calculate_losses + backward (:316-396): fills ``self.out``,
+        ``self.losses`` (device float[2]) and ``self.grads``."""
+        rays = self.data_rays
+        R, stride = rays.shape[0], _ray_stride(rays)
+        if draws is None:
+            draws = self.draw(R)
+        draws = {k: (None if v is None else _f32(torch.as_tensor(v, device=self.device), k)) for k, v in draws.items()
+                 if k != "noise_std"}
+        nc, nf = self.N_coarse, self.N_coarse + self.N_importance
+        chunk = min(self.ray_chunk, R) if self.ray_chunk > 0 else R
+        lib = _lib.load()
+        need = lib.nsr_train_workspace_bytes(chunk, nc, self.N_importance)
+        if need == 0:
+            raise _lib.NsrError("sample counts outside the built path")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        dev = self.device
+        o = {"coarse_comp_rgbs": torch.empty(R, 3, device=dev), "coarse_depth": torch.empty(R, device=dev),
+             "coarse_opacity": torch.empty(R, device=dev), "coarse_weights": torch.empty(R, nc, device=dev),
+             "fine_comp_rgbs": torch.empty(R, 3, device=dev), "fine_depth": torch.empty(R, device=dev),
+             "fine_opacity": torch.empty(R, device=dev), "fine_weights": torch.empty(R, nf, device=dev)}
+        lr_c = torch.empty(R // self.s2, 3, device=dev)
+        lr_f = torch.empty(R // self.s2, 3, device=dev)
+        outs = (c_void_p * 8)(*[c_void_p(o[k].data_ptr()) for k in OUT_KEYS])
+        wc, wf = _ptr_array(list(self.params[0].values())), _ptr_array(list(self.params[1].values()))
+        gc, gf = _ptr_array(list(self.grads[0].values())), _ptr_array(list(self.grads[1].values()))
+        _lib.check(lib.nsr_train_loss_and_grads(
+            wc, wf, gc, gf, _p(rays), stride, R, self.s2, _p(self.data_rgbs), nc, self.N_importance,
+            int(self.white_bkgd), int(self.lindisp), _p(draws.get("u_coarse")), _p(draws.get("u_fine")),
+            _p(draws.get("noise_coarse")), _p(draws.get("noise_fine")), self.noise_std, self.lambda_coarse,
+            self.lambda_fine, chunk, outs, _p(lr_c), _p(lr_f), _p(self.losses), _p(self._ws), self._ws.numel(),
+            _stream()), "nsr_train_loss_and_grads")
+        o["lr_coarse"], o["lr_fine"] = lr_c, lr_f
+        self.out = o
+        return self.losses, self.grads
+
+    def optimizer_step(self):
+        """torch.optim.Adam.step over both networks (:201-204, :408)."""
+        self.step += 1
+        for n in range(2):
+            _lib.check(_lib.load().nsr_adam_step(
+                _ptr_array(list(self.params[n].values())), _ptr_array(list(self.grads[n].values())),
+                _ptr_array(list(self.exp_avg[n].values())), _ptr_array(list(self.exp_avg_sq[n].values())),
+                self.step, self.lr, self.beta1, self.beta2, self.eps, _stream()), "nsr_adam_step")
+
+    def optimize_parameters(self, draws=None):
+        """One training iteration (:398-408); returns the device tensor [coarse_mse, fine_mse] (lambda-weighted)."""
+        self.loss_and_grads(draws)
+        self.optimizer_step()
+        return self.losses
+
+    def state_dicts(self):
+        return [{k: v.clone() for k, v in p.items()} for p in self.params]

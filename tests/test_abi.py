@@ -21,7 +21,7 @@ def lib():
 
 
 def _declared_symbols():
-    text = open(os.path.join(REPO, "include", "nsr.h")).read()
+    text = open(os.path.join(REPO, "include", "nsr.h")).read() + open(os.path.join(REPO, "include", "nsr_train.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(nsr_[a-z_0-9]+)\s*\(", text)))
 
