@@ -91,6 +91,90 @@ def measured_traffic(precision: str):
         return None
 
 
+def main_train(args):
+    """Training-step benchmark (not the headline): scripts/train_llff_downX.sh's batch -- 512 LR pixels x 4
+    sub-rays = 2,048 rays per GPU per step, 64 + 128 samples, randomized sampling, noise_std 1 -- through
+    Trainer.optimize_parameters (forward, s^2-mean MSE losses, backward, one gradient all-reduce for N > 1, Adam)."""
+    from nerf_sr_amd import train as nsr_train
+    rank, local, world = nsr_dist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    R = args.train_rays - args.train_rays % 4
+    sd_c, sd_f = make_state_dict(99), make_state_dict(100)
+    t = nsr_train.Trainer(sd_c, sd_f, randomized=True, noise_std=1.0, downscale=DOWNSCALE, ray_chunk=R, device=dev)
+    t.grad_scale = 1.0 / world
+    frame = ops.subpixel_rays(cameras.spiral_pose(0.4 + 0.35 * rank), IMG_WH, cameras.llff_focal(IMG_WH[0]), DOWNSCALE,
+                              True, device=dev)                       # (N_lr, 4, 8)
+    torch.manual_seed(1234 + rank)
+    sel = torch.randperm(frame.shape[0], device=dev)[: R // 4]
+    rays = frame[sel].reshape(-1, 8).contiguous()
+    target = torch.rand(R // 4, 3, device=dev)
+    t.set_input(rays, target)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        t.optimize_parameters()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t.optimize_parameters()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        value = R * world * args.steps / dt
+        flop_step = 3 * FLOP_PER_RAY * R            # forward + input gradients + weight gradients, per GPU
+        achieved = flop_step / (dt / args.steps) / 1e12
+        res = {
+            "metric": "training rays/sec (64+128 samples, 2x SS; forward + backward + Adam)", "value": value,
+            "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"training iteration of nerf_downX (scripts/train_llff_downX.sh shape): {R // 4} LR "
+                                   f"pixels x 4 sub-rays = {R} rays per GPU per step, 64 coarse + 128 fine samples, "
+                                   "randomized sampling, noise_std 1, s^2-mean MSE on coarse + fine, Adam lr 5e-4"
+                                   + ("" if world == 1 else f"; data parallel x{world}, one gradient all-reduce per network per step"),
+                       "rays_per_step": R * world, "parallelism": f"data-parallel x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "whole training step (fp32-MFMA GEMMs: forward, dgrad, wgrad)",
+                         "achieved": achieved, "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_TFLOPS["fp32"], "traffic": None,
+                         "flop_per_step": flop_step,
+                         "note": "algorithmic flops = 3 x 593,408 MAC x 2 per sample point x 192 points per ray"},
+            "losses": [float(x) * world for x in t.losses.tolist()],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import train_oracle as to     # checker/baseline only; never on the product path
+            n = 256
+            draws = {k: (None if v is None else v[: n].cpu()) for k, v in t.draw(n).items()}
+            all_cores = torch.get_num_threads()
+            torch.set_num_threads(min(32, all_cores))
+            tc = time.perf_counter()
+            to.loss_and_grads(sd_c, sd_f, rays[:n].cpu(), target[: n // 4].cpu(), 4, N_COARSE, N_IMPORTANCE, False,
+                              noise_std=1.0, **draws)
+            dtc = time.perf_counter() - tc
+            torch.set_num_threads(all_cores)
+            res["cpu_baseline"] = {"value": n / dtc, "unit": "rays/s", "cores": min(32, all_cores), "kind": "port",
+                                   "sample": f"{n} rays of the same batch, torch-CPU training oracle (autograd, fp32), "
+                                             f"forward + backward, {dtc:.1f} s"}
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,7 +184,13 @@ def main():
                     help="MLP arithmetic: f16x3 (default; split-fp16 MFMA, fp32-grade: passes the 1e-4 RGB contract) "
                          "or fp32 (fp32 MFMA); f16 / bf16 = single 16-bit operands, fast but outside the parity contract")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="render", choices=["render", "train"],
+                    help="render (default): the headline metric; train: one optimize_parameters iteration per step "
+                         "(SURVEY §8f N1: forward + backward + Adam, fp32) on a 2,048-ray batch per GPU")
+    ap.add_argument("--train-rays", type=int, default=2048, help="rays per GPU per training step (multiple of 4)")
     args = ap.parse_args()
+    if args.mode == "train":
+        return main_train(args)
 
     rank, local, world = nsr_dist.init_from_env()
     if world != args.gpus:

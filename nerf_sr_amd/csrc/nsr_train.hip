@@ -256,20 +256,34 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
   }
 }
 
-// bias gradients: dst[i] (+)= sum over the P entries of row (row0 + i) of a transposed gradient buffer
-__global__ void __launch_bounds__(256) rowsum_kernel(const float* __restrict__ src_t, int64_t P, int row0,
-                                                     float* __restrict__ dst, int accumulate) {
+// bias gradients: dst[i] (+)= sum over the P entries of row (row0 + i) of a transposed gradient buffer.
+// Two passes (kRowSplits slices per row, then a finishing pass) so that a 256-row sum fills the chip.
+constexpr int kRowSplits = 32;
+__global__ void __launch_bounds__(256) rowsum_partial_kernel(const float* __restrict__ src_t, int64_t P, int row0,
+                                                             double* __restrict__ partial) {
   __shared__ double red[256];
-  const float* row = src_t + (int64_t)(row0 + blockIdx.x) * P;
+  const float4* row = reinterpret_cast<const float4*>(src_t + (int64_t)(row0 + blockIdx.x) * P);
+  const int64_t n4 = P >> 2, per = (n4 + kRowSplits - 1) / kRowSplits;
+  const int64_t lo = per * blockIdx.y, hi = (lo + per < n4) ? lo + per : n4;
   double s = 0.0;
-  for (int64_t i = threadIdx.x; i < P; i += 256) s += (double)row[i];
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const float4 v = row[i];
+    s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) dst[blockIdx.x] = (accumulate ? dst[blockIdx.x] : 0.0f) + (float)red[0];
+  if (threadIdx.x == 0) partial[blockIdx.x * kRowSplits + blockIdx.y] = red[0];
+}
+__global__ void rowsum_finish_kernel(const double* __restrict__ partial, int rows, float* __restrict__ dst, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  double s = 0.0;
+  for (int j = 0; j < kRowSplits; ++j) s += partial[i * kRowSplits + j];
+  dst[i] = (accumulate ? dst[i] : 0.0f) + (float)s;
 }
 
 // second pass of the split-K weight gradient + scatter into the nn.Linear shape:
@@ -439,8 +453,13 @@ int reduce_place(hipStream_t st, float* dst, int dst_ld, int dc0, int rows, int 
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
-int rowsum(hipStream_t st, const float* src_t, int64_t P, int row0, int rows, float* dst, int accumulate) {
-  hipLaunchKernelGGL(rowsum_kernel, dim3(rows), dim3(256), 0, st, src_t, P, row0, dst, accumulate);
+// `scratch`: >= 288 * kRowSplits doubles (the split-K partial buffer is free between two weight gradients)
+int rowsum(hipStream_t st, const float* src_t, int64_t P, int row0, int rows, float* dst, int accumulate, float* scratch) {
+  if (P % 4 != 0) return NSR_ERR_INVALID_ARG;
+  double* part = reinterpret_cast<double*>(scratch);
+  hipLaunchKernelGGL(rowsum_partial_kernel, dim3(rows, kRowSplits), dim3(256), 0, st, src_t, P, row0, part);
+  NSR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rowsum_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, part, rows, dst, accumulate);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
@@ -469,20 +488,20 @@ int net_backward(hipStream_t st, const WeightPack& q, const Work& k, int64_t P, 
   // rgb head
   NSR_TRY(lin_wgrad(st, k.drgbt, kRgbPad, k.cct, kDirOut, P, part, sp));
   NSR_TRY(reduce_place(st, g[kRgbW], 128, 0, 3, 128, part, sp, kDirOut, 0, 0, acc));
-  NSR_TRY(rowsum(st, k.drgbt, P, 0, 3, g[kRgbB], acc));
+  NSR_TRY(rowsum(st, k.drgbt, P, 0, 3, g[kRgbB], acc, part));
   NSR_TRY(lin_dgrad(st, k.drgb, kRgbPad, kRgbPad, q.wrgbpt, 32, k.cc, kDirOut, k.g0, kDirOut, k.g0t, P, kDirOut));
   // dir_encoding
   NSR_TRY(lin_wgrad(st, k.g0t, kDirOut, k.gst, kGs, P, part, sp));
   NSR_TRY(reduce_place(st, g[kDirW], 283, 0, 128, 256, part, sp, kGs, 0, 0, acc));
   NSR_TRY(reduce_place(st, g[kDirW], 283, 256, 128, 27, part, sp, kGs, 0, kDeCol, acc));
-  NSR_TRY(rowsum(st, k.g0t, P, 0, 128, g[kDirB], acc));
+  NSR_TRY(rowsum(st, k.g0t, P, 0, 128, g[kDirB], acc, part));
   NSR_TRY(lin_dgrad(st, k.g0, kDirOut, kDirOut, q.wdirpt, 128, nullptr, 0, k.g1, kGs, k.g1t, P, kW));   // d g; column 256 keeps d sigma
   // xyz_encoding_final + sigma (288-row layer over h8)
   NSR_TRY(lin_wgrad(st, k.g1t, kGs, k.ht[8], kW, P, part, sp));
   NSR_TRY(reduce_place(st, g[kFinalW], 256, 0, 256, 256, part, sp, kW, 0, 0, acc));
   NSR_TRY(reduce_place(st, g[kSigmaW], 256, 0, 1, 256, part, sp, kW, 256, 0, acc));
-  NSR_TRY(rowsum(st, k.g1t, P, 0, 256, g[kFinalB], acc));
-  NSR_TRY(rowsum(st, k.g1t, P, 256, 1, g[kSigmaB], acc));
+  NSR_TRY(rowsum(st, k.g1t, P, 0, 256, g[kFinalB], acc, part));
+  NSR_TRY(rowsum(st, k.g1t, P, 256, 1, g[kSigmaB], acc, part));
   NSR_TRY(lin_dgrad(st, k.g1, kGs, kGs, q.w9pt, 288, k.h[8], kW, k.g0, kW, k.g0t, P, kW));
   // xyz_encoding_8 .. 1; the gradient of layer L's pre-activation alternates between the two buffer pairs
   const float* dy = k.g0;
@@ -499,7 +518,7 @@ int net_backward(hipStream_t st, const WeightPack& q, const Work& k, int64_t P, 
       NSR_TRY(reduce_place(st, gw, 319, 0, 256, 63, part, sp, kX5, 0, 0, acc));
       NSR_TRY(reduce_place(st, gw, 319, 63, 256, 256, part, sp, kX5, 0, kPe, acc));
     } else NSR_TRY(reduce_place(st, gw, 256, 0, 256, 256, part, sp, kW, 0, 0, acc));
-    NSR_TRY(rowsum(st, dyt, P, 0, 256, g[2 * (L - 1) + 1], acc));
+    NSR_TRY(rowsum(st, dyt, P, 0, 256, g[2 * (L - 1) + 1], acc, part));
     if (L == 1) break;
     // input of layer L is the output of layer L - 1 (relu'd): h4 sits in x5[:, 64:]
     const float* mask = (L - 1 == 4) ? k.x5 + kPe : k.h[L - 1];

@@ -73,6 +73,19 @@ def render_sharded(render_block: Callable[[int, int], torch.Tensor], n_lr: int, 
     return all_gather_pixels(render_block(lo, hi), n_lr, group)
 
 
+def all_reduce_sum_(buffers, group=None) -> None:
+    """Training-side exchange: in-place SUM all-reduce of each flat gradient buffer (one per network, 2.4 MB).
+
+    Replaces DistributedDataParallel's bucketed gradient all-reduce (models/networks.py:84).  Every rank scales its
+    loss by 1 / world (``Trainer.grad_scale``) so that the SUM is the gradient of the global-batch mean loss; the
+    optimiser step then runs replicated and the weights stay bit-identical across ranks.  No-op for world == 1."""
+    rank, world = _world(group)
+    if world == 1:
+        return
+    for b in buffers:
+        dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
+
+
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise the default process group from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR / MASTER_PORT).  Returns (rank, local_rank, world).  No-op for world == 1."""

@@ -31,6 +31,19 @@ def _ptr_array(tensors):
     return (c_void_p * len(tensors))(*[c_void_p(t.data_ptr()) for t in tensors])
 
 
+def _flat_like(params: Dict[str, torch.Tensor]):
+    """One flat fp32 buffer + per-tensor views with the state_dict's shapes (so a whole network's gradients or
+    Adam moments are ONE contiguous range: a single all-reduce / memset covers them).  Views start 16-byte aligned."""
+    sizes = [(k, v.numel(), tuple(v.shape)) for k, v in params.items()]
+    offs, total = [], 0
+    for _, n, _ in sizes:
+        offs.append(total)
+        total += (n + 3) // 4 * 4
+    flat = torch.zeros(total, dtype=torch.float32, device=next(iter(params.values())).device)
+    views = {k: flat[o:o + n].view(shape) for (k, n, shape), o in zip(sizes, offs)}
+    return flat, views
+
+
 def _to_dev(sd, device) -> Dict[str, torch.Tensor]:
     check_state_dict(sd)
     out = {}
@@ -63,9 +76,11 @@ class Trainer:
                  lambda_coarse_mse: float = 1.0, lambda_fine_mse: float = 1.0, ray_chunk: int = 4096, device="cuda"):
         self.device = torch.device(device)
         self.params = [_to_dev(sd_coarse, self.device), _to_dev(sd_fine, self.device)]
-        self.grads = [{k: torch.zeros_like(v) for k, v in p.items()} for p in self.params]
-        self.exp_avg = [{k: torch.zeros_like(v) for k, v in p.items()} for p in self.params]
-        self.exp_avg_sq = [{k: torch.zeros_like(v) for k, v in p.items()} for p in self.params]
+        flat = [_flat_like(p) for p in self.params]
+        self.flat_grads, self.grads = [f for f, _ in flat], [v for _, v in flat]
+        self.exp_avg = [_flat_like(p)[1] for p in self.params]
+        self.exp_avg_sq = [_flat_like(p)[1] for p in self.params]
+        self.grad_scale = 1.0      # 1 / world_size under data parallelism: the all-reduce SUM is then the global mean
         self.N_coarse, self.N_importance = int(N_coarse), int(N_importance)
         self.white_bkgd, self.lindisp = bool(white_bkgd), bool(lindisp)
         self.s2 = int(downscale) ** 2
@@ -101,7 +116,7 @@ class Trainer:
 
     def loss_and_grads(self, draws: Optional[Dict[str, Optional[torch.Tensor]]] = None):
         """forward + comp_low_res_output + calculate_losses + backward (:316-396): fills ``self.out``,
-        ``self.losses`` (device float[2]) and ``self.grads``."""
+        ``self.losses`` (device float[2], times ``grad_scale``) and ``self.grads``."""
         rays = self.data_rays
         R, stride = rays.shape[0], _ray_stride(rays)
         if draws is None:
@@ -129,12 +144,20 @@ class Trainer:
         _lib.check(lib.nsr_train_loss_and_grads(
             wc, wf, gc, gf, _p(rays), stride, R, self.s2, _p(self.data_rgbs), nc, self.N_importance,
             int(self.white_bkgd), int(self.lindisp), _p(draws.get("u_coarse")), _p(draws.get("u_fine")),
-            _p(draws.get("noise_coarse")), _p(draws.get("noise_fine")), self.noise_std, self.lambda_coarse,
-            self.lambda_fine, chunk, outs, _p(lr_c), _p(lr_f), _p(self.losses), _p(self._ws), self._ws.numel(),
+            _p(draws.get("noise_coarse")), _p(draws.get("noise_fine")), self.noise_std,
+            self.lambda_coarse * self.grad_scale, self.lambda_fine * self.grad_scale, chunk, outs, _p(lr_c), _p(lr_f), _p(self.losses), _p(self._ws), self._ws.numel(),
             _stream()), "nsr_train_loss_and_grads")
         o["lr_coarse"], o["lr_fine"] = lr_c, lr_f
         self.out = o
         return self.losses, self.grads
+
+    def all_reduce_grads(self, group=None):
+        """Data-parallel training (replaces DistributedDataParallel's bucketed gradient all-reduce,
+        models/networks.py:84): every rank renders its own ray batch with ``grad_scale = 1 / world`` and ONE
+        all-reduce (SUM) per network of the flat 2.4 MB gradient buffer (RCCL over xGMI; gloo in the CPU tests of
+        ``dist.py``) leaves the global-mean gradient on every rank; the Adam step then runs replicated."""
+        from .dist import all_reduce_sum_
+        all_reduce_sum_(self.flat_grads, group)
 
     def optimizer_step(self):
         """torch.optim.Adam.step over both networks (:201-204, :408)."""
@@ -148,6 +171,7 @@ class Trainer:
     def optimize_parameters(self, draws=None):
         """One training iteration (:398-408); returns the device tensor [coarse_mse, fine_mse] (lambda-weighted)."""
         self.loss_and_grads(draws)
+        self.all_reduce_grads()
         self.optimizer_step()
         return self.losses
 

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from nerf_sr_amd.dist import all_gather_pixels, render_sharded, shard_bounds
+from nerf_sr_amd.dist import all_gather_pixels, all_reduce_sum_, render_sharded, shard_bounds
 
 
 def test_shard_bounds_cover_and_balance():
@@ -46,6 +46,15 @@ def _worker(rank, world, port, n_lr, q):
         lo, hi = shard_bounds(n_lr, world)[rank]
         again = all_gather_pixels(want[lo:hi].clone(), n_lr)
         ok = ok and torch.equal(again, want)
+        # training-side exchange: each rank holds the gradient of ITS half of the batch scaled by 1 / world;
+        # after the SUM all-reduce every rank holds the global-batch mean gradient, bit-identical across ranks
+        gen = torch.Generator().manual_seed(7)
+        per_rank = [[torch.randn(1000, generator=gen), torch.randn(77, generator=gen)] for _ in range(world)]
+        mine = [b.clone() / world for b in per_rank[rank]]
+        all_reduce_sum_(mine)
+        for j in range(2):
+            mean = sum(per_rank[r][j] / world for r in range(world))
+            ok = ok and torch.allclose(mine[j], mean, rtol=0, atol=1e-6)
         q.put((rank, bool(ok)))
     finally:
         dist.barrier()
