@@ -1,10 +1,10 @@
-// fp32-MFMA GEMM used by the training step: C = epilogue(A · B^T), both operands K-contiguous.
-// One kernel serves the three products of a linear layer (nn.Linear, models/networks.py:150-170):
-//   forward   Y (P x N)  = act(X (P x K) · W (N x K)^T + b)                  A = X,    B = W
-//   dgrad     dX (P x K) = (dY (P x N) · W) ⊙ [X > 0]                        A = dY,   B = W^T (K x N)
-//   wgrad     dW (N x K) = dY^T (N x P) · X^T (K x P)   (split over P)        A = dY^T, B = X^T
-// which is why every activation / activation-gradient is kept in both orientations (the epilogue writes C and
-// C^T): no operand ever needs a transposing load.
+// fp32-MFMA GEMM used by the training step: C (M x N) = epilogue(sum_k A(i, k) B(j, k)).
+// Each operand is addressed either K-contiguous (element (i, k) at p[i * ld + k]) or K-major (p[k * ld + i]), so
+// the three products of a linear layer (nn.Linear, models/networks.py:150-170) run on ROW-MAJOR activations and the
+// nn.Linear weight layout as they are -- nothing is transposed in memory, nothing is stored twice:
+//   forward   Y (P x N)  = act(X (P x K) W (N x K)^T + b)     A = X  K-contiguous,  B = W  K-contiguous
+//   dgrad     dX (P x K) = (dY (P x N) W) * [X > 0]           A = dY K-contiguous,  B = W  K-major   (k = n)
+//   wgrad     dW (N x K) = sum_p dY[p][n] X[p][k]             A = dY K-major,       B = X  K-major   (k = p, split)
 #pragma once
 #include "nsr_common.h"
 
@@ -13,9 +13,9 @@ namespace nsr {
 enum GemmAct { kActNone = 0, kActRelu = 1, kActSigmoid = 2 };
 
 struct GemmArgs {
-  const float* A; int64_t lda;      // M x K, K contiguous
-  const float* B; int64_t ldb;      // N x K, K contiguous
-  float* C; int64_t ldc;            // M x N (may be null)
+  const float* A; int64_t lda; int a_kmajor;   // M x K
+  const float* B; int64_t ldb; int b_kmajor;   // N x K
+  float* C; int64_t ldc;            // M x N (may be null if Ct is given)
   float* Ct; int64_t ldct;          // N x M, the same values transposed (may be null)
   const float* bias;                // N (may be null)
   const float* mask; int64_t ldm;   // M x N (may be null): result *= (mask > 0)
@@ -24,9 +24,11 @@ struct GemmArgs {
   int act;                          // GemmAct, applied after the bias, before the mask
   int splits;                       // > 1: split-K, block z handles K range z; raw sums go to C + z * split_stride
   int64_t split_stride;             //      (bias / act / mask must be off; Ct unused)
+  float* col_sums;                  // may be null: (ceil(M / 128), N) per-row-tile column sums of the values written
+                                    // (the bias gradient of the layer whose pre-activation gradient this GEMM makes)
 };
 
-// enqueue; returns NSR_OK / NSR_ERR_*
-NSR_INTERNAL int gemm_nt(const GemmArgs& g, hipStream_t st);
+// enqueue; returns NSR_OK / NSR_ERR_*.  K-major operands need their non-K extent to be a multiple of 4.
+NSR_INTERNAL int gemm(const GemmArgs& g, hipStream_t st);
 
 }  // namespace nsr

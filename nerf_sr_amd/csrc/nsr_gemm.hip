@@ -1,11 +1,16 @@
-// fp32-MFMA GEMM of the training step: C = epilogue(A · B^T), see nsr_gemm.h.
+// fp32-MFMA GEMM of the training step, see nsr_gemm.h.
 //
-// v_mfma_f32_32x32x2_f32 (exact fp32 products, the arithmetic the reference trains in).  Workgroup = 4 waves,
-// tile 128 x 128 x 32, each wave a 64 x 64 quadrant (2 x 2 MFMA blocks, 64 accumulator registers), two
-// workgroups per CU.  Both operands are K-contiguous in memory, so the global -> LDS staging is a plain
-// float4 copy (row stride 36 floats: the fragment reads below are bank-conflict free) and a lane's ds_read_b128
-// feeds four consecutive MFMAs: lane (i, h) holds A[i][8q + 4h + t], t = 0..3, the B operand uses the same k
-// mapping, so the K permutation cancels.  LDS is double buffered with register prefetch: one barrier per tile.
+// v_mfma_f32_32x32x2_f32 (exact fp32 products, the arithmetic the reference trains in).  A wave owns a 64 x 64
+// quadrant (2 x 2 MFMA blocks, 64 accumulator registers); a workgroup is 2 x WN waves: tile 128 x 128 with 4 waves
+// (two workgroups per CU) or 128 x 256 with 8 waves when N >= 256, so that an A row panel is read once.
+// K advances in tiles of 32, LDS double buffered with register prefetch: one barrier per tile.
+// This MFMA takes ONE float per lane and operand, so either memory orientation of an operand is staged as it lies
+// in memory (coalesced float4 loads along its contiguous axis) and only the LDS read differs:
+//   K-contiguous operand: LDS [row][k], stride 36 floats; lane (i, h) reads the float4 at k = 8q + 4h and feeds four
+//                         consecutive MFMAs (k = 8q + 4h + t, t = 0..3); conflict free.
+//   K-major operand:      LDS [k][row], stride rows + 4; lane (i, h) reads the scalar at (k = 8q + 4h + t, i): the 32
+//                         lanes of a half read 32 consecutive floats, conflict free.
+// Both use the same k <-> (q, h, t) mapping, so the K permutation cancels in the product.
 #include "nsr_gemm.h"
 
 namespace nsr {
@@ -15,41 +20,67 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kTM = 128, kTN = 128, kTK = 32, kLd = kTK + 4;   // LDS row stride (floats), 16 B aligned
+constexpr int kTM = 128, kTK = 32, kLdK = kTK + 4;   // K-contiguous LDS row stride (floats), 16 B aligned
 
-struct Stage {
-  f32x4 a[4], b[4];
-};
+template <int ROWS>   // floats of one staged operand tile (either orientation fits)
+constexpr int tile_floats() { return (ROWS * kLdK > kTK * (ROWS + 4)) ? ROWS * kLdK : kTK * (ROWS + 4); }
 
-__device__ __forceinline__ void load_tile(Stage& s, const GemmArgs& g, int64_t m0, int n0, int64_t k0, int tid) {
+// global -> registers: tile of ROWS x 32 of an operand, NT threads, VEC float4 per thread
+template <int KMAJOR, int ROWS, int NT>
+__device__ __forceinline__ void load_tile(f32x4 (&v)[ROWS * 8 / NT], const float* __restrict__ p, int64_t ld, int64_t r0,
+                                          int64_t extent, int64_t k0, int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + 256 * i, row = idx >> 3, c4 = idx & 7;
-    int64_t m = m0 + row;
-    m = m < g.M ? m : g.M - 1;
-    int n = n0 + row;
-    n = n < g.N ? n : g.N - 1;
-    s.a[i] = *reinterpret_cast<const f32x4*>(g.A + m * g.lda + k0 + 4 * c4);
-    s.b[i] = *reinterpret_cast<const f32x4*>(g.B + (int64_t)n * g.ldb + k0 + 4 * c4);
+  for (int i = 0; i < ROWS * 8 / NT; ++i) {
+    const int idx = tid + NT * i;
+    if (KMAJOR) {
+      const int k = idx / (ROWS / 4), r4 = idx % (ROWS / 4);
+      int64_t r = r0 + 4 * r4;
+      r = (r + 3 < extent) ? r : extent - 4;                 // past the edge: any valid data, dropped later
+      v[i] = *reinterpret_cast<const f32x4*>(p + (k0 + k) * ld + r);
+    } else {
+      const int row = idx >> 3, c4 = idx & 7;
+      int64_t r = r0 + row;
+      r = r < extent ? r : extent - 1;
+      v[i] = *reinterpret_cast<const f32x4*>(p + r * ld + k0 + 4 * c4);
+    }
   }
 }
-__device__ __forceinline__ void store_tile(const Stage& s, float* As, float* Bs, int tid) {
+template <int KMAJOR, int ROWS, int NT>
+__device__ __forceinline__ void store_tile(const f32x4 (&v)[ROWS * 8 / NT], float* s, int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + 256 * i, row = idx >> 3, c4 = idx & 7;
-    *reinterpret_cast<f32x4*>(As + row * kLd + 4 * c4) = s.a[i];
-    *reinterpret_cast<f32x4*>(Bs + row * kLd + 4 * c4) = s.b[i];
+  for (int i = 0; i < ROWS * 8 / NT; ++i) {
+    const int idx = tid + NT * i;
+    if (KMAJOR) {
+      const int k = idx / (ROWS / 4), r4 = idx % (ROWS / 4);
+      *reinterpret_cast<f32x4*>(s + k * (ROWS + 4) + 4 * r4) = v[i];
+    } else {
+      const int row = idx >> 3, c4 = idx & 7;
+      *reinterpret_cast<f32x4*>(s + row * kLdK + 4 * c4) = v[i];
+    }
   }
 }
+// the four operand values lane (i, h) feeds to the MFMAs t = 0..3 of group q, for the 32-row block at `row`
+template <int KMAJOR, int ROWS>
+__device__ __forceinline__ f32x4 frag(const float* s, int row, int q, int h) {
+  if (KMAJOR) {
+    const float* p = s + (8 * q + 4 * h) * (ROWS + 4) + row;
+    return f32x4{p[0], p[ROWS + 4], p[2 * (ROWS + 4)], p[3 * (ROWS + 4)]};
+  }
+  return *reinterpret_cast<const f32x4*>(s + row * kLdK + 8 * q + 4 * h);
+}
 
-__global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs g, int n_col_tiles, int64_t k_chunk) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * (kTM + kTN) * kLd];
+template <int AK, int BK, int WN>
+__global__ void __launch_bounds__(128 * WN, WN == 2 ? 2 : 1)
+gemm_kernel(GemmArgs g, int n_col_tiles, int64_t k_chunk) {
+  constexpr int NT = 128 * WN, TN = 64 * WN;
+  constexpr int kAF = tile_floats<kTM>(), kBF = tile_floats<TN>();
+  __shared__ __attribute__((aligned(16))) float lds[2 * (kAF + kBF)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1, li = lane & 31, h = lane >> 5;
   // column tile fastest: the workgroups that share an A row panel are launched back to back
   const int64_t bid = blockIdx.x;
   const int64_t m0 = (bid / n_col_tiles) * kTM;
-  const int n0 = (int)(bid % n_col_tiles) * kTN;
+  const int n0 = (int)(bid % n_col_tiles) * TN;
   const int z = blockIdx.y;
   const int64_t k_begin = (int64_t)z * k_chunk;
   const int64_t k_end = (k_begin + k_chunk < g.K) ? k_begin + k_chunk : g.K;
@@ -67,25 +98,28 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs g, int n_col_t
 #pragma unroll
   for (int bj = 0; bj < 2; ++bj) col_on[bj] = (n0 + 64 * wn + 32 * bj) < g.N;
 
-  Stage st;
+  f32x4 sa[kTM * 8 / NT], sb[TN * 8 / NT];
   if (n_tiles > 0) {
-    load_tile(st, g, m0, n0, k_begin, tid);
-    store_tile(st, lds, lds + kTM * kLd, tid);
+    load_tile<AK, kTM, NT>(sa, g.A, g.lda, m0, g.M, k_begin, tid);
+    load_tile<BK, TN, NT>(sb, g.B, g.ldb, n0, g.N, k_begin, tid);
+    store_tile<AK, kTM, NT>(sa, lds, tid);
+    store_tile<BK, TN, NT>(sb, lds + kAF, tid);
   }
   __syncthreads();
   for (int t = 0; t < n_tiles; ++t) {
-    float* As = lds + (t & 1) * (kTM + kTN) * kLd;
-    float* Bs = As + kTM * kLd;
-    if (t + 1 < n_tiles) load_tile(st, g, m0, n0, k_begin + (int64_t)(t + 1) * kTK, tid);
-    const float* ap = As + (64 * wm + li) * kLd + 4 * h;
-    const float* bp = Bs + (64 * wn + li) * kLd + 4 * h;
+    const float* As = lds + (t & 1) * (kAF + kBF);
+    const float* Bs = As + kAF;
+    if (t + 1 < n_tiles) {
+      load_tile<AK, kTM, NT>(sa, g.A, g.lda, m0, g.M, k_begin + (int64_t)(t + 1) * kTK, tid);
+      load_tile<BK, TN, NT>(sb, g.B, g.ldb, n0, g.N, k_begin + (int64_t)(t + 1) * kTK, tid);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       f32x4 a[2], b[2];
 #pragma unroll
-      for (int bi = 0; bi < 2; ++bi) a[bi] = *reinterpret_cast<const f32x4*>(ap + 32 * bi * kLd + 8 * q);
+      for (int bi = 0; bi < 2; ++bi) a[bi] = frag<AK, kTM>(As, 64 * wm + 32 * bi + li, q, h);
 #pragma unroll
-      for (int bj = 0; bj < 2; ++bj) b[bj] = *reinterpret_cast<const f32x4*>(bp + 32 * bj * kLd + 8 * q);
+      for (int bj = 0; bj < 2; ++bj) b[bj] = frag<BK, TN>(Bs, 64 * wn + 32 * bj + li, q, h);
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -97,14 +131,16 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs g, int n_col_t
           }
     }
     if (t + 1 < n_tiles) {
-      float* An = lds + ((t + 1) & 1) * (kTM + kTN) * kLd;
-      store_tile(st, An, An + kTM * kLd, tid);
+      float* An = lds + ((t + 1) & 1) * (kAF + kBF);
+      store_tile<AK, kTM, NT>(sa, An, tid);
+      store_tile<BK, TN, NT>(sb, An + kAF, tid);
     }
     __syncthreads();
   }
 
   // ---- epilogue: lane (column li, half h) holds rows 8 (r >> 2) + 4 h + (r & 3) of each 32 x 32 block
   float* C = g.C ? g.C + (g.splits > 1 ? (int64_t)z * g.split_stride : 0) : nullptr;
+  float csum[2] = {0.0f, 0.0f};
 #pragma unroll
   for (int bj = 0; bj < 2; ++bj) {
     const int n = n0 + 64 * wn + 32 * bj + li;
@@ -113,6 +149,15 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs g, int n_col_t
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi) {
       const int64_t mb = m0 + 64 * wm + 32 * bi + 4 * h;
+      float mk[16];
+      if (g.mask) {   // all 16 loads in flight before the first use
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int64_t m = mb + 8 * (r >> 2) + (r & 3);
+          m = m < g.M ? m : g.M - 1;
+          mk[r] = g.mask[m * g.ldm + n];
+        }
+      }
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         f32x4 v;
@@ -122,9 +167,12 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs g, int n_col_t
           float x = acc[bi][bj][4 * rq + e] + bias;
           if (g.act == kActRelu) x = fmaxf(x, 0.0f);
           else if (g.act == kActSigmoid) x = 1.0f / (1.0f + expf(-x));
-          if (g.mask && m < g.M) x = g.mask[m * g.ldm + n] > 0.0f ? x : 0.0f;
+          if (g.mask) x = mk[4 * rq + e] > 0.0f ? x : 0.0f;
           v[e] = x;
-          if (C && m < g.M) C[m * g.ldc + n] = x;
+          if (m < g.M) {
+            if (C) C[m * g.ldc + n] = x;
+            csum[bj] += x;
+          }
         }
         if (g.Ct) {
           const int64_t m = mb + 8 * rq;
@@ -137,30 +185,53 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs g, int n_col_t
       }
     }
   }
+  if (g.col_sums) {   // column sums of this 128-row tile: halves by shuffle, the two row-waves through LDS
+    float* red = lds;   // the K loop is over (its last statement is a barrier)
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+      const float s = csum[bj] + __shfl_xor(csum[bj], 32, 64);
+      if (h == 0) red[wm * TN + 64 * wn + 32 * bj + li] = s;
+    }
+    __syncthreads();
+    if (tid < TN && n0 + tid < g.n_valid) g.col_sums[(bid / n_col_tiles) * g.N + n0 + tid] = red[tid] + red[TN + tid];
+  }
+}
+
+template <int AK, int BK>
+int launch(const GemmArgs& a, int splits, hipStream_t st) {
+  const bool wide = a.N >= 256;
+  const int tn = wide ? 256 : 128;
+  const int n_col_tiles = (a.N + tn - 1) / tn;
+  const int64_t row_tiles = (a.M + kTM - 1) / kTM;
+  const int64_t k_tiles = a.K / kTK;
+  const int64_t k_chunk = ((k_tiles + splits - 1) / splits) * kTK;
+  const dim3 grid((unsigned)(row_tiles * n_col_tiles), (unsigned)splits);
+  if (wide) hipLaunchKernelGGL((gemm_kernel<AK, BK, 4>), grid, dim3(512), 0, st, a, n_col_tiles, k_chunk);
+  else hipLaunchKernelGGL((gemm_kernel<AK, BK, 2>), grid, dim3(256), 0, st, a, n_col_tiles, k_chunk);
+  if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
+  return NSR_OK;
 }
 
 }  // namespace
 
-NSR_INTERNAL int gemm_nt(const GemmArgs& g, hipStream_t st) {
+NSR_INTERNAL int gemm(const GemmArgs& g, hipStream_t st) {
   if (g.M < 0 || g.N <= 0 || g.K < 0 || (g.K % kTK) != 0 || g.n_valid > g.N) return NSR_ERR_INVALID_ARG;
   if (!g.A || !g.B || (!g.C && !g.Ct)) return NSR_ERR_INVALID_ARG;
   if ((g.lda % 4) || (g.ldb % 4) || (g.Ct && (g.ldct % 4))) return NSR_ERR_INVALID_ARG;
   if ((reinterpret_cast<uintptr_t>(g.A) & 15) || (reinterpret_cast<uintptr_t>(g.B) & 15) ||
       (g.Ct && (reinterpret_cast<uintptr_t>(g.Ct) & 15)))
     return NSR_ERR_INVALID_ARG;
+  if (g.a_kmajor && (g.M % 4 != 0 || g.M < 4)) return NSR_ERR_INVALID_ARG;
+  if (g.b_kmajor && (g.N % 4 != 0 || g.N < 4)) return NSR_ERR_INVALID_ARG;
   const int splits = g.splits > 1 ? g.splits : 1;
-  if (splits > 1 && (g.bias || g.mask || g.act != kActNone || g.Ct || !g.C)) return NSR_ERR_INVALID_ARG;
+  if (splits > 1 && (g.bias || g.mask || g.act != kActNone || g.Ct || !g.C || g.col_sums)) return NSR_ERR_INVALID_ARG;
   if (g.M == 0) return NSR_OK;
-  const int n_col_tiles = (g.N + kTN - 1) / kTN;
-  const int64_t row_tiles = (g.M + kTM - 1) / kTM;
-  const int64_t k_tiles = g.K / kTK;
-  const int64_t k_chunk = ((k_tiles + splits - 1) / splits) * kTK;
   GemmArgs a = g;
   a.splits = splits;
-  hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(row_tiles * n_col_tiles), (unsigned)splits), dim3(256), 0, st, a,
-                     n_col_tiles, k_chunk);
-  if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
-  return NSR_OK;
+  if (!g.a_kmajor && !g.b_kmajor) return launch<0, 0>(a, splits, st);
+  if (!g.a_kmajor && g.b_kmajor) return launch<0, 1>(a, splits, st);
+  if (g.a_kmajor && g.b_kmajor) return launch<1, 1>(a, splits, st);
+  return NSR_ERR_UNSUPPORTED;
 }
 
 }  // namespace nsr

@@ -6,11 +6,11 @@
 //
 // Shape of the computation on MI355X.  A training batch is small next to a rendered frame (thousands of rays), and
 // its activations have to be kept for the backward pass anyway, so the MLP runs layer by layer on one fp32-MFMA GEMM
-// kernel (nsr_gemm.hip) whose epilogue fuses bias / ReLU / sigmoid / the ReLU mask of the backward pass and writes
-// every activation and activation gradient in BOTH orientations (row-major (P, C) and transposed (C, P)).  With
-// that, all three products of a linear layer (forward, input gradient, weight gradient) are K-contiguous "NT"
-// GEMMs and nothing is ever transposed on the fly; the weight gradient is a split-K GEMM over the sample points
-// with a deterministic second-pass reduction (no atomics: results are run-to-run identical).
+// kernel (nsr_gemm.hip) whose epilogue fuses bias / ReLU / sigmoid / the ReLU mask of the backward pass.  The kernel
+// takes either memory orientation of each operand, so all three products of a linear layer (forward, input gradient,
+// weight gradient) read the row-major (P, C) activations and the nn.Linear weights as they lie: nothing is
+// transposed and nothing is stored twice.  The weight gradient is a split-K GEMM over the sample points with a
+// deterministic second-pass reduction (no atomics: results are run-to-run identical).
 // Layers are padded to MFMA-friendly shapes once per step (63 -> 64 input channels, the skip concat as
 // [pe64 | h4], the density head stacked under xyz_encoding_final as one 288-row layer, the colour head as 32 rows);
 // the gradients are scattered back to the nn.Linear shapes by the reduction kernel.
@@ -63,12 +63,11 @@ __global__ void place_kernel(float* __restrict__ dst, int dst_ld, int r0, int c0
 }
 
 // E1 + cast_rays for the training layout: one thread per sample point.
-//   x5 (P, 320) columns 0..63  = [pe63, 0]          x5t (320, P) rows 0..63
-//   gs (P, 288) columns 257..287 = [0 0 0, de27, 0]  gst (288, P) rows 257..287
+//   x5 (P, 320) columns 0..63  = [pe63, 0]
+//   gs (P, 288) columns 257..287 = [0 0 0, de27, 0]
 __global__ void __launch_bounds__(256) encode_train_kernel(const float* __restrict__ rays, int stride,
                                                            const float* __restrict__ z, int64_t P, int N,
-                                                           float* __restrict__ x5, float* __restrict__ x5t,
-                                                           float* __restrict__ gs, float* __restrict__ gst) {
+                                                           float* __restrict__ x5, float* __restrict__ gs) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   const NsrRay q = nsr_load_ray(rays, p / N, stride);
@@ -84,8 +83,6 @@ __global__ void __launch_bounds__(256) encode_train_kernel(const float* __restri
   float4* row = reinterpret_cast<float4*>(x5 + p * kX5);
 #pragma unroll
   for (int i = 0; i < 16; ++i) row[i] = make_float4(pe[4 * i], pe[4 * i + 1], pe[4 * i + 2], pe[4 * i + 3]);
-#pragma unroll
-  for (int c = 0; c < 64; ++c) x5t[(int64_t)c * P + p] = pe[c];
   float de[31];   // columns 257..287
   de[0] = de[1] = de[2] = 0.0f;
 #pragma unroll
@@ -96,10 +93,7 @@ __global__ void __launch_bounds__(256) encode_train_kernel(const float* __restri
     for (int c = 0; c < 3; ++c) nsr_sincos(ldexpf(q.v[c], f), de[6 + 6 * f + c], de[6 + 6 * f + 3 + c]);
   de[30] = 0.0f;
 #pragma unroll
-  for (int c = 0; c < 31; ++c) {
-    gs[p * kGs + 257 + c] = de[c];
-    gst[(int64_t)(257 + c) * P + p] = de[c];
-  }
+  for (int c = 0; c < 31; ++c) gs[p * kGs + 257 + c] = de[c];
 }
 
 // N1: sigma + noise * std (models/utils.py:199-212); noise == nullptr copies
@@ -165,14 +159,13 @@ __global__ void __launch_bounds__(256) loss_finish_kernel(const double* __restri
 //   dL/dalpha_k = gw_k T_k - (sum_{i>k} gw_i w_i) / f_k
 //   dL/dsigma_k = dL/dalpha_k * delta_k exp(-delta_k relu(sigma_k)) * [sigma_k > 0];   dL/drgb_k = gC w_k
 // and through the sigmoid of the colour head: d(rgb_pre) = d(rgb) * rgb (1 - rgb).
-// Outputs in the training layout: d_rgb (P, 32) columns 0..2 (3..31 zeroed), d_rgb_t (32, P) rows 0..2;
-// d_sigma into column 256 of g1 (P, 288) (257..287 zeroed) and row 256 of g1t (288, P).
+// Outputs in the training layout: d_rgb (P, 32) columns 0..2 (3..31 zeroed); d_sigma into column 256 of
+// g1 (P, 288) (257..287 zeroed).
 template <int K>
 __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restrict__ rgb4, const float* __restrict__ sigma,
                                                             const float* __restrict__ z, const float* __restrict__ g_comp,
-                                                            int64_t R, int N, int white, int64_t P,
-                                                            float* __restrict__ d_rgb, float* __restrict__ d_rgb_t,
-                                                            float* __restrict__ g1, float* __restrict__ g1t) {
+                                                            int64_t R, int N, int white,
+                                                            float* __restrict__ d_rgb, float* __restrict__ g1) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r >= R) return;
@@ -245,45 +238,55 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
     dr[0] = make_float4(dr0, dr1, dr2, 0.0f);
 #pragma unroll
     for (int j = 1; j < 8; ++j) dr[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    d_rgb_t[p] = dr0;
-    d_rgb_t[P + p] = dr1;
-    d_rgb_t[2 * P + p] = dr2;
     float* gp = g1 + p * kGs + kSigmaCol;
     gp[0] = d_sigma;
 #pragma unroll
     for (int j = 1; j < 32; ++j) gp[j] = 0.0f;
-    g1t[(int64_t)kSigmaCol * P + p] = d_sigma;
   }
 }
 
-// bias gradients: dst[i] (+)= sum over the P entries of row (row0 + i) of a transposed gradient buffer.
-// Two passes (kRowSplits slices per row, then a finishing pass) so that a 256-row sum fills the chip.
-constexpr int kRowSplits = 32;
-__global__ void __launch_bounds__(256) rowsum_partial_kernel(const float* __restrict__ src_t, int64_t P, int row0,
-                                                             double* __restrict__ partial) {
-  __shared__ double red[256];
-  const float4* row = reinterpret_cast<const float4*>(src_t + (int64_t)(row0 + blockIdx.x) * P);
-  const int64_t n4 = P >> 2, per = (n4 + kRowSplits - 1) / kRowSplits;
-  const int64_t lo = per * blockIdx.y, hi = (lo + per < n4) ? lo + per : n4;
-  double s = 0.0;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
-    const float4 v = row[i];
-    s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
-  }
-  red[threadIdx.x] = s;
+// bias gradients.  Two deterministic passes each (double accumulation, then one finishing block):
+//   colsum_few:  sums of <= 4 columns of a row-major buffer over all P rows (colour-head and density-head biases,
+//                whose pre-activation gradients come from the compositing backward, not from a GEMM)
+//   tilesum:     sums over the per-row-tile column sums a dgrad GEMM's epilogue left behind (every other bias)
+constexpr int kSumBlocks = 256;
+__global__ void __launch_bounds__(256) colsum_few_kernel(const float* __restrict__ src, int64_t ld, int64_t P, int col0,
+                                                         int cols, double* __restrict__ partial) {
+  __shared__ double red[4][256];
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < P; r += (int64_t)kSumBlocks * 256)
+    for (int c = 0; c < cols; ++c) s[c] += (double)src[r * ld + col0 + c];
+  for (int c = 0; c < 4; ++c) red[c][threadIdx.x] = s[c];
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    if ((int)threadIdx.x < o)
+      for (int c = 0; c < 4; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) partial[blockIdx.x * kRowSplits + blockIdx.y] = red[0];
+  if ((int)threadIdx.x < cols) partial[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
 }
-__global__ void rowsum_finish_kernel(const double* __restrict__ partial, int rows, float* __restrict__ dst, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows) return;
+// block (x: 64-column group, y: slice of the row tiles): 64 columns x 4 row phases
+__global__ void __launch_bounds__(256) tilesum_partial_kernel(const float* __restrict__ tiles, int64_t n_tiles, int ld,
+                                                              int cols, double* __restrict__ partial) {
+  __shared__ double red[4][64];
+  const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, phase = threadIdx.x >> 6;
+  const int64_t per = (n_tiles + gridDim.y - 1) / gridDim.y;
+  const int64_t lo = per * blockIdx.y, hi = (lo + per < n_tiles) ? lo + per : n_tiles;
   double s = 0.0;
-  for (int j = 0; j < kRowSplits; ++j) s += partial[i * kRowSplits + j];
-  dst[i] = (accumulate ? dst[i] : 0.0f) + (float)s;
+  if (c < cols)
+    for (int64_t t = lo + phase; t < hi; t += 4) s += (double)tiles[t * ld + c];
+  red[phase][cl] = s;
+  __syncthreads();
+  if (phase == 0 && c < cols) partial[(int64_t)blockIdx.y * ld + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+// dst[c] (+)= sum_j partial[j * ld + c]
+__global__ void __launch_bounds__(256) sum_finish_kernel(const double* __restrict__ partial, int n, int ld, int cols,
+                                                         float* __restrict__ dst, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  double s = 0.0;
+  for (int j = 0; j < n; ++j) s += partial[(int64_t)j * ld + c];
+  dst[c] = (accumulate ? dst[c] : 0.0f) + (float)s;
 }
 
 // second pass of the split-K weight gradient + scatter into the nn.Linear shape:
@@ -326,14 +329,13 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamPtrs a, float beta1, floa
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-struct WeightPack {   // padded / transposed copies of one network's weights (floats, all in one block)
+struct WeightPack {   // zero-padded copies of the weights whose shapes are not MFMA friendly (floats, one block)
   float *w1p, *w5p, *w9p, *wdirp, *wrgbp, *b9p, *brgbp;
-  float* wt[9];       // wt[L], L = 2..8: transposes for the input gradients (wt[5] = W5[:, 63:]^T)
-  float *w9pt, *wdirpt, *wrgbpt;
 };
-struct Work {   // per-pass buffers, sized for P_max = chunk * (Nc + Ni) sample points
-  float *x5, *x5t, *h[9], *ht[9], *gs, *gst, *cc, *cct, *rgb, *sig;
-  float *g0, *g0t, *g1, *g1t, *drgb, *drgbt;
+
+struct Work {   // per-pass buffers, sized for P_max = chunk * (Nc + Ni) sample points; all row-major
+  float *x5, *h[9], *gs, *cc, *rgb, *sig;
+  float *g0, *g1, *drgb, *col_tiles;
   float *z_c, *z_f, *w_c, *comp, *g_comp, *partial, *scratch_out;
   double *block_sums, *carry;
   WeightPack pack[2];
@@ -349,30 +351,24 @@ int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base) {
   };
   Work tmp;
   Work& k = w ? *w : tmp;
-  k.x5 = take(P * kX5);   k.x5t = take(P * kX5);
-  for (int L = 1; L <= 8; ++L) {
-    if (L == 4) { k.h[L] = nullptr; k.ht[L] = nullptr; continue; }   // h4 lives in x5[:, 64:]
-    k.h[L] = take(P * kW);
-    k.ht[L] = take(P * kW);
-  }
-  k.gs = take(P * kGs);   k.gst = take(P * kGs);
-  k.cc = take(P * kDirOut);   k.cct = take(P * kDirOut);
+  k.x5 = take(P * kX5);
+  for (int L = 1; L <= 8; ++L) k.h[L] = (L == 4) ? nullptr : take(P * kW);   // h4 lives in x5[:, 64:]
+  k.gs = take(P * kGs);
+  k.cc = take(P * kDirOut);
   k.rgb = take(P * 4);   k.sig = take(P);
-  k.g0 = take(P * kGs);   k.g0t = take(P * kGs);
-  k.g1 = take(P * kGs);   k.g1t = take(P * kGs);
-  k.drgb = take(P * kRgbPad);   k.drgbt = take(P * kRgbPad);
+  k.g0 = take(P * kGs);   k.g1 = take(P * kGs);
+  k.drgb = take(P * kRgbPad);
+  k.col_tiles = take((P / 128 + 1) * kW + 2 * 64 * kW + 64);   // per-tile column sums + 64 slices of doubles
   k.z_c = take(chunk * nc);   k.z_f = take(chunk * nf);   k.w_c = take(chunk * nc);
   k.comp = take(chunk * 3);   k.g_comp = take(chunk * 3);
   k.scratch_out = take(chunk * (nf + 8));
-  k.partial = take(kMaxSplits * kPartialFloats);
+  k.partial = take(kMaxSplits * kPartialFloats);           // also scratch of the small bias sums
   k.block_sums = reinterpret_cast<double*>(take(2 * (chunk / 256 + 2)));
   k.carry = reinterpret_cast<double*>(take(8));
   for (int n = 0; n < 2; ++n) {
     WeightPack& q = k.pack[n];
     q.w1p = take(256 * 64);   q.w5p = take(256 * 320);   q.w9p = take(288 * 256);   q.wdirp = take(128 * 288);
     q.wrgbp = take(32 * 128);   q.b9p = take(320);   q.brgbp = take(64);
-    for (int L = 2; L <= 8; ++L) q.wt[L] = take(65536);
-    q.w9pt = take(256 * 288);   q.wdirpt = take(256 * 128);   q.wrgbpt = take(128 * 32);
   }
   return off;
 }
@@ -394,7 +390,7 @@ int place(hipStream_t st, float* dst, int dst_ld, int r0, int c0, const float* s
 
 int prepare_weights(hipStream_t st, const float* const* w, const WeightPack& q) {
   // zero the whole pack first (padding rows / columns), it is one contiguous block starting at w1p
-  if (hipMemsetAsync(q.w1p, 0, (size_t)((q.wrgbpt + align64(128 * 32)) - q.w1p) * sizeof(float), st) != hipSuccess)
+  if (hipMemsetAsync(q.w1p, 0, (size_t)((q.brgbp + align64(64)) - q.w1p) * sizeof(float), st) != hipSuccess)
     return NSR_ERR_LAUNCH;
   NSR_TRY(place(st, q.w1p, 64, 0, 0, w[0], 63, 256, 63, 0, 0));
   NSR_TRY(place(st, q.w5p, 320, 0, 0, w[8], 319, 256, 63, 0, 0));
@@ -407,43 +403,47 @@ int prepare_weights(hipStream_t st, const float* const* w, const WeightPack& q) 
   NSR_TRY(place(st, q.b9p, 320, 0, 0, w[kFinalB], 256, 1, 256, 0, 0));
   NSR_TRY(place(st, q.b9p, 320, 0, 256, w[kSigmaB], 1, 1, 1, 0, 0));
   NSR_TRY(place(st, q.brgbp, 64, 0, 0, w[kRgbB], 3, 1, 3, 0, 0));
-  for (int L = 2; L <= 8; ++L) {
-    if (L == 5) NSR_TRY(place(st, q.wt[5], 256, 0, 0, w[8], 319, 256, 256, 63, 1));
-    else NSR_TRY(place(st, q.wt[L], 256, 0, 0, w[2 * (L - 1)], 256, 256, 256, 0, 1));
-  }
-  NSR_TRY(place(st, q.w9pt, 288, 0, 0, w[kFinalW], 256, 256, 256, 0, 1));
-  NSR_TRY(place(st, q.w9pt, 288, 0, 256, w[kSigmaW], 256, 1, 256, 0, 1));
-  NSR_TRY(place(st, q.wdirpt, 128, 0, 0, w[kDirW], 283, 128, 256, 0, 1));
-  NSR_TRY(place(st, q.wrgbpt, 32, 0, 0, w[kRgbW], 128, 3, 128, 0, 1));
   return NSR_OK;
 }
 
-// y = act(x w^T + b) in both orientations
+// y (P, N) = act(x (P, K) w (N, K)^T + b)
 int lin_fwd(hipStream_t st, const float* x, int64_t ldx, int K, const float* w, int ldw, const float* b, int act,
-            float* y, int64_t ldy, float* yt, int64_t P, int N, int n_valid) {
+            float* y, int64_t ldy, int64_t P, int N, int n_valid) {
   GemmArgs g{};
-  g.A = x; g.lda = ldx; g.B = w; g.ldb = ldw; g.C = y; g.ldc = ldy; g.Ct = yt; g.ldct = P; g.bias = b;
+  g.A = x; g.lda = ldx; g.B = w; g.ldb = ldw; g.C = y; g.ldc = ldy; g.bias = b;
   g.M = P; g.N = N; g.K = K; g.n_valid = n_valid; g.act = act; g.splits = 1;
-  return gemm_nt(g, st);
+  return gemm(g, st);
 }
-// dx = (dy w) * [x > 0] in both orientations (mask may be null)
-int lin_dgrad(hipStream_t st, const float* dy, int64_t lddy, int K, const float* wt, int ldwt, const float* mask,
-              int64_t ldm, float* dx, int64_t lddx, float* dxt, int64_t P, int N) {
+// dx (P, N) = (dy (P, K) w[:, 0 : N]) * [mask > 0], w (K, ldw) in the nn.Linear layout (mask may be null);
+// bias_grad (N) (+)= column sums of dx = the bias gradient of the layer that produced the masked activation
+int lin_dgrad(hipStream_t st, const Work& k, const float* dy, int64_t lddy, int K, const float* w, int ldw,
+              const float* mask, int64_t ldm, float* dx, int64_t lddx, int64_t P, int N, float* bias_grad, int acc) {
   GemmArgs g{};
-  g.A = dy; g.lda = lddy; g.B = wt; g.ldb = ldwt; g.C = dx; g.ldc = lddx; g.Ct = dxt; g.ldct = P;
+  g.A = dy; g.lda = lddy; g.B = w; g.ldb = ldw; g.b_kmajor = 1; g.C = dx; g.ldc = lddx;
   g.mask = mask; g.ldm = ldm; g.M = P; g.N = N; g.K = K; g.n_valid = N; g.act = kActNone; g.splits = 1;
-  return gemm_nt(g, st);
+  g.col_sums = bias_grad ? k.col_tiles : nullptr;
+  const int rc = gemm(g, st);
+  if (rc != NSR_OK || !bias_grad) return rc;
+  double* part = reinterpret_cast<double*>(k.col_tiles + ((P + 127) / 128) * N);   // behind the tile sums
+  const int slices = 64;
+  hipLaunchKernelGGL(tilesum_partial_kernel, dim3((N + 63) / 64, slices), dim3(256), 0, st, k.col_tiles, (P + 127) / 128, N,
+                     N, part);
+  NSR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, st, part, slices, N, N, bias_grad, acc);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
 }
 int n_splits(int64_t P) {
   int64_t s = P / 2048;
   return (int)(s < 1 ? 1 : (s > kMaxSplits ? kMaxSplits : s));
 }
-// partial[z] (M x N) = dy_t (M x P) x_t (N x P)^T over the z-th slice of the points
-int lin_wgrad(hipStream_t st, const float* dyt, int M, const float* xt, int N, int64_t P, float* partial, int splits) {
+// partial[z] (M x N) = sum over the z-th slice of the points of dy[p][0..M) x[p][0..N)^T
+int lin_wgrad(hipStream_t st, const float* dy, int64_t lddy, int M, const float* x, int64_t ldx, int N, int64_t P,
+              float* partial, int splits) {
   GemmArgs g{};
-  g.A = dyt; g.lda = P; g.B = xt; g.ldb = P; g.C = partial; g.ldc = N; g.M = M; g.N = N; g.K = P; g.n_valid = N;
-  g.act = kActNone; g.splits = splits; g.split_stride = kPartialFloats;
-  return gemm_nt(g, st);
+  g.A = dy; g.lda = lddy; g.a_kmajor = 1; g.B = x; g.ldb = ldx; g.b_kmajor = 1; g.C = partial; g.ldc = N;
+  g.M = M; g.N = N; g.K = P; g.n_valid = N; g.act = kActNone; g.splits = splits; g.split_stride = kPartialFloats;
+  return gemm(g, st);
 }
 int reduce_place(hipStream_t st, float* dst, int dst_ld, int dc0, int rows, int cols, const float* partial, int splits,
                  int p_ld, int pr0, int pc0, int accumulate) {
@@ -453,92 +453,89 @@ int reduce_place(hipStream_t st, float* dst, int dst_ld, int dc0, int rows, int 
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
-// `scratch`: >= 288 * kRowSplits doubles (the split-K partial buffer is free between two weight gradients)
-int rowsum(hipStream_t st, const float* src_t, int64_t P, int row0, int rows, float* dst, int accumulate, float* scratch) {
-  if (P % 4 != 0) return NSR_ERR_INVALID_ARG;
+// `scratch`: >= kSumBlocks * 4 doubles (the split-K partial buffer is free between two weight gradients)
+int colsum(hipStream_t st, const float* src, int64_t ld, int64_t P, int col0, int cols, float* dst, int accumulate,
+           float* scratch) {
+  if (cols > 4) return NSR_ERR_INVALID_ARG;
   double* part = reinterpret_cast<double*>(scratch);
-  hipLaunchKernelGGL(rowsum_partial_kernel, dim3(rows, kRowSplits), dim3(256), 0, st, src_t, P, row0, part);
+  hipLaunchKernelGGL(colsum_few_kernel, dim3(kSumBlocks), dim3(256), 0, st, src, ld, P, col0, cols, part);
   NSR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rowsum_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, part, rows, dst, accumulate);
+  hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, st, part, kSumBlocks, 4, cols, dst, accumulate);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
 
 // M1 forward with everything kept for the backward pass
 int net_forward(hipStream_t st, const float* const* w, const WeightPack& q, const Work& k, int64_t P) {
-  NSR_TRY(lin_fwd(st, k.x5, kX5, kPe, q.w1p, 64, w[1], kActRelu, k.h[1], kW, k.ht[1], P, kW, kW));
-  NSR_TRY(lin_fwd(st, k.h[1], kW, kW, w[2], 256, w[3], kActRelu, k.h[2], kW, k.ht[2], P, kW, kW));
-  NSR_TRY(lin_fwd(st, k.h[2], kW, kW, w[4], 256, w[5], kActRelu, k.h[3], kW, k.ht[3], P, kW, kW));
-  NSR_TRY(lin_fwd(st, k.h[3], kW, kW, w[6], 256, w[7], kActRelu, k.x5 + kPe, kX5, k.x5t + kPe * P, P, kW, kW));
-  NSR_TRY(lin_fwd(st, k.x5, kX5, kX5, q.w5p, 320, w[9], kActRelu, k.h[5], kW, k.ht[5], P, kW, kW));
-  NSR_TRY(lin_fwd(st, k.h[5], kW, kW, w[10], 256, w[11], kActRelu, k.h[6], kW, k.ht[6], P, kW, kW));
-  NSR_TRY(lin_fwd(st, k.h[6], kW, kW, w[12], 256, w[13], kActRelu, k.h[7], kW, k.ht[7], P, kW, kW));
-  NSR_TRY(lin_fwd(st, k.h[7], kW, kW, w[14], 256, w[15], kActRelu, k.h[8], kW, k.ht[8], P, kW, kW));
+  NSR_TRY(lin_fwd(st, k.x5, kX5, kPe, q.w1p, 64, w[1], kActRelu, k.h[1], kW, P, kW, kW));
+  NSR_TRY(lin_fwd(st, k.h[1], kW, kW, w[2], 256, w[3], kActRelu, k.h[2], kW, P, kW, kW));
+  NSR_TRY(lin_fwd(st, k.h[2], kW, kW, w[4], 256, w[5], kActRelu, k.h[3], kW, P, kW, kW));
+  NSR_TRY(lin_fwd(st, k.h[3], kW, kW, w[6], 256, w[7], kActRelu, k.x5 + kPe, kX5, P, kW, kW));
+  NSR_TRY(lin_fwd(st, k.x5, kX5, kX5, q.w5p, 320, w[9], kActRelu, k.h[5], kW, P, kW, kW));
+  NSR_TRY(lin_fwd(st, k.h[5], kW, kW, w[10], 256, w[11], kActRelu, k.h[6], kW, P, kW, kW));
+  NSR_TRY(lin_fwd(st, k.h[6], kW, kW, w[12], 256, w[13], kActRelu, k.h[7], kW, P, kW, kW));
+  NSR_TRY(lin_fwd(st, k.h[7], kW, kW, w[14], 256, w[15], kActRelu, k.h[8], kW, P, kW, kW));
   // xyz_encoding_final stacked over the density head: [g | sigma] into columns 0..256 of the dir layer's input
-  NSR_TRY(lin_fwd(st, k.h[8], kW, kW, q.w9p, 256, q.b9p, kActNone, k.gs, kGs, k.gst, P, kGs, 257));
-  NSR_TRY(lin_fwd(st, k.gs, kGs, kGs, q.wdirp, 288, w[kDirB], kActRelu, k.cc, kDirOut, k.cct, P, kDirOut, kDirOut));
-  NSR_TRY(lin_fwd(st, k.cc, kDirOut, kDirOut, q.wrgbp, 128, q.brgbp, kActSigmoid, k.rgb, 4, nullptr, P, kRgbPad, 3));
+  NSR_TRY(lin_fwd(st, k.h[8], kW, kW, q.w9p, 256, q.b9p, kActNone, k.gs, kGs, P, kGs, 257));
+  NSR_TRY(lin_fwd(st, k.gs, kGs, kGs, q.wdirp, 288, w[kDirB], kActRelu, k.cc, kDirOut, P, kDirOut, kDirOut));
+  NSR_TRY(lin_fwd(st, k.cc, kDirOut, kDirOut, q.wrgbp, 128, q.brgbp, kActSigmoid, k.rgb, 4, P, kRgbPad, 3));
   return NSR_OK;
 }
 
-// backward of M1: d_rgb_pre in k.drgb / k.drgbt, d_sigma in column / row 256 of k.g1 / k.g1t
-int net_backward(hipStream_t st, const WeightPack& q, const Work& k, int64_t P, float* const* g, int acc) {
+// backward of M1: d_rgb_pre in k.drgb (P, 32), d_sigma in column 256 of k.g1 (P, 288)
+int net_backward(hipStream_t st, const float* const* w, const WeightPack& q, const Work& k, int64_t P, float* const* g,
+                 int acc) {
   const int sp = n_splits(P);
   float* part = k.partial;
   // rgb head
-  NSR_TRY(lin_wgrad(st, k.drgbt, kRgbPad, k.cct, kDirOut, P, part, sp));
+  NSR_TRY(lin_wgrad(st, k.drgb, kRgbPad, kRgbPad, k.cc, kDirOut, kDirOut, P, part, sp));
   NSR_TRY(reduce_place(st, g[kRgbW], 128, 0, 3, 128, part, sp, kDirOut, 0, 0, acc));
-  NSR_TRY(rowsum(st, k.drgbt, P, 0, 3, g[kRgbB], acc, part));
-  NSR_TRY(lin_dgrad(st, k.drgb, kRgbPad, kRgbPad, q.wrgbpt, 32, k.cc, kDirOut, k.g0, kDirOut, k.g0t, P, kDirOut));
+  NSR_TRY(colsum(st, k.drgb, kRgbPad, P, 0, 3, g[kRgbB], acc, part));
+  NSR_TRY(lin_dgrad(st, k, k.drgb, kRgbPad, kRgbPad, q.wrgbp, 128, k.cc, kDirOut, k.g0, kDirOut, P, kDirOut, g[kDirB], acc));
   // dir_encoding
-  NSR_TRY(lin_wgrad(st, k.g0t, kDirOut, k.gst, kGs, P, part, sp));
+  NSR_TRY(lin_wgrad(st, k.g0, kDirOut, kDirOut, k.gs, kGs, kGs, P, part, sp));
   NSR_TRY(reduce_place(st, g[kDirW], 283, 0, 128, 256, part, sp, kGs, 0, 0, acc));
   NSR_TRY(reduce_place(st, g[kDirW], 283, 256, 128, 27, part, sp, kGs, 0, kDeCol, acc));
-  NSR_TRY(rowsum(st, k.g0t, P, 0, 128, g[kDirB], acc, part));
-  NSR_TRY(lin_dgrad(st, k.g0, kDirOut, kDirOut, q.wdirpt, 128, nullptr, 0, k.g1, kGs, k.g1t, P, kW));   // d g; column 256 keeps d sigma
+  // d g (its column sums are xyz_encoding_final's bias gradient); column 256 keeps d sigma
+  NSR_TRY(lin_dgrad(st, k, k.g0, kDirOut, kDirOut, q.wdirp, 288, nullptr, 0, k.g1, kGs, P, kW, g[kFinalB], acc));
   // xyz_encoding_final + sigma (288-row layer over h8)
-  NSR_TRY(lin_wgrad(st, k.g1t, kGs, k.ht[8], kW, P, part, sp));
+  NSR_TRY(lin_wgrad(st, k.g1, kGs, kGs, k.h[8], kW, kW, P, part, sp));
   NSR_TRY(reduce_place(st, g[kFinalW], 256, 0, 256, 256, part, sp, kW, 0, 0, acc));
   NSR_TRY(reduce_place(st, g[kSigmaW], 256, 0, 1, 256, part, sp, kW, 256, 0, acc));
-  NSR_TRY(rowsum(st, k.g1t, P, 0, 256, g[kFinalB], acc, part));
-  NSR_TRY(rowsum(st, k.g1t, P, 256, 1, g[kSigmaB], acc, part));
-  NSR_TRY(lin_dgrad(st, k.g1, kGs, kGs, q.w9pt, 288, k.h[8], kW, k.g0, kW, k.g0t, P, kW));
-  // xyz_encoding_8 .. 1; the gradient of layer L's pre-activation alternates between the two buffer pairs
+  NSR_TRY(colsum(st, k.g1, kGs, P, 256, 1, g[kSigmaB], acc, part));
+  NSR_TRY(lin_dgrad(st, k, k.g1, kGs, kGs, q.w9p, 256, k.h[8], kW, k.g0, kW, P, kW, g[15], acc));   // + bias of layer 8
+  // xyz_encoding_8 .. 1; the gradient of layer L's pre-activation alternates between the two buffers
   const float* dy = k.g0;
-  const float* dyt = k.g0t;
   float* nx = k.g1;
-  float* nxt = k.g1t;
   for (int L = 8; L >= 1; --L) {
-    const float* xin_t = (L == 1 || L == 5) ? k.x5t : k.ht[L - 1];
+    const float* xin = (L == 1 || L == 5) ? k.x5 : k.h[L - 1];
+    const int64_t ldx = (L == 1 || L == 5) ? kX5 : kW;
     const int kin = (L == 1) ? kPe : (L == 5 ? kX5 : kW);
-    NSR_TRY(lin_wgrad(st, dyt, kW, xin_t, kin, P, part, sp));
+    NSR_TRY(lin_wgrad(st, dy, kW, kW, xin, ldx, kin, P, part, sp));
     float* gw = g[2 * (L - 1)];
     if (L == 1) NSR_TRY(reduce_place(st, gw, 63, 0, 256, 63, part, sp, kPe, 0, 0, acc));
     else if (L == 5) {
       NSR_TRY(reduce_place(st, gw, 319, 0, 256, 63, part, sp, kX5, 0, 0, acc));
       NSR_TRY(reduce_place(st, gw, 319, 63, 256, 256, part, sp, kX5, 0, kPe, acc));
     } else NSR_TRY(reduce_place(st, gw, 256, 0, 256, 256, part, sp, kW, 0, 0, acc));
-    NSR_TRY(rowsum(st, dyt, P, 0, 256, g[2 * (L - 1) + 1], acc, part));
     if (L == 1) break;
     // input of layer L is the output of layer L - 1 (relu'd): h4 sits in x5[:, 64:]
     const float* mask = (L - 1 == 4) ? k.x5 + kPe : k.h[L - 1];
     const int64_t ldm = (L - 1 == 4) ? kX5 : kW;
-    NSR_TRY(lin_dgrad(st, dy, kW, kW, q.wt[L], 256, mask, ldm, nx, kW, nxt, P, kW));
+    // weights in the nn.Linear layout (out, in) ARE the K-major B operand of the input gradient
+    const float* wl = (L == 5) ? q.w5p + kPe : w[2 * (L - 1)];
+    const int ldw = (L == 5) ? kX5 : kW;
+    NSR_TRY(lin_dgrad(st, k, dy, kW, kW, wl, ldw, mask, ldm, nx, kW, P, kW, g[2 * (L - 2) + 1], acc));   // + bias of layer L - 1
     const float* t0 = dy; dy = nx; nx = const_cast<float*>(t0);
-    const float* t1 = dyt; dyt = nxt; nxt = const_cast<float*>(t1);
   }
   return NSR_OK;
 }
 
-int composite_bwd(hipStream_t st, const Work& k, const float* z, int64_t R, int N, int white, int64_t P) {
-  // rows 3..31 of d_rgb_t and 257..287 of g1t are never written by anyone else
-  if (hipMemsetAsync(k.drgbt + 3 * P, 0, (size_t)(29 * P) * sizeof(float), st) != hipSuccess) return NSR_ERR_LAUNCH;
-  if (hipMemsetAsync(k.g1t + 257 * P, 0, (size_t)(31 * P) * sizeof(float), st) != hipSuccess) return NSR_ERR_LAUNCH;
+int composite_bwd(hipStream_t st, const Work& k, const float* z, int64_t R, int N, int white) {
   const dim3 block(256), grid((unsigned)((R + 3) / 4));
   const int K = (N + 63) / 64;
-#define NSR_LAUNCH_CB(KK)                                                                                          \
-  hipLaunchKernelGGL(composite_bwd_kernel<KK>, grid, block, 0, st, k.rgb, k.sig, z, k.g_comp, R, N, white, P, k.drgb, \
-                     k.drgbt, k.g1, k.g1t)
+#define NSR_LAUNCH_CB(KK) \
+  hipLaunchKernelGGL(composite_bwd_kernel<KK>, grid, block, 0, st, k.rgb, k.sig, z, k.g_comp, R, N, white, k.drgb, k.g1)
   switch (K) {
     case 1: NSR_LAUNCH_CB(1); break;
     case 2: NSR_LAUNCH_CB(2); break;
@@ -611,7 +608,7 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
                                         u_fine ? u_fine + r0 * n_importance : nullptr, z, nullptr, stream));
       }
       hipLaunchKernelGGL(encode_train_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, rays_c, ray_stride, z,
-                         P, N, k.x5, k.x5t, k.gs, k.gst);
+                         P, N, k.x5, k.gs);
       NSR_CHECK_LAUNCH();
       NSR_TRY(net_forward(st, w, k.pack[net], k, P));
       const float* noise = net ? noise_fine : noise_coarse;
@@ -632,8 +629,8 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
       hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, k.block_sums, nblk, mse_scale, lambda, losses, net,
                          k.carry);
       NSR_CHECK_LAUNCH();
-      NSR_TRY(composite_bwd(st, k, z, rc, N, white_bkgd, P));
-      NSR_TRY(net_backward(st, k.pack[net], k, P, g, acc));
+      NSR_TRY(composite_bwd(st, k, z, rc, N, white_bkgd));
+      NSR_TRY(net_backward(st, w, k.pack[net], k, P, g, acc));
     }
   }
   return NSR_OK;
@@ -663,5 +660,5 @@ extern "C" int nsr_linear(const float* x, int64_t ldx, const float* w, int64_t l
   GemmArgs g{};
   g.A = x; g.lda = ldx; g.B = w; g.ldb = ldw; g.C = y; g.ldc = ldy; g.Ct = y_t; g.ldct = ldyt; g.bias = b;
   g.M = P; g.N = N; g.K = K; g.n_valid = N; g.act = act; g.splits = 1;
-  return gemm_nt(g, nsr_stream(stream));
+  return gemm(g, nsr_stream(stream));
 }
