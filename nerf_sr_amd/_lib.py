@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("NSR_LIB_PATH", os.path.join(_HERE, "libnsr.so"))   # 
 NSR_FP32, NSR_BF16, NSR_F16X3, NSR_F16 = 0, 1, 2, 3
 PRECISIONS = {"fp32": NSR_FP32, "bf16": NSR_BF16, "f16x3": NSR_F16X3, "f16": NSR_F16}
 
-# symbol -> (restype, argtypes); must list every function of include/nsr.h and include/nsr_train.h
+# symbol -> (restype, argtypes); must list every function of include/*.h
 SIGNATURES = {
     "nsr_version": (c_int, []),
     "nsr_status_string": (c_char_p, [c_int]),
@@ -50,6 +50,9 @@ SIGNATURES = {
                                          POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nsr_adam_step": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int,
                               c_float, c_float, c_float, c_float, c_void_p]),
+    # ---- include/nsr_warp.h
+    "nsr_depth_warp": (c_int, [c_void_p, c_int, c_int, c_double, POINTER(c_float), POINTER(c_double), c_int, c_void_p,
+                               c_void_p, c_void_p, c_void_p]),
     "nsr_linear": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64,
                            c_int64, c_int, c_int, c_void_p]),
 }

@@ -21,7 +21,8 @@ def lib():
 
 
 def _declared_symbols():
-    text = open(os.path.join(REPO, "include", "nsr.h")).read() + open(os.path.join(REPO, "include", "nsr_train.h")).read()
+    inc = os.path.join(REPO, "include")
+    text = "".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(nsr_[a-z_0-9]+)\s*\(", text)))
 
