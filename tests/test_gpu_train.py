@@ -172,3 +172,35 @@ def test_loss_decreases_over_steps(tr):
         hist.append(float(t.optimize_parameters().sum()))
     assert hist[-1] < hist[0] * 0.9, hist
     assert all(np.isfinite(hist))
+
+
+def test_config1_vanilla_model_iteration(tr):
+    """BASELINE config #1: one training iteration of the vanilla `nerf` model (scripts/train_llff.sh): 11-wide rays
+    (view direction in columns 8:11, models/nerf_model.py:207-242), no supersampling (s2 = 1), randomized sampling,
+    noise_std 1 -- against the CPU training oracle on the same draws."""
+    from nerf_sr_amd import ops, cameras
+    gen = torch.Generator().manual_seed(11)
+    R = 96
+    rays8 = ops.subpixel_rays(cameras.spiral_pose(0.6), (252, 189), cameras.llff_focal(252), 1, True).reshape(-1, 8)
+    sel = torch.randperm(rays8.shape[0], generator=gen)[:R]
+    rays8 = rays8.cpu()[sel]
+    view = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    rays = torch.cat([rays8, view], 1).contiguous()                       # (R, 11)
+    tgt = torch.rand(R, 3, generator=gen)
+    draws = {"u_coarse": torch.rand(R, 64, generator=gen), "noise_coarse": torch.randn(R, 64, generator=gen),
+             "u_fine": torch.rand(R, 64, generator=gen), "noise_fine": torch.randn(R, 128, generator=gen)}
+    sd_c, sd_f = make_state_dict(99), make_state_dict(100)
+    t = tr.Trainer(sd_c, sd_f, downscale=1, randomized=True, noise_std=1.0)
+    t.set_input(rays.cuda(), tgt.cuda())
+    t.loss_and_grads(draws)
+    res, gc, gf = to.loss_and_grads(sd_c, sd_f, rays, tgt, 1, 64, 64, False, dtype=torch.float64, noise_std=1.0, **draws)
+    losses = t.losses.cpu().numpy()
+    assert abs(losses[0] - res["loss_coarse_mse"]) < 1e-6 and abs(losses[1] - res["loss_fine_mse"]) < 2e-5
+    np.testing.assert_allclose(t.out["coarse_comp_rgbs"].cpu().numpy(), res["coarse_comp_rgbs"].numpy(), rtol=0, atol=2e-6)
+    for n, ref in enumerate((gc, gf)):
+        num = sum(float((t.grads[n][k].cpu().double() - ref[k]).norm()) ** 2 for k in STATE_DICT_SPEC)
+        den = sum(float(ref[k].norm()) ** 2 for k in STATE_DICT_SPEC)
+        assert (num / den) ** 0.5 < (1e-3 if n == 0 else 5e-3), (n, (num / den) ** 0.5)
+    with pytest.raises(ValueError):
+        t.set_input(rays[:, :9].cuda(), tgt.cuda())
+        t.loss_and_grads(draws)
