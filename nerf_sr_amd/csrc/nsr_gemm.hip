@@ -2,11 +2,13 @@
 //
 // v_mfma_f32_32x32x2_f32 (exact fp32 products, the arithmetic the reference trains in).  A wave owns a 64 x 64
 // quadrant (2 x 2 MFMA blocks, 64 accumulator registers); a workgroup is 2 x WN waves: tile 128 x 128 with 4 waves
-// (two workgroups per CU) or 128 x 256 with 8 waves when N >= 256, so that an A row panel is read once.
-// K advances in tiles of 32, LDS double buffered with register prefetch: one barrier per tile.
+// and K tiles of 32, or 128 x 256 with 8 waves and K tiles of 16 when N >= 256 (an A row panel is read once; 61 KB
+// of LDS and 128 VGPRs) -- in both cases TWO workgroups share a CU, so the prologue and the store-heavy epilogue of
+// one hide behind the MFMAs of the other (with K = 256 a workgroup lives for only 16 K tiles).
+// LDS is double buffered with register prefetch: one barrier per K tile.
 // This MFMA takes ONE float per lane and operand, so either memory orientation of an operand is staged as it lies
 // in memory (coalesced float4 loads along its contiguous axis) and only the LDS read differs:
-//   K-contiguous operand: LDS [row][k], stride 36 floats; lane (i, h) reads the float4 at k = 8q + 4h and feeds four
+//   K-contiguous operand: LDS [row][k], stride TK + 4 floats; lane (i, h) reads the float4 at k = 8q + 4h and feeds four
 //                         consecutive MFMAs (k = 8q + 4h + t, t = 0..3); conflict free.
 //   K-major operand:      LDS [k][row], stride rows + 4; lane (i, h) reads the scalar at (k = 8q + 4h + t, i): the 32
 //                         lanes of a half read 32 consecutive floats, conflict free.
@@ -20,17 +22,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kTM = 128, kTK = 32, kLdK = kTK + 4;   // K-contiguous LDS row stride (floats), 16 B aligned
+constexpr int kTM = 128;
+// K tile TK (16 or 32); K-contiguous LDS row stride TK + 4 floats (16 B aligned, conflict free for float4 reads)
 
-template <int ROWS>   // floats of one staged operand tile (either orientation fits)
-constexpr int tile_floats() { return (ROWS * kLdK > kTK * (ROWS + 4)) ? ROWS * kLdK : kTK * (ROWS + 4); }
+template <int ROWS, int TK>   // floats of one staged operand tile (either orientation fits)
+constexpr int tile_floats() { return (ROWS * (TK + 4) > TK * (ROWS + 4)) ? ROWS * (TK + 4) : TK * (ROWS + 4); }
 
 // global -> registers: tile of ROWS x 32 of an operand, NT threads, VEC float4 per thread
-template <int KMAJOR, int ROWS, int NT>
-__device__ __forceinline__ void load_tile(f32x4 (&v)[ROWS * 8 / NT], const float* __restrict__ p, int64_t ld, int64_t r0,
-                                          int64_t extent, int64_t k0, int tid) {
+template <int KMAJOR, int ROWS, int NT, int TK>
+__device__ __forceinline__ void load_tile(f32x4 (&v)[ROWS * TK / 4 / NT], const float* __restrict__ p, int64_t ld,
+                                          int64_t r0, int64_t extent, int64_t k0, int tid) {
 #pragma unroll
-  for (int i = 0; i < ROWS * 8 / NT; ++i) {
+  for (int i = 0; i < ROWS * TK / 4 / NT; ++i) {
     const int idx = tid + NT * i;
     if (KMAJOR) {
       const int k = idx / (ROWS / 4), r4 = idx % (ROWS / 4);
@@ -38,42 +41,42 @@ __device__ __forceinline__ void load_tile(f32x4 (&v)[ROWS * 8 / NT], const float
       r = (r + 3 < extent) ? r : extent - 4;                 // past the edge: any valid data, dropped later
       v[i] = *reinterpret_cast<const f32x4*>(p + (k0 + k) * ld + r);
     } else {
-      const int row = idx >> 3, c4 = idx & 7;
+      const int row = idx / (TK / 4), c4 = idx % (TK / 4);
       int64_t r = r0 + row;
       r = r < extent ? r : extent - 1;
       v[i] = *reinterpret_cast<const f32x4*>(p + r * ld + k0 + 4 * c4);
     }
   }
 }
-template <int KMAJOR, int ROWS, int NT>
-__device__ __forceinline__ void store_tile(const f32x4 (&v)[ROWS * 8 / NT], float* s, int tid) {
+template <int KMAJOR, int ROWS, int NT, int TK>
+__device__ __forceinline__ void store_tile(const f32x4 (&v)[ROWS * TK / 4 / NT], float* s, int tid) {
 #pragma unroll
-  for (int i = 0; i < ROWS * 8 / NT; ++i) {
+  for (int i = 0; i < ROWS * TK / 4 / NT; ++i) {
     const int idx = tid + NT * i;
     if (KMAJOR) {
       const int k = idx / (ROWS / 4), r4 = idx % (ROWS / 4);
       *reinterpret_cast<f32x4*>(s + k * (ROWS + 4) + 4 * r4) = v[i];
     } else {
-      const int row = idx >> 3, c4 = idx & 7;
-      *reinterpret_cast<f32x4*>(s + row * kLdK + 4 * c4) = v[i];
+      const int row = idx / (TK / 4), c4 = idx % (TK / 4);
+      *reinterpret_cast<f32x4*>(s + row * (TK + 4) + 4 * c4) = v[i];
     }
   }
 }
 // the four operand values lane (i, h) feeds to the MFMAs t = 0..3 of group q, for the 32-row block at `row`
-template <int KMAJOR, int ROWS>
+template <int KMAJOR, int ROWS, int TK>
 __device__ __forceinline__ f32x4 frag(const float* s, int row, int q, int h) {
   if (KMAJOR) {
     const float* p = s + (8 * q + 4 * h) * (ROWS + 4) + row;
     return f32x4{p[0], p[ROWS + 4], p[2 * (ROWS + 4)], p[3 * (ROWS + 4)]};
   }
-  return *reinterpret_cast<const f32x4*>(s + row * kLdK + 8 * q + 4 * h);
+  return *reinterpret_cast<const f32x4*>(s + row * (TK + 4) + 8 * q + 4 * h);
 }
 
-template <int AK, int BK, int WN>
-__global__ void __launch_bounds__(128 * WN, WN == 2 ? 2 : 1)
+template <int AK, int BK, int WN, int TK>
+__global__ void __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(WN, WN)))   // two workgroups per CU
 gemm_kernel(GemmArgs g, int n_col_tiles, int64_t k_chunk) {
   constexpr int NT = 128 * WN, TN = 64 * WN;
-  constexpr int kAF = tile_floats<kTM>(), kBF = tile_floats<TN>();
+  constexpr int kAF = tile_floats<kTM, TK>(), kBF = tile_floats<TN, TK>();
   __shared__ __attribute__((aligned(16))) float lds[2 * (kAF + kBF)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1, li = lane & 31, h = lane >> 5;
@@ -84,7 +87,7 @@ gemm_kernel(GemmArgs g, int n_col_tiles, int64_t k_chunk) {
   const int z = blockIdx.y;
   const int64_t k_begin = (int64_t)z * k_chunk;
   const int64_t k_end = (k_begin + k_chunk < g.K) ? k_begin + k_chunk : g.K;
-  const int n_tiles = (int)((k_end - k_begin) / kTK);
+  const int n_tiles = (int)((k_end - k_begin) / TK);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -98,28 +101,28 @@ gemm_kernel(GemmArgs g, int n_col_tiles, int64_t k_chunk) {
 #pragma unroll
   for (int bj = 0; bj < 2; ++bj) col_on[bj] = (n0 + 64 * wn + 32 * bj) < g.N;
 
-  f32x4 sa[kTM * 8 / NT], sb[TN * 8 / NT];
+  f32x4 sa[kTM * TK / 4 / NT], sb[TN * TK / 4 / NT];
   if (n_tiles > 0) {
-    load_tile<AK, kTM, NT>(sa, g.A, g.lda, m0, g.M, k_begin, tid);
-    load_tile<BK, TN, NT>(sb, g.B, g.ldb, n0, g.N, k_begin, tid);
-    store_tile<AK, kTM, NT>(sa, lds, tid);
-    store_tile<BK, TN, NT>(sb, lds + kAF, tid);
+    load_tile<AK, kTM, NT, TK>(sa, g.A, g.lda, m0, g.M, k_begin, tid);
+    load_tile<BK, TN, NT, TK>(sb, g.B, g.ldb, n0, g.N, k_begin, tid);
+    store_tile<AK, kTM, NT, TK>(sa, lds, tid);
+    store_tile<BK, TN, NT, TK>(sb, lds + kAF, tid);
   }
   __syncthreads();
   for (int t = 0; t < n_tiles; ++t) {
     const float* As = lds + (t & 1) * (kAF + kBF);
     const float* Bs = As + kAF;
     if (t + 1 < n_tiles) {
-      load_tile<AK, kTM, NT>(sa, g.A, g.lda, m0, g.M, k_begin + (int64_t)(t + 1) * kTK, tid);
-      load_tile<BK, TN, NT>(sb, g.B, g.ldb, n0, g.N, k_begin + (int64_t)(t + 1) * kTK, tid);
+      load_tile<AK, kTM, NT, TK>(sa, g.A, g.lda, m0, g.M, k_begin + (int64_t)(t + 1) * TK, tid);
+      load_tile<BK, TN, NT, TK>(sb, g.B, g.ldb, n0, g.N, k_begin + (int64_t)(t + 1) * TK, tid);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < TK / 8; ++q) {
       f32x4 a[2], b[2];
 #pragma unroll
-      for (int bi = 0; bi < 2; ++bi) a[bi] = frag<AK, kTM>(As, 64 * wm + 32 * bi + li, q, h);
+      for (int bi = 0; bi < 2; ++bi) a[bi] = frag<AK, kTM, TK>(As, 64 * wm + 32 * bi + li, q, h);
 #pragma unroll
-      for (int bj = 0; bj < 2; ++bj) b[bj] = frag<BK, TN>(Bs, 64 * wn + 32 * bj + li, q, h);
+      for (int bj = 0; bj < 2; ++bj) b[bj] = frag<BK, TN, TK>(Bs, 64 * wn + 32 * bj + li, q, h);
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -132,8 +135,8 @@ gemm_kernel(GemmArgs g, int n_col_tiles, int64_t k_chunk) {
     }
     if (t + 1 < n_tiles) {
       float* An = lds + ((t + 1) & 1) * (kAF + kBF);
-      store_tile<AK, kTM, NT>(sa, An, tid);
-      store_tile<BK, TN, NT>(sb, An + kAF, tid);
+      store_tile<AK, kTM, NT, TK>(sa, An, tid);
+      store_tile<BK, TN, NT, TK>(sb, An + kAF, tid);
     }
     __syncthreads();
   }
@@ -203,11 +206,13 @@ int launch(const GemmArgs& a, int splits, hipStream_t st) {
   const int tn = wide ? 256 : 128;
   const int n_col_tiles = (a.N + tn - 1) / tn;
   const int64_t row_tiles = (a.M + kTM - 1) / kTM;
-  const int64_t k_tiles = a.K / kTK;
-  const int64_t k_chunk = ((k_tiles + splits - 1) / splits) * kTK;
+  const int64_t k_tiles = a.K / 32;
+  const int64_t k_chunk = ((k_tiles + splits - 1) / splits) * 32;
   const dim3 grid((unsigned)(row_tiles * n_col_tiles), (unsigned)splits);
-  if (wide) hipLaunchKernelGGL((gemm_kernel<AK, BK, 4>), grid, dim3(512), 0, st, a, n_col_tiles, k_chunk);
-  else hipLaunchKernelGGL((gemm_kernel<AK, BK, 2>), grid, dim3(256), 0, st, a, n_col_tiles, k_chunk);
+  // wide tile: K tiles of 16 keep the double-buffered LDS at 61 KB, so TWO 8-wave workgroups share a CU and one's
+  // prologue / epilogue hides behind the other's MFMAs (with K = 256 a workgroup lives for only 8-16 K tiles)
+  if (wide) hipLaunchKernelGGL((gemm_kernel<AK, BK, 4, 16>), grid, dim3(512), 0, st, a, n_col_tiles, k_chunk);
+  else hipLaunchKernelGGL((gemm_kernel<AK, BK, 2, 32>), grid, dim3(256), 0, st, a, n_col_tiles, k_chunk);
   if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
   return NSR_OK;
 }
@@ -215,7 +220,7 @@ int launch(const GemmArgs& a, int splits, hipStream_t st) {
 }  // namespace
 
 NSR_INTERNAL int gemm(const GemmArgs& g, hipStream_t st) {
-  if (g.M < 0 || g.N <= 0 || g.K < 0 || (g.K % kTK) != 0 || g.n_valid > g.N) return NSR_ERR_INVALID_ARG;
+  if (g.M < 0 || g.N <= 0 || g.K < 0 || (g.K % 32) != 0 || g.n_valid > g.N) return NSR_ERR_INVALID_ARG;
   if (!g.A || !g.B || (!g.C && !g.Ct)) return NSR_ERR_INVALID_ARG;
   if ((g.lda % 4) || (g.ldb % 4) || (g.Ct && (g.ldct % 4))) return NSR_ERR_INVALID_ARG;
   if ((reinterpret_cast<uintptr_t>(g.A) & 15) || (reinterpret_cast<uintptr_t>(g.B) & 15) ||

@@ -26,7 +26,7 @@ namespace {
 
 constexpr int kW = 256, kPe = 64, kX5 = 320, kGs = 288, kDirOut = 128, kRgbPad = 32;
 constexpr int kSigmaCol = 256, kDeCol = 260;     // columns of the [g | sigma | 0 0 0 | de27 | 0] buffer
-constexpr int kMaxSplits = 128;
+constexpr int kMaxSplits = 256;
 constexpr int64_t kPartialFloats = (int64_t)kGs * kX5;   // >= every padded weight-gradient shape
 
 // state_dict indices (nsr.h): layer i (1..8) weight = 2 (i - 1), bias = 2 (i - 1) + 1
@@ -298,8 +298,16 @@ __global__ void __launch_bounds__(256) reduce_place_kernel(float* __restrict__ d
   if (idx >= rows * cols) return;
   const int i = idx / cols, j = idx % cols;
   const float* src = partial + (int64_t)(pr0 + i) * p_ld + pc0 + j;
-  double s = 0.0;
-  for (int zc = 0; zc < splits; ++zc) s += (double)src[zc * stride];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four independent chains: the loads of a round are all in flight
+  int zc = 0;
+  for (; zc + 4 <= splits; zc += 4) {
+    s0 += (double)src[(zc + 0) * stride];
+    s1 += (double)src[(zc + 1) * stride];
+    s2 += (double)src[(zc + 2) * stride];
+    s3 += (double)src[(zc + 3) * stride];
+  }
+  for (; zc < splits; ++zc) s0 += (double)src[zc * stride];
+  const double s = (s0 + s1) + (s2 + s3);
   float* d = dst + (int64_t)i * dst_ld + dc0 + j;
   *d = (accumulate ? *d : 0.0f) + (float)s;
 }
@@ -433,8 +441,9 @@ int lin_dgrad(hipStream_t st, const Work& k, const float* dy, int64_t lddy, int 
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
+// split-K factor of the weight gradients: 2 row tiles x splits workgroups should cover the 256 CUs at least once
 int n_splits(int64_t P) {
-  int64_t s = P / 2048;
+  int64_t s = (P + 511) / 512;
   return (int)(s < 1 ? 1 : (s > kMaxSplits ? kMaxSplits : s));
 }
 // partial[z] (M x N) = sum over the z-th slice of the points of dy[p][0..M) x[p][0..N)^T
@@ -476,7 +485,10 @@ int net_forward(hipStream_t st, const float* const* w, const WeightPack& q, cons
   NSR_TRY(lin_fwd(st, k.h[6], kW, kW, w[12], 256, w[13], kActRelu, k.h[7], kW, P, kW, kW));
   NSR_TRY(lin_fwd(st, k.h[7], kW, kW, w[14], 256, w[15], kActRelu, k.h[8], kW, P, kW, kW));
   // xyz_encoding_final stacked over the density head: [g | sigma] into columns 0..256 of the dir layer's input
-  NSR_TRY(lin_fwd(st, k.h[8], kW, kW, q.w9p, 256, q.b9p, kActNone, k.gs, kGs, P, kGs, 257));
+  // (two launches: the 256 wide columns on the 8-wave tile, the density row on the narrow one, instead of a second
+  // 256-wide column tile that would be 7/8 padding)
+  NSR_TRY(lin_fwd(st, k.h[8], kW, kW, q.w9p, 256, q.b9p, kActNone, k.gs, kGs, P, kW, kW));
+  NSR_TRY(lin_fwd(st, k.h[8], kW, kW, q.w9p + 256 * 256, 256, q.b9p + 256, kActNone, k.gs + kSigmaCol, kGs, P, 32, 1));
   NSR_TRY(lin_fwd(st, k.gs, kGs, kGs, q.wdirp, 288, w[kDirB], kActRelu, k.cc, kDirOut, P, kDirOut, kDirOut));
   NSR_TRY(lin_fwd(st, k.cc, kDirOut, kDirOut, q.wrgbp, 128, q.brgbp, kActSigmoid, k.rgb, 4, P, kRgbPad, 3));
   return NSR_OK;
@@ -499,9 +511,10 @@ int net_backward(hipStream_t st, const float* const* w, const WeightPack& q, con
   // d g (its column sums are xyz_encoding_final's bias gradient); column 256 keeps d sigma
   NSR_TRY(lin_dgrad(st, k, k.g0, kDirOut, kDirOut, q.wdirp, 288, nullptr, 0, k.g1, kGs, P, kW, g[kFinalB], acc));
   // xyz_encoding_final + sigma (288-row layer over h8)
-  NSR_TRY(lin_wgrad(st, k.g1, kGs, kGs, k.h[8], kW, kW, P, part, sp));
+  NSR_TRY(lin_wgrad(st, k.g1, kGs, kW, k.h[8], kW, kW, P, part, sp));                 // rows 0..255: xyz_encoding_final
   NSR_TRY(reduce_place(st, g[kFinalW], 256, 0, 256, 256, part, sp, kW, 0, 0, acc));
-  NSR_TRY(reduce_place(st, g[kSigmaW], 256, 0, 1, 256, part, sp, kW, 256, 0, acc));
+  NSR_TRY(lin_wgrad(st, k.g1 + kSigmaCol, kGs, 32, k.h[8], kW, kW, P, part, sp));     // row 256 (+ 31 zero rows): sigma
+  NSR_TRY(reduce_place(st, g[kSigmaW], 256, 0, 1, 256, part, sp, kW, 0, 0, acc));
   NSR_TRY(colsum(st, k.g1, kGs, P, 256, 1, g[kSigmaB], acc, part));
   NSR_TRY(lin_dgrad(st, k, k.g1, kGs, kGs, q.w9p, 256, k.h[8], kW, k.g0, kW, P, kW, g[15], acc));   // + bias of layer 8
   // xyz_encoding_8 .. 1; the gradient of layer L's pre-activation alternates between the two buffers
