@@ -1,0 +1,42 @@
+/* nsr_refine.h — C ABI of the refinement network's forward pass.
+ *
+ * Replaces MaxPoolingModel.forward(x_synth, list_x_candi) in eval mode (models/networks.py:735-990: the
+ * Model_VNPCAT encoder on the synthesised patch and on each of its R reference patches, a max over the references
+ * at every scale, the Model_VNPCAT decoder), as refine_model.py:99 calls it (`self.netRefine(sr_patch, ref_patches)`).
+ * fp32; every 3x3 convolution runs as an im2col + the fp32-MFMA GEMM of the training step (nsr_gemm.hip) with
+ * bias / ReLU / tanh in its epilogue; BatchNorm (eval: running statistics, eps 1e-5) is folded into the packed
+ * weights; activations are NHWC so that channel concatenations and nearest-neighbour upsampling cost nothing
+ * (GEMM outputs land directly in the concatenated buffers, the upsampling is an index map of the next im2col).
+ *
+ * Weights: the float tensors of MaxPoolingModel.state_dict() in state_dict order WITHOUT the 17 int64
+ * `num_batches_tracked` entries: per layer weight (Cout, Cin, 3, 3), bias (Cout) and, for layers followed by a
+ * BatchNorm2d, its weight, bias, running_mean, running_var.  Layer order (NSR_REFINE_N_LAYERS = 19):
+ *   E.conv1 (no BN), E.conv2 .. E.conv7, D.conv1, D.conv2, D.conv2_up, D.conv3, D.conv4, D.conv4_up, D.conv5, D.conv6,
+ *   D.conv6_up, D.conv7, D.conv8, D.conv9 (no BN)        ->  NSR_REFINE_N_TENSORS = 2 * 19 + 4 * 17 = 106.
+ */
+#ifndef NSR_REFINE_H_
+#define NSR_REFINE_H_
+
+#include "nsr.h"
+
+#define NSR_REFINE_N_LAYERS 19
+#define NSR_REFINE_N_TENSORS 106
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+size_t nsr_refine_packed_bytes(void);
+/* tensors: HOST array of NSR_REFINE_N_TENSORS DEVICE pointers (order above); packed: DEVICE, 16-byte aligned */
+int nsr_refine_pack_weights(const float* const* tensors, void* packed, void* stream);
+
+/* H and W multiples of 8 (three stride-2 levels); 0 on invalid arguments */
+size_t nsr_refine_workspace_bytes(int B, int R, int H, int W);
+/* x_synth (B, 3, H, W), x_candi (B, R, 3, H, W), out (B, 3, H, W): NCHW fp32 DEVICE (the reference's tensors) */
+int nsr_refine_forward(const void* packed, const float* x_synth, const float* x_candi, int B, int R, int H, int W,
+                       float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSR_REFINE_H_ */

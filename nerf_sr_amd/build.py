@@ -27,6 +27,7 @@ UNITS = [
     ("nsr_gemm.hip", ["-ffp-contract=off"]),
     ("nsr_train.hip", ["-ffp-contract=off"]),
     ("nsr_warp.hip", ["-ffp-contract=off"]),
+    ("nsr_refine.hip", ["-ffp-contract=off"]),
     ("nsr_api.hip", []),
 ]
 

@@ -10,7 +10,7 @@
 
 namespace nsr {
 
-enum GemmAct { kActNone = 0, kActRelu = 1, kActSigmoid = 2 };
+enum GemmAct { kActNone = 0, kActRelu = 1, kActSigmoid = 2, kActTanh = 3 };
 
 struct GemmArgs {
   const float* A; int64_t lda; int a_kmajor;   // M x K

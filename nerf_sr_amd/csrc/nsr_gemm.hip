@@ -170,6 +170,7 @@ gemm_kernel(GemmArgs g, int n_col_tiles, int64_t k_chunk) {
           float x = acc[bi][bj][4 * rq + e] + bias;
           if (g.act == kActRelu) x = fmaxf(x, 0.0f);
           else if (g.act == kActSigmoid) x = 1.0f / (1.0f + expf(-x));
+          else if (g.act == kActTanh) x = tanhf(x);
           if (g.mask) x = mk[4 * rq + e] > 0.0f ? x : 0.0f;
           v[e] = x;
           if (m < g.M) {

@@ -1,0 +1,292 @@
+// N3: forward pass of the refinement network (include/nsr_refine.h; reference: models/networks.py:735-990,
+// MaxPoolingModel = Model_VNPCAT_Encoder + max over the reference patches + Model_VNPCAT_Decoder, eval mode).
+//
+// Every 3x3 convolution is im2col (NHWC, taps-major K = (ky, kx, cin)) + the fp32-MFMA GEMM of nsr_gemm.hip:
+// M = images x output pixels, N = Cout, K = 9 Cin.  NHWC makes a row of the im2col matrix nine contiguous channel
+// runs (coalesced float4 copies), makes the GEMM output (pixels x Cout) the next layer's activation as it is, and
+// lets a GEMM write straight into a slice of a concatenated buffer (row stride = total channels), so torch.cat costs
+// nothing; nn.Upsample(scale_factor=2) (nearest) is an index map (y >> 1, x >> 1) inside the next layer's im2col.
+// BatchNorm2d in eval mode is an affine map per channel: folded into the packed weights and bias.
+#include "nsr_common.h"
+#include "nsr_gemm.h"
+#include "../../include/nsr_refine.h"
+
+using namespace nsr;
+
+namespace {
+
+struct Layer {
+  int cin, cout, stride, bn, up, act;
+};
+// forward order = state_dict order (E.conv1..7, D.conv1, 2, 2_up, 3, 4, 4_up, 5, 6, 6_up, 7, 8, 9)
+constexpr Layer kLayers[NSR_REFINE_N_LAYERS] = {
+    {3, 128, 1, 0, 0, kActRelu},    {128, 128, 1, 1, 0, kActRelu}, {128, 256, 2, 1, 0, kActRelu},
+    {256, 256, 1, 1, 0, kActRelu},  {256, 512, 2, 1, 0, kActRelu}, {512, 512, 1, 1, 0, kActRelu},
+    {512, 512, 2, 1, 0, kActRelu},
+    {1024, 512, 1, 1, 0, kActRelu}, {512, 512, 1, 1, 0, kActRelu}, {512, 512, 1, 1, 1, kActRelu},
+    {1536, 512, 1, 1, 0, kActRelu}, {512, 512, 1, 1, 0, kActRelu}, {512, 256, 1, 1, 1, kActRelu},
+    {768, 256, 1, 1, 0, kActRelu},  {256, 256, 1, 1, 0, kActRelu}, {256, 128, 1, 1, 1, kActRelu},
+    {384, 128, 1, 1, 0, kActRelu},  {128, 128, 1, 1, 0, kActRelu}, {128, 3, 1, 0, 0, kActTanh},
+};
+constexpr int pad32(int n) { return (n + 31) & ~31; }
+constexpr int kpad(int l) { return pad32(9 * kLayers[l].cin); }
+constexpr int npad(int l) { return pad32(kLayers[l].cout); }
+constexpr int64_t layer_floats(int l) { return (int64_t)npad(l) * kpad(l) + npad(l); }   // W' (npad x kpad) | b' (npad)
+constexpr int64_t layer_offset(int l) { return l == 0 ? 0 : layer_offset(l - 1) + layer_floats(l - 1); }
+constexpr int64_t kPackFloats = layer_offset(NSR_REFINE_N_LAYERS - 1) + layer_floats(NSR_REFINE_N_LAYERS - 1);
+constexpr float kBnEps = 1e-5f;   // nn.BatchNorm2d default
+
+inline int64_t align64(int64_t n) { return (n + 63) & ~(int64_t)63; }
+
+// W'[n][(ky * 3 + kx) * cin + c] = s_n * W[n][c][ky][kx],  b'[n] = (b[n] - mean[n]) * s_n + beta[n],
+// s_n = gamma[n] / sqrt(var[n] + eps)  (1 and the plain bias without a BatchNorm); padding rows / columns are zero
+__global__ void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var,
+                                 int cin, int cout, int kp, int np, float* __restrict__ dst) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nw = (int64_t)np * kp;
+  if (idx >= nw + np) return;
+  if (idx < nw) {
+    const int n = (int)(idx / kp), k = (int)(idx % kp);
+    float v = 0.0f;
+    if (n < cout && k < 9 * cin) {
+      const int tap = k / cin, c = k % cin;
+      const float s = gamma ? __fdiv_rn(gamma[n], sqrtf(__fadd_rn(var[n], kBnEps))) : 1.0f;
+      v = __fmul_rn(s, w[((int64_t)n * cin + c) * 9 + tap]);
+    }
+    dst[idx] = v;
+  } else {
+    const int n = (int)(idx - nw);
+    float v = 0.0f;
+    if (n < cout) {
+      if (gamma) {
+        const float s = __fdiv_rn(gamma[n], sqrtf(__fadd_rn(var[n], kBnEps)));
+        v = __fadd_rn(__fmul_rn(__fsub_rn(b[n], mean[n]), s), beta[n]);
+      } else {
+        v = b[n];
+      }
+    }
+    dst[idx] = v;
+  }
+}
+
+// im2col of a 3x3 / pad 1 convolution.  Source: NHWC with row stride `ld` (channels [0, cin) of a possibly wider
+// buffer), or NCHW (first layer: the reference's input tensor); `up`: the source is read through a nearest x2 upsample.
+// col (M, kp), M = n_img * Ho * Wo; one thread per (row, tap, channel quad)
+template <bool NCHW>
+__global__ void __launch_bounds__(256) im2col_kernel(const float* __restrict__ src, int64_t ld, int cin, int n_img, int Hs,
+                                                     int Ws, int stride, int up, int Ho, int Wo, int kp,
+                                                     float* __restrict__ col) {
+  const int q_per_row = kp / 4;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)n_img * Ho * Wo * q_per_row;
+  if (idx >= total) return;
+  const int64_t m = idx / q_per_row;
+  const int k0 = (int)(idx % q_per_row) * 4;
+  const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), img = (int)(m / ((int64_t)Wo * Ho));
+  const int Hin = up ? 2 * Hs : Hs, Win = up ? 2 * Ws : Ws;     // extent the convolution sees
+  float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (!NCHW && (cin & 3) == 0) {
+    if (k0 < 9 * cin) {
+      const int tap = k0 / cin, c = k0 % cin;
+      const int iy = oy * stride + tap / 3 - 1, ix = ox * stride + tap % 3 - 1;
+      if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
+        const int sy = up ? iy >> 1 : iy, sx = up ? ix >> 1 : ix;
+        const float4 t = *reinterpret_cast<const float4*>(src + (((int64_t)img * Hs + sy) * Ws + sx) * ld + c);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + e;
+      if (k >= 9 * cin) continue;
+      const int tap = k / cin, c = k % cin;
+      const int iy = oy * stride + tap / 3 - 1, ix = ox * stride + tap % 3 - 1;
+      if (iy < 0 || iy >= Hin || ix < 0 || ix >= Win) continue;
+      const int sy = up ? iy >> 1 : iy, sx = up ? ix >> 1 : ix;
+      v[e] = NCHW ? src[(((int64_t)img * cin + c) * Hs + sy) * Ws + sx]
+                  : src[(((int64_t)img * Hs + sy) * Ws + sx) * ld + c];
+    }
+  }
+  *reinterpret_cast<float4*>(col + m * kp + k0) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// dst[(b, px)][c] = max_r src[(b * R + r, px)][c]   (torch.max over the reference patches, networks.py:980-983)
+__global__ void __launch_bounds__(256) max_refs_kernel(const float* __restrict__ src, int C, int R, int64_t px_per_img,
+                                                       int64_t n, float* __restrict__ dst, int64_t ld) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B * px * C / 4
+  if (idx >= n) return;
+  const int c4 = (int)(idx % (C / 4));
+  const int64_t bp = idx / (C / 4), b = bp / px_per_img, px = bp % px_per_img;
+  float4 m = *reinterpret_cast<const float4*>(src + ((b * R) * px_per_img + px) * C + 4 * c4);
+  for (int r = 1; r < R; ++r) {
+    const float4 t = *reinterpret_cast<const float4*>(src + ((b * R + r) * px_per_img + px) * C + 4 * c4);
+    m.x = fmaxf(m.x, t.x); m.y = fmaxf(m.y, t.y); m.z = fmaxf(m.z, t.z); m.w = fmaxf(m.w, t.w);
+  }
+  *reinterpret_cast<float4*>(dst + bp * ld + 4 * c4) = m;
+}
+
+// (B * H * W, 3) NHWC -> (B, 3, H, W)
+__global__ void nhwc3_to_nchw_kernel(const float* __restrict__ src, int64_t px_per_img, int64_t n, float* __restrict__ dst) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B * 3 * px
+  if (idx >= n) return;
+  const int64_t px = idx % px_per_img, c = (idx / px_per_img) % 3, b = idx / (3 * px_per_img);
+  dst[idx] = src[(b * px_per_img + px) * 3 + c];
+}
+
+struct Work {
+  float *col, *a, *b;                 // im2col matrix, two ping-pong activation buffers
+  float *cat1, *cat3, *cat5, *cat7;   // decoder inputs [F_synth_3 | F_max_3], [x2_up | F_synth_2 | F_max_2], ...
+  float *fc0, *fc1, *fc2, *fc3;       // encoder features of the reference patches, before the max
+  float* rgb;                         // NHWC output of conv9
+};
+
+int64_t work_floats(int B, int R, int H, int W, Work* w, float* base) {
+  const int64_t px0 = (int64_t)H * W, px1 = px0 / 4, px2 = px0 / 16, px3 = px0 / 64, nimg = (int64_t)B * (R > 1 ? R : 1);
+  int64_t off = 0;
+  auto take = [&](int64_t n) {
+    float* p = base ? base + off : nullptr;
+    off += align64(n);
+    return p;
+  };
+  Work tmp;
+  Work& k = w ? *w : tmp;
+  // largest im2col matrices: encoder conv2 over the reference patches, decoder conv7
+  int64_t col = nimg * px0 * kpad(1);
+  const int64_t dec[] = {B * px3 * kpad(7), B * px2 * kpad(9), B * px2 * kpad(10), B * px1 * kpad(12), B * px1 * kpad(13),
+                         B * px0 * kpad(15), B * px0 * kpad(16), nimg * px1 * kpad(3), nimg * px2 * kpad(5), nimg * px1 * kpad(2)};
+  for (int64_t d : dec) col = d > col ? d : col;
+  k.col = take(col);
+  const int64_t act = nimg * px0 * 128;   // largest plain activation: conv1 / conv2 outputs of the reference patches
+  k.a = take(act);
+  k.b = take(act);
+  k.cat1 = take(B * px3 * 1024);
+  k.cat3 = take(B * px2 * 1536);
+  k.cat5 = take(B * px1 * 768);
+  k.cat7 = take(B * px0 * 384);
+  k.fc0 = take(nimg * px0 * 128);
+  k.fc1 = take(nimg * px1 * 256);
+  k.fc2 = take(nimg * px2 * 512);
+  k.fc3 = take(nimg * px3 * 512);
+  k.rgb = take(B * px0 * 3);
+  return off;
+}
+
+#define NSR_TRY(expr)            \
+  do {                           \
+    const int rc_ = (expr);      \
+    if (rc_ != NSR_OK) return rc_; \
+  } while (0)
+
+// one convolution layer: src (NHWC, row stride src_ld; NCHW for layer 0) -> dst (NHWC slice, row stride dst_ld)
+int conv(hipStream_t st, const float* packed, int l, const float* src, int64_t src_ld, bool nchw, int n_img, int Hs, int Ws,
+         float* col, float* dst, int64_t dst_ld) {
+  const Layer& L = kLayers[l];
+  const int Hin = L.up ? 2 * Hs : Hs, Win = L.up ? 2 * Ws : Ws;
+  const int Ho = (Hin - 1) / L.stride + 1, Wo = (Win - 1) / L.stride + 1;   // k = 3, pad = 1
+  const int kp = kpad(l);
+  const int64_t M = (int64_t)n_img * Ho * Wo, total = M * (kp / 4);
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (nchw) hipLaunchKernelGGL(im2col_kernel<true>, grid, block, 0, st, src, src_ld, L.cin, n_img, Hs, Ws, L.stride, L.up, Ho, Wo, kp, col);
+  else hipLaunchKernelGGL(im2col_kernel<false>, grid, block, 0, st, src, src_ld, L.cin, n_img, Hs, Ws, L.stride, L.up, Ho, Wo, kp, col);
+  NSR_CHECK_LAUNCH();
+  const float* wp = packed + layer_offset(l);
+  GemmArgs g{};
+  g.A = col; g.lda = kp; g.B = wp; g.ldb = kp; g.C = dst; g.ldc = dst_ld; g.bias = wp + (int64_t)npad(l) * kp;
+  g.M = M; g.N = npad(l); g.K = kp; g.n_valid = L.cout; g.act = L.act; g.splits = 1;
+  return gemm(g, st);
+}
+
+// Model_VNPCAT_Encoder.forward (networks.py:760-774): features x2, x4, x6, x7 into the four (pointer, row stride) slots
+int encoder(hipStream_t st, const float* packed, const Work& k, const float* x_nchw, int n_img, int H, int W, float* d0,
+            int64_t ld0, float* d1, int64_t ld1, float* d2, int64_t ld2, float* d3, int64_t ld3) {
+  NSR_TRY(conv(st, packed, 0, x_nchw, 0, true, n_img, H, W, k.col, k.a, 128));
+  NSR_TRY(conv(st, packed, 1, k.a, 128, false, n_img, H, W, k.col, d0, ld0));
+  NSR_TRY(conv(st, packed, 2, d0, ld0, false, n_img, H, W, k.col, k.a, 256));
+  NSR_TRY(conv(st, packed, 3, k.a, 256, false, n_img, H / 2, W / 2, k.col, d1, ld1));
+  NSR_TRY(conv(st, packed, 4, d1, ld1, false, n_img, H / 2, W / 2, k.col, k.a, 512));
+  NSR_TRY(conv(st, packed, 5, k.a, 512, false, n_img, H / 4, W / 4, k.col, d2, ld2));
+  NSR_TRY(conv(st, packed, 6, d2, ld2, false, n_img, H / 4, W / 4, k.col, d3, ld3));
+  return NSR_OK;
+}
+
+int max_refs(hipStream_t st, const float* src, int C, int B, int R, int64_t px, float* dst, int64_t ld) {
+  const int64_t n = (int64_t)B * px * (C / 4);
+  hipLaunchKernelGGL(max_refs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, C, R, px, n, dst, ld);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
+}  // namespace
+
+extern "C" size_t nsr_refine_packed_bytes(void) { return (size_t)kPackFloats * sizeof(float); }
+
+extern "C" int nsr_refine_pack_weights(const float* const* t, void* packed, void* stream) {
+  if (!t || !packed || (reinterpret_cast<uintptr_t>(packed) & 15) != 0) return NSR_ERR_INVALID_ARG;
+  for (int i = 0; i < NSR_REFINE_N_TENSORS; ++i)
+    if (!t[i]) return NSR_ERR_INVALID_ARG;
+  float* dst = static_cast<float*>(packed);
+  int ti = 0;
+  for (int l = 0; l < NSR_REFINE_N_LAYERS; ++l) {
+    const Layer& L = kLayers[l];
+    const float *w = t[ti], *b = t[ti + 1];
+    const float *gamma = nullptr, *beta = nullptr, *mean = nullptr, *var = nullptr;
+    ti += 2;
+    if (L.bn) {
+      gamma = t[ti]; beta = t[ti + 1]; mean = t[ti + 2]; var = t[ti + 3];
+      ti += 4;
+    }
+    const int64_t n = layer_floats(l);
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nsr_stream(stream), w, b, gamma, beta,
+                       mean, var, L.cin, L.cout, kpad(l), npad(l), dst + layer_offset(l));
+    NSR_CHECK_LAUNCH();
+  }
+  return NSR_OK;
+}
+
+extern "C" size_t nsr_refine_workspace_bytes(int B, int R, int H, int W) {
+  if (B <= 0 || R <= 0 || H <= 0 || W <= 0 || (H % 8) || (W % 8)) return 0;
+  return (size_t)work_floats(B, R, H, W, nullptr, nullptr) * sizeof(float);
+}
+
+extern "C" int nsr_refine_forward(const void* packed_v, const float* x_synth, const float* x_candi, int B, int R, int H, int W,
+                                  float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (B < 0 || R <= 0 || H <= 0 || W <= 0) return NSR_ERR_INVALID_ARG;
+  if ((H % 8) || (W % 8)) return NSR_ERR_UNSUPPORTED;
+  if (B == 0) return NSR_OK;
+  if (!packed_v || !x_synth || !x_candi || !out || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) != 0)
+    return NSR_ERR_INVALID_ARG;
+  if (workspace_bytes < nsr_refine_workspace_bytes(B, R, H, W)) return NSR_ERR_WORKSPACE;
+  const float* packed = static_cast<const float*>(packed_v);
+  hipStream_t st = nsr_stream(stream);
+  Work k;
+  work_floats(B, R, H, W, &k, static_cast<float*>(workspace));
+  const int64_t px0 = (int64_t)H * W, px1 = px0 / 4, px2 = px0 / 16, px3 = px0 / 64;
+  // encoder on the synthesised patches: features land in their decoder concat slots (F_synth_i)
+  NSR_TRY(encoder(st, packed, k, x_synth, B, H, W, k.cat7 + 128, 384, k.cat5 + 256, 768, k.cat3 + 512, 1536, k.cat1, 1024));
+  // encoder on the B * R reference patches, then the max over the R references (F_max_i)
+  NSR_TRY(encoder(st, packed, k, x_candi, B * R, H, W, k.fc0, 128, k.fc1, 256, k.fc2, 512, k.fc3, 512));
+  NSR_TRY(max_refs(st, k.fc0, 128, B, R, px0, k.cat7 + 256, 384));
+  NSR_TRY(max_refs(st, k.fc1, 256, B, R, px1, k.cat5 + 512, 768));
+  NSR_TRY(max_refs(st, k.fc2, 512, B, R, px2, k.cat3 + 1024, 1536));
+  NSR_TRY(max_refs(st, k.fc3, 512, B, R, px3, k.cat1 + 512, 1024));
+  // Model_VNPCAT_Decoder.forward (networks.py:827-857)
+  const int h3 = H / 8, w3 = W / 8;
+  NSR_TRY(conv(st, packed, 7, k.cat1, 1024, false, B, h3, w3, k.col, k.a, 512));
+  NSR_TRY(conv(st, packed, 8, k.a, 512, false, B, h3, w3, k.col, k.b, 512));
+  NSR_TRY(conv(st, packed, 9, k.b, 512, false, B, h3, w3, k.col, k.cat3, 1536));                 // upsample + conv2_up
+  NSR_TRY(conv(st, packed, 10, k.cat3, 1536, false, B, 2 * h3, 2 * w3, k.col, k.a, 512));
+  NSR_TRY(conv(st, packed, 11, k.a, 512, false, B, 2 * h3, 2 * w3, k.col, k.b, 512));
+  NSR_TRY(conv(st, packed, 12, k.b, 512, false, B, 2 * h3, 2 * w3, k.col, k.cat5, 768));         // upsample + conv4_up
+  NSR_TRY(conv(st, packed, 13, k.cat5, 768, false, B, 4 * h3, 4 * w3, k.col, k.a, 256));
+  NSR_TRY(conv(st, packed, 14, k.a, 256, false, B, 4 * h3, 4 * w3, k.col, k.b, 256));
+  NSR_TRY(conv(st, packed, 15, k.b, 256, false, B, 4 * h3, 4 * w3, k.col, k.cat7, 384));         // upsample + conv6_up
+  NSR_TRY(conv(st, packed, 16, k.cat7, 384, false, B, H, W, k.col, k.a, 128));
+  NSR_TRY(conv(st, packed, 17, k.a, 128, false, B, H, W, k.col, k.b, 128));
+  NSR_TRY(conv(st, packed, 18, k.b, 128, false, B, H, W, k.col, k.rgb, 3));                       // conv9 + tanh
+  const int64_t n = (int64_t)B * 3 * px0;
+  hipLaunchKernelGGL(nhwc3_to_nchw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, k.rgb, px0, n, out);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}

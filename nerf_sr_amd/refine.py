@@ -1,0 +1,122 @@
+"""Host mirror of the reference's refinement network over ``include/nsr_refine.h``.
+
+``MaxPoolingModel`` mirrors ``models/networks.py:945-990`` in eval mode: ``forward(x_synth, list_x_candi)`` with
+``x_synth`` (B, 3, H, W) and ``list_x_candi`` (B, R, 3, H, W) in [-1, 1] -> refined patch (B, 3, H, W) (tanh).
+Weights enter as the reference's ``state_dict`` (``load_state_dict``; the int64 ``num_batches_tracked`` entries are
+ignored).  All arithmetic runs in libnsr.so; there is no CPU path.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from ctypes import c_void_p
+from typing import Dict
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import _f32, _p, _stream
+
+# (name, cin, cout, stride, batch-norm name or None) in forward = state_dict order
+LAYERS = [
+    ("E.conv1", 3, 128, None), ("E.conv2", 128, 128, "E.conv2_bnorm"), ("E.conv3", 128, 256, "E.conv3_bnorm"),
+    ("E.conv4", 256, 256, "E.conv4_bnorm"), ("E.conv5", 256, 512, "E.conv5_bnorm"), ("E.conv6", 512, 512, "E.conv6_bnorm"),
+    ("E.conv7", 512, 512, "E.conv7_bnorm"),
+    ("D.conv1", 1024, 512, "D.conv1_bnorm"), ("D.conv2", 512, 512, "D.conv2_bnorm"), ("D.conv2_up", 512, 512, "D.conv2_up_bnorm"),
+    ("D.conv3", 1536, 512, "D.conv3_bnorm"), ("D.conv4", 512, 512, "D.conv4_bnorm"), ("D.conv4_up", 512, 256, "D.conv4_up_bnorm"),
+    ("D.conv5", 768, 256, "D.conv5_bnorm"), ("D.conv6", 256, 256, "D.conv6_bnorm"), ("D.conv6_up", 256, 128, "D.conv6_up_bnorm"),
+    ("D.conv7", 384, 128, "D.conv7_bnorm"), ("D.conv8", 128, 128, "D.conv8_bnorm"), ("D.conv9", 128, 3, None),
+]
+
+
+def _spec() -> "OrderedDict[str, tuple]":
+    s = OrderedDict()
+    for name, cin, cout, bn in LAYERS:
+        s[f"{name}.weight"] = (cout, cin, 3, 3)
+        s[f"{name}.bias"] = (cout,)
+        if bn:
+            for k in ("weight", "bias", "running_mean", "running_var"):
+                s[f"{bn}.{k}"] = (cout,)
+    return s
+
+
+#: the 106 float tensors of MaxPoolingModel.state_dict(), in order
+REFINE_SPEC = _spec()
+assert len(REFINE_SPEC) == 106
+
+
+def make_refine_state_dict(seed: int) -> Dict[str, np.ndarray]:
+    """Deterministic synthetic weights (no checkpoint can be downloaded): xavier-normal convolutions
+    (``initialize_weight``, networks.py:776-783), BatchNorm weight ~ N(1, 0.02), and NON-trivial running statistics
+    (mean ~ N(0, 0.1), var ~ U(0.5, 1.5)) and biases so that the folded affine map is exercised."""
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    for k, shape in REFINE_SPEC.items():
+        if k.endswith("running_var"):
+            v = rng.uniform(0.5, 1.5, shape)
+        elif k.endswith("running_mean"):
+            v = rng.normal(0.0, 0.1, shape)
+        elif len(shape) == 4:
+            fan_in, fan_out = shape[1] * 9, shape[0] * 9
+            v = rng.normal(0.0, np.sqrt(2.0 / (fan_in + fan_out)), shape)
+        elif "bnorm.weight" in k:
+            v = rng.normal(1.0, 0.02, shape)
+        else:
+            v = rng.normal(0.0, 0.05, shape)
+        sd[k] = v.astype(np.float32)
+    return sd
+
+
+class MaxPoolingModel:
+    """Encoder + max over the reference patches + decoder, eval mode (BatchNorm uses its running statistics)."""
+
+    def __init__(self, opt=None, device="cuda"):
+        if opt is not None and getattr(opt, "not_use_ref", False):
+            raise NotImplementedError("not_use_ref (Model_VNPCAT_Decoder_NoPooling) is outside the built path")
+        self.device = torch.device(device)
+        self.packed = torch.empty(_lib.load().nsr_refine_packed_bytes(), dtype=torch.uint8, device=self.device)
+        self._loaded = False
+        self._ws = None
+
+    def load_state_dict(self, sd):
+        missing = [k for k in REFINE_SPEC if k not in sd]
+        if missing:
+            raise KeyError(f"state_dict lacks {missing[:3]}{'...' if len(missing) > 3 else ''}")
+        dev = []
+        for k, shape in REFINE_SPEC.items():
+            v = sd[k]
+            v = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v.detach()
+            if tuple(v.shape) != tuple(shape):
+                raise ValueError(f"{k}: expected shape {shape}, got {tuple(v.shape)}")
+            dev.append(v.to(device=self.device, dtype=torch.float32).contiguous())
+        ptrs = (c_void_p * len(dev))(*[c_void_p(t.data_ptr()) for t in dev])
+        _lib.check(_lib.load().nsr_refine_pack_weights(ptrs, _p(self.packed), _stream()), "nsr_refine_pack_weights")
+        torch.cuda.current_stream().synchronize()       # `dev` may be freed once the pack kernels have run
+        self._loaded = True
+        return self
+
+    def eval(self):
+        return self
+
+    def forward(self, x_synth: torch.Tensor, list_x_candi: torch.Tensor) -> torch.Tensor:
+        if not self._loaded:
+            raise RuntimeError("MaxPoolingModel.forward called before load_state_dict")
+        x, c = _f32(x_synth, "x_synth"), _f32(list_x_candi, "list_x_candi")
+        if x.ndim != 4 or x.shape[1] != 3 or c.ndim != 5 or c.shape[0] != x.shape[0] or tuple(c.shape[2:]) != tuple(x.shape[1:]):
+            raise ValueError("expected x_synth (B, 3, H, W) and list_x_candi (B, R, 3, H, W)")
+        B, _, H, W = x.shape
+        R = c.shape[1]
+        out = torch.empty(B, 3, H, W, dtype=torch.float32, device=x.device)
+        if B == 0:
+            return out
+        lib = _lib.load()
+        need = lib.nsr_refine_workspace_bytes(B, R, H, W)
+        if need == 0:
+            raise ValueError("H and W must be positive multiples of 8 and R >= 1")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        _lib.check(lib.nsr_refine_forward(_p(self.packed), _p(x), _p(c), B, R, H, W, _p(out), _p(self._ws), self._ws.numel(),
+                                          _stream()), "nsr_refine_forward")
+        return out
+
+    __call__ = forward

@@ -1,0 +1,19 @@
+"""Pins oracle/refine_oracle.py to the fixture produced by the reference's own MaxPoolingModel
+(tests/golden/make_golden_refine.py).  CPU only."""
+import os
+
+import numpy as np
+
+from nerf_sr_amd.refine import make_refine_state_dict, REFINE_SPEC
+from oracle import refine_oracle as ro
+
+
+def test_refine_forward_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "refine.npz"))
+    sd = make_refine_state_dict(int(g["seed"]))
+    assert list(sd) == list(REFINE_SPEC)
+    for tag in ("a", "b"):
+        y, fs, _ = ro.forward(sd, g[f"x_{tag}"], g[f"c_{tag}"], return_features=True)
+        # same ATen convolutions on the same build
+        np.testing.assert_allclose(y.numpy(), g[f"y_{tag}"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(fs[3].numpy(), g[f"f3_{tag}"], rtol=0, atol=1e-5)
