@@ -42,6 +42,13 @@ N_COARSE, N_IMPORTANCE = 64, 64
 RAYS_PER_FRAME = IMG_WH[0] * IMG_WH[1]                      # 190,512
 N_LR = RAYS_PER_FRAME // DOWNSCALE ** 2                     # 47,628
 FLOP_PER_RAY = FLOP_PER_POINT * (N_COARSE + N_COARSE + N_IMPORTANCE)   # 227,868,672
+# render configurations of BASELINE.json; #2 is the one the headline metric is quoted on
+RENDER_CONFIGS = {
+    2: {"name": "LLFF-like (NDC)", "img_wh": (504, 378), "downscale": 2, "ndc": True, "white_bkgd": False},
+    3: {"name": "Blender-like (near/far 2/6, white background)", "img_wh": (400, 400), "downscale": 2, "ndc": False, "white_bkgd": True},
+    4: {"name": "LLFF-like (NDC)", "img_wh": (1008, 756), "downscale": 4, "ndc": True, "white_bkgd": False},
+    5: {"name": "Blender-like (near/far 2/6, white background), render pass", "img_wh": (800, 800), "downscale": 4, "ndc": False, "white_bkgd": True},
+}
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_TFLOPS = {"fp32": 157.3, "f16x3": 2500.0, "f16": 2500.0, "bf16": 2500.0}
 DTYPE_NAME = {"fp32": "f32", "f16x3": "f16x3 (fp16 MFMA, hi+lo split operands, fp32 accumulate)",
@@ -49,7 +56,7 @@ DTYPE_NAME = {"fp32": "f32", "f16x3": "f16x3 (fp16 MFMA, hi+lo split operands, f
               "bf16": "bf16 (bf16 MFMA operands, fp32 accumulate; fast path, not a parity path)"}
 
 
-def cpu_baseline(sd_c, sd_f, rays_cpu: torch.Tensor, target_s: float = 12.0):
+def cpu_baseline(sd_c, sd_f, rays_cpu: torch.Tensor, target_s: float = 12.0, white_bkgd: bool = False):
     """Time the oracle port on a bounded ray sample (rank 0, N=1 only).
 
     The torch-CPU port is GEMM-bound with small matrices: oversubscribing a many-core host slows it down, so
@@ -59,13 +66,13 @@ def cpu_baseline(sd_c, sd_f, rays_cpu: torch.Tensor, target_s: float = 12.0):
     all_cores = torch.get_num_threads()
     cands = sorted({c for c in (all_cores, 64, 32, 16, 8) if 1 <= c <= all_cores}, reverse=True)
     with torch.no_grad():
-        oc.forward_rays(sdc, sdf, rays_cpu[:256], N_COARSE, N_IMPORTANCE, False)      # warm-up (allocator, MKL)
+        oc.forward_rays(sdc, sdf, rays_cpu[:256], N_COARSE, N_IMPORTANCE, white_bkgd)      # warm-up (allocator, MKL)
         best, best_rate = all_cores, 0.0
         n0 = 1024
         for c in cands:
             torch.set_num_threads(c)
             t0 = time.perf_counter()
-            oc.forward_rays(sdc, sdf, rays_cpu[:n0], N_COARSE, N_IMPORTANCE, False)
+            oc.forward_rays(sdc, sdf, rays_cpu[:n0], N_COARSE, N_IMPORTANCE, white_bkgd)
             rate = n0 / (time.perf_counter() - t0)
             if rate > best_rate:
                 best, best_rate = c, rate
@@ -73,7 +80,7 @@ def cpu_baseline(sd_c, sd_f, rays_cpu: torch.Tensor, target_s: float = 12.0):
         n = int(min(max(n0, best_rate * target_s), 32768, rays_cpu.shape[0]))
         n -= n % 4
         t0 = time.perf_counter()
-        out = oc.forward_rays(sdc, sdf, rays_cpu[:n], N_COARSE, N_IMPORTANCE, False)
+        out = oc.forward_rays(sdc, sdf, rays_cpu[:n], N_COARSE, N_IMPORTANCE, white_bkgd)
         dt = time.perf_counter() - t0
         torch.set_num_threads(all_cores)
     return {"value": n / dt, "unit": "rays/s", "cores": best, "kind": "port",
@@ -188,9 +195,16 @@ def main():
                     help="render (default): the headline metric; train: one optimize_parameters iteration per step "
                          "(SURVEY §8f N1: forward + backward + Adam, fp32) on a 2,048-ray batch per GPU")
     ap.add_argument("--train-rays", type=int, default=2048, help="rays per GPU per training step (multiple of 4)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(RENDER_CONFIGS),
+                    help="BASELINE.json render configuration (default 2 = the one the metric is quoted on; 3-5: the other "
+                         "frame geometries, one frame per GPU)")
     args = ap.parse_args()
     if args.mode == "train":
         return main_train(args)
+    cfg = RENDER_CONFIGS[args.config]
+    IMG_WH, DOWNSCALE, ndc, white = cfg["img_wh"], cfg["downscale"], cfg["ndc"], cfg["white_bkgd"]
+    RAYS_PER_FRAME = IMG_WH[0] * IMG_WH[1]
+    N_LR = RAYS_PER_FRAME // DOWNSCALE ** 2
 
     rank, local, world = nsr_dist.init_from_env()
     if world != args.gpus:
@@ -203,8 +217,10 @@ def main():
     sd_c, sd_f = make_state_dict(99), make_state_dict(100)
     net_c = ops.VanillaMLP(precision=args.precision, device=dev).load_state_dict(sd_c)
     net_f = ops.VanillaMLP(precision=args.precision, device=dev).load_state_dict(sd_f)
-    c2w = cameras.spiral_pose(0.4 + 0.35 * rank)             # frame `rank` of the N-frame batch
-    focal = cameras.llff_focal(IMG_WH[0])
+    if ndc:
+        c2w, focal, nf = cameras.spiral_pose(0.4 + 0.35 * rank), cameras.llff_focal(IMG_WH[0]), (0.0, 1.0)   # frame `rank`
+    else:
+        c2w, focal, nf = cameras.spheric_pose(40.0 * rank, -30.0, 4.0), cameras.blender_focal(IMG_WH[0]), (2.0, 6.0)
     ws = torch.empty(ops._lib.load().nsr_forward_rays_workspace_bytes(RAYS_PER_FRAME, N_COARSE, N_IMPORTANCE),
                      dtype=torch.uint8, device=dev)
     outs = {}
@@ -212,8 +228,8 @@ def main():
     events = [ops.HipEvents(4) for _ in range(n_ev)]
 
     def step(i):
-        rays = ops.subpixel_rays(c2w, IMG_WH, focal, DOWNSCALE, True, device=dev).view(-1, 8)
-        o = ops.forward_rays(net_c, net_f, rays, N_COARSE, N_IMPORTANCE, False, workspace=ws, outs=outs,
+        rays = ops.subpixel_rays(c2w, IMG_WH, focal, DOWNSCALE, ndc, *nf, device=dev).view(-1, 8)
+        o = ops.forward_rays(net_c, net_f, rays, N_COARSE, N_IMPORTANCE, white, workspace=ws, outs=outs,
                              events=events[i].handles)
         lr = ops.sr_mean(o["fine_comp_rgbs"], N_LR, DOWNSCALE ** 2)
         frames = nsr_dist.all_gather_pixels(lr, N_LR * world) if world > 1 else lr
@@ -247,20 +263,21 @@ def main():
         achieved = fine_flop / (fine_avg * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
         res = {
-            "metric": "rays/sec (64+128 samples, 2x SS)", "value": value, "unit": "rays/s",
+            "metric": f"rays/sec (64+128 samples, {DOWNSCALE}x SS)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
-            "config": {"workload": "BASELINE config #2: LLFF-like 504x378 <- 252x189, 2x supersampling, "
-                                   "64 coarse + 128 fine samples/ray, 190,512 rays per GPU per step"
+            "config": {"workload": f"BASELINE config #{args.config}: {cfg['name']} {IMG_WH[0]}x{IMG_WH[1]} <- "
+                                   f"{IMG_WH[0] // DOWNSCALE}x{IMG_WH[1] // DOWNSCALE}, {DOWNSCALE}x supersampling, "
+                                   f"64 coarse + 128 fine samples/ray, {RAYS_PER_FRAME:,} rays per GPU per step"
                                    + ("" if world == 1 else f"; {world}-frame batch, contiguous ray shards, "
                                       "one all-gather of LR pixels per step"),
                        "rays_per_step": RAYS_PER_FRAME * world, "n_coarse": N_COARSE, "n_importance": N_IMPORTANCE,
                        "precision": args.precision, "parallelism": f"ray-shard x{world}"},
             "achieved_tflops_whole_path": value * FLOP_PER_RAY / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "mlp kernel, fine pass (190,512 rays x 128 samples)",
+            "roofline": {"bound": "mfma", "kernel": f"mlp kernel, fine pass ({RAYS_PER_FRAME:,} rays x 128 samples)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": measured_traffic(args.precision), "traffic_unit": "bytes/launch (PMC, profiles/r1_traffic.json)",
+                         "traffic": measured_traffic(args.precision) if args.config == 2 else None, "traffic_unit": "bytes/launch (PMC, profiles/r1_traffic.json)",
                          "launch_ms": fine_avg, "coarse_launch_ms": sum(coarse_ms) / len(coarse_ms),
                          "flop_per_launch": fine_flop,
                          "note": ("achieved counts ALGORITHMIC flops (2 x 593,408 MAC per point); f16x3 issues 3 MFMAs "
@@ -272,7 +289,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             lo = (RAYS_PER_FRAME // 2) - (RAYS_PER_FRAME // 2) % 4
-            base, ref, n = cpu_baseline(sd_c, sd_f, rays[lo:lo + 32768].cpu())
+            base, ref, n = cpu_baseline(sd_c, sd_f, rays[lo:lo + 32768].cpu(), white_bkgd=white)
             res["cpu_baseline"] = base
             from oracle import nerf_oracle as oc
             got = o["fine_comp_rgbs"][lo:lo + n].cpu()
