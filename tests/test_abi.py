@@ -81,3 +81,36 @@ def test_product_has_no_cpu_fallback():
     from nerf_sr_amd import ops
     with pytest.raises(ValueError, match="no CPU path"):
         ops.PositionalEncoding(3, 10)(torch.zeros(4, 3))
+
+
+def test_next_row_entry_points_validate_before_any_launch(lib):
+    """include/nsr_train.h, nsr_warp.h, nsr_refine.h: sizes and argument checks that need no GPU."""
+    from ctypes import c_double, c_float
+    null, one = c_void_p(0), c_void_p(256)
+    # training step
+    ws = lib.nsr_train_workspace_bytes(2048, 64, 64)
+    assert ws > 2048 * 128 * 3000 * 4                       # > 12 KB of activations per sample point
+    assert lib.nsr_train_workspace_bytes(0, 64, 64) == 0 and lib.nsr_train_workspace_bytes(64, 64, 300) == 0
+    p24 = (c_void_p * 24)(*[one] * 24)
+    outs = (c_void_p * 8)(*[one] * 8)
+    args = lambda R, s2, nc, ni, chunk, wsb: (p24, p24, p24, p24, one, 8, R, s2, one, nc, ni, 0, 0, null, null, null, null,
+                                               0.0, 1.0, 1.0, chunk, outs, one, one, one, one, wsb, null)
+    assert lib.nsr_train_loss_and_grads(*args(64, 4, 64, 64, 0, 16)) == -4           # workspace too small
+    assert lib.nsr_train_loss_and_grads(*args(66, 4, 64, 64, 0, ws)) == -1           # R not a multiple of s2
+    assert lib.nsr_train_loss_and_grads(*args(64, 4, 64, 300, 0, ws)) == -2          # sample count outside the path
+    assert lib.nsr_train_loss_and_grads(*args(64, 4, 64, 64, 6, ws)) == -1           # chunk not a multiple of s2
+    assert lib.nsr_train_loss_and_grads(*args(0, 4, 64, 64, 0, 0)) == 0              # empty batch
+    assert lib.nsr_adam_step(p24, p24, p24, p24, 0, 5e-4, 0.9, 0.999, 1e-8, null) == -1   # steps count from 1
+    assert lib.nsr_linear(one, 64, one, 64, null, 7, one, 32, null, 0, 4, 64, 32, null) == -1
+    assert lib.nsr_linear(one, 64, one, 64, null, 0, one, 32, null, 0, 4, 48, 32, null) == -1   # K % 32
+    # depth warp
+    c2w, ref = (c_float * 12)(), (c_double * 12)()
+    assert lib.nsr_depth_warp(one, 4, 4, -1.0, c2w, ref, 1, null, one, null, null) == -1
+    assert lib.nsr_depth_warp(one, 4, 4, 100.0, c2w, ref, 1, null, one, one, null) == -1        # warped without ref_rgb
+    assert lib.nsr_depth_warp(null, 0, 4, 100.0, c2w, ref, 1, null, null, null, null) == 0
+    # refinement network
+    assert lib.nsr_refine_packed_bytes() > 4 * 30_000_000                                       # ~35 M padded weights
+    assert lib.nsr_refine_workspace_bytes(1, 8, 64, 60) == 0 and lib.nsr_refine_workspace_bytes(1, 8, 64, 64) > 0
+    assert lib.nsr_refine_forward(one, one, one, 1, 8, 64, 60, one, one, 1 << 40, null) == -2
+    assert lib.nsr_refine_forward(one, one, one, 1, 8, 64, 64, one, one, 16, null) == -4
+    assert lib.nsr_refine_forward(one, one, one, 0, 8, 64, 64, one, one, 0, null) == 0
