@@ -26,15 +26,17 @@
 extern "C" {
 #endif
 
-size_t nsr_refine_packed_bytes(void);
+/* precision: NSR_FP32 (explicit im2col + fp32-MFMA GEMM) or NSR_F16X3 (split-fp16 MFMA, products exact to ~2^-21, with
+ * implicit im2col: no col matrix is materialised); 0 / NSR_ERR_UNSUPPORTED for anything else */
+size_t nsr_refine_packed_bytes(int precision);
 /* tensors: HOST array of NSR_REFINE_N_TENSORS DEVICE pointers (order above); packed: DEVICE, 16-byte aligned */
-int nsr_refine_pack_weights(const float* const* tensors, void* packed, void* stream);
+int nsr_refine_pack_weights(const float* const* tensors, void* packed, int precision, void* stream);
 
 /* H and W multiples of 8 (three stride-2 levels); 0 on invalid arguments */
 size_t nsr_refine_workspace_bytes(int B, int R, int H, int W);
 /* x_synth (B, 3, H, W), x_candi (B, R, 3, H, W), out (B, 3, H, W): NCHW fp32 DEVICE (the reference's tensors) */
-int nsr_refine_forward(const void* packed, const float* x_synth, const float* x_candi, int B, int R, int H, int W,
-                       float* out, void* workspace, size_t workspace_bytes, void* stream);
+int nsr_refine_forward(const void* packed, int precision, const float* x_synth, const float* x_candi, int B, int R, int H,
+                       int W, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

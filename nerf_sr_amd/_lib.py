@@ -54,11 +54,11 @@ SIGNATURES = {
     "nsr_depth_warp": (c_int, [c_void_p, c_int, c_int, c_double, POINTER(c_float), POINTER(c_double), c_int, c_void_p,
                                c_void_p, c_void_p, c_void_p]),
     # ---- include/nsr_refine.h
-    "nsr_refine_packed_bytes": (c_size_t, []),
-    "nsr_refine_pack_weights": (c_int, [POINTER(c_void_p), c_void_p, c_void_p]),
+    "nsr_refine_packed_bytes": (c_size_t, [c_int]),
+    "nsr_refine_pack_weights": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p]),
     "nsr_refine_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "nsr_refine_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
-                                   c_void_p]),
+    "nsr_refine_forward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                   c_size_t, c_void_p]),
     "nsr_linear": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64,
                            c_int64, c_int, c_int, c_void_p]),
 }

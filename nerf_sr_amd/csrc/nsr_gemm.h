@@ -31,4 +31,25 @@ struct GemmArgs {
 // enqueue; returns NSR_OK / NSR_ERR_*.  K-major operands need their non-K extent to be a multiple of 4.
 NSR_INTERNAL int gemm(const GemmArgs& g, hipStream_t st);
 
+// ---- split-fp16 variant (nsr_gemm_f16.hip): the same product on v_mfma_f32_32x32x16_f16 with every fp32 value carried
+// as hi + lo fp16 halves (a b = a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulate: products exact to ~2^-21, the
+// scheme of the NSR_F16X3 inference kernel) at 3/16 of the fp32-MFMA cycle cost.  Forward products only: A (fp32,
+// K-contiguous, values within fp16 range) is split while it is staged into LDS; B (weights, N x K, K-contiguous) is
+// given pre-split (split_f16).  With `conv.cin > 0` A is not a matrix but an NHWC activation and the rows of the 3 x 3 /
+// pad 1 im2col matrix (K = 9 cin, taps-major) are gathered on the fly (cin % 32 == 0): g.A = activation base,
+// g.lda = its row stride in floats, g.M = n_img * Ho * Wo.
+struct ConvGather {
+  int cin, Hs, Ws, Ho, Wo, stride, up;   // source height / width (before the optional nearest x2 upsample), output size
+};
+struct GemmF16Args {
+  GemmArgs g;                       // g.B / g.ldb unused; a_kmajor = b_kmajor = 0, splits <= 1, Ct unsupported
+  const unsigned short* Bh;         // N x K fp16 bit patterns: high parts
+  const unsigned short* Bl;         //                          low parts
+  int64_t ldbh;                     // row stride of Bh / Bl in halves (multiple of 8)
+  ConvGather conv;
+};
+NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st);
+// hi[i] = fp16(w[i]), lo[i] = fp16(w[i] - hi[i])
+NSR_INTERNAL int split_f16(const float* w, int64_t n, unsigned short* hi, unsigned short* lo, hipStream_t st);
+
 }  // namespace nsr

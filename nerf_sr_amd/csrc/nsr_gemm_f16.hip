@@ -1,0 +1,201 @@
+// Split-fp16 GEMM of the forward products (nsr_gemm.h: gemm_f16x3), v_mfma_f32_32x32x16_f16 x 3 per product.
+//
+// Workgroup = 4 waves on a 128 x 128 tile, each wave a 64 x 64 quadrant (2 x 2 accumulator blocks); K tiles of 32 =
+// two MFMA k-steps.  LDS holds the tile as four fp16 arrays (A hi, A lo, B hi, B lo; row stride 40 halves = 80 B,
+// which makes the 16-byte fragment reads of eight consecutive rows hit eight different 16-byte bank groups);
+// single buffered with register prefetch (40 KB per workgroup, three workgroups per CU: the MFMAs of one hide the
+// staging, barriers and epilogue of the others).  A is fp32 in memory and is split into (hi, lo) on its way from
+// registers to LDS; B arrives pre-split.  Optional implicit im2col: the A rows are gathered from an NHWC activation
+// (a K tile of 32 channels never straddles a tap because cin % 32 == 0), so a 3 x 3 convolution needs no col matrix.
+#include "nsr_gemm.h"
+#include "nsr_gemm_epilogue.h"
+
+namespace nsr {
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTM = 128, kTN = 128, kTK = 32, kLd = kTK + 8;   // LDS row stride in halves
+constexpr int kArr = kTM * kLd;                                // halves per staged array
+
+__global__ void split_f16_kernel(const float* __restrict__ w, int64_t n, unsigned short* __restrict__ hi,
+                                 unsigned short* __restrict__ lo) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = w[i];
+  const _Float16 h = (_Float16)x;
+  const _Float16 l = (_Float16)(x - (float)h);
+  hi[i] = __builtin_bit_cast(unsigned short, h);
+  lo[i] = __builtin_bit_cast(unsigned short, l);
+}
+
+struct RowSrc {   // where the four A rows this thread stages come from (implicit im2col)
+  int img, oy, ox;
+  bool ok;
+};
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3)))
+gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
+  __shared__ __attribute__((aligned(16))) _Float16 lds[4 * kArr];   // A hi | A lo | B hi | B lo  (40,960 B)
+  const GemmArgs& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1, li = lane & 31, h = lane >> 5;
+  const int64_t bid = blockIdx.x;
+  const int64_t m0 = (bid / n_col_tiles) * kTM;
+  const int n0 = (int)(bid % n_col_tiles) * kTN;
+  const int n_tiles = (int)(g.K / kTK);
+  const bool conv = a.conv.cin > 0;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.0f;
+  bool col_on[2];
+#pragma unroll
+  for (int bj = 0; bj < 2; ++bj) col_on[bj] = (n0 + 64 * wn + 32 * bj) < g.N;
+
+  // ---- staging assignment: A: 4 x (row = (tid >> 3) + 32 i, float4 column c4 = tid & 7); B: 2 x 2 x (row = (tid >> 2) + 64 i,
+  // 8-half chunk c8 = tid & 3)
+  const int c4 = tid & 7, ar0 = tid >> 3, c8 = tid & 3, br0 = tid >> 2;
+  const float* arow[4];
+  RowSrc rs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int64_t m = m0 + ar0 + 32 * i;
+    m = m < g.M ? m : g.M - 1;
+    if (conv) {
+      const int64_t per = (int64_t)a.conv.Ho * a.conv.Wo;
+      rs[i].img = (int)(m / per);
+      rs[i].oy = (int)((m % per) / a.conv.Wo);
+      rs[i].ox = (int)(m % a.conv.Wo);
+      arow[i] = g.A;
+    } else {
+      arow[i] = g.A + m * g.lda;
+    }
+  }
+  const unsigned short* bh_row[2];
+  const unsigned short* bl_row[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int n = n0 + br0 + 64 * i;
+    n = n < g.N ? n : g.N - 1;
+    bh_row[i] = a.Bh + (int64_t)n * a.ldbh;
+    bl_row[i] = a.Bl + (int64_t)n * a.ldbh;
+  }
+  f32x4 sa[4];
+  u32x4 sbh[2], sbl[2];
+  auto load = [&](int t) {
+    const int64_t k0 = (int64_t)t * kTK;
+    if (conv) {
+      const int tap = (int)(k0 / a.conv.cin), cbase = (int)(k0 % a.conv.cin), ky = tap / 3, kx = tap % 3;
+      const int Hin = a.conv.up ? 2 * a.conv.Hs : a.conv.Hs, Win = a.conv.up ? 2 * a.conv.Ws : a.conv.Ws;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iy = rs[i].oy * a.conv.stride + ky - 1, ix = rs[i].ox * a.conv.stride + kx - 1;
+        sa[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
+          const int sy = a.conv.up ? iy >> 1 : iy, sx = a.conv.up ? ix >> 1 : ix;
+          sa[i] = *reinterpret_cast<const f32x4*>(g.A + (((int64_t)rs[i].img * a.conv.Hs + sy) * a.conv.Ws + sx) * g.lda +
+                                                  cbase + 4 * c4);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sa[i] = *reinterpret_cast<const f32x4*>(arow[i] + k0 + 4 * c4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      sbh[i] = *reinterpret_cast<const u32x4*>(bh_row[i] + k0 + 8 * c8);
+      sbl[i] = *reinterpret_cast<const u32x4*>(bl_row[i] + k0 + 8 * c8);
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      h4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const _Float16 x = (_Float16)sa[i][e];
+        hi[e] = x;
+        lo[e] = (_Float16)(sa[i][e] - (float)x);
+      }
+      const int off = (ar0 + 32 * i) * kLd + 4 * c4;
+      *reinterpret_cast<h4*>(lds + off) = hi;
+      *reinterpret_cast<h4*>(lds + kArr + off) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = (br0 + 64 * i) * kLd + 8 * c8;
+      *reinterpret_cast<u32x4*>(lds + 2 * kArr + off) = sbh[i];
+      *reinterpret_cast<u32x4*>(lds + 3 * kArr + off) = sbl[i];
+    }
+  };
+
+  if (n_tiles > 0) load(0);
+  for (int t = 0; t < n_tiles; ++t) {
+    store();
+    __syncthreads();
+    if (t + 1 < n_tiles) load(t + 1);
+    const _Float16* ap = lds + (64 * wm + li) * kLd + 8 * h;
+    const _Float16* bp = lds + 2 * kArr + (64 * wn + li) * kLd + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int bi = 0; bi < 2; ++bi) {
+        ah[bi] = *reinterpret_cast<const h8*>(ap + 32 * bi * kLd + 16 * s);
+        al[bi] = *reinterpret_cast<const h8*>(ap + kArr + 32 * bi * kLd + 16 * s);
+      }
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj) {
+        bh[bj] = *reinterpret_cast<const h8*>(bp + 32 * bj * kLd + 16 * s);
+        bl[bj] = *reinterpret_cast<const h8*>(bp + kArr + 32 * bj * kLd + 16 * s);
+      }
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj)
+        if (col_on[bj]) {
+#pragma unroll
+          for (int bi = 0; bi < 2; ++bi) {
+            acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[bi], bh[bj], acc[bi][bj], 0, 0, 0);   // small terms first
+            acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[bi], bl[bj], acc[bi][bj], 0, 0, 0);
+            acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[bi], bh[bj], acc[bi][bj], 0, 0, 0);
+          }
+        }
+    }
+    __syncthreads();
+  }
+  gemm_epilogue<kTN>(g, acc, col_on, m0, n0, wm, wn, li, h, tid, 0, bid / n_col_tiles, reinterpret_cast<float*>(lds));
+}
+
+}  // namespace
+
+NSR_INTERNAL int split_f16(const float* w, int64_t n, unsigned short* hi, unsigned short* lo, hipStream_t st) {
+  if (!w || !hi || !lo || n < 0) return NSR_ERR_INVALID_ARG;
+  if (n == 0) return NSR_OK;
+  hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, n, hi, lo);
+  if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
+  return NSR_OK;
+}
+
+NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
+  const GemmArgs& g = a.g;
+  if (g.M < 0 || g.N <= 0 || g.K <= 0 || (g.K % kTK) != 0 || g.n_valid > g.N) return NSR_ERR_INVALID_ARG;
+  if (!g.A || !a.Bh || !a.Bl || !g.C || g.Ct || g.splits > 1 || g.a_kmajor || g.b_kmajor) return NSR_ERR_INVALID_ARG;
+  if ((g.lda % 4) || (a.ldbh % 8) || (reinterpret_cast<uintptr_t>(g.A) & 15) || (reinterpret_cast<uintptr_t>(a.Bh) & 15) ||
+      (reinterpret_cast<uintptr_t>(a.Bl) & 15))
+    return NSR_ERR_INVALID_ARG;
+  if (a.conv.cin > 0 && ((a.conv.cin % kTK) != 0 || g.K != 9 * a.conv.cin)) return NSR_ERR_INVALID_ARG;
+  if (g.M == 0) return NSR_OK;
+  const int n_col_tiles = (g.N + kTN - 1) / kTN;
+  const int64_t row_tiles = (g.M + kTM - 1) / kTM;
+  hipLaunchKernelGGL(gemm_f16x3_kernel, dim3((unsigned)(row_tiles * n_col_tiles)), dim3(256), 0, st, a, n_col_tiles);
+  if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
+  return NSR_OK;
+}
+
+}  // namespace nsr

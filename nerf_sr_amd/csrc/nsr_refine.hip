@@ -7,6 +7,9 @@
 // lets a GEMM write straight into a slice of a concatenated buffer (row stride = total channels), so torch.cat costs
 // nothing; nn.Upsample(scale_factor=2) (nearest) is an index map (y >> 1, x >> 1) inside the next layer's im2col.
 // BatchNorm2d in eval mode is an affine map per channel: folded into the packed weights and bias.
+// Two arithmetic modes (include/nsr_refine.h): NSR_FP32 = explicit im2col + the fp32-MFMA GEMM; NSR_F16X3 = the
+// split-fp16 GEMM with IMPLICIT im2col (the 3 x 3 gather happens while the A tile is staged, no col matrix exists;
+// only the 3-channel first layer still goes through a 32-column col matrix).
 #include "nsr_common.h"
 #include "nsr_gemm.h"
 #include "../../include/nsr_refine.h"
@@ -42,7 +45,7 @@ inline int64_t align64(int64_t n) { return (n + 63) & ~(int64_t)63; }
 // s_n = gamma[n] / sqrt(var[n] + eps)  (1 and the plain bias without a BatchNorm); padding rows / columns are zero
 __global__ void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var,
-                                 int cin, int cout, int kp, int np, float* __restrict__ dst) {
+                                 int cin, int cout, int kp, int np, int f16x3, float* __restrict__ dst) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nw = (int64_t)np * kp;
   if (idx >= nw + np) return;
@@ -54,7 +57,15 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, const float* __res
       const float s = gamma ? __fdiv_rn(gamma[n], sqrtf(__fadd_rn(var[n], kBnEps))) : 1.0f;
       v = __fmul_rn(s, w[((int64_t)n * cin + c) * 9 + tap]);
     }
-    dst[idx] = v;
+    if (f16x3) {   // [hi halves (np x kp)] [lo halves (np x kp)] [bias]: the same number of bytes as the fp32 layout
+      const _Float16 hi = (_Float16)v;
+      const _Float16 lo = (_Float16)(v - (float)hi);
+      unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+      d16[idx] = __builtin_bit_cast(unsigned short, hi);
+      d16[nw + idx] = __builtin_bit_cast(unsigned short, lo);
+    } else {
+      dst[idx] = v;
+    }
   } else {
     const int n = (int)(idx - nw);
     float v = 0.0f;
@@ -180,34 +191,49 @@ int64_t work_floats(int B, int R, int H, int W, Work* w, float* base) {
   } while (0)
 
 // one convolution layer: src (NHWC, row stride src_ld; NCHW for layer 0) -> dst (NHWC slice, row stride dst_ld)
-int conv(hipStream_t st, const float* packed, int l, const float* src, int64_t src_ld, bool nchw, int n_img, int Hs, int Ws,
-         float* col, float* dst, int64_t dst_ld) {
+int conv(hipStream_t st, const float* packed, int precision, int l, const float* src, int64_t src_ld, bool nchw, int n_img,
+         int Hs, int Ws, float* col, float* dst, int64_t dst_ld) {
   const Layer& L = kLayers[l];
   const int Hin = L.up ? 2 * Hs : Hs, Win = L.up ? 2 * Ws : Ws;
   const int Ho = (Hin - 1) / L.stride + 1, Wo = (Win - 1) / L.stride + 1;   // k = 3, pad = 1
   const int kp = kpad(l);
   const int64_t M = (int64_t)n_img * Ho * Wo, total = M * (kp / 4);
-  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-  if (nchw) hipLaunchKernelGGL(im2col_kernel<true>, grid, block, 0, st, src, src_ld, L.cin, n_img, Hs, Ws, L.stride, L.up, Ho, Wo, kp, col);
-  else hipLaunchKernelGGL(im2col_kernel<false>, grid, block, 0, st, src, src_ld, L.cin, n_img, Hs, Ws, L.stride, L.up, Ho, Wo, kp, col);
-  NSR_CHECK_LAUNCH();
+  const bool implicit = precision == NSR_F16X3 && !nchw && (L.cin % 32) == 0;
+  if (!implicit) {
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (nchw) hipLaunchKernelGGL(im2col_kernel<true>, grid, block, 0, st, src, src_ld, L.cin, n_img, Hs, Ws, L.stride, L.up, Ho, Wo, kp, col);
+    else hipLaunchKernelGGL(im2col_kernel<false>, grid, block, 0, st, src, src_ld, L.cin, n_img, Hs, Ws, L.stride, L.up, Ho, Wo, kp, col);
+    NSR_CHECK_LAUNCH();
+  }
   const float* wp = packed + layer_offset(l);
   GemmArgs g{};
   g.A = col; g.lda = kp; g.B = wp; g.ldb = kp; g.C = dst; g.ldc = dst_ld; g.bias = wp + (int64_t)npad(l) * kp;
   g.M = M; g.N = npad(l); g.K = kp; g.n_valid = L.cout; g.act = L.act; g.splits = 1;
-  return gemm(g, st);
+  if (precision != NSR_F16X3) return gemm(g, st);
+  GemmF16Args a{};
+  a.g = g;
+  a.g.B = nullptr;
+  a.Bh = reinterpret_cast<const unsigned short*>(wp);
+  a.Bl = a.Bh + (int64_t)npad(l) * kp;
+  a.ldbh = kp;
+  if (implicit) {
+    a.g.A = src;
+    a.g.lda = src_ld;
+    a.conv = ConvGather{L.cin, Hs, Ws, Ho, Wo, L.stride, L.up};
+  }
+  return gemm_f16x3(a, st);
 }
 
 // Model_VNPCAT_Encoder.forward (networks.py:760-774): features x2, x4, x6, x7 into the four (pointer, row stride) slots
-int encoder(hipStream_t st, const float* packed, const Work& k, const float* x_nchw, int n_img, int H, int W, float* d0,
+int encoder(hipStream_t st, const float* packed, int prec, const Work& k, const float* x_nchw, int n_img, int H, int W, float* d0,
             int64_t ld0, float* d1, int64_t ld1, float* d2, int64_t ld2, float* d3, int64_t ld3) {
-  NSR_TRY(conv(st, packed, 0, x_nchw, 0, true, n_img, H, W, k.col, k.a, 128));
-  NSR_TRY(conv(st, packed, 1, k.a, 128, false, n_img, H, W, k.col, d0, ld0));
-  NSR_TRY(conv(st, packed, 2, d0, ld0, false, n_img, H, W, k.col, k.a, 256));
-  NSR_TRY(conv(st, packed, 3, k.a, 256, false, n_img, H / 2, W / 2, k.col, d1, ld1));
-  NSR_TRY(conv(st, packed, 4, d1, ld1, false, n_img, H / 2, W / 2, k.col, k.a, 512));
-  NSR_TRY(conv(st, packed, 5, k.a, 512, false, n_img, H / 4, W / 4, k.col, d2, ld2));
-  NSR_TRY(conv(st, packed, 6, d2, ld2, false, n_img, H / 4, W / 4, k.col, d3, ld3));
+  NSR_TRY(conv(st, packed, prec, 0, x_nchw, 0, true, n_img, H, W, k.col, k.a, 128));
+  NSR_TRY(conv(st, packed, prec, 1, k.a, 128, false, n_img, H, W, k.col, d0, ld0));
+  NSR_TRY(conv(st, packed, prec, 2, d0, ld0, false, n_img, H, W, k.col, k.a, 256));
+  NSR_TRY(conv(st, packed, prec, 3, k.a, 256, false, n_img, H / 2, W / 2, k.col, d1, ld1));
+  NSR_TRY(conv(st, packed, prec, 4, d1, ld1, false, n_img, H / 2, W / 2, k.col, k.a, 512));
+  NSR_TRY(conv(st, packed, prec, 5, k.a, 512, false, n_img, H / 4, W / 4, k.col, d2, ld2));
+  NSR_TRY(conv(st, packed, prec, 6, d2, ld2, false, n_img, H / 4, W / 4, k.col, d3, ld3));
   return NSR_OK;
 }
 
@@ -220,10 +246,13 @@ int max_refs(hipStream_t st, const float* src, int C, int B, int R, int64_t px, 
 
 }  // namespace
 
-extern "C" size_t nsr_refine_packed_bytes(void) { return (size_t)kPackFloats * sizeof(float); }
+extern "C" size_t nsr_refine_packed_bytes(int precision) {
+  return (precision == NSR_FP32 || precision == NSR_F16X3) ? (size_t)kPackFloats * sizeof(float) : 0;
+}
 
-extern "C" int nsr_refine_pack_weights(const float* const* t, void* packed, void* stream) {
+extern "C" int nsr_refine_pack_weights(const float* const* t, void* packed, int precision, void* stream) {
   if (!t || !packed || (reinterpret_cast<uintptr_t>(packed) & 15) != 0) return NSR_ERR_INVALID_ARG;
+  if (precision != NSR_FP32 && precision != NSR_F16X3) return NSR_ERR_UNSUPPORTED;
   for (int i = 0; i < NSR_REFINE_N_TENSORS; ++i)
     if (!t[i]) return NSR_ERR_INVALID_ARG;
   float* dst = static_cast<float*>(packed);
@@ -239,7 +268,7 @@ extern "C" int nsr_refine_pack_weights(const float* const* t, void* packed, void
     }
     const int64_t n = layer_floats(l);
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nsr_stream(stream), w, b, gamma, beta,
-                       mean, var, L.cin, L.cout, kpad(l), npad(l), dst + layer_offset(l));
+                       mean, var, L.cin, L.cout, kpad(l), npad(l), precision == NSR_F16X3, dst + layer_offset(l));
     NSR_CHECK_LAUNCH();
   }
   return NSR_OK;
@@ -250,9 +279,10 @@ extern "C" size_t nsr_refine_workspace_bytes(int B, int R, int H, int W) {
   return (size_t)work_floats(B, R, H, W, nullptr, nullptr) * sizeof(float);
 }
 
-extern "C" int nsr_refine_forward(const void* packed_v, const float* x_synth, const float* x_candi, int B, int R, int H, int W,
-                                  float* out, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int nsr_refine_forward(const void* packed_v, int prec, const float* x_synth, const float* x_candi, int B, int R, int H,
+                                  int W, float* out, void* workspace, size_t workspace_bytes, void* stream) {
   if (B < 0 || R <= 0 || H <= 0 || W <= 0) return NSR_ERR_INVALID_ARG;
+  if (prec != NSR_FP32 && prec != NSR_F16X3) return NSR_ERR_UNSUPPORTED;
   if ((H % 8) || (W % 8)) return NSR_ERR_UNSUPPORTED;
   if (B == 0) return NSR_OK;
   if (!packed_v || !x_synth || !x_candi || !out || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) != 0)
@@ -264,27 +294,27 @@ extern "C" int nsr_refine_forward(const void* packed_v, const float* x_synth, co
   work_floats(B, R, H, W, &k, static_cast<float*>(workspace));
   const int64_t px0 = (int64_t)H * W, px1 = px0 / 4, px2 = px0 / 16, px3 = px0 / 64;
   // encoder on the synthesised patches: features land in their decoder concat slots (F_synth_i)
-  NSR_TRY(encoder(st, packed, k, x_synth, B, H, W, k.cat7 + 128, 384, k.cat5 + 256, 768, k.cat3 + 512, 1536, k.cat1, 1024));
+  NSR_TRY(encoder(st, packed, prec, k, x_synth, B, H, W, k.cat7 + 128, 384, k.cat5 + 256, 768, k.cat3 + 512, 1536, k.cat1, 1024));
   // encoder on the B * R reference patches, then the max over the R references (F_max_i)
-  NSR_TRY(encoder(st, packed, k, x_candi, B * R, H, W, k.fc0, 128, k.fc1, 256, k.fc2, 512, k.fc3, 512));
+  NSR_TRY(encoder(st, packed, prec, k, x_candi, B * R, H, W, k.fc0, 128, k.fc1, 256, k.fc2, 512, k.fc3, 512));
   NSR_TRY(max_refs(st, k.fc0, 128, B, R, px0, k.cat7 + 256, 384));
   NSR_TRY(max_refs(st, k.fc1, 256, B, R, px1, k.cat5 + 512, 768));
   NSR_TRY(max_refs(st, k.fc2, 512, B, R, px2, k.cat3 + 1024, 1536));
   NSR_TRY(max_refs(st, k.fc3, 512, B, R, px3, k.cat1 + 512, 1024));
   // Model_VNPCAT_Decoder.forward (networks.py:827-857)
   const int h3 = H / 8, w3 = W / 8;
-  NSR_TRY(conv(st, packed, 7, k.cat1, 1024, false, B, h3, w3, k.col, k.a, 512));
-  NSR_TRY(conv(st, packed, 8, k.a, 512, false, B, h3, w3, k.col, k.b, 512));
-  NSR_TRY(conv(st, packed, 9, k.b, 512, false, B, h3, w3, k.col, k.cat3, 1536));                 // upsample + conv2_up
-  NSR_TRY(conv(st, packed, 10, k.cat3, 1536, false, B, 2 * h3, 2 * w3, k.col, k.a, 512));
-  NSR_TRY(conv(st, packed, 11, k.a, 512, false, B, 2 * h3, 2 * w3, k.col, k.b, 512));
-  NSR_TRY(conv(st, packed, 12, k.b, 512, false, B, 2 * h3, 2 * w3, k.col, k.cat5, 768));         // upsample + conv4_up
-  NSR_TRY(conv(st, packed, 13, k.cat5, 768, false, B, 4 * h3, 4 * w3, k.col, k.a, 256));
-  NSR_TRY(conv(st, packed, 14, k.a, 256, false, B, 4 * h3, 4 * w3, k.col, k.b, 256));
-  NSR_TRY(conv(st, packed, 15, k.b, 256, false, B, 4 * h3, 4 * w3, k.col, k.cat7, 384));         // upsample + conv6_up
-  NSR_TRY(conv(st, packed, 16, k.cat7, 384, false, B, H, W, k.col, k.a, 128));
-  NSR_TRY(conv(st, packed, 17, k.a, 128, false, B, H, W, k.col, k.b, 128));
-  NSR_TRY(conv(st, packed, 18, k.b, 128, false, B, H, W, k.col, k.rgb, 3));                       // conv9 + tanh
+  NSR_TRY(conv(st, packed, prec, 7, k.cat1, 1024, false, B, h3, w3, k.col, k.a, 512));
+  NSR_TRY(conv(st, packed, prec, 8, k.a, 512, false, B, h3, w3, k.col, k.b, 512));
+  NSR_TRY(conv(st, packed, prec, 9, k.b, 512, false, B, h3, w3, k.col, k.cat3, 1536));                 // upsample + conv2_up
+  NSR_TRY(conv(st, packed, prec, 10, k.cat3, 1536, false, B, 2 * h3, 2 * w3, k.col, k.a, 512));
+  NSR_TRY(conv(st, packed, prec, 11, k.a, 512, false, B, 2 * h3, 2 * w3, k.col, k.b, 512));
+  NSR_TRY(conv(st, packed, prec, 12, k.b, 512, false, B, 2 * h3, 2 * w3, k.col, k.cat5, 768));         // upsample + conv4_up
+  NSR_TRY(conv(st, packed, prec, 13, k.cat5, 768, false, B, 4 * h3, 4 * w3, k.col, k.a, 256));
+  NSR_TRY(conv(st, packed, prec, 14, k.a, 256, false, B, 4 * h3, 4 * w3, k.col, k.b, 256));
+  NSR_TRY(conv(st, packed, prec, 15, k.b, 256, false, B, 4 * h3, 4 * w3, k.col, k.cat7, 384));         // upsample + conv6_up
+  NSR_TRY(conv(st, packed, prec, 16, k.cat7, 384, false, B, H, W, k.col, k.a, 128));
+  NSR_TRY(conv(st, packed, prec, 17, k.a, 128, false, B, H, W, k.col, k.b, 128));
+  NSR_TRY(conv(st, packed, prec, 18, k.b, 128, false, B, H, W, k.col, k.rgb, 3));                       // conv9 + tanh
   const int64_t n = (int64_t)B * 3 * px0;
   hipLaunchKernelGGL(nhwc3_to_nchw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, k.rgb, px0, n, out);
   NSR_CHECK_LAUNCH();

@@ -70,11 +70,14 @@ def make_refine_state_dict(seed: int) -> Dict[str, np.ndarray]:
 class MaxPoolingModel:
     """Encoder + max over the reference patches + decoder, eval mode (BatchNorm uses its running statistics)."""
 
-    def __init__(self, opt=None, device="cuda"):
+    def __init__(self, opt=None, precision: str = "f16x3", device="cuda"):
         if opt is not None and getattr(opt, "not_use_ref", False):
             raise NotImplementedError("not_use_ref (Model_VNPCAT_Decoder_NoPooling) is outside the built path")
+        if precision not in ("fp32", "f16x3"):
+            raise ValueError("precision must be 'fp32' or 'f16x3'")
+        self.precision, self._prec = precision, _lib.PRECISIONS[precision]
         self.device = torch.device(device)
-        self.packed = torch.empty(_lib.load().nsr_refine_packed_bytes(), dtype=torch.uint8, device=self.device)
+        self.packed = torch.empty(_lib.load().nsr_refine_packed_bytes(self._prec), dtype=torch.uint8, device=self.device)
         self._loaded = False
         self._ws = None
 
@@ -90,7 +93,7 @@ class MaxPoolingModel:
                 raise ValueError(f"{k}: expected shape {shape}, got {tuple(v.shape)}")
             dev.append(v.to(device=self.device, dtype=torch.float32).contiguous())
         ptrs = (c_void_p * len(dev))(*[c_void_p(t.data_ptr()) for t in dev])
-        _lib.check(_lib.load().nsr_refine_pack_weights(ptrs, _p(self.packed), _stream()), "nsr_refine_pack_weights")
+        _lib.check(_lib.load().nsr_refine_pack_weights(ptrs, _p(self.packed), self._prec, _stream()), "nsr_refine_pack_weights")
         torch.cuda.current_stream().synchronize()       # `dev` may be freed once the pack kernels have run
         self._loaded = True
         return self
@@ -115,7 +118,7 @@ class MaxPoolingModel:
             raise ValueError("H and W must be positive multiples of 8 and R >= 1")
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-        _lib.check(lib.nsr_refine_forward(_p(self.packed), _p(x), _p(c), B, R, H, W, _p(out), _p(self._ws), self._ws.numel(),
+        _lib.check(lib.nsr_refine_forward(_p(self.packed), self._prec, _p(x), _p(c), B, R, H, W, _p(out), _p(self._ws), self._ws.numel(),
                                           _stream()), "nsr_refine_forward")
         return out
 

@@ -3,7 +3,8 @@ import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_sr_amd import refine
 from nerf_sr_amd.refine import LAYERS
-net = refine.MaxPoolingModel().load_state_dict(refine.make_refine_state_dict(7))
+prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
+net = refine.MaxPoolingModel(precision=prec).load_state_dict(refine.make_refine_state_dict(7))
 def macs(H, W, R):
     px = [H * W, H * W // 4, H * W // 16, H * W // 64]
     enc = [(0, 1), (0, 1), (1, 2), (1, 1), (2, 2), (2, 1), (3, 2)]           # (output level, stride)
@@ -23,4 +24,4 @@ for B in (1, 8, 32):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     fl = 2 * macs(64, 64, 8) * B
-    print(f"B={B}: {ms:.2f} ms per batch, {ms / B:.3f} ms per patch set, {fl / ms / 1e9:.1f} TFLOP/s (true conv MACs, fp32)")
+    print(f"{prec} B={B}: {ms:.2f} ms per batch, {ms / B:.3f} ms per patch set, {fl / ms / 1e9:.1f} TFLOP/s (true conv MACs)")

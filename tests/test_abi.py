@@ -109,8 +109,9 @@ def test_next_row_entry_points_validate_before_any_launch(lib):
     assert lib.nsr_depth_warp(one, 4, 4, 100.0, c2w, ref, 1, null, one, one, null) == -1        # warped without ref_rgb
     assert lib.nsr_depth_warp(null, 0, 4, 100.0, c2w, ref, 1, null, null, null, null) == 0
     # refinement network
-    assert lib.nsr_refine_packed_bytes() > 4 * 30_000_000                                       # ~35 M padded weights
+    assert lib.nsr_refine_packed_bytes(0) > 4 * 30_000_000 and lib.nsr_refine_packed_bytes(1) == 0                                       # ~35 M padded weights
     assert lib.nsr_refine_workspace_bytes(1, 8, 64, 60) == 0 and lib.nsr_refine_workspace_bytes(1, 8, 64, 64) > 0
-    assert lib.nsr_refine_forward(one, one, one, 1, 8, 64, 60, one, one, 1 << 40, null) == -2
-    assert lib.nsr_refine_forward(one, one, one, 1, 8, 64, 64, one, one, 16, null) == -4
-    assert lib.nsr_refine_forward(one, one, one, 0, 8, 64, 64, one, one, 0, null) == 0
+    assert lib.nsr_refine_forward(one, 2, one, one, 1, 8, 64, 60, one, one, 1 << 40, null) == -2
+    assert lib.nsr_refine_forward(one, 1, one, one, 1, 8, 64, 64, one, one, 1 << 40, null) == -2     # bf16: not a mode
+    assert lib.nsr_refine_forward(one, 2, one, one, 1, 8, 64, 64, one, one, 16, null) == -4
+    assert lib.nsr_refine_forward(one, 0, one, one, 0, 8, 64, 64, one, one, 0, null) == 0

@@ -1,6 +1,7 @@
 """N3 refinement network of the HIP path (include/nsr_refine.h) against the fixture produced by the reference's own
-MaxPoolingModel and against the CPU oracle.  fp32 convolutions as im2col + fp32-MFMA GEMM with BatchNorm folded into
-the weights: the output (tanh, |y| < 1) is held to 2e-5 absolute (19 layers of re-associated fp32 sums)."""
+MaxPoolingModel and against the CPU oracle, in both arithmetic modes (fp32 MFMA with explicit im2col; split-fp16 MFMA
+with implicit im2col).  BatchNorm is folded into the weights; the output (tanh, |y| < 1) is held to 2e-5 absolute
+(19 layers of re-associated fp32 sums; the split-fp16 products add ~2^-21 relative)."""
 import os
 
 import numpy as np
@@ -14,12 +15,12 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
-@pytest.fixture(scope="module")
-def net():
+@pytest.fixture(scope="module", params=["f16x3", "fp32"])
+def net(request):
     if not torch.cuda.is_available():
         pytest.fail("GPU tests selected (-m gpu) but no GPU is visible")
     from nerf_sr_amd import refine as _r
-    return _r.MaxPoolingModel().load_state_dict(make_refine_state_dict(7)).eval()
+    return _r.MaxPoolingModel(precision=request.param).load_state_dict(make_refine_state_dict(7)).eval()
 
 
 def test_refine_vs_reference_fixture(net, golden_dir):
