@@ -112,7 +112,8 @@ def main_train(args):
     dev = torch.device("cuda", local)
     R = args.train_rays - args.train_rays % 4
     sd_c, sd_f = make_state_dict(99), make_state_dict(100)
-    t = nsr_train.Trainer(sd_c, sd_f, randomized=True, noise_std=1.0, downscale=DOWNSCALE, ray_chunk=R, device=dev)
+    t = nsr_train.Trainer(sd_c, sd_f, randomized=True, noise_std=1.0, downscale=DOWNSCALE, ray_chunk=R,
+                          precision=args.train_precision, device=dev)
     t.grad_scale = 1.0 / world
     frame = ops.subpixel_rays(cameras.spiral_pose(0.4 + 0.35 * rank), IMG_WH, cameras.llff_focal(IMG_WH[0]), DOWNSCALE,
                               True, device=dev)                       # (N_lr, 4, 8)
@@ -147,7 +148,8 @@ def main_train(args):
             "metric": "training rays/sec (64+128 samples, 2x SS; forward + backward + Adam)", "value": value,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (forward products split-fp16 x3, fp32-grade)" if args.train_precision == "f16x3" else "f32",
+            "data": "synthetic",
             "config": {"workload": f"training iteration of nerf_downX (scripts/train_llff_downX.sh shape): {R // 4} LR "
                                    f"pixels x 4 sub-rays = {R} rays per GPU per step, 64 coarse + 128 fine samples, "
                                    "randomized sampling, noise_std 1, s^2-mean MSE on coarse + fine, Adam lr 5e-4"
@@ -195,6 +197,8 @@ def main():
                     help="render (default): the headline metric; train: one optimize_parameters iteration per step "
                          "(SURVEY §8f N1: forward + backward + Adam, fp32) on a 2,048-ray batch per GPU")
     ap.add_argument("--train-rays", type=int, default=2048, help="rays per GPU per training step (multiple of 4)")
+    ap.add_argument("--train-precision", default="f16x3", choices=["f16x3", "fp32"],
+                    help="training step: forward products on the split-fp16 MFMA (default, fp32-grade) or everything on the fp32 MFMA")
     ap.add_argument("--config", type=int, default=2, choices=sorted(RENDER_CONFIGS),
                     help="BASELINE.json render configuration (default 2 = the one the metric is quoted on; 3-5: the other "
                          "frame geometries, one frame per GPU)")

@@ -10,7 +10,8 @@
  * (see NSR_N_STATE_TENSORS in nsr.h), handed over as HOST arrays of 24 DEVICE pointers, so a binding can
  * pass `p.data_ptr()` / `p.grad.data_ptr()` of the reference's own parameters.
  *
- * Arithmetic: fp32 throughout (v_mfma_f32_32x32x2_f32 for the contractions), like the reference.
+ * Arithmetic: fp32 storage and accumulation throughout, like the reference; contractions on v_mfma_f32_32x32x2_f32,
+ * optionally (precision = NSR_F16X3) the forward ones on split-fp16 v_mfma_f32_32x32x16_f16 with fp32-grade products.
  */
 #ifndef NSR_TRAIN_H_
 #define NSR_TRAIN_H_
@@ -35,6 +36,8 @@ size_t nsr_train_workspace_bytes(int64_t ray_chunk, int n_coarse, int n_importan
  * (R, Nc), noise_fine (R, Nc + Ni) standard normal, scaled by noise_std.  NULL selects the deterministic
  * branch of the corresponding stage (randomized = False / noise off).
  * g_coarse / g_fine: 24 gradient tensors each, OVERWRITTEN.
+ * precision: NSR_FP32 = every product on the fp32 MFMA; NSR_F16X3 = the forward products of both networks on the
+ * split-fp16 MFMA (exact to ~2^-21, the inference path's scheme), gradients on the fp32 MFMA.
  * ray_chunk: rays per pass (bounds the workspace; multiple of s2; 0 = R); gradients and losses of the passes
  * are accumulated, the result does not depend on the chunking beyond fp32 summation order.
  * outs: the 8 forward outputs in nsr_forward_rays order (entries may be NULL except the two comp_rgbs).
@@ -45,7 +48,7 @@ int nsr_train_loss_and_grads(const float* const* w_coarse, const float* const* w
                              const float* target_lr, int n_coarse, int n_importance, int white_bkgd, int lindisp,
                              const float* u_coarse, const float* u_fine, const float* noise_coarse,
                              const float* noise_fine, float noise_std, float lambda_coarse, float lambda_fine,
-                             int64_t ray_chunk, float* const* outs, float* lr_coarse, float* lr_fine, float* losses,
+                             int precision, int64_t ray_chunk, float* const* outs, float* lr_coarse, float* lr_fine, float* losses,
                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* torch.optim.Adam (no weight decay, no amsgrad) on the 24 tensors of one network, in place:

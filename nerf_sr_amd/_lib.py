@@ -46,7 +46,7 @@ SIGNATURES = {
     "nsr_train_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "nsr_train_loss_and_grads": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                          c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int,
-                                         c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_int64,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_int, c_int64,
                                          POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nsr_adam_step": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int,
                               c_float, c_float, c_float, c_float, c_void_p]),

@@ -1,10 +1,11 @@
 // Split-fp16 GEMM of the forward products (nsr_gemm.h: gemm_f16x3), v_mfma_f32_32x32x16_f16 x 3 per product.
 //
-// Workgroup = 4 waves on a 128 x 128 tile, each wave a 64 x 64 quadrant (2 x 2 accumulator blocks); K tiles of 32 =
+// Workgroup = 2 x WN waves, each wave a 64 x 64 quadrant (2 x 2 accumulator blocks): 4 waves on a 128 x 128 tile, or
+// 8 waves on 128 x 256 when N >= 256 (the A panel -- activations, HBM traffic -- is then read once); K tiles of 32 =
 // two MFMA k-steps.  LDS holds the tile as four fp16 arrays (A hi, A lo, B hi, B lo; row stride 40 halves = 80 B,
 // which makes the 16-byte fragment reads of eight consecutive rows hit eight different 16-byte bank groups);
-// single buffered with register prefetch (40 KB per workgroup, three workgroups per CU: the MFMAs of one hide the
-// staging, barriers and epilogue of the others).  A is fp32 in memory and is split into (hi, lo) on its way from
+// single buffered with register prefetch (40 / 60 KB per workgroup; two waves per SIMD: two 4-wave workgroups or
+// one 8-wave workgroup per CU, so the MFMAs of one wave hide the staging and barriers of the other).  A is fp32 in memory and is split into (hi, lo) on its way from
 // registers to LDS; B arrives pre-split.  Optional implicit im2col: the A rows are gathered from an NHWC activation
 // (a K tile of 32 channels never straddles a tap because cin % 32 == 0), so a 3 x 3 convolution needs no col matrix.
 #include "nsr_gemm.h"
@@ -17,8 +18,8 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kTM = 128, kTN = 128, kTK = 32, kLd = kTK + 8;   // LDS row stride in halves
-constexpr int kArr = kTM * kLd;                                // halves per staged array
+constexpr int kTM = 128, kTK = 32, kLd = kTK + 8;   // LDS row stride in halves
+constexpr int kArrA = kTM * kLd;                    // halves per staged A array
 
 __global__ void split_f16_kernel(const float* __restrict__ w, int64_t n, unsigned short* __restrict__ hi,
                                  unsigned short* __restrict__ lo) {
@@ -36,9 +37,11 @@ struct RowSrc {   // where the four A rows this thread stages come from (implici
   bool ok;
 };
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3)))
+template <int WN>
+__global__ void __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))   // <= 256 registers
 gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
-  __shared__ __attribute__((aligned(16))) _Float16 lds[4 * kArr];   // A hi | A lo | B hi | B lo  (40,960 B)
+  constexpr int NT = 128 * WN, kTN = 64 * WN, kArrB = kTN * kLd;
+  __shared__ __attribute__((aligned(16))) _Float16 lds[2 * kArrA + 2 * kArrB];   // A hi | A lo | B hi | B lo
   const GemmArgs& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1, li = lane & 31, h = lane >> 5;
@@ -59,14 +62,15 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
 #pragma unroll
   for (int bj = 0; bj < 2; ++bj) col_on[bj] = (n0 + 64 * wn + 32 * bj) < g.N;
 
-  // ---- staging assignment: A: 4 x (row = (tid >> 3) + 32 i, float4 column c4 = tid & 7); B: 2 x 2 x (row = (tid >> 2) + 64 i,
-  // 8-half chunk c8 = tid & 3)
+  // ---- staging assignment: A: NA x (row = (tid >> 3) + (NT / 8) i, float4 column c4 = tid & 7); B: 2 x 2 x
+  // (row = (tid >> 2) + (NT / 4) i, 8-half chunk c8 = tid & 3)
+  constexpr int NA = 1024 / NT, kARows = NT / 8, kBRows = NT / 4;
   const int c4 = tid & 7, ar0 = tid >> 3, c8 = tid & 3, br0 = tid >> 2;
-  const float* arow[4];
-  RowSrc rs[4];
+  const float* arow[NA];
+  RowSrc rs[NA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int64_t m = m0 + ar0 + 32 * i;
+  for (int i = 0; i < NA; ++i) {
+    int64_t m = m0 + ar0 + kARows * i;
     m = m < g.M ? m : g.M - 1;
     if (conv) {
       const int64_t per = (int64_t)a.conv.Ho * a.conv.Wo;
@@ -82,12 +86,12 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
   const unsigned short* bl_row[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    int n = n0 + br0 + 64 * i;
+    int n = n0 + br0 + kBRows * i;
     n = n < g.N ? n : g.N - 1;
     bh_row[i] = a.Bh + (int64_t)n * a.ldbh;
     bl_row[i] = a.Bl + (int64_t)n * a.ldbh;
   }
-  f32x4 sa[4];
+  f32x4 sa[NA];
   u32x4 sbh[2], sbl[2];
   auto load = [&](int t) {
     const int64_t k0 = (int64_t)t * kTK;
@@ -95,7 +99,7 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
       const int tap = (int)(k0 / a.conv.cin), cbase = (int)(k0 % a.conv.cin), ky = tap / 3, kx = tap % 3;
       const int Hin = a.conv.up ? 2 * a.conv.Hs : a.conv.Hs, Win = a.conv.up ? 2 * a.conv.Ws : a.conv.Ws;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NA; ++i) {
         const int iy = rs[i].oy * a.conv.stride + ky - 1, ix = rs[i].ox * a.conv.stride + kx - 1;
         sa[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
@@ -106,7 +110,7 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sa[i] = *reinterpret_cast<const f32x4*>(arow[i] + k0 + 4 * c4);
+      for (int i = 0; i < NA; ++i) sa[i] = *reinterpret_cast<const f32x4*>(arow[i] + k0 + 4 * c4);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -116,7 +120,7 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
   };
   auto store = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       h4 hi, lo;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -124,15 +128,15 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
         hi[e] = x;
         lo[e] = (_Float16)(sa[i][e] - (float)x);
       }
-      const int off = (ar0 + 32 * i) * kLd + 4 * c4;
+      const int off = (ar0 + kARows * i) * kLd + 4 * c4;
       *reinterpret_cast<h4*>(lds + off) = hi;
-      *reinterpret_cast<h4*>(lds + kArr + off) = lo;
+      *reinterpret_cast<h4*>(lds + kArrA + off) = lo;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int off = (br0 + 64 * i) * kLd + 8 * c8;
-      *reinterpret_cast<u32x4*>(lds + 2 * kArr + off) = sbh[i];
-      *reinterpret_cast<u32x4*>(lds + 3 * kArr + off) = sbl[i];
+      const int off = (br0 + kBRows * i) * kLd + 8 * c8;
+      *reinterpret_cast<u32x4*>(lds + 2 * kArrA + off) = sbh[i];
+      *reinterpret_cast<u32x4*>(lds + 2 * kArrA + kArrB + off) = sbl[i];
     }
   };
 
@@ -142,19 +146,19 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
     __syncthreads();
     if (t + 1 < n_tiles) load(t + 1);
     const _Float16* ap = lds + (64 * wm + li) * kLd + 8 * h;
-    const _Float16* bp = lds + 2 * kArr + (64 * wn + li) * kLd + 8 * h;
+    const _Float16* bp = lds + 2 * kArrA + (64 * wn + li) * kLd + 8 * h;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       h8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int bi = 0; bi < 2; ++bi) {
         ah[bi] = *reinterpret_cast<const h8*>(ap + 32 * bi * kLd + 16 * s);
-        al[bi] = *reinterpret_cast<const h8*>(ap + kArr + 32 * bi * kLd + 16 * s);
+        al[bi] = *reinterpret_cast<const h8*>(ap + kArrA + 32 * bi * kLd + 16 * s);
       }
 #pragma unroll
       for (int bj = 0; bj < 2; ++bj) {
         bh[bj] = *reinterpret_cast<const h8*>(bp + 32 * bj * kLd + 16 * s);
-        bl[bj] = *reinterpret_cast<const h8*>(bp + kArr + 32 * bj * kLd + 16 * s);
+        bl[bj] = *reinterpret_cast<const h8*>(bp + kArrB + 32 * bj * kLd + 16 * s);
       }
 #pragma unroll
       for (int bj = 0; bj < 2; ++bj)
@@ -191,9 +195,13 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
     return NSR_ERR_INVALID_ARG;
   if (a.conv.cin > 0 && ((a.conv.cin % kTK) != 0 || g.K != 9 * a.conv.cin)) return NSR_ERR_INVALID_ARG;
   if (g.M == 0) return NSR_OK;
-  const int n_col_tiles = (g.N + kTN - 1) / kTN;
+  const bool wide = g.N >= 256;
+  const int tn = wide ? 256 : 128;
+  const int n_col_tiles = (g.N + tn - 1) / tn;
   const int64_t row_tiles = (g.M + kTM - 1) / kTM;
-  hipLaunchKernelGGL(gemm_f16x3_kernel, dim3((unsigned)(row_tiles * n_col_tiles)), dim3(256), 0, st, a, n_col_tiles);
+  const dim3 grid((unsigned)(row_tiles * n_col_tiles));
+  if (wide) hipLaunchKernelGGL(gemm_f16x3_kernel<4>, grid, dim3(512), 0, st, a, n_col_tiles);
+  else hipLaunchKernelGGL(gemm_f16x3_kernel<2>, grid, dim3(256), 0, st, a, n_col_tiles);
   if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
   return NSR_OK;
 }

@@ -339,7 +339,13 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamPtrs a, float beta1, floa
 // ---------------------------------------------------------------------------------------------------------
 struct WeightPack {   // zero-padded copies of the weights whose shapes are not MFMA friendly (floats, one block)
   float *w1p, *w5p, *w9p, *wdirp, *wrgbp, *b9p, *brgbp;
+  unsigned short* split;   // NSR_F16X3: (hi, lo) fp16 halves of the twelve forward weight matrices (kSplit* below)
 };
+// forward weight matrices in split-fp16 form: index, rows, K
+constexpr int kSplitRows[12] = {256, 256, 256, 256, 256, 256, 256, 256, 256, 32, 128, 32};
+constexpr int kSplitK[12] = {64, 256, 256, 256, 320, 256, 256, 256, 256, 256, 288, 128};
+constexpr int64_t split_offset(int e) { return e == 0 ? 0 : split_offset(e - 1) + 2 * (int64_t)kSplitRows[e - 1] * kSplitK[e - 1]; }
+constexpr int64_t kSplitHalves = split_offset(11) + 2 * (int64_t)kSplitRows[11] * kSplitK[11];
 
 struct Work {   // per-pass buffers, sized for P_max = chunk * (Nc + Ni) sample points; all row-major
   float *x5, *h[9], *gs, *cc, *rgb, *sig;
@@ -377,6 +383,7 @@ int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base) {
     WeightPack& q = k.pack[n];
     q.w1p = take(256 * 64);   q.w5p = take(256 * 320);   q.w9p = take(288 * 256);   q.wdirp = take(128 * 288);
     q.wrgbp = take(32 * 128);   q.b9p = take(320);   q.brgbp = take(64);
+    q.split = reinterpret_cast<unsigned short*>(take((kSplitHalves + 1) / 2));
   }
   return off;
 }
@@ -396,7 +403,7 @@ int place(hipStream_t st, float* dst, int dst_ld, int r0, int c0, const float* s
   return NSR_OK;
 }
 
-int prepare_weights(hipStream_t st, const float* const* w, const WeightPack& q) {
+int prepare_weights(hipStream_t st, const float* const* w, const WeightPack& q, int precision) {
   // zero the whole pack first (padding rows / columns), it is one contiguous block starting at w1p
   if (hipMemsetAsync(q.w1p, 0, (size_t)((q.brgbp + align64(64)) - q.w1p) * sizeof(float), st) != hipSuccess)
     return NSR_ERR_LAUNCH;
@@ -411,16 +418,29 @@ int prepare_weights(hipStream_t st, const float* const* w, const WeightPack& q) 
   NSR_TRY(place(st, q.b9p, 320, 0, 0, w[kFinalB], 256, 1, 256, 0, 0));
   NSR_TRY(place(st, q.b9p, 320, 0, 256, w[kSigmaB], 1, 1, 1, 0, 0));
   NSR_TRY(place(st, q.brgbp, 64, 0, 0, w[kRgbB], 3, 1, 3, 0, 0));
+  if (precision == NSR_F16X3) {
+    const float* src[12] = {q.w1p, w[2], w[4], w[6], q.w5p, w[10], w[12], w[14], q.w9p, q.w9p + 256 * 256, q.wdirp, q.wrgbp};
+    for (int e = 0; e < 12; ++e) {
+      const int64_t n = (int64_t)kSplitRows[e] * kSplitK[e];
+      NSR_TRY(split_f16(src[e], n, q.split + split_offset(e), q.split + split_offset(e) + n, st));
+    }
+  }
   return NSR_OK;
 }
 
-// y (P, N) = act(x (P, K) w (N, K)^T + b)
+// y (P, N) = act(x (P, K) w (N, K)^T + b); `split` (entry e of the pack's split block) selects the split-fp16 product
 int lin_fwd(hipStream_t st, const float* x, int64_t ldx, int K, const float* w, int ldw, const float* b, int act,
-            float* y, int64_t ldy, int64_t P, int N, int n_valid) {
+            float* y, int64_t ldy, int64_t P, int N, int n_valid, const unsigned short* split = nullptr, int e = 0) {
   GemmArgs g{};
   g.A = x; g.lda = ldx; g.B = w; g.ldb = ldw; g.C = y; g.ldc = ldy; g.bias = b;
   g.M = P; g.N = N; g.K = K; g.n_valid = n_valid; g.act = act; g.splits = 1;
-  return gemm(g, st);
+  if (!split) return gemm(g, st);
+  GemmF16Args a{};
+  a.g = g;
+  a.Bh = split + split_offset(e);
+  a.Bl = a.Bh + (int64_t)kSplitRows[e] * kSplitK[e];
+  a.ldbh = kSplitK[e];
+  return gemm_f16x3(a, st);
 }
 // dx (P, N) = (dy (P, K) w[:, 0 : N]) * [mask > 0], w (K, ldw) in the nn.Linear layout (mask may be null);
 // bias_grad (N) (+)= column sums of dx = the bias gradient of the layer that produced the masked activation
@@ -475,22 +495,23 @@ int colsum(hipStream_t st, const float* src, int64_t ld, int64_t P, int col0, in
 }
 
 // M1 forward with everything kept for the backward pass
-int net_forward(hipStream_t st, const float* const* w, const WeightPack& q, const Work& k, int64_t P) {
-  NSR_TRY(lin_fwd(st, k.x5, kX5, kPe, q.w1p, 64, w[1], kActRelu, k.h[1], kW, P, kW, kW));
-  NSR_TRY(lin_fwd(st, k.h[1], kW, kW, w[2], 256, w[3], kActRelu, k.h[2], kW, P, kW, kW));
-  NSR_TRY(lin_fwd(st, k.h[2], kW, kW, w[4], 256, w[5], kActRelu, k.h[3], kW, P, kW, kW));
-  NSR_TRY(lin_fwd(st, k.h[3], kW, kW, w[6], 256, w[7], kActRelu, k.x5 + kPe, kX5, P, kW, kW));
-  NSR_TRY(lin_fwd(st, k.x5, kX5, kX5, q.w5p, 320, w[9], kActRelu, k.h[5], kW, P, kW, kW));
-  NSR_TRY(lin_fwd(st, k.h[5], kW, kW, w[10], 256, w[11], kActRelu, k.h[6], kW, P, kW, kW));
-  NSR_TRY(lin_fwd(st, k.h[6], kW, kW, w[12], 256, w[13], kActRelu, k.h[7], kW, P, kW, kW));
-  NSR_TRY(lin_fwd(st, k.h[7], kW, kW, w[14], 256, w[15], kActRelu, k.h[8], kW, P, kW, kW));
+int net_forward(hipStream_t st, const float* const* w, const WeightPack& q, const Work& k, int64_t P, int precision) {
+  const unsigned short* sp = precision == NSR_F16X3 ? q.split : nullptr;
+  NSR_TRY(lin_fwd(st, k.x5, kX5, kPe, q.w1p, 64, w[1], kActRelu, k.h[1], kW, P, kW, kW, sp, 0));
+  NSR_TRY(lin_fwd(st, k.h[1], kW, kW, w[2], 256, w[3], kActRelu, k.h[2], kW, P, kW, kW, sp, 1));
+  NSR_TRY(lin_fwd(st, k.h[2], kW, kW, w[4], 256, w[5], kActRelu, k.h[3], kW, P, kW, kW, sp, 2));
+  NSR_TRY(lin_fwd(st, k.h[3], kW, kW, w[6], 256, w[7], kActRelu, k.x5 + kPe, kX5, P, kW, kW, sp, 3));
+  NSR_TRY(lin_fwd(st, k.x5, kX5, kX5, q.w5p, 320, w[9], kActRelu, k.h[5], kW, P, kW, kW, sp, 4));
+  NSR_TRY(lin_fwd(st, k.h[5], kW, kW, w[10], 256, w[11], kActRelu, k.h[6], kW, P, kW, kW, sp, 5));
+  NSR_TRY(lin_fwd(st, k.h[6], kW, kW, w[12], 256, w[13], kActRelu, k.h[7], kW, P, kW, kW, sp, 6));
+  NSR_TRY(lin_fwd(st, k.h[7], kW, kW, w[14], 256, w[15], kActRelu, k.h[8], kW, P, kW, kW, sp, 7));
   // xyz_encoding_final stacked over the density head: [g | sigma] into columns 0..256 of the dir layer's input
   // (two launches: the 256 wide columns on the 8-wave tile, the density row on the narrow one, instead of a second
   // 256-wide column tile that would be 7/8 padding)
-  NSR_TRY(lin_fwd(st, k.h[8], kW, kW, q.w9p, 256, q.b9p, kActNone, k.gs, kGs, P, kW, kW));
-  NSR_TRY(lin_fwd(st, k.h[8], kW, kW, q.w9p + 256 * 256, 256, q.b9p + 256, kActNone, k.gs + kSigmaCol, kGs, P, 32, 1));
-  NSR_TRY(lin_fwd(st, k.gs, kGs, kGs, q.wdirp, 288, w[kDirB], kActRelu, k.cc, kDirOut, P, kDirOut, kDirOut));
-  NSR_TRY(lin_fwd(st, k.cc, kDirOut, kDirOut, q.wrgbp, 128, q.brgbp, kActSigmoid, k.rgb, 4, P, kRgbPad, 3));
+  NSR_TRY(lin_fwd(st, k.h[8], kW, kW, q.w9p, 256, q.b9p, kActNone, k.gs, kGs, P, kW, kW, sp, 8));
+  NSR_TRY(lin_fwd(st, k.h[8], kW, kW, q.w9p + 256 * 256, 256, q.b9p + 256, kActNone, k.gs + kSigmaCol, kGs, P, 32, 1, sp, 9));
+  NSR_TRY(lin_fwd(st, k.gs, kGs, kGs, q.wdirp, 288, w[kDirB], kActRelu, k.cc, kDirOut, P, kDirOut, kDirOut, sp, 10));
+  NSR_TRY(lin_fwd(st, k.cc, kDirOut, kDirOut, q.wrgbp, 128, q.brgbp, kActSigmoid, k.rgb, 4, P, kRgbPad, 3, sp, 11));
   return NSR_OK;
 }
 
@@ -573,12 +594,13 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
                                         const float* target_lr, int n_coarse, int n_importance, int white_bkgd,
                                         int lindisp, const float* u_coarse, const float* u_fine,
                                         const float* noise_coarse, const float* noise_fine, float noise_std,
-                                        float lambda_coarse, float lambda_fine, int64_t ray_chunk, float* const* outs,
+                                        float lambda_coarse, float lambda_fine, int precision, int64_t ray_chunk, float* const* outs,
                                         float* lr_coarse, float* lr_fine, float* losses, void* workspace,
                                         size_t workspace_bytes, void* stream) {
   if (!w_coarse || !w_fine || !g_coarse || !g_fine || !outs || R < 0 || s2 <= 0 || !nsr_ray_stride_ok(ray_stride))
     return NSR_ERR_INVALID_ARG;
   if (n_coarse < 2 || n_importance < 1 || n_coarse + n_importance > 256) return NSR_ERR_UNSUPPORTED;
+  if (precision != NSR_FP32 && precision != NSR_F16X3) return NSR_ERR_UNSUPPORTED;
   if (R % s2 != 0) return NSR_ERR_INVALID_ARG;
   if (ray_chunk <= 0 || ray_chunk > R) ray_chunk = R;
   if (ray_chunk % s2 != 0) return NSR_ERR_INVALID_ARG;
@@ -597,8 +619,8 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
   const int64_t n_lr_total = R / s2;
   const double mse_scale = 1.0 / (3.0 * (double)n_lr_total);
 
-  NSR_TRY(prepare_weights(st, w_coarse, k.pack[0]));
-  NSR_TRY(prepare_weights(st, w_fine, k.pack[1]));
+  NSR_TRY(prepare_weights(st, w_coarse, k.pack[0], precision));
+  NSR_TRY(prepare_weights(st, w_fine, k.pack[1], precision));
   if (hipMemsetAsync(k.carry, 0, 4 * sizeof(double), st) != hipSuccess) return NSR_ERR_LAUNCH;
 
   for (int64_t r0 = 0; r0 < R; r0 += ray_chunk) {
@@ -623,7 +645,7 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
       hipLaunchKernelGGL(encode_train_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, rays_c, ray_stride, z,
                          P, N, k.x5, k.gs);
       NSR_CHECK_LAUNCH();
-      NSR_TRY(net_forward(st, w, k.pack[net], k, P));
+      NSR_TRY(net_forward(st, w, k.pack[net], k, P, precision));
       const float* noise = net ? noise_fine : noise_coarse;
       hipLaunchKernelGGL(sigma_noise_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, k.gs,
                          (noisy && noise) ? noise + r0 * N : nullptr, noise_std, P, k.sig);

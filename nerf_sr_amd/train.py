@@ -73,7 +73,12 @@ class Trainer:
     def __init__(self, sd_coarse, sd_fine, N_coarse: int = 64, N_importance: int = 64, white_bkgd: bool = False,
                  lindisp: bool = False, downscale: int = 2, randomized: bool = True, noise_std: float = 0.0,
                  lr: float = 5e-4, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
-                 lambda_coarse_mse: float = 1.0, lambda_fine_mse: float = 1.0, ray_chunk: int = 4096, device="cuda"):
+                 lambda_coarse_mse: float = 1.0, lambda_fine_mse: float = 1.0, ray_chunk: int = 4096,
+                 precision: str = "f16x3", device="cuda"):
+        if precision not in ("fp32", "f16x3"):
+            raise ValueError("precision must be 'fp32' (all products on the fp32 MFMA) or 'f16x3' (forward products on "
+                             "the split-fp16 MFMA, fp32-grade; gradients on the fp32 MFMA)")
+        self.precision, self._prec = precision, _lib.PRECISIONS[precision]
         self.device = torch.device(device)
         self.params = [_to_dev(sd_coarse, self.device), _to_dev(sd_fine, self.device)]
         flat = [_flat_like(p) for p in self.params]
@@ -145,7 +150,7 @@ class Trainer:
             wc, wf, gc, gf, _p(rays), stride, R, self.s2, _p(self.data_rgbs), nc, self.N_importance,
             int(self.white_bkgd), int(self.lindisp), _p(draws.get("u_coarse")), _p(draws.get("u_fine")),
             _p(draws.get("noise_coarse")), _p(draws.get("noise_fine")), self.noise_std,
-            self.lambda_coarse * self.grad_scale, self.lambda_fine * self.grad_scale, chunk, outs, _p(lr_c), _p(lr_f), _p(self.losses), _p(self._ws), self._ws.numel(),
+            self.lambda_coarse * self.grad_scale, self.lambda_fine * self.grad_scale, self._prec, chunk, outs, _p(lr_c), _p(lr_f), _p(self.losses), _p(self._ws), self._ws.numel(),
             _stream()), "nsr_train_loss_and_grads")
         o["lr_coarse"], o["lr_fine"] = lr_c, lr_f
         self.out = o

@@ -94,7 +94,7 @@ def test_next_row_entry_points_validate_before_any_launch(lib):
     p24 = (c_void_p * 24)(*[one] * 24)
     outs = (c_void_p * 8)(*[one] * 8)
     args = lambda R, s2, nc, ni, chunk, wsb: (p24, p24, p24, p24, one, 8, R, s2, one, nc, ni, 0, 0, null, null, null, null,
-                                               0.0, 1.0, 1.0, chunk, outs, one, one, one, one, wsb, null)
+                                               0.0, 1.0, 1.0, 0, chunk, outs, one, one, one, one, wsb, null)
     assert lib.nsr_train_loss_and_grads(*args(64, 4, 64, 64, 0, 16)) == -4           # workspace too small
     assert lib.nsr_train_loss_and_grads(*args(66, 4, 64, 64, 0, ws)) == -1           # R not a multiple of s2
     assert lib.nsr_train_loss_and_grads(*args(64, 4, 64, 300, 0, ws)) == -2          # sample count outside the path

@@ -8,7 +8,7 @@ xyz_encoding_1.weight of the `blender_rand` fixture), and one flipped unit among
 moves the gradient of its layer and of every layer below it by ~1/sqrt(points x width) ~ 5e-4 of its norm.  So:
 losses and forward outputs are held to 1e-6 / the inference tolerances, each gradient tensor to 2e-3 of its norm
 against the fp64 oracle (flip allowance at fixture size), the layers above the trunk -- which no flip reaches
-unless it happens in them -- and the whole-network gradient to 5e-4 / 1e-3.
+unless it happens in them -- to 5e-4, the whole-network gradient to 2e-3.
 """
 import os
 
@@ -66,14 +66,22 @@ def test_training_gemm(tr):
     assert tr.linear(torch.zeros(0, 64).cuda(), torch.zeros(32, 64).cuda()).shape == (0, 32)
 
 
-@pytest.fixture(scope="module", params=CASES)
+_ORACLE64 = {}
+
+
+@pytest.fixture(scope="module", params=[(c, p) for c in CASES for p in ("f16x3", "fp32")], ids=lambda cp: f"{cp[0]}-{cp[1]}")
 def case(request, golden_dir, tr):
-    g = np.load(os.path.join(golden_dir, f"train_{request.param}.npz"))
-    t, sd_c, sd_f = _trainer(tr, g)
+    """Both arithmetic modes of the step: forward products on the split-fp16 MFMA (default) or everything on the fp32
+    MFMA; the same tolerances hold (split-fp16 products are exact to ~2^-21)."""
+    name, prec = request.param
+    g = np.load(os.path.join(golden_dir, f"train_{name}.npz"))
+    t, sd_c, sd_f = _trainer(tr, g, precision=prec)
     t.loss_and_grads(_draws(g))
-    res64, gc64, gf64 = to.loss_and_grads(sd_c, sd_f, g["rays"], g["target_lr"], int(g["s2"]), 64, 64,
-                                          bool(g["white_bkgd"]), float(g["lambda_coarse"]), float(g["lambda_fine"]),
-                                          dtype=torch.float64, **train_draws(g))
+    if name not in _ORACLE64:
+        _ORACLE64[name] = to.loss_and_grads(sd_c, sd_f, g["rays"], g["target_lr"], int(g["s2"]), 64, 64,
+                                            bool(g["white_bkgd"]), float(g["lambda_coarse"]), float(g["lambda_fine"]),
+                                            dtype=torch.float64, **train_draws(g))
+    res64, gc64, gf64 = _ORACLE64[name]
     return g, t, res64, (gc64, gf64)
 
 
@@ -108,7 +116,7 @@ def test_gradients_vs_oracle_and_reference(case):
             sub = got.reshape(-1).numpy()[sample_idx(got.numel())]
             want_sub = g[f"grad_{name}.{k}"].astype(np.float64)
             assert np.linalg.norm(sub - want_sub) <= 4e-3 * np.linalg.norm(want_sub) + 1e-9, (name, k)
-        assert (num / den) ** 0.5 < 1e-3, (name, (num / den) ** 0.5)
+        assert (num / den) ** 0.5 < 2e-3, (name, (num / den) ** 0.5)
 
 
 def test_adam_step_vs_reference(case, tr):
