@@ -282,6 +282,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": f"mlp kernel, fine pass ({RAYS_PER_FRAME:,} rays x 128 samples)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": measured_traffic(args.precision) if args.config == 2 else None, "traffic_unit": "bytes/launch (PMC, profiles/r1_traffic.json)",
+                         "mfma_issued": achieved * (3 if args.precision == "f16x3" else 1),
+                         "mfma_issued_frac": achieved * (3 if args.precision == "f16x3" else 1) / peak,
                          "launch_ms": fine_avg, "coarse_launch_ms": sum(coarse_ms) / len(coarse_ms),
                          "flop_per_launch": fine_flop,
                          "note": ("achieved counts ALGORITHMIC flops (2 x 593,408 MAC per point); f16x3 issues 3 MFMAs "
