@@ -38,6 +38,17 @@ size_t nsr_refine_workspace_bytes(int B, int R, int H, int W);
 int nsr_refine_forward(const void* packed, int precision, const float* x_synth, const float* x_candi, int B, int R, int H,
                        int W, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- patch tiler / stitcher around the network (the 'test' path of data/llff_refine_dataset.py:303-340 and
+ * models/refine_model.py:205-216): an SR image is cut into `patch` x `patch` tiles on a grid (x outer, y inner, starts
+ * clamped to size - patch); each tile gets `n_ref` reference patches whose top-left corners are the first `n_ref`
+ * in-image warp targets locs[y][x] (nsr_depth_warp / `{i}_locs.npz`) of the tile's pixels scanned x outer / y inner,
+ * clamped likewise; missing ones are the SR tile itself (ref start -1); predictions are pasted back in tile order.
+ * n = ceil(W / patch) * ceil(H / patch) tiles.  All pointers DEVICE. */
+int nsr_refine_tile(const double* locs, int H, int W, int patch, int n_ref, int* starts, int* ref_starts, void* stream);
+int nsr_refine_gather(const float* sr_img, const float* ref_img, int H, int W, int patch, int n_ref, const int* starts,
+                      const int* ref_starts, int n, float* sr_patch, float* ref_patches, void* stream);
+int nsr_refine_stitch(const float* patches, const int* starts, int n, int patch, int H, int W, float* image, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

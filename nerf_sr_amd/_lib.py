@@ -59,6 +59,10 @@ SIGNATURES = {
     "nsr_refine_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "nsr_refine_forward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                    c_size_t, c_void_p]),
+    "nsr_refine_tile": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "nsr_refine_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                  c_void_p, c_void_p]),
+    "nsr_refine_stitch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nsr_linear": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64,
                            c_int64, c_int, c_int, c_void_p]),
 }

@@ -320,3 +320,127 @@ extern "C" int nsr_refine_forward(const void* packed_v, int prec, const float* x
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// patch tiler / gather / stitcher (data/llff_refine_dataset.py:303-340, models/refine_model.py:205-216)
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+// one workgroup per tile: ordered compaction of the in-image warp targets, x outer / y inner, first n_ref win
+__global__ void __launch_bounds__(256) tile_refs_kernel(const double* __restrict__ locs, int H, int W, int patch, int n_ref,
+                                                        int tiles_y, int* __restrict__ starts, int* __restrict__ ref_starts) {
+  __shared__ int wave_cnt[4];
+  __shared__ int running;
+  const int t = blockIdx.x, ti = t / tiles_y, tj = t % tiles_y;
+  const int x0 = min(W - patch, ti * patch), y0 = min(H - patch, tj * patch);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {
+    starts[2 * t] = x0;
+    starts[2 * t + 1] = y0;
+    running = 0;
+  }
+  for (int i = tid; i < 2 * n_ref; i += 256) ref_starts[(int64_t)t * 2 * n_ref + i] = -1;
+  __syncthreads();
+  const int total = patch * patch;
+  for (int base = 0; base < total; base += 256) {
+    const int s = base + tid;
+    bool ok = false;
+    int rx = 0, ry = 0;
+    if (s < total) {
+      const int m = x0 + s / patch, n = y0 + s % patch;
+      const double lx = locs[((int64_t)n * W + m) * 3], ly = locs[((int64_t)n * W + m) * 3 + 1];
+      ok = lx >= 0.0 && lx < (double)W && ly >= 0.0 && ly < (double)H;
+      rx = min(W - patch, (int)lx);
+      ry = min(H - patch, (int)ly);
+    }
+    const unsigned long long mask = __ballot(ok);
+    if (lane == 0) wave_cnt[wave] = __popcll(mask);
+    __syncthreads();
+    int before = running;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+    before += __popcll(mask & ((1ull << lane) - 1ull));
+    if (ok && before < n_ref) {
+      ref_starts[((int64_t)t * n_ref + before) * 2] = rx;
+      ref_starts[((int64_t)t * n_ref + before) * 2 + 1] = ry;
+    }
+    __syncthreads();
+    if (tid == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+    if (running >= n_ref) break;   // uniform: every thread reads the same shared value
+  }
+}
+
+// idx over n * (1 + n_ref) * 3 * patch * patch: slot 0 = the SR tile, slots 1.. = its reference patches
+__global__ void __launch_bounds__(256) gather_patches_kernel(const float* __restrict__ sr_img, const float* __restrict__ ref_img,
+                                                             int H, int W, int patch, int n_ref, const int* __restrict__ starts,
+                                                             const int* __restrict__ ref_starts, int64_t total,
+                                                             float* __restrict__ sr_patch, float* __restrict__ ref_patches) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int pp = patch * patch;
+  const int px = (int)(idx % pp), c = (int)((idx / pp) % 3), slot = (int)((idx / (3 * pp)) % (1 + n_ref));
+  const int t = (int)(idx / ((int64_t)3 * pp * (1 + n_ref)));
+  const int dy = px / patch, dx = px % patch;
+  int x = starts[2 * t], y = starts[2 * t + 1];
+  const float* src = sr_img;
+  if (slot > 0) {
+    const int rx = ref_starts[((int64_t)t * n_ref + slot - 1) * 2], ry = ref_starts[((int64_t)t * n_ref + slot - 1) * 2 + 1];
+    if (rx >= 0) { x = rx; y = ry; src = ref_img; }
+  }
+  const float v = src[((int64_t)c * H + y + dy) * W + x + dx];
+  if (slot == 0) sr_patch[((int64_t)t * 3 + c) * pp + px] = v;
+  else ref_patches[(((int64_t)t * n_ref + slot - 1) * 3 + c) * pp + px] = v;
+}
+
+// image[c][y][x] = the LAST tile (in order) that covers (x, y), 0 if none
+__global__ void __launch_bounds__(256) stitch_kernel(const float* __restrict__ patches, const int* __restrict__ starts, int n,
+                                                     int patch, int H, int W, float* __restrict__ image) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)3 * H * W) return;
+  const int x = (int)(idx % W), y = (int)((idx / W) % H), c = (int)(idx / ((int64_t)W * H));
+  float v = 0.0f;
+  for (int t = n - 1; t >= 0; --t) {
+    const int x0 = starts[2 * t], y0 = starts[2 * t + 1];
+    if (x >= x0 && x < x0 + patch && y >= y0 && y < y0 + patch) {
+      v = patches[(((int64_t)t * 3 + c) * patch + (y - y0)) * patch + (x - x0)];
+      break;
+    }
+  }
+  image[idx] = v;
+}
+
+}  // namespace
+
+extern "C" int nsr_refine_tile(const double* locs, int H, int W, int patch, int n_ref, int* starts, int* ref_starts,
+                               void* stream) {
+  if (H <= 0 || W <= 0 || patch <= 0 || patch > H || patch > W || n_ref <= 0 || !locs || !starts || !ref_starts)
+    return NSR_ERR_INVALID_ARG;
+  const int tiles_x = (W + patch - 1) / patch, tiles_y = (H + patch - 1) / patch;
+  hipLaunchKernelGGL(tile_refs_kernel, dim3(tiles_x * tiles_y), dim3(256), 0, nsr_stream(stream), locs, H, W, patch, n_ref,
+                     tiles_y, starts, ref_starts);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
+extern "C" int nsr_refine_gather(const float* sr_img, const float* ref_img, int H, int W, int patch, int n_ref,
+                                 const int* starts, const int* ref_starts, int n, float* sr_patch, float* ref_patches,
+                                 void* stream) {
+  if (H <= 0 || W <= 0 || patch <= 0 || n_ref <= 0 || n < 0) return NSR_ERR_INVALID_ARG;
+  if (n == 0) return NSR_OK;
+  if (!sr_img || !ref_img || !starts || !ref_starts || !sr_patch || !ref_patches) return NSR_ERR_INVALID_ARG;
+  const int64_t total = (int64_t)n * (1 + n_ref) * 3 * patch * patch;
+  hipLaunchKernelGGL(gather_patches_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nsr_stream(stream), sr_img,
+                     ref_img, H, W, patch, n_ref, starts, ref_starts, total, sr_patch, ref_patches);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
+extern "C" int nsr_refine_stitch(const float* patches, const int* starts, int n, int patch, int H, int W, float* image,
+                                 void* stream) {
+  if (H <= 0 || W <= 0 || patch <= 0 || n < 0 || !image || (n > 0 && (!patches || !starts))) return NSR_ERR_INVALID_ARG;
+  const int64_t total = (int64_t)3 * H * W;
+  hipLaunchKernelGGL(stitch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nsr_stream(stream), patches, starts, n,
+                     patch, H, W, image);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}

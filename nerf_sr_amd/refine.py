@@ -123,3 +123,52 @@ class MaxPoolingModel:
         return out
 
     __call__ = forward
+
+
+# ------------------------------------------------------------------------------------------------ tiler / stitcher
+def tile_refs(locs: torch.Tensor, patch_len: int = 64, num_ref_patches: int = 8):
+    """locs (H, W, 3) float64 on the GPU (``nerf_sr_amd.warp.depth_warp`` / ``{i}_locs.npz``) -> ``starts`` (n, 2)
+    int32 [x, y] of the SR tiles and ``ref_starts`` (n, num_ref_patches, 2) int32 of their reference patches (-1: use
+    the SR tile), as ``LLFFRefineDataset.__getitem__`` picks them (data/llff_refine_dataset.py:303-329)."""
+    if not locs.is_cuda or locs.dtype != torch.float64 or locs.ndim != 3 or locs.shape[2] != 3:
+        raise ValueError("locs must be a (H, W, 3) float64 tensor on the GPU")
+    locs = locs.contiguous()
+    H, W = locs.shape[:2]
+    n = -(-W // patch_len) * -(-H // patch_len)
+    starts = torch.empty(n, 2, dtype=torch.int32, device=locs.device)
+    refs = torch.empty(n, num_ref_patches, 2, dtype=torch.int32, device=locs.device)
+    _lib.check(_lib.load().nsr_refine_tile(_p(locs), H, W, patch_len, num_ref_patches, _p(starts), _p(refs), _stream()),
+               "nsr_refine_tile")
+    return starts, refs
+
+
+def gather_patches(sr_img: torch.Tensor, ref_img: torch.Tensor, starts: torch.Tensor, ref_starts: torch.Tensor, patch_len: int = 64):
+    """sr_img, ref_img (3, H, W) -> sr_patch (n, 3, p, p), ref_patches (n, R, 3, p, p) (the dataset's sample)."""
+    sr_img, ref_img = _f32(sr_img, "sr_img"), _f32(ref_img, "ref_img")
+    _, H, W = sr_img.shape
+    n, R = ref_starts.shape[:2]
+    sr = torch.empty(n, 3, patch_len, patch_len, dtype=torch.float32, device=sr_img.device)
+    ref = torch.empty(n, R, 3, patch_len, patch_len, dtype=torch.float32, device=sr_img.device)
+    _lib.check(_lib.load().nsr_refine_gather(_p(sr_img), _p(ref_img), H, W, patch_len, R, _p(starts.contiguous()),
+                                             _p(ref_starts.contiguous()), n, _p(sr), _p(ref), _stream()), "nsr_refine_gather")
+    return sr, ref
+
+
+def stitch_patches(patches: torch.Tensor, starts: torch.Tensor, img_wh) -> torch.Tensor:
+    """Paste predictions back in tile order, later tiles overwrite earlier ones (models/refine_model.py:211-214)."""
+    patches = _f32(patches, "patches")
+    W, H = int(img_wh[0]), int(img_wh[1])
+    img = torch.empty(3, H, W, dtype=torch.float32, device=patches.device)
+    _lib.check(_lib.load().nsr_refine_stitch(_p(patches), _p(starts.contiguous()), patches.shape[0], patches.shape[-1], H, W,
+                                             _p(img), _stream()), "nsr_refine_stitch")
+    return img
+
+
+def refine_image(net: MaxPoolingModel, sr_img: torch.Tensor, ref_img: torch.Tensor, locs: torch.Tensor, patch_len: int = 64,
+                 num_ref_patches: int = 8, batch: int = 32) -> torch.Tensor:
+    """The refinement pass over one synthesised view (config #5 tail): tile -> network on batches of tiles -> stitch.
+    Images are (3, H, W) in [-1, 1] (the dataset's Normalize(0.5, 0.5)); returns the refined (3, H, W) image."""
+    starts, refs = tile_refs(locs, patch_len, num_ref_patches)
+    sr, ref = gather_patches(sr_img, ref_img, starts, refs, patch_len)
+    pred = torch.cat([net(sr[i:i + batch], ref[i:i + batch]) for i in range(0, sr.shape[0], batch)], 0)
+    return stitch_patches(pred, starts, (sr_img.shape[2], sr_img.shape[1]))

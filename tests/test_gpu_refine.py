@@ -45,3 +45,46 @@ def test_refine_patch_64_vs_oracle(net):
     with pytest.raises(ValueError):
         net(x[:, :, :60].cuda(), c[:, :, :, :60].cuda())
     assert net(x[:0].cuda(), c[:0].cuda()).shape == (0, 3, 64, 64)
+
+
+def test_tiler_gather_stitch_vs_reference_fixture(golden_dir):
+    """Patch tiler around the network: bit-exact with what the reference's own dataset class and stitching loop
+    produced (tests/golden/refine_tiler.npz), and with the oracle on a full-size random case."""
+    from nerf_sr_amd import refine as r
+    from oracle import refine_tiler_oracle as rt
+    g = np.load(os.path.join(golden_dir, "refine_tiler.npz"))
+    W, H, P, NR = int(g["W"]), int(g["H"]), int(g["patch_len"]), int(g["num_ref"])
+    ref_img = torch.from_numpy(g["ref_img"]).cuda()
+    for img in range(2):
+        starts, refs = r.tile_refs(torch.from_numpy(g[f"locs_{img}"]).cuda(), P, NR)
+        assert np.array_equal(starts.cpu().numpy(), g[f"start_locs_{img}"].astype(np.int32))
+        sr, ref = r.gather_patches(torch.from_numpy(g["sr_imgs"][img]).cuda(), ref_img, starts, refs, P)
+        assert np.array_equal(sr.cpu().numpy(), g[f"sr_patch_{img}"])
+        assert np.array_equal(ref.cpu().numpy(), g[f"ref_patches_{img}"])
+        out = r.stitch_patches(torch.from_numpy(g[f"pred_{img}"]).cuda(), starts, (W, H))
+        assert np.array_equal(out.cpu().numpy(), g[f"stitched_{img}"])
+    # the reference's sizes: 504 x 378, 64-pixel tiles, 8 references
+    rng = np.random.default_rng(2)
+    W, H = 504, 378
+    locs = np.stack([rng.integers(-200, W + 200, (H, W)), rng.integers(-200, H + 200, (H, W)), -np.ones((H, W))], -1).astype(np.float64)
+    locs[:100, :130] = -1.0
+    starts, refs = r.tile_refs(torch.from_numpy(locs).cuda(), 64, 8)
+    want_s, want_r = rt.tile(locs, W, H, 64, 8)
+    assert np.array_equal(starts.cpu().numpy(), want_s) and np.array_equal(refs.cpu().numpy(), want_r)
+
+
+def test_refine_image_end_to_end(net):
+    """tile -> network -> stitch on a small frame equals the same steps done through the oracle's tiler."""
+    from nerf_sr_amd import refine as r
+    from oracle import refine_tiler_oracle as rt
+    rng = np.random.default_rng(4)
+    W, H, P, NR = 80, 48, 32, 4
+    sr = (rng.random((3, H, W)) * 2 - 1).astype(np.float32)
+    ref = (rng.random((3, H, W)) * 2 - 1).astype(np.float32)
+    locs = np.stack([rng.integers(-20, W + 20, (H, W)), rng.integers(-20, H + 20, (H, W)), -np.ones((H, W))], -1).astype(np.float64)
+    got = r.refine_image(net, torch.from_numpy(sr).cuda(), torch.from_numpy(ref).cuda(), torch.from_numpy(locs).cuda(), P, NR, batch=4)
+    starts, refs = rt.tile(locs, W, H, P, NR)
+    srp, refp = rt.gather(sr, ref, starts, refs, P)
+    pred = ro.forward(make_refine_state_dict(7), srp, refp, dtype=torch.float64).numpy()
+    want = rt.stitch(pred, starts, P, W, H)
+    assert float(np.abs(got.cpu().numpy() - want).max()) <= TOL
