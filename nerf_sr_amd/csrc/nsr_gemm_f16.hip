@@ -96,18 +96,25 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
   auto load = [&](int t) {
     const int64_t k0 = (int64_t)t * kTK;
     if (conv) {
-      const int tap = (int)(k0 / a.conv.cin), cbase = (int)(k0 % a.conv.cin), ky = tap / 3, kx = tap % 3;
-      const int Hin = a.conv.up ? 2 * a.conv.Hs : a.conv.Hs, Win = a.conv.up ? 2 * a.conv.Ws : a.conv.Ws;
+      // the gather address of a row changes only when the K tile enters the next tap (every cin / 32 tiles):
+      // arow[i] then points at channel 0 of the source pixel under that tap, or is null inside the zero padding
+      const int cbase = (int)(k0 % a.conv.cin);
+      if (cbase == 0) {
+        const int tap = (int)(k0 / a.conv.cin), ky = tap / 3, kx = tap % 3;
+        const int Hin = a.conv.up ? 2 * a.conv.Hs : a.conv.Hs, Win = a.conv.up ? 2 * a.conv.Ws : a.conv.Ws;
 #pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const int iy = rs[i].oy * a.conv.stride + ky - 1, ix = rs[i].ox * a.conv.stride + kx - 1;
-        sa[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
-          const int sy = a.conv.up ? iy >> 1 : iy, sx = a.conv.up ? ix >> 1 : ix;
-          sa[i] = *reinterpret_cast<const f32x4*>(g.A + (((int64_t)rs[i].img * a.conv.Hs + sy) * a.conv.Ws + sx) * g.lda +
-                                                  cbase + 4 * c4);
+        for (int i = 0; i < NA; ++i) {
+          const int iy = rs[i].oy * a.conv.stride + ky - 1, ix = rs[i].ox * a.conv.stride + kx - 1;
+          arow[i] = nullptr;
+          if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
+            const int sy = a.conv.up ? iy >> 1 : iy, sx = a.conv.up ? ix >> 1 : ix;
+            arow[i] = g.A + (((int64_t)rs[i].img * a.conv.Hs + sy) * a.conv.Ws + sx) * g.lda + 4 * c4;
+          }
         }
       }
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        sa[i] = arow[i] ? *reinterpret_cast<const f32x4*>(arow[i] + cbase) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     } else {
 #pragma unroll
       for (int i = 0; i < NA; ++i) sa[i] = *reinterpret_cast<const f32x4*>(arow[i] + k0 + 4 * c4);
