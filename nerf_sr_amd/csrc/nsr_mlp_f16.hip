@@ -17,6 +17,8 @@
 using namespace nsr;
 using namespace nsr::hx;
 
+// NSR_ABL_*: ablation switches for the measurement ladder in profiles/r1_f16x3_pmc.txt (scripts/ablate.sh builds
+// variant libraries with them); never defined in the product build.
 #ifdef NSR_ABL_NO_BARRIER
 #define NSR_SYNC() ((void)0)
 #else
