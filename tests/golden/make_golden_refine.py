@@ -30,6 +30,9 @@ def main():
     net.eval()
     gen = torch.Generator().manual_seed(5)
     out = {"seed": 7}
+    ref_sd = net.state_dict()
+    out["float_keys"] = np.array([k for k, v in ref_sd.items() if v.dtype.is_floating_point])
+    out["float_shapes"] = np.array([str(tuple(v.shape)) for v in ref_sd.values() if v.dtype.is_floating_point])
     for tag, (B, R, H, W) in {"a": (2, 3, 16, 24), "b": (1, 8, 32, 32)}.items():
         x = torch.rand(B, 3, H, W, generator=gen) * 2 - 1
         c = torch.rand(B, R, 3, H, W, generator=gen) * 2 - 1

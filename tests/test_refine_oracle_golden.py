@@ -17,3 +17,11 @@ def test_refine_forward_matches_reference(golden_dir):
         # same ATen convolutions on the same build
         np.testing.assert_allclose(y.numpy(), g[f"y_{tag}"], rtol=0, atol=1e-6)
         np.testing.assert_allclose(fs[3].numpy(), g[f"f3_{tag}"], rtol=0, atol=1e-5)
+
+
+def test_state_dict_layout_matches_reference(golden_dir):
+    """REFINE_SPEC = the float tensors of the reference's MaxPoolingModel.state_dict(), same order and shapes (this is
+    the order nsr_refine_pack_weights expects)."""
+    g = np.load(os.path.join(golden_dir, "refine.npz"))
+    assert list(REFINE_SPEC) == list(g["float_keys"])
+    assert [str(tuple(s)) for s in REFINE_SPEC.values()] == list(g["float_shapes"])
