@@ -287,7 +287,9 @@ def main():
                          "launch_ms": fine_avg, "coarse_launch_ms": sum(coarse_ms) / len(coarse_ms),
                          "flop_per_launch": fine_flop,
                          "note": ("achieved counts ALGORITHMIC flops (2 x 593,408 MAC per point); f16x3 issues 3 MFMAs "
-                                  "per product, so its matrix pipe is busy for 3x this figure"
+                                  "per product, so its matrix pipe is busy for 3x this figure (mfma_issued); ~1.4 PFLOP/s "
+                                  "issued is the power-limited fp16-MFMA rate of this part: the one-MFMA f16/bf16 kernels "
+                                  "issue the same rate at 82 % pipe utilisation and 1.68 GHz (DESIGN.md section 12)"
                                   if args.precision == "f16x3" else
                                   "algorithmic flops, exact fp32 MFMA" if args.precision == "fp32" else
                                   "algorithmic flops, one 16-bit MFMA per product; fast path outside the 1e-4 "
