@@ -279,14 +279,16 @@ __global__ void __launch_bounds__(256) tilesum_partial_kernel(const float* __res
   __syncthreads();
   if (phase == 0 && c < cols) partial[(int64_t)blockIdx.y * ld + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
-// dst[c] (+)= sum_j partial[j * ld + c]
+// dst[c] (+)= sum_j partial[j * ld + c]: one wavefront per column (4 columns per block), so the n partials of a
+// column are loaded in parallel and combined by shuffles in a fixed order
 __global__ void __launch_bounds__(256) sum_finish_kernel(const double* __restrict__ partial, int n, int ld, int cols,
                                                          float* __restrict__ dst, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+  const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= cols) return;   // wave-uniform
   double s = 0.0;
-  for (int j = 0; j < n; ++j) s += partial[(int64_t)j * ld + c];
-  dst[c] = (accumulate ? dst[c] : 0.0f) + (float)s;
+  for (int j = lane; j < n; j += 64) s += partial[(int64_t)j * ld + c];
+  s = wave_sum_d(s);
+  if (lane == 0) dst[c] = (accumulate ? dst[c] : 0.0f) + (float)s;
 }
 
 // second pass of the split-K weight gradient + scatter into the nn.Linear shape:
@@ -457,7 +459,7 @@ int lin_dgrad(hipStream_t st, const Work& k, const float* dy, int64_t lddy, int 
   hipLaunchKernelGGL(tilesum_partial_kernel, dim3((N + 63) / 64, slices), dim3(256), 0, st, k.col_tiles, (P + 127) / 128, N,
                      N, part);
   NSR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, st, part, slices, N, N, bias_grad, acc);
+  hipLaunchKernelGGL(sum_finish_kernel, dim3((N + 3) / 4), dim3(256), 0, st, part, slices, N, N, bias_grad, acc);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
@@ -489,7 +491,7 @@ int colsum(hipStream_t st, const float* src, int64_t ld, int64_t P, int col0, in
   double* part = reinterpret_cast<double*>(scratch);
   hipLaunchKernelGGL(colsum_few_kernel, dim3(kSumBlocks), dim3(256), 0, st, src, ld, P, col0, cols, part);
   NSR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, st, part, kSumBlocks, 4, cols, dst, accumulate);
+  hipLaunchKernelGGL(sum_finish_kernel, dim3((cols + 3) / 4), dim3(256), 0, st, part, kSumBlocks, 4, cols, dst, accumulate);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
