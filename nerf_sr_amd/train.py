@@ -180,5 +180,24 @@ class Trainer:
         self.optimizer_step()
         return self.losses
 
+    def update_learning_rate(self, epoch: int, lr_policy: str = "exp", n_epochs: int = 20, n_epochs_decay: int = 10,
+                             lr_final: float = 5e-6, lr_decay_epochs: int = 10, lr_decay_gamma: float = 0.1,
+                             lr_initial: Optional[float] = None) -> float:
+        """The reference's per-epoch schedules (models/networks.py:89-118 `get_scheduler`, called from
+        base_model.update_learning_rate): 'linear' / 'exp' interpolate (in lr / in log lr) from ``lr`` to ``lr_final``
+        over the last ``n_epochs_decay`` of ``n_epochs`` epochs, 'step' multiplies by gamma every ``lr_decay_epochs``.
+        ``epoch`` is the number of finished epochs (the scheduler's ``last_epoch``); returns and installs the new lr."""
+        import math
+        lr0 = self._lr_initial = lr_initial if lr_initial is not None else getattr(self, "_lr_initial", self.lr)
+        if lr_policy in ("linear", "exp"):
+            t = max(0, epoch + 1 - n_epochs + n_epochs_decay) / float(n_epochs_decay + 1)
+            self.lr = (lr0 * (1 - t) + lr_final * t) if lr_policy == "linear" else \
+                math.exp(math.log(lr0) * (1 - t) + math.log(lr_final) * t)
+        elif lr_policy == "step":
+            self.lr = lr0 * lr_decay_gamma ** (epoch // lr_decay_epochs)
+        else:
+            raise NotImplementedError(f"learning rate policy [{lr_policy}] is not implemented")
+        return self.lr
+
     def state_dicts(self):
         return [{k: v.clone() for k, v in p.items()} for p in self.params]

@@ -79,3 +79,32 @@ def test_blender_transforms(tmp_path):
     assert abs(s["focal"] - 0.5 * 800 / np.tan(0.5 * 0.6911112070083618) * 0.5) < 1e-9     # 555.555 at 400 px
     assert s["poses"].shape == (3, 3, 4) and np.array_equal(s["poses"][2], (np.eye(4) + 2)[:3])
     assert (s["near"], s["far"]) == (2.0, 6.0) and s["files"][1] == "./train/r_1"
+
+
+def test_lr_schedules_match_torch_lambda_lr():
+    """Trainer.update_learning_rate restates get_scheduler (models/networks.py:89-118): compare with torch's LambdaLR /
+    StepLR driven the way the reference drives them (host-side logic only; no GPU needed)."""
+    import math
+    from types import SimpleNamespace
+    from nerf_sr_amd.train import Trainer
+    opt = SimpleNamespace(lr=5e-4, lr_final=5e-6, n_epochs=30, n_epochs_decay=10, lr_decay_epochs=10, lr_decay_gamma=0.1)
+    t = Trainer.__new__(Trainer)            # schedule logic only
+    t.lr = opt.lr
+    for policy in ("exp", "linear", "step"):
+        p = torch.nn.Parameter(torch.zeros(1))
+        o = torch.optim.Adam([{"params": [p], "initial_lr": opt.lr}], lr=opt.lr)
+        if policy == "step":
+            sch = torch.optim.lr_scheduler.StepLR(o, step_size=opt.lr_decay_epochs, gamma=opt.lr_decay_gamma)
+        else:
+            def rule(epoch, policy=policy):
+                tt = max(0, epoch + 1 - opt.n_epochs + opt.n_epochs_decay) / float(opt.n_epochs_decay + 1)
+                lr = opt.lr * (1 - tt) + opt.lr_final * tt if policy == "linear" else \
+                    math.exp(math.log(opt.lr) * (1 - tt) + math.log(opt.lr_final) * tt)
+                return lr / opt.lr
+            sch = torch.optim.lr_scheduler.LambdaLR(o, lr_lambda=rule)
+        for epoch in range(1, 32):
+            o.step()
+            sch.step()
+            got = t.update_learning_rate(epoch, policy, opt.n_epochs, opt.n_epochs_decay, opt.lr_final, opt.lr_decay_epochs,
+                                         opt.lr_decay_gamma, lr_initial=opt.lr)
+            assert abs(got - o.param_groups[0]["lr"]) <= 1e-12 * opt.lr + 1e-18, (policy, epoch, got, o.param_groups[0]["lr"])
