@@ -1,0 +1,1 @@
+"""CPU oracles of the NeRF-SR paths (test infrastructure only: never imported by the product)."""
