@@ -1,22 +1,23 @@
 #!/usr/bin/env python3
-"""Headline benchmark of the render hot path: rendered rays/s on BASELINE.json config #2.
+"""Headline benchmark of the render hot path: rendered rays/s.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp32] [--config 2|3|4|5] [--scaling strong|weak]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one full pass of the hot path over one synthetic frame per GPU:
-sub-pixel ray generation (504x378 <- 252x189, 2x supersampling, NDC, 190,512 rays) ->
-coarse MLP @64 samples -> compositing -> inverse-CDF resampling -> fine MLP @128 samples ->
-compositing -> s^2 mean; with N > 1 every rank renders its own frame (contiguous ray
-shard of an N-frame batch; N = 4 is exactly config #4's 762,048 rays) and ONE all-gather
-of the rendered LR pixels closes the step (weak scaling).  Weights are synthetic
-(nerf_sr_amd.weights, "smooth" field), inputs are generated on the device: nothing
-crosses PCIe inside the timed region.
+One "step" = one full pass of the hot path over one synthetic frame: sub-pixel ray generation -> coarse MLP @64
+samples -> compositing -> inverse-CDF resampling -> fine MLP @128 samples -> compositing -> s^2 mean.
+N = 1 (default): BASELINE config #2, the one the metric is quoted on (504x378 <- 252x189, 2x supersampling, NDC,
+190,512 rays).  N > 1 (default): BASELINE config #4 as written -- ONE 1008x756 <- 252x189 frame (4x supersampling,
+762,048 rays) cut into N contiguous LR-pixel blocks, every rank generates and renders its own block and ONE
+all-gather of the rendered LR pixels closes the step: strong scaling (the per-ray work of configs #2 and #4 is
+identical, so rays/s is comparable across N).  ``--scaling weak`` renders one whole frame per rank instead;
+``--config`` picks the frame geometry explicitly.  Weights are synthetic (nerf_sr_amd.weights, "smooth" field),
+inputs are generated on the device: nothing crosses PCIe inside the timed region.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-``roofline`` (fine-MLP launch, algorithmic FLOPs / HIP-event duration vs the dense MFMA
-peak of the dtype) and ``cpu_baseline`` (the torch-CPU oracle port timed on this host).
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects: ``roofline`` (fine-MLP
+launch, algorithmic FLOPs / HIP-event duration vs the dense MFMA peak of the dtype) and ``cpu_baseline`` (the
+torch-CPU oracle port timed on this host, N = 1 only).
 """
 from __future__ import annotations
 
@@ -56,46 +57,51 @@ DTYPE_NAME = {"fp32": "f32", "f16x3": "f16x3 (fp16 MFMA, hi+lo split operands, f
               "bf16": "bf16 (bf16 MFMA operands, fp32 accumulate; fast path, not a parity path)"}
 
 
-def cpu_baseline(sd_c, sd_f, rays_cpu: torch.Tensor, target_s: float = 12.0, white_bkgd: bool = False):
-    """Time the oracle port on a bounded ray sample (rank 0, N=1 only).
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
-    The torch-CPU port is GEMM-bound with small matrices: oversubscribing a many-core host slows it down, so
-    a short probe picks the best thread count among {all, 64, 32, 16, 8} first and the timed run uses it."""
+
+CPU_THREADS = 32     # fixed policy: the torch-CPU port is GEMM-bound on small matrices and stops scaling (or slows
+                     # down) beyond ~32 threads on the many-core hosts of the GPU boxes; fewer if the host has fewer
+
+
+def cpu_baseline(sd_c, sd_f, rays_cpu: torch.Tensor, white_bkgd: bool = False):
+    """Time the oracle port on a bounded ray sample (rank 0, N=1 only): min(32, host threads) threads, 32,768 rays
+    (or what the caller hands over), one untimed 256-ray warm-up."""
     from oracle import nerf_oracle as oc     # checker/baseline only; never on the product path
     sdc, sdf = oc.to_torch_sd(sd_c), oc.to_torch_sd(sd_f)
     all_cores = torch.get_num_threads()
-    cands = sorted({c for c in (all_cores, 64, 32, 16, 8) if 1 <= c <= all_cores}, reverse=True)
+    cores = min(CPU_THREADS, all_cores)
+    n = rays_cpu.shape[0] - rays_cpu.shape[0] % 16
     with torch.no_grad():
+        torch.set_num_threads(cores)
         oc.forward_rays(sdc, sdf, rays_cpu[:256], N_COARSE, N_IMPORTANCE, white_bkgd)      # warm-up (allocator, MKL)
-        best, best_rate = all_cores, 0.0
-        n0 = 1024
-        for c in cands:
-            torch.set_num_threads(c)
-            t0 = time.perf_counter()
-            oc.forward_rays(sdc, sdf, rays_cpu[:n0], N_COARSE, N_IMPORTANCE, white_bkgd)
-            rate = n0 / (time.perf_counter() - t0)
-            if rate > best_rate:
-                best, best_rate = c, rate
-        torch.set_num_threads(best)
-        n = int(min(max(n0, best_rate * target_s), 32768, rays_cpu.shape[0]))
-        n -= n % 4
         t0 = time.perf_counter()
         out = oc.forward_rays(sdc, sdf, rays_cpu[:n], N_COARSE, N_IMPORTANCE, white_bkgd)
         dt = time.perf_counter() - t0
         torch.set_num_threads(all_cores)
-    return {"value": n / dt, "unit": "rays/s", "cores": best, "kind": "port",
+    return {"value": n / dt, "unit": "rays/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "host_threads": all_cores,
             "sample": f"{n} rays of the same frame (middle rows), torch-CPU oracle (fp32, MKL), {dt:.1f} s, "
-                      f"{best} threads (best of {cands} on a {all_cores}-thread host)"}, out, n
+                      f"{cores} threads (fixed policy: min({CPU_THREADS}, host threads)) of a {all_cores}-thread host"}, out, n
 
 
-def measured_traffic(precision: str):
-    """HBM bytes per fine-pass MLP launch from the committed PMC passes (profiles/r1_traffic.json:
-    (2 x FETCH_SIZE + WRITE_SIZE) x 1024, gfx950 correction); None if the file is absent."""
+def committed_pmc(precision: str) -> dict:
+    """Counter-derived figures of the fine-pass MLP launch from the committed PMC passes (profiles/r2_pmc.json,
+    written from separate rocprofv3 --pmc runs of this build): HBM bytes per launch ((2 x FETCH_SIZE + WRITE_SIZE) x
+    1024, the guide's gfx950 correction), matrix-pipe busy fraction, effective clock.  {} if absent."""
     try:
-        with open(os.path.join(REPO, "profiles", "r1_traffic.json")) as f:
-            return json.load(f)[precision]["hbm_bytes_per_launch"]
+        with open(os.path.join(REPO, "profiles", "r2_pmc.json")) as f:
+            return json.load(f).get(precision, {})
     except Exception:
-        return None
+        return {}
 
 
 def main_train(args):
@@ -114,7 +120,6 @@ def main_train(args):
     sd_c, sd_f = make_state_dict(99), make_state_dict(100)
     t = nsr_train.Trainer(sd_c, sd_f, randomized=True, noise_std=1.0, downscale=DOWNSCALE, ray_chunk=R,
                           precision=args.train_precision, device=dev)
-    t.grad_scale = 1.0 / world
     frame = ops.subpixel_rays(cameras.spiral_pose(0.4 + 0.35 * rank), IMG_WH, cameras.llff_focal(IMG_WH[0]), DOWNSCALE,
                               True, device=dev)                       # (N_lr, 4, 8)
     torch.manual_seed(1234 + rank)
@@ -160,7 +165,7 @@ def main_train(args):
                          "frac": achieved / PEAK_TFLOPS["fp32"], "traffic": None,
                          "flop_per_step": flop_step,
                          "note": "algorithmic flops = 3 x 593,408 MAC x 2 per sample point x 192 points per ray"},
-            "losses": [float(x) * world for x in t.losses.tolist()],
+            "losses": [float(x) for x in t.losses.tolist()],
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import train_oracle as to     # checker/baseline only; never on the product path
@@ -184,6 +189,48 @@ def main_train(args):
         dist.destroy_process_group()
 
 
+def refine_pass(img_wh, downscale, c2w, focal, o, dev, reps: int = 3):
+    """BASELINE config #5's tail on the frame the timed steps just rendered: HR depth map -> nsr_depth_warp (ray
+    distance -> camera-axis depth, include/nsr_warp.h) into a reference view 15 degrees away -> 64 x 64 tiles with up
+    to 8 depth-warped reference patches each -> refinement network -> stitch.  Reported separately from `value`
+    (the render pass); the reference image is synthetic noise (its content does not change the work)."""
+    from nerf_sr_amd import pipeline, refine, warp
+    W, H = img_wh
+    net = refine.MaxPoolingModel(device=dev).load_state_dict(refine.make_refine_state_dict(7))
+    ref_c2w = cameras.spheric_pose(-15.0, -30.0, 4.0)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    ref_img = (torch.rand(3, H, W, generator=g) * 2 - 1).to(dev)
+    hr = ops.unflatten_reshape(o["fine_comp_rgbs"], img_wh, downscale)
+    depth = ops.unflatten_reshape(o["fine_depth"].reshape(-1, 1).contiguous(), img_wh, downscale)[..., 0].contiguous()
+    sr = (hr.permute(2, 0, 1) * 2 - 1).contiguous()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t_warp, t_ref = [], []
+    for i in range(reps + 1):
+        ev[0].record()
+        locs = warp.depth_warp(depth, c2w, pipeline.world_to_camera(ref_c2w), focal, "ray")
+        ev[1].record()
+        out = refine.refine_image(net, sr, ref_img, locs)
+        ev[2].record()
+        torch.cuda.synchronize()
+        if i:                    # first trip = warm-up (workspace allocation)
+            t_warp.append(ev[0].elapsed_time(ev[1]))
+            t_ref.append(ev[1].elapsed_time(ev[2]))
+    n_tiles = -(-W // 64) * -(-H // 64)
+    flop = 2 * refine.refine_macs(64, 64, 8) * n_tiles
+    ms = sum(t_ref) / len(t_ref)
+    inside = ((locs[..., 0] >= 0) & (locs[..., 0] < W) & (locs[..., 1] >= 0) & (locs[..., 1] < H)).double().mean()
+    return {"what": f"depth warp + {n_tiles} tiles of 64 x 64 with 8 reference patches through the refinement network "
+                    "(split-fp16 MFMA, fp32-grade) + stitch, one 800 x 800 frame",
+            "warp_ms": sum(t_warp) / len(t_warp), "refine_ms": ms, "tiles": n_tiles,
+            "pixels_warped_inside_reference_view": float(inside),
+            "finite": bool(torch.isfinite(out).all()),
+            "roofline": {"bound": "mfma", "kernel": "refinement network (implicit-im2col split-fp16 GEMMs)",
+                         "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["f16x3"], "unit": "TFLOP/s",
+                         "frac": flop / (ms * 1e-3) / 1e12 / PEAK_TFLOPS["f16x3"], "traffic": None,
+                         "flop_per_pass": flop,
+                         "note": "true convolution MACs x 2; three MFMAs are issued per product (split-fp16)"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,16 +246,18 @@ def main():
     ap.add_argument("--train-rays", type=int, default=2048, help="rays per GPU per training step (multiple of 4)")
     ap.add_argument("--train-precision", default="f16x3", choices=["f16x3", "fp32"],
                     help="training step: forward products on the split-fp16 MFMA (default, fp32-grade) or everything on the fp32 MFMA")
-    ap.add_argument("--config", type=int, default=2, choices=sorted(RENDER_CONFIGS),
-                    help="BASELINE.json render configuration (default 2 = the one the metric is quoted on; 3-5: the other "
-                         "frame geometries, one frame per GPU)")
+    ap.add_argument("--config", type=int, default=0, choices=[0] + sorted(RENDER_CONFIGS),
+                    help="BASELINE.json render configuration; default: #2 (the one the metric is quoted on) on one GPU, "
+                         "#4 (one 1008x756 frame sharded over the ranks, as BASELINE states it) on several")
+    ap.add_argument("--scaling", default="", choices=["", "strong", "weak"],
+                    help="N > 1: strong (default) = ONE frame cut into N contiguous LR-pixel blocks + one all-gather; "
+                         "weak = one whole frame per rank (an N-frame batch)")
+    ap.add_argument("--with-refine", action="store_true",
+                    help="config #5 only: after the timed render steps run depth -> warp -> refinement network on the "
+                         "rendered frame and report that pass separately (`refine` object; not part of `value`)")
     args = ap.parse_args()
     if args.mode == "train":
         return main_train(args)
-    cfg = RENDER_CONFIGS[args.config]
-    IMG_WH, DOWNSCALE, ndc, white = cfg["img_wh"], cfg["downscale"], cfg["ndc"], cfg["white_bkgd"]
-    RAYS_PER_FRAME = IMG_WH[0] * IMG_WH[1]
-    N_LR = RAYS_PER_FRAME // DOWNSCALE ** 2
 
     rank, local, world = nsr_dist.init_from_env()
     if world != args.gpus:
@@ -218,26 +267,39 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    cfg_id = args.config or (2 if world == 1 else 4)
+    cfg = RENDER_CONFIGS[cfg_id]
+    IMG_WH, DOWNSCALE, ndc, white = cfg["img_wh"], cfg["downscale"], cfg["ndc"], cfg["white_bkgd"]
+    S2 = DOWNSCALE ** 2
+    RAYS_PER_FRAME = IMG_WH[0] * IMG_WH[1]
+    N_LR = RAYS_PER_FRAME // S2
+    strong = world > 1 and args.scaling != "weak"
+    # this rank's share: a contiguous LR-pixel block of THE frame (strong) or a whole frame of its own (weak / N = 1)
+    lo, hi = nsr_dist.shard_bounds(N_LR, world)[rank] if strong else (0, N_LR)
+    my_rays = (hi - lo) * S2
+    frame_id = 0 if strong else rank
+
     sd_c, sd_f = make_state_dict(99), make_state_dict(100)
     net_c = ops.VanillaMLP(precision=args.precision, device=dev).load_state_dict(sd_c)
     net_f = ops.VanillaMLP(precision=args.precision, device=dev).load_state_dict(sd_f)
     if ndc:
-        c2w, focal, nf = cameras.spiral_pose(0.4 + 0.35 * rank), cameras.llff_focal(IMG_WH[0]), (0.0, 1.0)   # frame `rank`
+        c2w, focal, nf = cameras.spiral_pose(0.4 + 0.35 * frame_id), cameras.llff_focal(IMG_WH[0]), (0.0, 1.0)
     else:
-        c2w, focal, nf = cameras.spheric_pose(40.0 * rank, -30.0, 4.0), cameras.blender_focal(IMG_WH[0]), (2.0, 6.0)
-    ws = torch.empty(ops._lib.load().nsr_forward_rays_workspace_bytes(RAYS_PER_FRAME, N_COARSE, N_IMPORTANCE),
+        c2w, focal, nf = cameras.spheric_pose(40.0 * frame_id, -30.0, 4.0), cameras.blender_focal(IMG_WH[0]), (2.0, 6.0)
+    ws = torch.empty(ops._lib.load().nsr_forward_rays_workspace_bytes(my_rays, N_COARSE, N_IMPORTANCE),
                      dtype=torch.uint8, device=dev)
     outs = {}
     n_ev = args.steps + args.warmup
     events = [ops.HipEvents(4) for _ in range(n_ev)]
 
     def step(i):
-        rays = ops.subpixel_rays(c2w, IMG_WH, focal, DOWNSCALE, ndc, *nf, device=dev).view(-1, 8)
+        rays = ops.subpixel_rays(c2w, IMG_WH, focal, DOWNSCALE, ndc, *nf, device=dev, lr_range=(lo, hi)).view(-1, 8)
         o = ops.forward_rays(net_c, net_f, rays, N_COARSE, N_IMPORTANCE, white, workspace=ws, outs=outs,
                              events=events[i].handles)
-        lr = ops.sr_mean(o["fine_comp_rgbs"], N_LR, DOWNSCALE ** 2)
-        frames = nsr_dist.all_gather_pixels(lr, N_LR * world) if world > 1 else lr
-        return rays, o, frames
+        lr = ops.sr_mean(o["fine_comp_rgbs"], hi - lo, S2)
+        if world > 1:      # strong: the blocks of one frame; weak: the frames of the batch -- one collective either way
+            lr = nsr_dist.all_gather_pixels(lr, N_LR if strong else N_LR * world)
+        return rays, o, lr
 
     def fence():
         if world > 1:
@@ -258,57 +320,74 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        total_rays = RAYS_PER_FRAME * world * args.steps
-        value = total_rays / dt
+        rays_per_step = RAYS_PER_FRAME if strong else RAYS_PER_FRAME * world
+        value = rays_per_step * args.steps / dt
         fine_ms = [events[args.warmup + i].elapsed_ms(2, 3) for i in range(args.steps)]
         coarse_ms = [events[args.warmup + i].elapsed_ms(0, 1) for i in range(args.steps)]
         fine_avg = sum(fine_ms) / len(fine_ms)
-        fine_flop = RAYS_PER_FRAME * (N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT
+        fine_flop = my_rays * (N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT
         achieved = fine_flop / (fine_avg * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
+        pmc = committed_pmc(args.precision) if (cfg_id == 2 and world == 1) else {}
+        mfma_per_product = 3 if args.precision == "f16x3" else 1
+        if world == 1:
+            how = ""
+        elif strong:
+            how = (f"; ONE frame cut into {world} contiguous LR-pixel blocks ({my_rays:,} rays on rank 0), every rank "
+                   "generates and renders its own block, one all-gather of LR pixels per step")
+        else:
+            how = f"; {world}-frame batch, one frame per rank, one all-gather of LR pixels per step"
         res = {
             "metric": f"rays/sec (64+128 samples, {DOWNSCALE}x SS)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
-            "config": {"workload": f"BASELINE config #{args.config}: {cfg['name']} {IMG_WH[0]}x{IMG_WH[1]} <- "
+            "config": {"workload": f"BASELINE config #{cfg_id}: {cfg['name']} {IMG_WH[0]}x{IMG_WH[1]} <- "
                                    f"{IMG_WH[0] // DOWNSCALE}x{IMG_WH[1] // DOWNSCALE}, {DOWNSCALE}x supersampling, "
-                                   f"64 coarse + 128 fine samples/ray, {RAYS_PER_FRAME:,} rays per GPU per step"
-                                   + ("" if world == 1 else f"; {world}-frame batch, contiguous ray shards, "
-                                      "one all-gather of LR pixels per step"),
-                       "rays_per_step": RAYS_PER_FRAME * world, "n_coarse": N_COARSE, "n_importance": N_IMPORTANCE,
-                       "precision": args.precision, "parallelism": f"ray-shard x{world}"},
+                                   f"64 coarse + 128 fine samples/ray, {RAYS_PER_FRAME:,} rays per frame" + how,
+                       "rays_per_step": rays_per_step, "n_coarse": N_COARSE, "n_importance": N_IMPORTANCE,
+                       "precision": args.precision,
+                       "parallelism": f"LR-pixel blocks of one frame x{world}" if strong else f"frame per rank x{world}"},
             "achieved_tflops_whole_path": value * FLOP_PER_RAY / 1e12,
-            "roofline": {"bound": "mfma", "kernel": f"mlp kernel, fine pass ({RAYS_PER_FRAME:,} rays x 128 samples)",
+            "roofline": {"bound": "mfma", "kernel": f"mlp kernel, fine pass ({my_rays:,} rays x 128 samples, rank 0)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": measured_traffic(args.precision) if args.config == 2 else None, "traffic_unit": "bytes/launch (PMC, profiles/r1_traffic.json)",
-                         "mfma_issued": achieved * (3 if args.precision == "f16x3" else 1),
-                         "mfma_issued_frac": achieved * (3 if args.precision == "f16x3" else 1) / peak,
+                         "traffic": pmc.get("hbm_bytes_per_launch"),
+                         "traffic_unit": "HBM bytes/launch (PMC, profiles/r2_pmc.json); algorithmic = SURVEY 8d: 32 B in + 40 B out "
+                                         "per ray (+ 768 B/ray when both weights arrays are written)",
+                         "algorithmic_bytes_per_launch": my_rays * (32 + 40),
+                         "mfma_issued": achieved * mfma_per_product,
+                         "mfma_issued_frac": achieved * mfma_per_product / peak,
+                         "mfma_busy": pmc.get("mfma_busy"), "effective_clock_ghz": pmc.get("effective_clock_ghz"),
                          "launch_ms": fine_avg, "coarse_launch_ms": sum(coarse_ms) / len(coarse_ms),
                          "flop_per_launch": fine_flop,
                          "note": ("achieved counts ALGORITHMIC flops (2 x 593,408 MAC per point); f16x3 issues 3 MFMAs "
-                                  "per product, so its matrix pipe is busy for 3x this figure (mfma_issued); ~1.4 PFLOP/s "
-                                  "issued is the power-limited fp16-MFMA rate of this part: the one-MFMA f16/bf16 kernels "
-                                  "issue the same rate at 82 % pipe utilisation and 1.68 GHz (DESIGN.md section 12)"
+                                  "per product, so its matrix pipe is busy for 3x this figure (mfma_issued); mfma_busy / "
+                                  "effective_clock_ghz are the committed rocprofv3 counters of this build (config #2)"
                                   if args.precision == "f16x3" else
                                   "algorithmic flops, exact fp32 MFMA" if args.precision == "fp32" else
                                   "algorithmic flops, one 16-bit MFMA per product; fast path outside the 1e-4 "
                                   "RGB contract (see the parity block)")},
         }
         if world == 1 and not args.no_cpu_baseline:
-            lo = (RAYS_PER_FRAME // 2) - (RAYS_PER_FRAME // 2) % 4
-            base, ref, n = cpu_baseline(sd_c, sd_f, rays[lo:lo + 32768].cpu(), white_bkgd=white)
+            mid = (RAYS_PER_FRAME // 2) - (RAYS_PER_FRAME // 2) % S2
+            base, ref, n = cpu_baseline(sd_c, sd_f, rays[mid:mid + 32768].cpu(), white_bkgd=white)
             res["cpu_baseline"] = base
             from oracle import nerf_oracle as oc
-            got = o["fine_comp_rgbs"][lo:lo + n].cpu()
+            got = o["fine_comp_rgbs"][mid:mid + n].cpu()
+            d = (got - ref["fine_comp_rgbs"]).abs().max(-1)[0]
             res["parity"] = {
-                "max_abs_rgb_vs_oracle": float((got - ref["fine_comp_rgbs"]).abs().max()),
+                "max_abs_rgb_vs_oracle": float(d.max()),
+                "rays_over_1e-4": int((d > 1e-4).sum()), "p999_abs_rgb": float(torch.quantile(d, 0.999)),
+                "lr_max_abs_rgb_vs_oracle": float((ops.sr_mean(o["fine_comp_rgbs"][mid:mid + n].contiguous(), n // S2, S2).cpu()
+                                                   - oc.sr_mean(ref["fine_comp_rgbs"], n // S2, S2)).abs().max()),
                 "psnr_build_vs_oracle_db": oc.psnr(got, ref["fine_comp_rgbs"]),
                 "psnr_delta_db_vs_common_target": abs(oc.psnr(got, ref["coarse_comp_rgbs"]) -
                                                       oc.psnr(ref["fine_comp_rgbs"], ref["coarse_comp_rgbs"])),
                 "rays_checked": n}
         else:
             res["cpu_baseline"] = None
+        if args.with_refine:
+            res["refine"] = refine_pass(IMG_WH, DOWNSCALE, c2w, focal, o, dev) if (cfg_id == 5 and world == 1) else None
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -87,6 +87,13 @@ int nsr_pack_weights(const float* const* w, void* packed_dev, int precision, voi
  * sub-pixel index dy*s+dx.  H % s == 0 and W % s == 0 required. */
 int nsr_gen_rays(const float* c2w, int H, int W, double focal, int s, int ndc, float near_, float far_,
                  float* rays_dev, void* stream);
+/* The same for the LR pixels [lr_lo, lr_hi) only (row-major LR index): rays_dev is ((lr_hi - lr_lo) * s*s, 8) and
+ * holds exactly the rows [lr_lo * s*s, lr_hi * s*s) of what nsr_gen_rays writes.  This is the ray shard one GPU
+ * renders when a frame is cut into contiguous LR-pixel blocks (replaces the scatter of
+ * nn.DataParallel, models/networks.py:54-69): nothing is scattered, every rank generates its own block.
+ * lr_lo == lr_hi is a valid empty shard. */
+int nsr_gen_rays_range(const float* c2w, int H, int W, double focal, int s, int ndc, float near_, float far_,
+                       int64_t lr_lo, int64_t lr_hi, float* rays_dev, void* stream);
 
 /* ---- E1: positional encoding ------------------------------------------------
  * Replaces PositionalEncoding.__call__ (models/embedding.py:44-62), 3 input

@@ -39,7 +39,12 @@ size_t nsr_train_workspace_bytes(int64_t ray_chunk, int n_coarse, int n_importan
  * precision: NSR_FP32 = every product on the fp32 MFMA; NSR_F16X3 = the forward products of both networks on the
  * split-fp16 MFMA (exact to ~2^-21, the inference path's scheme), gradients on the fp32 MFMA.
  * ray_chunk: rays per pass (bounds the workspace; multiple of s2; 0 = R); gradients and losses of the passes
- * are accumulated, the result does not depend on the chunking beyond fp32 summation order.
+ * are accumulated, the result does not depend on the chunking beyond fp32 summation order.  Every pass -- the
+ * shorter last one included -- must hold a multiple of 32 sample points in both networks
+ * (rays_in_pass * n_coarse and rays_in_pass * (n_coarse + n_importance) divisible by 32: the weight-gradient
+ * GEMM contracts over the points in K tiles of 32); otherwise NSR_ERR_UNSUPPORTED is returned before anything
+ * is enqueued (outputs and gradients untouched).  All of the reference's scripts (64 + 64 samples) satisfy it
+ * for any ray count.
  * outs: the 8 forward outputs in nsr_forward_rays order (entries may be NULL except the two comp_rgbs).
  * lr_coarse / lr_fine: (R / s2, 3) s2-means (comp_low_res_output, :326-348); losses: DEVICE float[2] =
  * { lambda_coarse * mse_coarse, lambda_fine * mse_fine }. */

@@ -24,6 +24,8 @@ SIGNATURES = {
     "nsr_packed_weights_bytes": (c_size_t, [c_int]),
     "nsr_pack_weights": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p]),
     "nsr_gen_rays": (c_int, [POINTER(c_float), c_int, c_int, c_double, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
+    "nsr_gen_rays_range": (c_int, [POINTER(c_float), c_int, c_int, c_double, c_int, c_int, c_float, c_float, c_int64, c_int64,
+                                   c_void_p, c_void_p]),
     "nsr_posenc": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "nsr_sample_along_rays": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsr_mlp_forward": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]),

@@ -23,6 +23,7 @@ UNITS = [
     ("nsr_render.hip", ["-ffp-contract=off"]),
     ("nsr_mlp.hip", ["-ffp-contract=off"]),
     ("nsr_mlp_f16.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("nsr_mlp_f16p.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("nsr_mlp_h1.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("nsr_gemm.hip", ["-ffp-contract=off"]),
     ("nsr_gemm_f16.hip", ["-ffp-contract=off"]),

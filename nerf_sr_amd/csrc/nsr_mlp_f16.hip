@@ -98,9 +98,9 @@ __global__ void __launch_bounds__(256) pack_f16x3_kernel(PackPtrsH w, unsigned* 
   out[idx] = v;
 }
 
-extern "C" NSR_INTERNAL size_t nsr_f16x3_packed_bytes(void) { return 4 * (size_t)(kPiecesTotal * 256 + hx::kAuxFloats); }
+extern "C" NSR_INTERNAL size_t nsr_f16x3v1_packed_bytes(void) { return 4 * (size_t)(kPiecesTotal * 256 + hx::kAuxFloats); }
 
-extern "C" NSR_INTERNAL int nsr_f16x3_pack(const float* const* w, void* packed_dev, void* stream) {
+extern "C" NSR_INTERNAL int nsr_f16x3v1_pack(const float* const* w, void* packed_dev, void* stream) {
   PackPtrsH pp;
   for (int i = 0; i < NSR_N_STATE_TENSORS; ++i) {
     if (!w[i]) return NSR_ERR_INVALID_ARG;
@@ -756,13 +756,13 @@ static int launch_f16x3(const void* packed, const float* x, const float* z, int6
   return NSR_OK;
 }
 
-extern "C" NSR_INTERNAL int nsr_f16x3_mlp_forward(const void* packed, const float* x, int64_t P, int sigma_only, float* out,
+extern "C" NSR_INTERNAL int nsr_f16x3v1_mlp_forward(const void* packed, const float* x, int64_t P, int sigma_only, float* out,
                                      void* stream) {
   return sigma_only ? launch_f16x3<0, true>(packed, x, nullptr, P, 1, 8, out, nsr_stream(stream))
                     : launch_f16x3<0, false>(packed, x, nullptr, P, 1, 8, out, nsr_stream(stream));
 }
 
-extern "C" NSR_INTERNAL int nsr_f16x3_render_rays(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
+extern "C" NSR_INTERNAL int nsr_f16x3v1_render_rays(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
                                      int N, float* out, void* stream) {
   return launch_f16x3<1, false>(packed, rays, z, R * N, N, ray_stride, out, nsr_stream(stream));
 }

@@ -16,12 +16,14 @@ struct GenRaysArgs {
   float near_, far_;
 };
 
-__global__ void __launch_bounds__(256) gen_rays_kernel(GenRaysArgs a, float* __restrict__ rays, int64_t n_rays) {
+// rays of the LR pixels [lr0, lr0 + n_rays / s^2): output row r holds ray  lr0 * s^2 + r  of the frame
+__global__ void __launch_bounds__(256) gen_rays_kernel(GenRaysArgs a, float* __restrict__ rays, int64_t lr0,
+                                                       int64_t n_rays) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rays) return;
   const int s = a.s, s2 = s * s, w_lr = a.W / s;
-  const int64_t lr = r / s2;
-  const int sub = (int)(r - lr * s2);
+  const int64_t lr = lr0 + r / s2;
+  const int sub = (int)(r % s2);
   const int py = (int)(lr / w_lr) * s + sub / s;   // HR row  (h s1)
   const int px = (int)(lr % w_lr) * s + sub % s;   // HR col  (w s2)
   // camera-space direction through the pixel centre
@@ -62,9 +64,17 @@ __global__ void __launch_bounds__(256) gen_rays_kernel(GenRaysArgs a, float* __r
 
 extern "C" int nsr_gen_rays(const float* c2w, int H, int W, double focal, int s, int ndc, float near_, float far_,
                             float* rays_dev, void* stream) {
-  if (!c2w || !rays_dev || H <= 0 || W <= 0 || s <= 0 || !(focal > 0.0)) return NSR_ERR_INVALID_ARG;
+  if (H <= 0 || W <= 0 || s <= 0) return NSR_ERR_INVALID_ARG;
+  return nsr_gen_rays_range(c2w, H, W, focal, s, ndc, near_, far_, 0, (int64_t)(H / s) * (W / s), rays_dev, stream);
+}
+
+extern "C" int nsr_gen_rays_range(const float* c2w, int H, int W, double focal, int s, int ndc, float near_, float far_,
+                                  int64_t lr_lo, int64_t lr_hi, float* rays_dev, void* stream) {
+  if (!c2w || H <= 0 || W <= 0 || s <= 0 || !(focal > 0.0)) return NSR_ERR_INVALID_ARG;
   if (H % s != 0 || W % s != 0) return NSR_ERR_INVALID_ARG;
-  if ((reinterpret_cast<uintptr_t>(rays_dev) & 15) != 0) return NSR_ERR_INVALID_ARG;
+  if (lr_lo < 0 || lr_hi < lr_lo || lr_hi > (int64_t)(H / s) * (W / s)) return NSR_ERR_INVALID_ARG;
+  if (lr_hi == lr_lo) return NSR_OK;   // empty shard: nothing to write (the pointer may be null)
+  if (!rays_dev || (reinterpret_cast<uintptr_t>(rays_dev) & 15) != 0) return NSR_ERR_INVALID_ARG;
   GenRaysArgs a;
   for (int i = 0; i < 12; ++i) a.c2w[i] = c2w[i];
   a.H = H; a.W = W; a.s = s; a.ndc = ndc;
@@ -74,10 +84,10 @@ extern "C" int nsr_gen_rays(const float* c2w, int H, int W, double focal, int s,
   a.ndc_ax = (float)(-1.0 / (W / (2.0 * focal)));
   a.ndc_ay = (float)(-1.0 / (H / (2.0 * focal)));
   a.near_ = near_; a.far_ = far_;
-  const int64_t n = (int64_t)H * W;
+  const int64_t n = (lr_hi - lr_lo) * s * s;
   const int threads = 256;
   const int64_t blocks = (n + threads - 1) / threads;
-  hipLaunchKernelGGL(gen_rays_kernel, dim3((unsigned)blocks), dim3(threads), 0, nsr_stream(stream), a, rays_dev, n);
+  hipLaunchKernelGGL(gen_rays_kernel, dim3((unsigned)blocks), dim3(threads), 0, nsr_stream(stream), a, rays_dev, lr_lo, n);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }

@@ -606,6 +606,13 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
   if (R % s2 != 0) return NSR_ERR_INVALID_ARG;
   if (ray_chunk <= 0 || ray_chunk > R) ray_chunk = R;
   if (ray_chunk % s2 != 0) return NSR_ERR_INVALID_ARG;
+  // the split-K weight-gradient GEMM contracts over the chunk's sample points in K tiles of 32: every chunk,
+  // the shorter last one included, must hold a multiple of 32 points in both passes -- checked BEFORE anything
+  // is enqueued, so a rejected call leaves outputs and gradients untouched
+  for (int64_t r0 = 0; r0 < R; r0 += ray_chunk) {
+    const int64_t rc = (R - r0 < ray_chunk) ? R - r0 : ray_chunk;
+    if ((rc * n_coarse) % 32 != 0 || (rc * (n_coarse + n_importance)) % 32 != 0) return NSR_ERR_UNSUPPORTED;
+  }
   for (int i = 0; i < NSR_N_STATE_TENSORS; ++i)
     if (!w_coarse[i] || !w_fine[i] || !g_coarse[i] || !g_fine[i]) return NSR_ERR_INVALID_ARG;
   if (R == 0) return NSR_OK;

@@ -10,8 +10,8 @@ struct WarpArgs {
   float c2w[12];
   double ref[12];
   double focal, half_w, half_h;
-  float half_w32, half_h32;
-  int H, W, ndc;
+  float half_w32, half_h32, focal32;
+  int H, W, ndc;   // ndc: nsr_depth_kind
 };
 
 __device__ __forceinline__ double affine_row(const double* m, double x0, double x1, double x2) {
@@ -26,8 +26,15 @@ __global__ void __launch_bounds__(256) depth_warp_kernel(WarpArgs a, const float
   if (p >= n) return;
   const int y = (int)(p / a.W), x = (int)(p % a.W);
   float D = depth[p];
-  if (a.ndc) D = __fdiv_rn(1.0f, __fadd_rn(__fsub_rn(1.0f, D), 1e-6f));
   const float gx = __fsub_rn((float)x + 0.5f, a.half_w32), gy = -__fsub_rn((float)y + 0.5f, a.half_h32);
+  if (a.ndc == NSR_DEPTH_NDC) {
+    D = __fdiv_rn(1.0f, __fadd_rn(__fsub_rn(1.0f, D), 1e-6f));
+  } else if (a.ndc == NSR_DEPTH_RAY) {
+    // distance along the UNIT-norm ray through the pixel centre (get_rays normalises, models/utils.py:150) -> depth
+    // along the camera axis: divide by |(gx/f, gy/f, -1)|, float32
+    const float cx = __fdiv_rn(gx, a.focal32), cy = __fdiv_rn(gy, a.focal32);
+    D = __fdiv_rn(D, sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(cx, cx), __fmul_rn(cy, cy)), 1.0f)));
+  }
   const double Dd = (double)D;
   const double x0 = __dmul_rn(__ddiv_rn((double)gx, a.focal), Dd);
   const double x1 = __dmul_rn(__ddiv_rn((double)gy, a.focal), Dd);
@@ -56,6 +63,7 @@ __global__ void __launch_bounds__(256) depth_warp_kernel(WarpArgs a, const float
 extern "C" int nsr_depth_warp(const float* depth, int H, int W, double focal, const float* c2w, const double* ref_w2c,
                               int ndc, const float* ref_rgb, double* locs, float* warped, void* stream) {
   if (H < 0 || W < 0 || !c2w || !ref_w2c || !(focal > 0.0)) return NSR_ERR_INVALID_ARG;
+  if (ndc != NSR_DEPTH_METRIC && ndc != NSR_DEPTH_NDC && ndc != NSR_DEPTH_RAY) return NSR_ERR_UNSUPPORTED;
   if ((int64_t)H * W == 0) return NSR_OK;
   if (!depth || !locs || (warped && !ref_rgb)) return NSR_ERR_INVALID_ARG;
   WarpArgs a;
@@ -68,6 +76,7 @@ extern "C" int nsr_depth_warp(const float* depth, int H, int W, double focal, co
   a.half_h = H / 2.0;
   a.half_w32 = (float)(W / 2.0);
   a.half_h32 = (float)(H / 2.0);
+  a.focal32 = (float)focal;
   a.H = H; a.W = W; a.ndc = ndc;
   const int64_t n = (int64_t)H * W;
   hipLaunchKernelGGL(depth_warp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nsr_stream(stream), a, depth,

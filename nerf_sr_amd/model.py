@@ -132,3 +132,32 @@ class NeRFDownXModel:
         hr = self.unflatten_reshape(self.out_fine_comp_rgbs)
         self.comp_low_res_output()
         return {"hr_rgb": hr, "lr_rgb": self.out_fine_comp_rgbs, "lr_depth": self.out_fine_depth}
+
+    @torch.no_grad()
+    def render_image_sharded(self, c2w, focal: float, ndc: bool, near: float = 0.0, far: float = 1.0, group=None,
+                             lr_range=None, workspace=None, outs=None):
+        """One frame rendered by all ranks of ``group`` together (BASELINE config #4): the LR-pixel range
+        is cut into contiguous blocks (``dist.shard_bounds``; an LR pixel's s*s sub-rays stay on one GPU), every rank
+        GENERATES its own ray block on its device (nothing is scattered), runs the eval-mode ``forward_rays`` on it,
+        takes the s*s means, and ONE all-gather of [r, g, b, depth] per LR pixel assembles the image on every rank.
+        Replaces the per-MLP-call scatter / gather of nn.DataParallel (models/networks.py:54-69).  No reduction
+        crosses a block boundary, so the result is bit-identical to ``render_image`` on one GPU.
+        ``lr_range`` overrides this rank's block (single-process tests).  Returns the full LR image and depth plus
+        this rank's own outputs."""
+        from . import dist as nsr_dist
+        opt = self.opt
+        s, s2 = int(opt.downscale), int(opt.downscale) ** 2
+        n_lr = (opt.img_wh[1] // s) * (opt.img_wh[0] // s)
+        rank, world = nsr_dist._world(group)
+        lo, hi = lr_range if lr_range is not None else nsr_dist.shard_bounds(n_lr, world)[rank]
+        rays = ops.subpixel_rays(c2w, opt.img_wh, focal, s, ndc, near, far, self.device, lr_range=(lo, hi)).view(-1, 8)
+        fine = opt.N_importance > 0
+        out = ops.forward_rays(self.netCoarse, self.netFine if fine else None, rays, opt.N_coarse, opt.N_importance,
+                               opt.white_bkgd, opt.lindisp, workspace=workspace, outs=outs)
+        tag = "fine" if fine else "coarse"
+        local = torch.empty(hi - lo, 4, dtype=torch.float32, device=self.device)
+        if hi > lo:
+            local[:, :3] = ops.sr_mean(out[f"{tag}_comp_rgbs"], hi - lo, s2)
+            local[:, 3:] = ops.sr_mean(out[f"{tag}_depth"], hi - lo, s2)
+        full = local if lr_range is not None else nsr_dist.all_gather_pixels(local, n_lr, group)
+        return {"lr_rgb": full[:, :3], "lr_depth": full[:, 3], "lr_range": (lo, hi), "local": out}

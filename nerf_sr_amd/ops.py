@@ -24,7 +24,21 @@ __all__ = [
 
 
 def _stream() -> c_void_p:
+    """torch's current stream on the CURRENT device: libnsr enqueues on the caller's current HIP device
+    (include/nsr.h), so every tensor handed to an op must live there (``_check_device``)."""
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check_device(dev, name: str) -> None:
+    """Kernels run on torch's current device against raw pointers: a tensor on another GPU would fault or be
+    reached over the fabric silently.  Fail loudly instead (``torch.cuda.set_device`` / ``with torch.cuda.device``)."""
+    dev = torch.device(dev)
+    if dev.type != "cuda":
+        raise ValueError(f"{name} must live on the GPU (nerf_sr_amd has no CPU path)")
+    cur = torch.cuda.current_device()
+    if dev.index is not None and dev.index != cur:
+        raise ValueError(f"{name} lives on cuda:{dev.index} but the current device is cuda:{cur}; "
+                         f"call torch.cuda.set_device({dev.index}) (one process per GPU) before using nerf_sr_amd")
 
 
 def _p(t: Optional[torch.Tensor]) -> c_void_p:
@@ -38,6 +52,7 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
         raise ValueError(f"{name} must live on the GPU (nerf_sr_amd has no CPU path)")
     if t.dtype != torch.float32:
         raise TypeError(f"{name} must be float32, got {t.dtype}")
+    _check_device(t.device, name)
     return t.contiguous()
 
 
@@ -57,20 +72,25 @@ def _pack_rays(ori, dir, near, far) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------- R1-R4
 def subpixel_rays(c2w, img_wh: Tuple[int, int], focal: float, downscale: int, ndc: bool,
-                  near: float = 0.0, far: float = 1.0, device="cuda") -> torch.Tensor:
+                  near: float = 0.0, far: float = 1.0, device="cuda",
+                  lr_range: Optional[Tuple[int, int]] = None) -> torch.Tensor:
     """(H/s*W/s, s*s, 8) sub-pixel ray tensor of one pose, generated on the device.
 
     Replaces get_ray_directions + get_rays (+ get_ndc_rays) + the einops regroup
     (models/utils.py:98-196, data/llff_downX_dataset.py:473-490,
     data/blender_downX_dataset.py:207-215).  ``img_wh`` is the HR size (W, H).
+    ``lr_range = (lo, hi)`` generates only the LR pixels [lo, hi) (row-major LR index): the ray shard of one
+    GPU when the frame is cut into contiguous LR-pixel blocks -> (hi - lo, s*s, 8).
     """
     lib = _lib.load()
     W, H = int(img_wh[0]), int(img_wh[1])
     s = int(downscale)
     c = np.ascontiguousarray(np.asarray(c2w, dtype=np.float32).reshape(12))
-    rays = torch.empty((H // s) * (W // s), s * s, 8, dtype=torch.float32, device=device)
-    _lib.check(lib.nsr_gen_rays(c.ctypes.data_as(ctypes.POINTER(c_float)), H, W, float(focal), s, int(bool(ndc)),
-                                float(near), float(far), _p(rays), _stream()), "nsr_gen_rays")
+    lo, hi = (0, (H // s) * (W // s)) if lr_range is None else (int(lr_range[0]), int(lr_range[1]))
+    _check_device(device, "device")
+    rays = torch.empty(max(hi - lo, 0), s * s, 8, dtype=torch.float32, device=device)
+    _lib.check(lib.nsr_gen_rays_range(c.ctypes.data_as(ctypes.POINTER(c_float)), H, W, float(focal), s, int(bool(ndc)),
+                                      float(near), float(far), lo, hi, _p(rays), _stream()), "nsr_gen_rays_range")
     return rays
 
 
@@ -159,6 +179,7 @@ class VanillaMLP:
         self.precision = precision
         self._prec = _lib.PRECISIONS[precision]
         self.device = torch.device(device)
+        _check_device(self.device, "VanillaMLP device")
         nbytes = _lib.load().nsr_packed_weights_bytes(self._prec)
         if nbytes == 0:
             raise _lib.NsrError(f"precision {precision!r} is not built into libnsr.so")

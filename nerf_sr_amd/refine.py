@@ -67,6 +67,20 @@ def make_refine_state_dict(seed: int) -> Dict[str, np.ndarray]:
     return sd
 
 
+def refine_macs(H: int = 64, W: int = 64, R: int = 8) -> int:
+    """True convolution MACs of one forward on a (H, W) patch with R reference patches (networks.py:735-990):
+    the encoder runs on 1 + R images, the decoder once; no padding or im2col overhead counted."""
+    px = [H * W, H * W // 4, H * W // 16, H * W // 64]
+    enc_level = [0, 0, 1, 1, 2, 2, 3]
+    dec_level = [3, 3, 2, 2, 2, 1, 1, 1, 0, 0, 0, 0]
+    m = 0
+    for i, (_, cin, cout, _bn) in enumerate(LAYERS[:7]):
+        m += (1 + R) * px[enc_level[i]] * 9 * cin * cout
+    for i, (_, cin, cout, _bn) in enumerate(LAYERS[7:]):
+        m += px[dec_level[i]] * 9 * cin * cout
+    return m
+
+
 class MaxPoolingModel:
     """Encoder + max over the reference patches + decoder, eval mode (BatchNorm uses its running statistics)."""
 

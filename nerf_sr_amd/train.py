@@ -85,7 +85,11 @@ class Trainer:
         self.flat_grads, self.grads = [f for f, _ in flat], [v for _, v in flat]
         self.exp_avg = [_flat_like(p)[1] for p in self.params]
         self.exp_avg_sq = [_flat_like(p)[1] for p in self.params]
-        self.grad_scale = 1.0      # 1 / world_size under data parallelism: the all-reduce SUM is then the global mean
+        # data parallelism: every rank scales its loss by 1 / world so that the all-reduce SUM is the gradient of the
+        # global-batch MEAN loss, like DistributedDataParallel's averaging (models/networks.py:84).  None = derive it
+        # from the default process group at each step; a number pins it (e.g. a custom group).
+        self.grad_scale: Optional[float] = None
+        self.check_finite = False  # debug: raise when the loss is not finite (see optimize_parameters)
         self.N_coarse, self.N_importance = int(N_coarse), int(N_importance)
         self.white_bkgd, self.lindisp = bool(white_bkgd), bool(lindisp)
         self.s2 = int(downscale) ** 2
@@ -121,7 +125,10 @@ class Trainer:
 
     def loss_and_grads(self, draws: Optional[Dict[str, Optional[torch.Tensor]]] = None):
         """forward + comp_low_res_output + calculate_losses + backward (:316-396): fills ``self.out``,
-        ``self.losses`` (device float[2], times ``grad_scale``) and ``self.grads``."""
+        ``self.losses`` (device float[2], UNscaled: this rank's lambda-weighted MSEs) and ``self.grads`` (already
+        scaled by 1 / world for the data-parallel SUM, see ``grad_scale``)."""
+        from .dist import _world
+        gs = float(self.grad_scale) if self.grad_scale is not None else 1.0 / _world()[1]
         rays = self.data_rays
         R, stride = rays.shape[0], _ray_stride(rays)
         if draws is None:
@@ -150,8 +157,10 @@ class Trainer:
             wc, wf, gc, gf, _p(rays), stride, R, self.s2, _p(self.data_rgbs), nc, self.N_importance,
             int(self.white_bkgd), int(self.lindisp), _p(draws.get("u_coarse")), _p(draws.get("u_fine")),
             _p(draws.get("noise_coarse")), _p(draws.get("noise_fine")), self.noise_std,
-            self.lambda_coarse * self.grad_scale, self.lambda_fine * self.grad_scale, self._prec, chunk, outs, _p(lr_c), _p(lr_f), _p(self.losses), _p(self._ws), self._ws.numel(),
-            _stream()), "nsr_train_loss_and_grads")
+            self.lambda_coarse * gs, self.lambda_fine * gs, self._prec, chunk, outs, _p(lr_c), _p(lr_f), _p(self.losses),
+            _p(self._ws), self._ws.numel(), _stream()), "nsr_train_loss_and_grads")
+        if gs != 1.0:
+            self.losses.mul_(1.0 / gs)          # report this rank's own losses, not the 1 / world share
         o["lr_coarse"], o["lr_fine"] = lr_c, lr_f
         self.out = o
         return self.losses, self.grads
@@ -174,8 +183,18 @@ class Trainer:
                 self.step, self.lr, self.beta1, self.beta2, self.eps, _stream()), "nsr_adam_step")
 
     def optimize_parameters(self, draws=None):
-        """One training iteration (:398-408); returns the device tensor [coarse_mse, fine_mse] (lambda-weighted)."""
+        """One training iteration (:398-408); returns the device tensor [coarse_mse, fine_mse] (lambda-weighted).
+
+        ``precision='f16x3'`` carries the forward activations as fp16 (hi, lo) pairs: values beyond 65,504 saturate.
+        None of the reference's configurations come near (|h| ~ 1e2), but a diverging run would turn into inf / NaN
+        weights silently; ``self.check_finite = True`` adds a host check of the loss (one sync per step) that raises
+        and points at ``precision='fp32'`` (the reference itself drops into pdb on NaN, nerf_downX_model.py:273)."""
         self.loss_and_grads(draws)
+        if self.check_finite and not bool(torch.isfinite(self.losses).all()):
+            raise FloatingPointError(
+                f"non-finite training loss {self.losses.tolist()} at step {self.step + 1}: the run diverged"
+                + (" or left the fp16 range of the split-fp16 forward; retry with precision='fp32'"
+                   if self.precision == "f16x3" else ""))
         self.all_reduce_grads()
         self.optimizer_step()
         return self.losses

@@ -16,11 +16,18 @@ from . import _lib
 from .ops import _f32, _p, _stream
 
 
-def depth_warp(depth: torch.Tensor, c2w, ref_w2c, focal: float, ndc: bool = True,
+DEPTH_KINDS = {"metric": 0, "ndc": 1, "ray": 2}
+
+
+def depth_warp(depth: torch.Tensor, c2w, ref_w2c, focal: float, ndc=True,
                ref_rgb: Optional[torch.Tensor] = None):
-    """depth (H, W) fp32 on the GPU (``{i}-fine-depth-ori``: NDC depth for LLFF scenes, ``ndc=True``); c2w (3, 4);
-    ref_w2c (3, 4).  Returns ``locs`` (H, W, 3) float64 -- the content of ``{i}_locs.npz`` -- and, if ``ref_rgb``
-    (3, H, W) is given, the warped image (3, H, W) (``{i}-wrapped.png`` before quantisation)."""
+    """depth (H, W) fp32 on the GPU (``{i}-fine-depth-ori``); c2w (3, 4); ref_w2c (3, 4).  ``ndc`` says what the depth
+    map holds: True / ``'ndc'`` = NDC depth of an LLFF scene (``warp.py:118``), False / ``'metric'`` = depth along the
+    camera axis, used as it is (the reference's ``spheric_poses`` branch, ``warp.py:120-126``), ``'ray'`` = distance
+    along a unit-norm ray (what the render path yields for Blender scenes: config #5; defined by this build, see
+    include/nsr_warp.h).  Returns ``locs`` (H, W, 3) float64 -- the content of ``{i}_locs.npz`` -- and, if
+    ``ref_rgb`` (3, H, W) is given, the warped image (3, H, W) (``{i}-wrapped.png`` before quantisation)."""
+    kind = DEPTH_KINDS[ndc] if isinstance(ndc, str) else int(bool(ndc))
     depth = _f32(depth, "depth")
     if depth.ndim != 2:
         raise ValueError("depth must be (H, W)")
@@ -35,6 +42,6 @@ def depth_warp(depth: torch.Tensor, c2w, ref_w2c, focal: float, ndc: bool = True
             raise ValueError("ref_rgb must be (3, H, W)")
         warped = torch.empty(3, H, W, dtype=torch.float32, device=depth.device)
     _lib.check(_lib.load().nsr_depth_warp(_p(depth), H, W, float(focal), (c_float * 12)(*c.tolist()),
-                                          (c_double * 12)(*r.tolist()), int(bool(ndc)), _p(ref_rgb), _p(locs), _p(warped),
+                                          (c_double * 12)(*r.tolist()), kind, _p(ref_rgb), _p(locs), _p(warped),
                                           _stream()), "nsr_depth_warp")
     return (locs, warped) if ref_rgb is not None else locs

@@ -28,13 +28,36 @@ def _affine(m: np.ndarray, x0, x1, x2):
     return [((m[r, 0] * x0 + m[r, 1] * x1) + m[r, 2] * x2) + m[r, 3] for r in range(3)]
 
 
-def depth_warp(depth: np.ndarray, c2w: np.ndarray, ref_w2c: np.ndarray, focal: float, ndc: bool = True,
+def axis_depth_from_ray_distance(t: np.ndarray, focal: float) -> np.ndarray:
+    """Distance along the unit-norm ray through each pixel centre -> depth along the camera axis, float32:
+    ``t / |((x + .5 - W/2) / f, -(y + .5 - H/2) / f, -1)|``.  NOT a restatement: the reference's warp script is
+    LLFF-only; this is the variant BASELINE config #5 (Blender rays: ``get_rays`` normalises, models/utils.py:150)
+    needs, defined in include/nsr_warp.h (NSR_DEPTH_RAY) and restated here operation by operation."""
+    t = np.asarray(t, np.float32)
+    H, W = t.shape
+    f32 = np.float32(focal)
+    gx, gy = np.meshgrid(np.arange(W, dtype=np.float32) + np.float32(0.5) - np.float32(W / 2),
+                         -(np.arange(H, dtype=np.float32) + np.float32(0.5) - np.float32(H / 2)), indexing="xy")
+    cx, cy = gx / f32, gy / f32
+    nrm = np.sqrt((cx * cx + cy * cy) + np.float32(1.0)).astype(np.float32)
+    return (t / nrm).astype(np.float32)
+
+
+def depth_warp(depth: np.ndarray, c2w: np.ndarray, ref_w2c: np.ndarray, focal: float, ndc=True,
                ref_rgb: np.ndarray = None):
-    """depth (H, W) float32 (NDC depth if ``ndc`` else metric); c2w (3, 4) float32; ref_w2c (3, 4) float64.
+    """depth (H, W) float32; ``ndc``: True / 'ndc' = NDC depth (:118), False / 'metric' = depth along the camera axis
+    as it is (the ``spheric_poses`` branch, :120-126), 'ray' = distance along a unit-norm ray (see
+    ``axis_depth_from_ray_distance``); c2w (3, 4) float32; ref_w2c (3, 4) float64.
     Returns locs (H, W, 3) float64 and, if ``ref_rgb`` (3, H, W) is given, the warped image (3, H, W) float32."""
     H, W = depth.shape
     f = np.float64(focal)
-    D = metric_depth_from_ndc(depth) if ndc else np.asarray(depth, np.float32)
+    kind = ndc if isinstance(ndc, str) else ("ndc" if ndc else "metric")
+    if kind == "ndc":
+        D = metric_depth_from_ndc(depth)
+    elif kind == "ray":
+        D = axis_depth_from_ray_distance(depth, focal)
+    else:
+        D = np.asarray(depth, np.float32)
     i_idx, j_idx = np.meshgrid(np.arange(W, dtype=np.float32) + np.float32(0.5),
                                np.arange(H, dtype=np.float32) + np.float32(0.5), indexing="xy")
     Dd = D.astype(np.float64)

@@ -5,15 +5,7 @@ from nerf_sr_amd import refine
 from nerf_sr_amd.refine import LAYERS
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 net = refine.MaxPoolingModel(precision=prec).load_state_dict(refine.make_refine_state_dict(7))
-def macs(H, W, R):
-    px = [H * W, H * W // 4, H * W // 16, H * W // 64]
-    enc = [(0, 1), (0, 1), (1, 2), (1, 1), (2, 2), (2, 1), (3, 2)]           # (output level, stride)
-    lv = [0, 0, 1, 1, 2, 2, 3]
-    m = 0
-    for i, (name, cin, cout, bn) in enumerate(LAYERS[:7]): m += (1 + R) * px[lv[i]] * 9 * cin * cout
-    dl = [3, 3, 2, 2, 2, 1, 1, 1, 0, 0, 0, 0]
-    for i, (name, cin, cout, bn) in enumerate(LAYERS[7:]): m += px[dl[i]] * 9 * cin * cout
-    return m
+macs = refine.refine_macs
 for B in (1, 8, 32):
     x = torch.rand(B, 3, 64, 64, device="cuda") * 2 - 1
     c = torch.rand(B, 8, 3, 64, 64, device="cuda") * 2 - 1

@@ -14,7 +14,12 @@ to its driver lines is compiled at run time, never stored) on a small synthetic 
   * ``torchvision.transforms.ToTensor / ToPILImage`` (absent here) are minimal stand-ins; ToPILImage records the
     warped tensor it is handed, which is what the fixture stores.
 
-Fixture ``warp_llff.npz``: per image the inputs of the per-pixel stage (depth map, the float32 pose, the float64
+A second pass takes the reference's OTHER depth branch (``warp.py:120-126``, ``spheric_poses = True``: the rendered
+depth is used as it is, no NDC -> metric conversion) by flipping that attribute in a subclass hook that runs between
+the constructor's ``self.spheric_poses = False`` and ``read_meta()``; its depth maps are metric (camera-axis depth
+2.5 .. 5).  This is the arithmetic BASELINE config #5 (Blender, near / far 2 / 6) goes through -> ``warp_spheric.npz``.
+
+Fixtures ``warp_llff.npz`` / ``warp_spheric.npz``: per image the inputs of the per-pixel stage (depth map, the float32 pose, the float64
 reference world-to-camera matrix, focal) and its outputs (``locs`` (H, W, 3) float64, warped image).  Note the
 arithmetic types are those NumPy >= 2 promotion gives ``warp.py:128-131`` (float32 grid / float64 focal -> float64).
 """
@@ -63,7 +68,13 @@ def main():
     mg.install_shim()
     import torchvision.transforms as T
     T.ToTensor, T.ToPILImage = ToTensor, ToPILImage
-    rng = np.random.default_rng(7)
+    run(False, "warp_llff.npz", 7)
+    run(True, "warp_spheric.npz", 11)
+
+
+def run(spheric: bool, fixture: str, seed: int):
+    ToPILImage.recorded = []
+    rng = np.random.default_rng(seed)
     W, H, n_img = 24, 18, 3
     root = tempfile.mkdtemp(prefix="nsr_warp_root_")
     result = tempfile.mkdtemp(prefix="nsr_warp_res_")
@@ -95,6 +106,8 @@ def main():
     for i in range(n_img):
         yy, xx = np.meshgrid(np.linspace(0, 1, H), np.linspace(0, 1, W), indexing="ij")
         d = 0.45 + 0.3 * np.sin(3 * xx + i) * np.cos(2 * yy) + 0.05 * rng.random((H, W))
+        if spheric:
+            d = 2.5 + 3.0 * d                                    # metric depth along the camera axis
         d = d.astype(np.float32)[..., None]                     # (H, W, 1) like out_fine_depth_ori reshaped by the visualiser
         np.savez(os.path.join(result, f"{i}-fine-depth-ori.npz"), d)
         depths.append(d[..., 0])
@@ -108,7 +121,15 @@ def main():
         exec(compile(src[:cut], os.path.join(mg.REF, "warp.py"), "exec"), ns)
     finally:
         os.chdir(cwd)
-    ds = ns["LLFFDataset"](root, result, W, H)
+    cls = ns["LLFFDataset"]
+    if spheric:
+        class SphericPoses(cls):
+            def define_transforms(self):      # runs after `self.spheric_poses = False`, before read_meta()
+                super().define_transforms()
+                self.spheric_poses = True
+        cls = SphericPoses
+    ds = cls(root, result, W, H)
+    assert bool(ds.spheric_poses) == spheric
     out = {"W": W, "H": H, "n_img": n_img, "focal": np.float64(ds.focal), "ref_w2c": np.asarray(ds.ref_w2c, np.float64),
            "ref_rgbs": mg.np32(ds.ref_rgbs)}
     assert len(ToPILImage.recorded) == n_img
@@ -120,7 +141,7 @@ def main():
         assert out[f"locs_{i}"].dtype == np.float64 and out[f"locs_{i}"].shape == (H, W, 3)
     inside = sum(int(((out[f"locs_{i}"][..., 0] >= 0) & (out[f"locs_{i}"][..., 0] < W) & (out[f"locs_{i}"][..., 1] >= 0)
                       & (out[f"locs_{i}"][..., 1] < H)).sum()) for i in range(n_img))
-    path = os.path.join(HERE, "warp_llff.npz")
+    path = os.path.join(HERE, fixture)
     np.savez_compressed(path, **out)
     print("warp fixture ->", path, f"{os.path.getsize(path) / 1024:.0f} KiB; pixels landing inside the reference view: {inside} of {n_img * H * W}")
 

@@ -17,9 +17,14 @@ def test_shard_bounds_cover_and_balance():
         assert len(b) == w and b[0][0] == 0 and b[-1][1] == n
         assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
         sizes = [hi - lo for lo, hi in b]
-        assert max(sizes) - min(sizes) <= 1
-    # config #4: 47,628 LR px over 8 GPUs -> 5,954/5,953 px per GPU
-    assert sorted({hi - lo for lo, hi in shard_bounds(47628, 8)}) == [5953, 5954]
+        cap = -(-n // w)
+        # every block but the tail has the common size (so the gathered buffer needs no compaction); imbalance < world
+        assert all(sz == cap for sz in sizes[:-1] if sz) or n < w * cap
+        assert all(sz <= cap for sz in sizes) and max(sizes) - min(sizes) <= max(w, 1)
+        assert sizes == sorted(sizes, reverse=True)
+    # config #4: 47,628 LR px over 8 GPUs -> 5,954 px on seven GPUs, 5,950 on the last (~5,953.5 each)
+    assert [hi - lo for lo, hi in shard_bounds(47628, 8)] == [5954] * 7 + [5950]
+    assert shard_bounds(5, 8) == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 5), (5, 5), (5, 5)]
     with pytest.raises(ValueError):
         shard_bounds(10, 0)
 
