@@ -65,6 +65,11 @@ SIGNATURES = {
     "nsr_refine_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                   c_void_p, c_void_p]),
     "nsr_refine_stitch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    # ---- include/nsr_image.h
+    "nsr_lanczos_ksize": (c_int, [c_int, c_int]),
+    "nsr_lanczos_coeffs": (c_int, [c_int, c_int, c_void_p, c_void_p]),
+    "nsr_resample_pass_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "nsr_image_to_targets": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nsr_linear": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64,
                            c_int64, c_int, c_int, c_void_p]),
 }

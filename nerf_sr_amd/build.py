@@ -23,15 +23,19 @@ UNITS = [
     ("nsr_render.hip", ["-ffp-contract=off"]),
     ("nsr_mlp.hip", ["-ffp-contract=off"]),
     ("nsr_mlp_f16.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
-    ("nsr_mlp_f16p.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("nsr_mlp_h1.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("nsr_gemm.hip", ["-ffp-contract=off"]),
     ("nsr_gemm_f16.hip", ["-ffp-contract=off"]),
     ("nsr_train.hip", ["-ffp-contract=off"]),
     ("nsr_warp.hip", ["-ffp-contract=off"]),
     ("nsr_refine.hip", ["-ffp-contract=off"]),
+    ("nsr_image.hip", ["-ffp-contract=off"]),
     ("nsr_api.hip", []),
 ]
+# experiment kernels: compiled (and dispatched, see the #ifdef in nsr_mlp.hip) only in a variant build that defines the flag
+VARIANT_UNITS = {
+    "-DNSR_F16X3_PAIR": ("nsr_mlp_f16p.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+}
 
 
 def _hipcc() -> str:
@@ -64,7 +68,7 @@ def build(force: bool = False, verbose: bool = True, variant: str = "", defines=
     os.makedirs(objdir, exist_ok=True)
     common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", *defines]
     objs = []
-    for src, extra in UNITS:
+    for src, extra in UNITS + [VARIANT_UNITS[d] for d in defines if d in VARIANT_UNITS]:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         srcp = os.path.join(CSRC, src)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < _newest_source_mtime():

@@ -67,13 +67,13 @@ __global__ void __launch_bounds__(256) pack_fp32_kernel(PackPtrs w, float* __res
 }
 
 // split-fp16 path (nsr_mlp_f16.hip)
-// split-fp16 kernels: nsr_mlp_f16p.hip (block-pair schedule, the product) -- or, in a -DNSR_F16X3_V1 ablation build,
-// the round-1 single-accumulator kernel of nsr_mlp_f16.hip
-#ifdef NSR_F16X3_V1
-#define nsr_f16x3_packed_bytes nsr_f16x3v1_packed_bytes
-#define nsr_f16x3_pack nsr_f16x3v1_pack
-#define nsr_f16x3_mlp_forward nsr_f16x3v1_mlp_forward
-#define nsr_f16x3_render_rays nsr_f16x3v1_render_rays
+// split-fp16 kernels: nsr_mlp_f16.hip (the product) -- or, in a -DNSR_F16X3_PAIR ablation build, the block-pair
+// schedule of nsr_mlp_f16p.hip (measured slower, profiles/r2_f16x3_pair_experiment.md)
+#ifdef NSR_F16X3_PAIR
+#define nsr_f16x3_packed_bytes nsr_f16x3p_packed_bytes
+#define nsr_f16x3_pack nsr_f16x3p_pack
+#define nsr_f16x3_mlp_forward nsr_f16x3p_mlp_forward
+#define nsr_f16x3_render_rays nsr_f16x3p_render_rays
 #endif
 extern "C" NSR_INTERNAL size_t nsr_f16x3_packed_bytes(void);
 extern "C" NSR_INTERNAL int nsr_f16x3_pack(const float* const* w, void* packed_dev, void* stream);

@@ -1,8 +1,15 @@
 // M1 / D2 on the fp16 matrix pipe with split operands ("f16x3", NSR_F16X3):
-// every fp32 value v is carried as hi = f16(v), lo = f16(v - hi) and each product is
+// every fp32 value v is carried as hi = RNE_f16(v), lo = RNE_f16(v - hi) and each product is
 // formed as a_hi*b_hi + (a_hi*b_lo + a_lo*b_hi) on v_mfma_f32_32x32x16_f16 with fp32
-// accumulation — products exact to ~2^-21, i.e. fp32-grade results (measured vs the
-// fp32 oracle: <= 3e-5 RGB) at 3/16 of the fp32-MFMA cycle cost.
+// accumulation, at 3/16 of the fp32-MFMA cycle cost.  Two details keep the split at its full
+// 22 bits, which is what puts the rendered colours as close to the fp32 oracle as the fp32-MFMA
+// kernel is (median |dRGB| 9e-8, worst non-exempt ray of 65,536 7e-5; round 1, without them: 5e-7 / 1.3e-4):
+//   * weights and biases are multiplied by 2^6 before they are split (exact): the lo part of a
+//     typical weight (|w| ~ 0.05 -> lo ~ 2^-16) otherwise sits on fp16's subnormal floor (2^-24)
+//     and loses three bits.  Accumulators therefore hold 64 x the layer output; the factor is
+//     removed, exactly, inside the conversion of a finished block (v_fma_mix: f16(x * 2^-6));
+//   * hi is rounded to nearest by that same v_fma_mix, so |lo| <= 2^-12 |v| (round 1: cvt_pkrtz,
+//     2^-11 |v|).
 //
 // Same register algebra as the fp32 kernel (nsr_mlp_layout.h): a wave owns 32 sample
 // points, activations never leave registers, weights stream global -> LDS by DMA.
@@ -24,6 +31,9 @@ using namespace nsr::hx;
 #else
 #define NSR_SYNC() do { dma_drain(); __syncthreads(); } while (0)
 #endif
+
+// weights and biases enter the stream multiplied by 2^6 (see the header); |w| < 1023 stays inside fp16
+constexpr float kWScale = 64.0f, kWInvScale = 1.0f / 64.0f;
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -70,9 +80,9 @@ __global__ void __launch_bounds__(256) pack_f16x3_kernel(PackPtrsH w, unsigned* 
     const int local = piece - c.piece0;
     const int npieces = chunk_pieces(c.steps, c.nnb);
     if (local == npieces - 1) {
-      // bias piece: fp32 bias of the chunk's output blocks, 32 per block
+      // bias piece: fp32 bias (x 2^6, like the weights) of the chunk's output blocks, 32 per block
       const int n_rows = (c.tensor == 20) ? 1 : 32 * c.nnb;     // sigma head: one real output row
-      if (word < n_rows) v = __float_as_uint(w.p[c.tensor + 1][32 * c.nb0 + word]);
+      if (word < n_rows) v = __float_as_uint(kWScale * w.p[c.tensor + 1][32 * c.nb0 + word]);
     } else {
       const int g = local / (2 * c.steps), rem = local % (2 * c.steps);
       const int s = rem >> 1, part = rem & 1;
@@ -84,23 +94,23 @@ __global__ void __launch_bounds__(256) pack_f16x3_kernel(PackPtrsH w, unsigned* 
       for (int e = 0; e < 2; ++e) {
         const int col = column_of(c.tensor, s, 2 * jj + e, h);
         const bool real_row = (c.tensor != 20) || n == 0;
-        f[e] = (col == kPad || !real_row) ? 0.0f : w.p[c.tensor][n * ld + col];
+        f[e] = (col == kPad || !real_row) ? 0.0f : kWScale * w.p[c.tensor][n * ld + col];
       }
       v = pack_hl(f[0], f[1], part);
     }
   } else {
     const int a = idx - stream_words;
     float f = 0.0f;
-    if (a < hx::kAuxRgbB) f = w.p[22][a];
+    if (a < hx::kAuxRgbB) f = kWInvScale * w.p[22][a];     // the colour head reads 64 x dir_encoding's output
     else if (a < hx::kAuxRgbB + 3) f = w.p[23][a - hx::kAuxRgbB];
     v = __float_as_uint(f);
   }
   out[idx] = v;
 }
 
-extern "C" NSR_INTERNAL size_t nsr_f16x3v1_packed_bytes(void) { return 4 * (size_t)(kPiecesTotal * 256 + hx::kAuxFloats); }
+extern "C" NSR_INTERNAL size_t nsr_f16x3_packed_bytes(void) { return 4 * (size_t)(kPiecesTotal * 256 + hx::kAuxFloats); }
 
-extern "C" NSR_INTERNAL int nsr_f16x3v1_pack(const float* const* w, void* packed_dev, void* stream) {
+extern "C" NSR_INTERNAL int nsr_f16x3_pack(const float* const* w, void* packed_dev, void* stream) {
   PackPtrsH pp;
   for (int i = 0; i < NSR_N_STATE_TENSORS; ++i) {
     if (!w[i]) return NSR_ERR_INVALID_ARG;
@@ -140,6 +150,18 @@ __device__ __forceinline__ void glds16_asm(const char* base_uniform, unsigned la
       "global_load_lds_dwordx4 %0, %1 offset:%3"
       :
       : "v"(lane_off), "s"(base_uniform), "s"(lds_dst_uniform), "i"(OFF)
+      : "memory");
+}
+// two consecutive pieces (OFF, OFF + 1024) with ONE M0 write
+template <int OFF>
+__device__ __forceinline__ void glds16x2_asm(const char* base_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1 offset:%3\n\t"
+      "global_load_lds_dwordx4 %0, %1 offset:%4"
+      :
+      : "v"(lane_off), "s"(base_uniform), "s"(lds_dst_uniform), "i"(OFF), "i"(OFF + 1024)
       : "memory");
 }
 // four consecutive pieces with ONE M0 write (6 issue slots instead of 12)
@@ -233,6 +255,17 @@ __device__ __forceinline__ void loader_issue(const Loader& ld, int i) {
   }
 }
 
+// pieces 2j, 2j + 1 (j = 0..3: always present) with one M0 write
+__device__ __forceinline__ void loader_issue2(const Loader& ld, int j) {
+#ifdef NSR_ABL_NO_DMA
+  return;
+#endif
+  const char* base = ld.dma_base + (j >> 1) * 4096;
+  const unsigned dst = ld.dma_lds + (unsigned)(j >> 1) * 4096u;
+  if (j & 1) glds16x2_asm<2048>(base, ld.lane_off, dst);
+  else glds16x2_asm<0>(base, ld.lane_off, dst);
+}
+
 // pieces 4g .. 4g+3 of the chunk being fetched, g = 0, 1 (always present)
 __device__ __forceinline__ void loader_issue4(const Loader& ld, int g) {
 #ifdef NSR_ABL_NO_DMA
@@ -277,7 +310,10 @@ struct Acc {
 
 // what a k-step sequence needs before its first MFMA: the A fragments of its first kPF k-steps (and, for
 // a new chunk, the accumulator init = bias).  Filled during the last k-steps of the preceding sequence.
-constexpr int kPF = 3;
+#ifndef NSR_F16X3_KPF
+#define NSR_F16X3_KPF 3
+#endif
+constexpr int kPF = NSR_F16X3_KPF;
 struct Pre {
   u32x4 ah[kPF], al[kPF];
   f32x16 bias;
@@ -335,19 +371,25 @@ __device__ __forceinline__ void block_mma(Acc& acc, const Pre& pre, unsigned a_a
     // sharing one M0 write -7 %: back-to-back LDS-DMA issues hold the wave longer than one MFMA; one piece per
     // k-step from an earlier publish point (k-step 5) -3 %.)
     if (BAR >= 0 && s >= BAR && s < BAR + 6) {
-      loader_issue(ld, 2 * (s - BAR));
-      loader_issue(ld, 2 * (s - BAR) + 1);
+#ifdef NSR_F16X3_DMA2
+      if (s - BAR < 4) loader_issue2(ld, s - BAR);   // pieces 0..7: every wave owns them, one M0 write per pair
+      else
+#endif
+      {
+        loader_issue(ld, 2 * (s - BAR));
+        loader_issue(ld, 2 * (s - BAR) + 1);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// v -> (hi, lo) fp16 pairs packed two per 32-bit register (round toward zero for hi; lo takes the rest)
+// v -> (hi, lo) fp16 pairs packed two per 32-bit register, both rounded to nearest (prologue only)
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
-  const auto ph = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-  const auto pl = __builtin_amdgcn_cvt_pkrtz(x0 - (float)ph[0], x1 - (float)ph[1]);
-  hi = __builtin_bit_cast(unsigned, ph);
-  lo = __builtin_bit_cast(unsigned, pl);
+  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+  const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+  hi = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+  lo = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
 }
 
 // Pair P (accumulator registers 2P, 2P+1) of the pending block -> operand registers of the consuming
@@ -367,11 +409,13 @@ __device__ __forceinline__ void pair_half_a(const Acc& p, float lower, PairTmp& 
 #ifdef NSR_ABL_NO_CONVERT
   t.hi = __float_as_uint(t.x0);
 #else
-  t.hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(t.x0, t.x1));
+  // hi = RNE_f16(x * 2^-6) for both values (removes the weight scale).  asm volatile pins the work HERE (MFMA
+  // shadow of the current k-step); LLVM would otherwise sink it to its first use, i.e. serialise all eight
+  // blocks' conversions at the layer end
+  asm volatile("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
+               : "=&v"(t.hi)
+               : "v"(t.x0), "v"(t.x1), "v"(kWInvScale));
 #endif
-  // pin the work HERE (MFMA shadow of the current k-step); LLVM would otherwise sink it to its first use,
-  // i.e. serialise all eight blocks' conversions at the layer end
-  asm volatile("" : "+v"(t.hi), "+v"(t.x0), "+v"(t.x1));
   if (P < 4) h0[P & 3] = t.hi; else h1[P & 3] = t.hi;
 }
 template <int P>
@@ -379,14 +423,14 @@ __device__ __forceinline__ void pair_half_b(const PairTmp& t, u32x4& l0, u32x4& 
 #ifdef NSR_ABL_NO_CONVERT
   unsigned lo = __float_as_uint(t.x1);
 #else
-  // lo = f16(x - hi) for both halves with two mixed-precision FMAs (f16 source half * -1.0 + f32 -> f16 half):
-  // 2 issues instead of unpack x2, subtract x2, pack
+  // lo = RNE_f16(x * 2^-6 - hi) for both halves with two mixed-precision FMAs (f32 * f32 - f16 half -> f16 half);
+  // the fma result is exact in fp32 (hi is within 2^-12 of x * 2^-6)
   unsigned lo;
   asm volatile(
-      "v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      "v_fma_mixlo_f16 %0, %2, %4, -%1 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %3, %4, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
       : "=&v"(lo)
-      : "v"(t.hi), "v"(t.x0), "v"(t.x1));
+      : "v"(t.hi), "v"(t.x0), "v"(t.x1), "v"(kWInvScale));
 #endif
   if (P < 4) l0[P & 3] = lo; else l1[P & 3] = lo;
 }
@@ -490,8 +534,11 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
       block_mma<4, -1>(
           cur, pre, a_addr, ld, c2, [&](int s, int part) -> u32x4 { return pe8[4 * part + s]; }, [&](int) {},
           [&](int k) { prefetch_frag(mid, k, a_addr + 8 * 1024); });
-      pre.ah[0] = mid.ah[0]; pre.ah[1] = mid.ah[1]; pre.ah[2] = mid.ah[2];
-      pre.al[0] = mid.al[0]; pre.al[1] = mid.al[1]; pre.al[2] = mid.al[2];
+#pragma unroll
+      for (int k = 0; k < kPF; ++k) {
+        pre.ah[k] = mid.ah[k];
+        pre.al[k] = mid.al[k];
+      }
       a_addr += 8 * 1024;
     }
     block_mma<16, kBar>(
@@ -695,7 +742,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
         [&](int k) {
           if (!SIGMA_ONLY) prefetch_next_chunk(nxt, k, ld, next_bias, h);
         });
-    sigma = cur.m[0];                        // row 0 of the block lives in register 0 of the h == 0 lanes
+    sigma = cur.m[0] * kWInvScale;           // row 0 of the block lives in register 0 of the h == 0 lanes
     pre = nxt;
     loader_advance(ld);
   }
@@ -756,13 +803,13 @@ static int launch_f16x3(const void* packed, const float* x, const float* z, int6
   return NSR_OK;
 }
 
-extern "C" NSR_INTERNAL int nsr_f16x3v1_mlp_forward(const void* packed, const float* x, int64_t P, int sigma_only, float* out,
+extern "C" NSR_INTERNAL int nsr_f16x3_mlp_forward(const void* packed, const float* x, int64_t P, int sigma_only, float* out,
                                      void* stream) {
   return sigma_only ? launch_f16x3<0, true>(packed, x, nullptr, P, 1, 8, out, nsr_stream(stream))
                     : launch_f16x3<0, false>(packed, x, nullptr, P, 1, 8, out, nsr_stream(stream));
 }
 
-extern "C" NSR_INTERNAL int nsr_f16x3v1_render_rays(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
+extern "C" NSR_INTERNAL int nsr_f16x3_render_rays(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
                                      int N, float* out, void* stream) {
   return launch_f16x3<1, false>(packed, rays, z, R * N, N, ray_stride, out, nsr_stream(stream));
 }

@@ -1,4 +1,9 @@
 // M1 / D2 on the fp16 matrix pipe with split operands ("f16x3", NSR_F16X3), block-PAIR schedule.
+// EXPERIMENT, not the product: built and dispatched only with -DNSR_F16X3_PAIR (python -m nerf_sr_amd.build --variant
+// pair -DNSR_F16X3_PAIR).  Measured on MI355X (profiles/r2_f16x3_pair_experiment.md): same results as the product
+// kernel (all parity tests pass), fine pass 66.7 ms against 60.7-62 ms: the premise below -- that back-to-back MFMAs
+// on ONE accumulator stall -- is wrong for this part (a bare loop issues them at the full rate), so the pair schedule
+// only adds 2 % of bias MFMAs and a clumpier DMA issue pattern.
 //
 // Arithmetic: every fp32 value v is carried as hi = RNE_f16(v), lo = RNE_f16(v - hi); a product is
 // a_hi*b_hi + (a_hi*b_lo + a_lo*b_hi) on v_mfma_f32_32x32x16_f16 with fp32 accumulation.  Two details keep
@@ -639,9 +644,9 @@ static int launch(const void* packed, const float* x, const float* z, int64_t P,
 
 }  // namespace fp
 
-extern "C" NSR_INTERNAL size_t nsr_f16x3_packed_bytes(void) { return 4 * (size_t)(fp::kPiecesTotal * 256 + fp::kAuxFloats); }
+extern "C" NSR_INTERNAL size_t nsr_f16x3p_packed_bytes(void) { return 4 * (size_t)(fp::kPiecesTotal * 256 + fp::kAuxFloats); }
 
-extern "C" NSR_INTERNAL int nsr_f16x3_pack(const float* const* w, void* packed_dev, void* stream) {
+extern "C" NSR_INTERNAL int nsr_f16x3p_pack(const float* const* w, void* packed_dev, void* stream) {
   fp::PackPtrs pp;
   for (int i = 0; i < NSR_N_STATE_TENSORS; ++i) {
     if (!w[i]) return NSR_ERR_INVALID_ARG;
@@ -654,13 +659,13 @@ extern "C" NSR_INTERNAL int nsr_f16x3_pack(const float* const* w, void* packed_d
   return NSR_OK;
 }
 
-extern "C" NSR_INTERNAL int nsr_f16x3_mlp_forward(const void* packed, const float* x, int64_t P, int sigma_only, float* out,
+extern "C" NSR_INTERNAL int nsr_f16x3p_mlp_forward(const void* packed, const float* x, int64_t P, int sigma_only, float* out,
                                                   void* stream) {
   return sigma_only ? fp::launch<0, true>(packed, x, nullptr, P, 1, 8, out, nsr_stream(stream))
                     : fp::launch<0, false>(packed, x, nullptr, P, 1, 8, out, nsr_stream(stream));
 }
 
-extern "C" NSR_INTERNAL int nsr_f16x3_render_rays(const void* packed, const float* rays, int ray_stride, const float* z,
+extern "C" NSR_INTERNAL int nsr_f16x3p_render_rays(const void* packed, const float* rays, int ray_stride, const float* z,
                                                   int64_t R, int N, float* out, void* stream) {
   return fp::launch<1, false>(packed, rays, z, R * N, N, ray_stride, out, nsr_stream(stream));
 }

@@ -8,6 +8,9 @@ Host-side, numpy only (the reference's versions are host-side Python too):
     identical in warp.py:35-92): focal rescale, camera-to-world, near/far bounds from the visible points,
     'right down front' -> 'right up back', centring on the average pose, rescaling so the nearest depth is 1 / 0.75
   * Blender ``transforms_{split}.json`` (data/blender_downX_dataset.py:60-95): focal from ``camera_angle_x``, 4x4 poses
+  * LR training targets (data/llff_downX_dataset.py:312-329): Pillow's 8-bit LANCZOS resize to the HR and LR sizes,
+    ``/ 255`` and the sub-pixel regroup -- these run ON THE DEVICE (include/nsr_image.h), bit-identical to Pillow;
+    decoding the image file itself (PNG / JPEG -> uint8 array) stays with the caller (PIL, like the reference)
 """
 from __future__ import annotations
 
@@ -150,63 +153,64 @@ def read_points3d_binary(path: str) -> Dict[int, Point3D]:
 # ------------------------------------------------------------------------------------------------ LLFF pose pipeline
 
 
-def _normalize(v):
+def _unit(v: np.ndarray) -> np.ndarray:
     return v / np.linalg.norm(v)
 
 
 def average_pose(poses: np.ndarray) -> np.ndarray:
-    """(3, 4) average pose: mean centre, z = mean z, x = y' cross z, y = z cross x (data/llff_dataset.py:21-56)."""
-    center = poses[..., 3].mean(0)
-    z = _normalize(poses[..., 2].mean(0))
-    y_ = poses[..., 1].mean(0)
-    x = _normalize(np.cross(y_, z))
-    y = np.cross(z, x)
-    return np.stack([x, y, z, center], 1)
+    """The (3, 4) frame the scene is re-centred on (data/llff_dataset.py:21-56): origin at the mean camera centre,
+    z along the mean viewing axis, x perpendicular to z and to the mean up vector, y completing the right-handed
+    frame -- an orthonormal basis by construction."""
+    mean_up, mean_back = poses[:, :, 1].mean(0), poses[:, :, 2].mean(0)
+    z = _unit(mean_back)
+    x = _unit(np.cross(mean_up, z))
+    return np.column_stack([x, np.cross(z, x), z, poses[:, :, 3].mean(0)])
 
 
 def center_poses(poses: np.ndarray):
-    """inv(average pose) @ poses (data/llff_dataset.py:59-83)."""
-    avg = average_pose(poses)
-    avg_h = np.eye(4)
-    avg_h[:3] = avg
-    last = np.tile(np.array([0, 0, 0, 1]), (len(poses), 1, 1))
-    poses_h = np.concatenate([poses, last], 1)
-    return (np.linalg.inv(avg_h) @ poses_h)[:, :3], avg
+    """Express every pose in the average pose's frame (data/llff_dataset.py:59-83).  The frame is a rigid transform
+    [R | t] with orthonormal R, so its inverse is [R^T | -R^T t]: no 4 x 4 homogeneous matrices are built or
+    inverted (the reference's np.linalg.inv route agrees to ~1e-16)."""
+    frame = average_pose(poses)
+    rot_t, origin = frame[:, :3].T, frame[:, 3]
+    centred = np.empty_like(poses, dtype=np.float64)
+    centred[:, :, :3] = rot_t @ poses[:, :, :3]
+    centred[:, :, 3] = (poses[:, :, 3] - origin) @ rot_t.T
+    return centred, frame
+
+
+def _visible_depth_bounds(centres: np.ndarray, view_axes: np.ndarray, pts3d: Dict[int, Point3D]) -> np.ndarray:
+    """Per camera: the 0.1 / 99.9 percentiles of the depth (along the camera's z axis) of the scene points COLMAP
+    saw in that image (read_meta, "Step 2: read bounds").  Like the reference, row ``image_id - 1`` of the visibility
+    table is taken to be the camera at position ``image_id - 1`` of the images file."""
+    ids = list(pts3d)
+    xyz = np.stack([pts3d[k].xyz for k in ids], 0)                                  # (P, 3)
+    counts = np.array([len(pts3d[k].image_ids) for k in ids])
+    seen = np.zeros((len(centres), len(ids)), dtype=bool)
+    seen[np.concatenate([pts3d[k].image_ids for k in ids]).astype(np.int64) - 1, np.repeat(np.arange(len(ids)), counts)] = True
+    depth = np.einsum("npc,nc->np", xyz[None] - centres[:, None], view_axes)        # (N, P)
+    return np.array([np.percentile(depth[i, seen[i]], (0.1, 99.9)) for i in range(len(centres))])
 
 
 def llff_scene_from_colmap(sparse_dir: str, img_w: int) -> Dict[str, object]:
-    """``read_meta`` steps 1-3 of the LLFF datasets (data/llff_downX_dataset.py; same code in warp.py:35-92):
-    returns focal (at width ``img_w``), image names (sorted), centred + rescaled camera-to-world poses (N, 3, 4)
-    float64, per-image near/far bounds (N, 2), the index of the validation view and the scale factor."""
+    """``read_meta`` steps 1-3 of the LLFF datasets (data/llff_downX_dataset.py:196-249; the same code is in
+    warp.py:35-92): returns focal (at width ``img_w``), image names (sorted), centred + rescaled camera-to-world
+    poses (N, 3, 4) float64, per-image near/far bounds (N, 2), the index of the validation view and the scale factor."""
     cam = read_cameras_binary(os.path.join(sparse_dir, "cameras.bin"))[1]
-    focal = cam.params[0] * img_w / cam.width
-    imdata = read_images_binary(os.path.join(sparse_dir, "images.bin"))
-    perm = np.argsort([imdata[k].name for k in imdata])
-    names = sorted(imdata[k].name for k in imdata)
-    bottom = np.array([0, 0, 0, 1.0]).reshape(1, 4)
-    w2c = np.stack([np.concatenate([np.concatenate([imdata[k].qvec2rotmat(), imdata[k].tvec.reshape(3, 1)], 1), bottom], 0)
-                    for k in imdata], 0)
-    poses = np.linalg.inv(w2c)[:, :3]
-    pts3d = read_points3d_binary(os.path.join(sparse_dir, "points3D.bin"))
-    pts_world = np.zeros((1, 3, len(pts3d)))
-    vis = np.zeros((len(poses), len(pts3d)))
-    for i, k in enumerate(pts3d):
-        pts_world[0, :, i] = pts3d[k].xyz
-        for j in pts3d[k].image_ids:
-            vis[j - 1, i] = 1
-    depths = ((pts_world - poses[..., 3:4]) * poses[..., 2:3]).sum(1)
-    bounds = np.zeros((len(poses), 2))
-    for i in range(len(poses)):
-        zs = depths[i][vis[i] == 1]
-        bounds[i] = [np.percentile(zs, 0.1), np.percentile(zs, 99.9)]
-    poses, bounds = poses[perm], bounds[perm]
-    poses = np.concatenate([poses[..., 0:1], -poses[..., 1:3], poses[..., 3:4]], -1)   # right down front -> right up back
-    poses, _ = center_poses(poses)
-    val_idx = int(np.argmin(np.linalg.norm(poses[..., 3], axis=1)))
-    scale = bounds.min() * 0.75
-    bounds = bounds / scale
-    poses[..., 3] /= scale
-    return {"focal": float(focal), "names": names, "poses": poses, "bounds": bounds, "val_idx": val_idx, "scale_factor": float(scale)}
+    images = list(read_images_binary(os.path.join(sparse_dir, "images.bin")).values())      # file order
+    # world-to-camera [R | t] of every image, inverted as a rigid transform: camera-to-world [R^T | -R^T t]
+    rot = np.stack([im.qvec2rotmat() for im in images], 0)
+    c2w = np.concatenate([rot.transpose(0, 2, 1), -np.einsum("nji,nj->ni", rot, np.stack([im.tvec for im in images]))[..., None]], 2)
+    bounds = _visible_depth_bounds(c2w[:, :, 3], c2w[:, :, 2], read_points3d_binary(os.path.join(sparse_dir, "points3D.bin")))
+    order = np.argsort([im.name for im in images])                                           # images sorted by file name
+    c2w, bounds = c2w[order], bounds[order]
+    c2w = c2w * np.array([1.0, -1.0, -1.0, 1.0])           # COLMAP "right down front" -> "right up back" (bmild/nerf#34)
+    poses, _ = center_poses(c2w)
+    scale = bounds.min() * 0.75                            # nearest depth ends up at 1 / 0.75 (kwea123/nerf_pl#50)
+    poses[:, :, 3] /= scale
+    return {"focal": float(cam.params[0] * img_w / cam.width), "names": [images[i].name for i in order], "poses": poses,
+            "bounds": bounds / scale, "val_idx": int(np.argmin(np.linalg.norm(poses[:, :, 3], axis=1))),
+            "scale_factor": float(scale)}
 
 
 # ------------------------------------------------------------------------------------------------ Blender scenes
@@ -220,3 +224,65 @@ def load_blender_transforms(path: str, img_w: int) -> Dict[str, object]:
     focal = 0.5 * 800 / np.tan(0.5 * meta["camera_angle_x"]) * img_w / 800
     poses = np.stack([np.array(fr["transform_matrix"], dtype=np.float64)[:3, :4] for fr in meta["frames"]], 0)
     return {"focal": float(focal), "poses": poses, "files": [fr["file_path"] for fr in meta["frames"]], "near": 2.0, "far": 6.0}
+
+
+# ------------------------------------------------------------------------------------------------ LR targets (device)
+
+
+def lanczos_tables(in_size: int, out_size: int):
+    """Pillow's fixed-point LANCZOS weights for resampling ``in_size`` -> ``out_size`` samples, computed on the host in
+    double precision by libnsr (``nsr_lanczos_coeffs``): ``bounds`` (out_size, 2) int32, ``kk`` (out_size, ksize) int32."""
+    from . import _lib
+    lib = _lib.load()
+    ksize = lib.nsr_lanczos_ksize(int(in_size), int(out_size))
+    if ksize <= 0:
+        raise ValueError("sizes must be positive")
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    _lib.check(lib.nsr_lanczos_coeffs(int(in_size), int(out_size), bounds.ctypes.data, kk.ctypes.data), "nsr_lanczos_coeffs")
+    return bounds, kk
+
+
+def resize_lanczos_u8(img, out_wh):
+    """``PIL.Image.resize(out_wh, Image.LANCZOS)`` of an (H, W, C) uint8 image ON THE DEVICE, bit-identical to Pillow
+    (horizontal pass, then vertical pass; include/nsr_image.h).  ``img``: uint8 torch tensor on the GPU."""
+    import torch
+    from . import _lib
+    from .ops import _check_device, _p, _stream
+    if img.dtype != torch.uint8 or img.ndim != 3:
+        raise TypeError("img must be an (H, W, C) uint8 tensor")
+    _check_device(img.device, "img")
+    img = img.contiguous()
+    lib = _lib.load()
+    w, h = int(out_wh[0]), int(out_wh[1])
+    for axis, out_size in ((1, w), (0, h)):
+        H, W, C = img.shape
+        in_size = W if axis == 1 else H
+        if out_size == in_size:
+            continue
+        bounds, kk = lanczos_tables(in_size, out_size)
+        b_dev, k_dev = torch.from_numpy(bounds).to(img.device), torch.from_numpy(kk).to(img.device)
+        dst = torch.empty((H, out_size, C) if axis == 1 else (out_size, W, C), dtype=torch.uint8, device=img.device)
+        _lib.check(lib.nsr_resample_pass_u8(_p(img), H, W, C, axis, out_size, _p(b_dev), _p(k_dev), kk.shape[1], _p(dst),
+                                            _stream()), "nsr_resample_pass_u8")
+        img = dst
+    return img
+
+
+def lr_targets(img_u8, img_wh, downscale: int):
+    """What the downX datasets keep per training image (data/llff_downX_dataset.py:312-329, ``ds_method='lanc'``):
+    the scene image -> HR ``img_wh`` -> LR ``img_wh / s`` (LANCZOS, 8 bit), then ``rgbs`` (N_lr, 3) = LR / 255 and
+    ``rgbs_ori`` (N_lr, s*s, 3) = HR / 255 in the ray tensor's LR-pixel-major order.  Everything on the device."""
+    import torch
+    from . import _lib
+    from .ops import _p, _stream
+    W, H = int(img_wh[0]), int(img_wh[1])
+    s = int(downscale)
+    hr = resize_lanczos_u8(img_u8, (W, H))
+    lr = resize_lanczos_u8(hr, (W // s, H // s))
+    lib = _lib.load()
+    rgbs = torch.empty((H // s) * (W // s), 3, dtype=torch.float32, device=hr.device)
+    ori = torch.empty((H // s) * (W // s), s * s, 3, dtype=torch.float32, device=hr.device)
+    _lib.check(lib.nsr_image_to_targets(_p(lr), H // s, W // s, 1, _p(rgbs), _stream()), "nsr_image_to_targets")
+    _lib.check(lib.nsr_image_to_targets(_p(hr), H, W, s, _p(ori), _stream()), "nsr_image_to_targets")
+    return rgbs, ori
