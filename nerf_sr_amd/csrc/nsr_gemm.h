@@ -26,7 +26,14 @@ struct GemmArgs {
   int64_t split_stride;             //      (bias / act / mask must be off; Ct unused)
   float* col_sums;                  // may be null: (ceil(M / 128), N) per-row-tile column sums of the values written
                                     // (the bias gradient of the layer whose pre-activation gradient this GEMM makes)
+  float acc_scale;                  // 0 or 1: off; else the accumulator is multiplied by it before the bias (removes the
+                                    // power-of-two scale of pre-scaled split-fp16 weights, kSplitScale)
 };
+
+// Weights handed to gemm_f16x3 are multiplied by 2^6 before they are split into fp16 (hi, lo) halves (exact), and the
+// consumer sets acc_scale = 2^-6: the lo half of a typical weight (|w| ~ 0.02-0.05 -> lo ~ 2^-17) otherwise sits on
+// fp16's subnormal floor (2^-24) and loses three of its eleven bits.  |w| < 1023 stays inside fp16.
+constexpr float kSplitScale = 64.0f, kSplitInvScale = 1.0f / 64.0f;
 
 // enqueue; returns NSR_OK / NSR_ERR_*.  K-major operands need their non-K extent to be a multiple of 4.
 NSR_INTERNAL int gemm(const GemmArgs& g, hipStream_t st);
@@ -49,7 +56,7 @@ struct GemmF16Args {
   ConvGather conv;
 };
 NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st);
-// hi[i] = fp16(w[i]), lo[i] = fp16(w[i] - hi[i])
+// v = kSplitScale * w[i];  hi[i] = fp16(v), lo[i] = fp16(v - hi[i])   (round to nearest)
 NSR_INTERNAL int split_f16(const float* w, int64_t n, unsigned short* hi, unsigned short* lo, hipStream_t st);
 
 }  // namespace nsr

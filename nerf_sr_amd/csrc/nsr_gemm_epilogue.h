@@ -22,6 +22,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
     const int n = n0 + 64 * wn + 32 * bj + li;
     if (!col_on[bj] || n >= g.n_valid) continue;
     const float bias = g.bias ? g.bias[n] : 0.0f;
+    const bool scaled = g.acc_scale != 0.0f && g.acc_scale != 1.0f;
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi) {
       const int64_t mb = m0 + 64 * wm + 32 * bi + 4 * h;
@@ -40,7 +41,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int64_t m = mb + 8 * rq + e;
-          float x = acc[bi][bj][4 * rq + e] + bias;
+          float x = scaled ? fmaf(acc[bi][bj][4 * rq + e], g.acc_scale, bias) : acc[bi][bj][4 * rq + e] + bias;
           if (g.act == kActRelu) x = fmaxf(x, 0.0f);
           else if (g.act == kActSigmoid) x = 1.0f / (1.0f + expf(-x));
           else if (g.act == kActTanh) x = tanhf(x);

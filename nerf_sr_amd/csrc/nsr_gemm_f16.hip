@@ -25,7 +25,7 @@ __global__ void split_f16_kernel(const float* __restrict__ w, int64_t n, unsigne
                                  unsigned short* __restrict__ lo) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float x = w[i];
+  const float x = kSplitScale * w[i];
   const _Float16 h = (_Float16)x;
   const _Float16 l = (_Float16)(x - (float)h);
   hi[i] = __builtin_bit_cast(unsigned short, h);

@@ -371,11 +371,9 @@ __device__ __forceinline__ void block_mma(Acc& acc, const Pre& pre, unsigned a_a
     // sharing one M0 write -7 %: back-to-back LDS-DMA issues hold the wave longer than one MFMA; one piece per
     // k-step from an earlier publish point (k-step 5) -3 %.)
     if (BAR >= 0 && s >= BAR && s < BAR + 6) {
-#ifdef NSR_F16X3_DMA2
-      if (s - BAR < 4) loader_issue2(ld, s - BAR);   // pieces 0..7: every wave owns them, one M0 write per pair
-      else
-#endif
-      {
+      if (s - BAR < 4) {
+        loader_issue2(ld, s - BAR);   // pieces 0..7: every wave owns them, one M0 write per pair
+      } else {
         loader_issue(ld, 2 * (s - BAR));
         loader_issue(ld, 2 * (s - BAR) + 1);
       }
@@ -392,79 +390,98 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
   lo = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
 }
 
-// Pair P (accumulator registers 2P, 2P+1) of the pending block -> operand registers of the consuming
-// layer: block nb becomes k-steps 2nb (P < 4 -> h0/l0) and 2nb+1 (P >= 4 -> h1/l1), element P & 3.
-// Done in two halves so that no k-step carries more than ~5 extra VALU issues (a wave has ~5 free
-// issue slots per MFMA): A = activation + hi, B = lo.
+// Re-split of the pending block: accumulator pair P (registers 2P, 2P+1; P = 0..7) -> activation -> (hi, lo) fp16
+// pairs in the operand registers of the consuming layer: block nb becomes k-steps 2nb (P < 4 -> h0 / l0) and 2nb + 1
+// (P >= 4 -> h1 / l1), element P & 3.  Six VALU instructions per pair:
+//   x0, x1 = max(acc, lower)           (raw v_max: fmaxf() would add a canonicalising v_max per operand)
+//   hi     = RNE_f16(x * 2^-6)         (v_fma_mixlo / mixhi: removes the weight scale)
+//   lo     = RNE_f16(x * 2^-6 - hi)    (v_fma_mixlo / mixhi, f16 source; the fma result is exact in fp32)
+// issued as 17 HALF-STEPS of three instructions in which neighbours never depend on each other -- the lo of pair
+// P - 1 is interleaved with the hi of pair P -- because a wave with the matrix pipe to feed cannot afford to wait for
+// its own VALU results (measured: the same six instructions as two dependent chains cost 8 % of the launch):
+//   half-step 2P     : max x0_P ; max x1_P ; hi_P.lo16 = mix(x0_P)
+//   half-step 2P + 1 : lo_{P-1}.lo16 = mix(x0_{P-1}, hi_{P-1}) ; hi_P.hi16 = mix(x1_P) ; lo_{P-1}.hi16 = mix(x1_{P-1}, hi_{P-1})
+//   half-step 16     : lo_7
+// asm volatile pins each half-step into its k-step (MFMA shadow); LLVM would otherwise sink the work to its first
+// use, i.e. serialise all eight blocks' conversions at the layer end.
 struct PairTmp {
   float x0, x1;
   unsigned hi;
 };
+struct Resplit {
+  PairTmp t[2];   // pairs alternate between the two sets: pair P - 1 is still live while pair P starts
+};
 template <int P>
-__device__ __forceinline__ void pair_half_a(const Acc& p, float lower, PairTmp& t, u32x4& h0, u32x4& h1) {
-  // activation = max(x, lower); raw v_max: fmaxf() would add a canonicalising v_max per operand
-  asm volatile("v_max_f32 %0, %2, %4\n\tv_max_f32 %1, %3, %4"
-               : "=&v"(t.x0), "=&v"(t.x1)
-               : "v"(p.m[2 * P]), "v"(p.m[2 * P + 1]), "v"(lower));
+__device__ __forceinline__ void put(unsigned v, u32x4& d0, u32x4& d1) {
+  if (P < 4) d0[P & 3] = v; else d1[P & 3] = v;
+}
+template <int P>
+__device__ __forceinline__ void resplit_a(const Acc& p, float lower, Resplit& r) {
+  PairTmp& t = r.t[P & 1];
 #ifdef NSR_ABL_NO_CONVERT
+  asm volatile("v_max_f32 %0, %2, %4\n\tv_max_f32 %1, %3, %4" : "=&v"(t.x0), "=&v"(t.x1) : "v"(p.m[2 * P]), "v"(p.m[2 * P + 1]), "v"(lower));
   t.hi = __float_as_uint(t.x0);
 #else
-  // hi = RNE_f16(x * 2^-6) for both values (removes the weight scale).  asm volatile pins the work HERE (MFMA
-  // shadow of the current k-step); LLVM would otherwise sink it to its first use, i.e. serialise all eight
-  // blocks' conversions at the layer end
-  asm volatile("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
-               : "=&v"(t.hi)
-               : "v"(t.x0), "v"(t.x1), "v"(kWInvScale));
-#endif
-  if (P < 4) h0[P & 3] = t.hi; else h1[P & 3] = t.hi;
-}
-template <int P>
-__device__ __forceinline__ void pair_half_b(const PairTmp& t, u32x4& l0, u32x4& l1) {
-#ifdef NSR_ABL_NO_CONVERT
-  unsigned lo = __float_as_uint(t.x1);
-#else
-  // lo = RNE_f16(x * 2^-6 - hi) for both halves with two mixed-precision FMAs (f32 * f32 - f16 half -> f16 half);
-  // the fma result is exact in fp32 (hi is within 2^-12 of x * 2^-6)
-  unsigned lo;
   asm volatile(
-      "v_fma_mixlo_f16 %0, %2, %4, -%1 op_sel_hi:[0,0,1]\n\t"
-      "v_fma_mixhi_f16 %0, %3, %4, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-      : "=&v"(lo)
-      : "v"(t.hi), "v"(t.x0), "v"(t.x1), "v"(kWInvScale));
+      "v_max_f32 %0, %3, %5\n\t"
+      "v_max_f32 %1, %4, %5\n\t"
+      "v_fma_mixlo_f16 %2, %0, %6, 0 op_sel_hi:[0,0,0]"
+      : "=&v"(t.x0), "=&v"(t.x1), "=&v"(t.hi)
+      : "v"(p.m[2 * P]), "v"(p.m[2 * P + 1]), "v"(lower), "v"(kWInvScale));
 #endif
-  if (P < 4) l0[P & 3] = lo; else l1[P & 3] = lo;
 }
-// half-pair number hp (0..15) of the pending block
-__device__ __forceinline__ void pending_half(int hp, const Acc& p, float lower, PairTmp& t, u32x4& h0, u32x4& l0,
-                                             u32x4& h1, u32x4& l1) {
-  switch (hp) {
-    case 0: pair_half_a<0>(p, lower, t, h0, h1); break;
-    case 1: pair_half_b<0>(t, l0, l1); break;
-    case 2: pair_half_a<1>(p, lower, t, h0, h1); break;
-    case 3: pair_half_b<1>(t, l0, l1); break;
-    case 4: pair_half_a<2>(p, lower, t, h0, h1); break;
-    case 5: pair_half_b<2>(t, l0, l1); break;
-    case 6: pair_half_a<3>(p, lower, t, h0, h1); break;
-    case 7: pair_half_b<3>(t, l0, l1); break;
-    case 8: pair_half_a<4>(p, lower, t, h0, h1); break;
-    case 9: pair_half_b<4>(t, l0, l1); break;
-    case 10: pair_half_a<5>(p, lower, t, h0, h1); break;
-    case 11: pair_half_b<5>(t, l0, l1); break;
-    case 12: pair_half_a<6>(p, lower, t, h0, h1); break;
-    case 13: pair_half_b<6>(t, l0, l1); break;
-    case 14: pair_half_a<7>(p, lower, t, h0, h1); break;
-    case 15: pair_half_b<7>(t, l0, l1); break;
+template <int P>   // P = 0..8: finishes hi of pair P (P < 8) and makes lo of pair P - 1 (P > 0)
+__device__ __forceinline__ void resplit_b(Resplit& r, u32x4& h0, u32x4& l0, u32x4& h1, u32x4& l1) {
+  PairTmp& cur = r.t[P & 1];
+  const PairTmp& prev = r.t[(P & 1) ^ 1];
+#ifdef NSR_ABL_NO_CONVERT
+  if (P < 8) put<(P < 8 ? P : 0)>(cur.hi, h0, h1);
+  if (P > 0) put<(P > 0 ? P - 1 : 0)>(__float_as_uint(prev.x1), l0, l1);
+#else
+  unsigned lo = 0;
+  if (P == 0) {
+    asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(cur.hi) : "v"(cur.x1), "v"(kWInvScale));
+  } else if (P < 8) {
+    asm volatile(
+        "v_fma_mixlo_f16 %1, %4, %6, -%3 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %2, %6, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %5, %6, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "+v"(cur.hi), "=&v"(lo)
+        : "v"(cur.x1), "v"(prev.hi), "v"(prev.x0), "v"(prev.x1), "v"(kWInvScale));
+  } else {
+    asm volatile(
+        "v_fma_mixlo_f16 %0, %2, %4, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(lo)
+        : "v"(prev.hi), "v"(prev.x0), "v"(prev.x1), "v"(kWInvScale));
+  }
+  if (P < 8) put<(P < 8 ? P : 0)>(cur.hi, h0, h1);
+  if (P > 0) put<(P > 0 ? P - 1 : 0)>(lo, l0, l1);
+#endif
+}
+// half-step hs (0..16) of the pending block
+__device__ __forceinline__ void pending_half(int hs, const Acc& p, float lower, Resplit& r, u32x4& h0, u32x4& l0, u32x4& h1,
+                                             u32x4& l1) {
+  switch (hs) {
+#define NSR_HS(P)                                          \
+    case 2 * P: resplit_a<P>(p, lower, r); break;          \
+    case 2 * P + 1: resplit_b<P>(r, h0, l0, h1, l1); break;
+    NSR_HS(0) NSR_HS(1) NSR_HS(2) NSR_HS(3) NSR_HS(4) NSR_HS(5) NSR_HS(6) NSR_HS(7)
+#undef NSR_HS
+    case 16: resplit_b<8>(r, h0, l0, h1, l1); break;
     default: break;
   }
 }
-// Schedule over the k-steps of a 16-step chunk: 16 halves in k-steps 0..13 (k-steps 0 and 7 take two), so
-// that even the operands of k-steps 14, 15 (block 7 of the previous layer) are ready before they are used.
-__device__ __forceinline__ void pending_step(int s, const Acc& p, float lower, PairTmp& t, u32x4& h0, u32x4& l0,
-                                             u32x4& h1, u32x4& l1) {
-  if (s == 0) { pending_half(0, p, lower, t, h0, l0, h1, l1); pending_half(1, p, lower, t, h0, l0, h1, l1); }
-  else if (s < 7) pending_half(s + 1, p, lower, t, h0, l0, h1, l1);
-  else if (s == 7) { pending_half(8, p, lower, t, h0, l0, h1, l1); pending_half(9, p, lower, t, h0, l0, h1, l1); }
-  else if (s < 14) pending_half(s + 2, p, lower, t, h0, l0, h1, l1);
+// Schedule over the k-steps of a 16-step chunk: 17 half-steps in k-steps 0..13 (k-steps 0, 1, 2 take two), so that
+// even the operands of k-steps 14, 15 (block 7 of the previous layer) are complete before they are used.
+__device__ __forceinline__ void pending_step(int s, const Acc& p, float lower, Resplit& r, u32x4& h0, u32x4& l0, u32x4& h1,
+                                             u32x4& l1) {
+  if (s < 3) {
+    pending_half(2 * s, p, lower, r, h0, l0, h1, l1);
+    pending_half(2 * s + 1, p, lower, r, h0, l0, h1, l1);
+  } else if (s < 14) {
+    pending_half(s + 3, p, lower, r, h0, l0, h1, l1);
+  }
 }
 // colour head: pair P of a finished dir_encoding block (relu) dotted with the three rgb rows
 template <int P>
@@ -520,7 +537,7 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
     if (nb == 7) c2 = after1;
     Acc cur;
     cur.m = pre.bias;
-    PairTmp ptmp;
+    Resplit ptmp;
     unsigned a_addr = ld.slot_cur + ld.lane_off;
     const unsigned next_bias = (unsigned)(c1.pieces - 1) * 1024u;
     Pre nxt;
@@ -684,16 +701,18 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
       prefetch_bias(mine, ld.slot_cur + 32 * 1024 + 128 * g, h);
       Acc cur;
       cur.m = mine.bias;
-      PairTmp ptmp;
+      Resplit ptmp;
       block_mma<4, -1>(
           cur, mine, a_addr, ld, end_ref(wave), [&](int s, int part) -> u32x4 { return part ? pel[s] : peh[s]; },
           [&](int s) {
             const int i = 4 * g + s;        // DMA of chunk j+2: one piece per k-step over the chunk's 16 k-steps
             if (i < 11) loader_issue(ld, i);
-            if (nb > 0) {   // four halves per k-step: the block has only four k-steps
+            if (nb > 0) {   // the block has only four k-steps: 5 + 4 + 4 + 4 of the 17 half-steps
 #pragma unroll
-              for (int q4 = 0; q4 < 4; ++q4)
-                pending_half(4 * s + q4, pend, 0.0f, ptmp, bh[2 * nb - 2], bl[2 * nb - 2], bh[2 * nb - 1], bl[2 * nb - 1]);
+              for (int q4 = 0; q4 < 5; ++q4)
+                if (q4 < 4 || s == 0)
+                  pending_half((s == 0 ? 0 : 4 * s + 1) + q4, pend, 0.0f, ptmp, bh[2 * nb - 2], bl[2 * nb - 2], bh[2 * nb - 1],
+                               bl[2 * nb - 1]);
             }
           },
           [&](int k) {
@@ -727,7 +746,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   {
     Acc cur;
     cur.m = pre.bias;
-    PairTmp ptmp;
+    Resplit ptmp;
     const unsigned next_bias = 36u * 1024u;       // dir_encoding chunks: 36 weight pieces, then the bias
     Pre nxt;
     block_mma<16, kBar>(

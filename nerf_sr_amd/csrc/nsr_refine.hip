@@ -58,6 +58,7 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, const float* __res
       v = __fmul_rn(s, w[((int64_t)n * cin + c) * 9 + tap]);
     }
     if (f16x3) {   // [hi halves (np x kp)] [lo halves (np x kp)] [bias]: the same number of bytes as the fp32 layout
+      v *= kSplitScale;   // see nsr_gemm.h: keeps the lo half clear of fp16's subnormal floor; undone by acc_scale
       const _Float16 hi = (_Float16)v;
       const _Float16 lo = (_Float16)(v - (float)hi);
       unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
@@ -212,6 +213,7 @@ int conv(hipStream_t st, const float* packed, int precision, int l, const float*
   if (precision != NSR_F16X3) return gemm(g, st);
   GemmF16Args a{};
   a.g = g;
+  a.g.acc_scale = kSplitInvScale;
   a.g.B = nullptr;
   a.Bh = reinterpret_cast<const unsigned short*>(wp);
   a.Bl = a.Bh + (int64_t)npad(l) * kp;

@@ -439,6 +439,7 @@ int lin_fwd(hipStream_t st, const float* x, int64_t ldx, int K, const float* w, 
   if (!split) return gemm(g, st);
   GemmF16Args a{};
   a.g = g;
+  a.g.acc_scale = kSplitInvScale;
   a.Bh = split + split_offset(e);
   a.Bl = a.Bh + (int64_t)kSplitRows[e] * kSplitK[e];
   a.ldbh = kSplitK[e];

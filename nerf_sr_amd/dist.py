@@ -55,6 +55,11 @@ def all_gather_pixels(local: torch.Tensor, n_items: int, group=None) -> torch.Te
     if hi - lo < cap:       # the tail rank(s): pad up to the common block size
         send = torch.zeros((cap, *c), dtype=local.dtype, device=local.device)
         send[: hi - lo] = local
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # development path only (N > 1 ranks sharing one GPU box, NSR_DIST_BACKEND=gloo): exchange through the host
+        recv_h = torch.empty((world * cap, *c), dtype=local.dtype)
+        dist.all_gather_into_tensor(recv_h, send.cpu().contiguous(), group=group)
+        return recv_h[:n_items].to(local.device)
     recv = torch.empty((world * cap, *c), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
     return recv[:n_items]
@@ -82,7 +87,12 @@ def all_reduce_sum_(buffers, group=None) -> None:
     if world == 1:
         return
     for b in buffers:
-        dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
+        if b.is_cuda and dist.get_backend(group) == "gloo":     # development path, see all_gather_pixels
+            h = b.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            b.copy_(h)
+        else:
+            dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
 
 
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
@@ -92,9 +102,13 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        # one process per GPU; with fewer GPUs than ranks (a 1-GPU box exercising the N > 1 code path under
+        # NSR_DIST_BACKEND=gloo -- RCCL itself refuses two ranks on one device) the ranks share devices round-robin
+        local = local % torch.cuda.device_count()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("NSR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if torch.cuda.is_available():
             torch.cuda.set_device(local)

@@ -3,7 +3,7 @@
 # the whole suite, bench lines of every configuration, rocprof stats and PMC passes of the fastest variant.
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
-O=$R/gpurun_out/r2c2
+O=$R/gpurun_out/r2c3
 mkdir -p $O
 cd $R
 echo "== quick f16x3 correctness" | tee $O/summary.txt
@@ -11,16 +11,16 @@ timeout 300 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "f16x3 or for
 tail -3 $O/quick.log | tee -a $O/summary.txt
 echo "== A/B timing" | tee -a $O/summary.txt
 best=""; bestms=1000000
-for v in "" dma2 kpf4 kpf2 dma2kpf4 pair; do
+for v in "" c2; do
   lib=$R/nerf_sr_amd/libnsr${v:+_$v}.so
   [ -f $lib ] || continue
   line=$(NSR_LIB_PATH=$lib timeout 200 python scripts/quick_time.py f16x3 2>&1 | tail -1)
   echo "variant '${v:-product}': $line" | tee -a $O/summary.txt
   ms=$(echo "$line" | sed -n 's/.*: \([0-9.]*\) ms\/image.*/\1/p')
-  if [ -n "$ms" ] && [ "$v" != "pair" ] && python -c "import sys; sys.exit(0 if float('$ms') < float('$bestms') else 1)"; then bestms=$ms; best=$v; fi
+  if [ -n "$ms" ] && python -c "import sys; sys.exit(0 if float('$ms') < float('$bestms') else 1)"; then bestms=$ms; best=$v; fi
 done
 echo "fastest: '${best:-product}' $bestms ms" | tee -a $O/summary.txt
-BEST_LIB=$R/nerf_sr_amd/libnsr${best:+_$best}.so
+BEST_LIB=$R/nerf_sr_amd/libnsr.so   # bench and profile the PRODUCT library
 echo "== full GPU suite (product library)" | tee -a $O/summary.txt
 timeout 1500 python -m pytest tests -q -m gpu -s > $O/gpu_suite.log 2>&1; echo "suite rc $?" | tee -a $O/summary.txt
 grep -E "^\.?\[config|passed|failed|Error" $O/gpu_suite.log | cut -c1-260 | tail -30 | tee -a $O/summary.txt
@@ -39,7 +39,7 @@ head -8 $O/trace/run_kernel_stats.csv | cut -c1-200 | tee -a $O/summary.txt
 echo "== PMC" | tee -a $O/summary.txt
 C1="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES"
 C2="SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES"
-timeout 300 bash scripts/pmc.sh r2c2/pmc_a f16x3 $C1 2>&1 | tail -2 | tee -a $O/summary.txt
-timeout 300 bash scripts/pmc.sh r2c2/pmc_b f16x3 $C2 2>&1 | tail -2 | tee -a $O/summary.txt
-timeout 300 bash scripts/pmc.sh r2c2/pmc_fetch f16x3 FETCH_SIZE 2>&1 | tail -2 | tee -a $O/summary.txt
-timeout 300 bash scripts/pmc.sh r2c2/pmc_write f16x3 WRITE_SIZE 2>&1 | tail -2 | tee -a $O/summary.txt
+timeout 300 bash scripts/pmc.sh r2c3/pmc_a f16x3 $C1 2>&1 | tail -2 | tee -a $O/summary.txt
+timeout 300 bash scripts/pmc.sh r2c3/pmc_b f16x3 $C2 2>&1 | tail -2 | tee -a $O/summary.txt
+timeout 300 bash scripts/pmc.sh r2c3/pmc_fetch f16x3 FETCH_SIZE 2>&1 | tail -2 | tee -a $O/summary.txt
+timeout 300 bash scripts/pmc.sh r2c3/pmc_write f16x3 WRITE_SIZE 2>&1 | tail -2 | tee -a $O/summary.txt

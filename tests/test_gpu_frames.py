@@ -216,3 +216,34 @@ def test_config5_full_size_end_to_end(ops):
     xs = torch.arange(800, device="cuda", dtype=torch.float64)
     assert float((out["locs"][..., 0] == xs[None, :]).double().mean()) > 0.97
     assert float((out["locs"][..., 1] == xs[:, None]).double().mean()) > 0.97
+
+
+# ------------------------------------------------------------------------------------------------- bench.py, N > 1
+def test_bench_two_ranks_on_one_gpu_gloo():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), on THIS box: both
+    ranks share the one GPU and exchange over gloo (NSR_DIST_BACKEND; RCCL refuses two ranks per device).  Checks the
+    N > 1 code path end to end: config #4's frame cut in two LR-pixel blocks, one all-gather per step, max-over-ranks
+    timing, one JSON line from rank 0 with the contract's fields."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, NSR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    res = subprocess.run(cmd, env=env, cwd=repo, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 2 and d["warmup"] == 1
+    assert d["unit"] == "rays/s" and d["higher_is_better"] is True and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "config #4" in d["config"]["workload"] and d["config"]["rays_per_step"] == 762048
+    assert abs(d["value"] - 762048 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert 2e5 < d["value"] < 1e7                       # two ranks time-slicing one GPU: about the single-GPU rate
+    assert d["roofline"]["bound"] == "mfma" and 0.0 < d["roofline"]["frac"] < 1.0 and d["cpu_baseline"] is None
