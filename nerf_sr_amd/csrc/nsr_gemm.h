@@ -54,6 +54,16 @@ struct GemmF16Args {
   const unsigned short* Bl;         //                          low parts
   int64_t ldbh;                     // row stride of Bh / Bl in halves (multiple of 8)
   ConvGather conv;
+  // PRE-SPLIT activations ("planes"): an fp32 tensor stored as two fp16 arrays of the same shape, hi = RNE(v) and
+  // lo = RNE(v - hi).  Ah != null: A is given that way (hi plane Ah, lo plane Ah + a_plane, g.lda = row stride in
+  // halves, multiple of 8; g.A unused) and is staged into LDS without any conversion -- a 3 x 3 convolution re-reads
+  // every activation nine times, so splitting it once in the producer's epilogue instead of at every staging removes
+  // 8/9 of that VALU work.  Ch != null: the result is WRITTEN that way (hi plane Ch, lo plane Ch + c_plane, g.ldc in
+  // halves, even; n_valid even; g.C unused; col_sums unsupported).
+  const unsigned short* Ah;
+  int64_t a_plane;
+  unsigned short* Ch;
+  int64_t c_plane;
 };
 NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st);
 // v = kSplitScale * w[i];  hi[i] = fp16(v), lo[i] = fp16(v - hi[i])   (round to nearest)

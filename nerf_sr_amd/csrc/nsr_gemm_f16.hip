@@ -37,7 +37,57 @@ struct RowSrc {   // where the four A rows this thread stages come from (implici
   bool ok;
 };
 
-template <int WN>
+// (hi, lo) fp16 planes out: bias -> activation -> split -> two 4-byte stores per lane and row pair.  Lane (column li)
+// of an accumulator block holds one column of 16 rows; neighbouring lanes swap one value per row pair so that every
+// lane owns TWO adjacent columns of ONE row and the 2-byte elements leave as packed 4-byte words.
+template <int TN>
+__device__ __forceinline__ void epilogue_planes(const GemmF16Args& a, f32x16 (&acc)[2][2], const bool (&col_on)[2], int64_t m0,
+                                                int n0, int wm, int wn, int li, int h) {
+  const GemmArgs& g = a.g;
+  const bool scaled = g.acc_scale != 0.0f && g.acc_scale != 1.0f;
+  const bool odd = li & 1;
+#pragma unroll
+  for (int bj = 0; bj < 2; ++bj) {
+    if (!col_on[bj]) continue;                       // wave-uniform
+    const int n = n0 + 64 * wn + 32 * bj + li;
+    const float bias = (g.bias && n < g.N) ? g.bias[n] : 0.0f;
+    const int col = n & ~1;
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi) {
+      const int64_t mb = m0 + 64 * wm + 32 * bi + 4 * h;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        float x[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = scaled ? fmaf(acc[bi][bj][4 * rq + e], g.acc_scale, bias) : acc[bi][bj][4 * rq + e] + bias;
+          if (g.act == kActRelu) v = fmaxf(v, 0.0f);
+          else if (g.act == kActSigmoid) v = 1.0f / (1.0f + expf(-v));
+          else if (g.act == kActTanh) v = tanhf(v);
+          x[e] = v;
+        }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const float xa = x[2 * pr], xb = x[2 * pr + 1];
+          const float got = __shfl_xor(odd ? xa : xb, 1, 64);     // even lanes receive the partner's xa, odd lanes its xb
+          const float c0 = odd ? got : xa, c1 = odd ? xb : got;   // columns col, col + 1 of row (odd ? b : a)
+          const int64_t m = mb + 8 * rq + 2 * pr + (odd ? 1 : 0);
+          const _Float16 h0 = (_Float16)c0, h1 = (_Float16)c1;
+          const _Float16 l0 = (_Float16)(c0 - (float)h0), l1 = (_Float16)(c1 - (float)h1);
+          if (m < g.M && col < g.n_valid) {
+            const int64_t off = m * g.ldc + col;
+            *reinterpret_cast<unsigned*>(a.Ch + off) =
+                (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            *reinterpret_cast<unsigned*>(a.Ch + a.c_plane + off) =
+                (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int WN, bool APL>   // APL: A comes as (hi, lo) fp16 planes
 __global__ void __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))   // <= 256 registers
 gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
   constexpr int NT = 128 * WN, kTN = 64 * WN, kArrB = kTN * kLd;
@@ -62,11 +112,15 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
 #pragma unroll
   for (int bj = 0; bj < 2; ++bj) col_on[bj] = (n0 + 64 * wn + 32 * bj) < g.N;
 
-  // ---- staging assignment: A: NA x (row = (tid >> 3) + (NT / 8) i, float4 column c4 = tid & 7); B: 2 x 2 x
-  // (row = (tid >> 2) + (NT / 4) i, 8-half chunk c8 = tid & 3)
-  constexpr int NA = 1024 / NT, kARows = NT / 8, kBRows = NT / 4;
-  const int c4 = tid & 7, ar0 = tid >> 3, c8 = tid & 3, br0 = tid >> 2;
-  const float* arow[NA];
+  // ---- staging assignment.  fp32 A: NA x (row = (tid >> 3) + (NT / 8) i, float4 column c4 = tid & 7), split on the way
+  // to LDS; plane A: NP x (row = (tid >> 2) + (NT / 4) i, 8-half chunk c8 = tid & 3) of each plane, copied as it is.
+  // B: 2 x 2 x (row = (tid >> 2) + (NT / 4) i, 8-half chunk c8 = tid & 3)
+  constexpr int NA = APL ? 512 / NT : 1024 / NT, kARows = APL ? NT / 4 : NT / 8, kBRows = NT / 4;
+  const int c4 = tid & 7, c8 = tid & 3, br0 = tid >> 2;
+  const int ar0 = APL ? (tid >> 2) : (tid >> 3);
+  const int a_col = APL ? 8 * c8 : 4 * c4;                  // column offset inside the K tile, in elements
+  // row base of the A operand in ELEMENTS from its base pointer (fp32: g.A floats; planes: a.Ah halves); -1 = zero row
+  int64_t arow[NA];
   RowSrc rs[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
@@ -77,9 +131,9 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
       rs[i].img = (int)(m / per);
       rs[i].oy = (int)((m % per) / a.conv.Wo);
       rs[i].ox = (int)(m % a.conv.Wo);
-      arow[i] = g.A;
+      arow[i] = 0;
     } else {
-      arow[i] = g.A + m * g.lda;
+      arow[i] = m * g.lda;
     }
   }
   const unsigned short* bh_row[2];
@@ -91,33 +145,41 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
     bh_row[i] = a.Bh + (int64_t)n * a.ldbh;
     bl_row[i] = a.Bl + (int64_t)n * a.ldbh;
   }
-  f32x4 sa[NA];
+  f32x4 sa[APL ? 1 : NA];
+  u32x4 sah[APL ? NA : 1], sal[APL ? NA : 1];
   u32x4 sbh[2], sbl[2];
   auto load = [&](int t) {
     const int64_t k0 = (int64_t)t * kTK;
+    int64_t koff = k0;
     if (conv) {
       // the gather address of a row changes only when the K tile enters the next tap (every cin / 32 tiles):
-      // arow[i] then points at channel 0 of the source pixel under that tap, or is null inside the zero padding
+      // arow[i] then points at channel 0 of the source pixel under that tap, or is -1 inside the zero padding
       const int cbase = (int)(k0 % a.conv.cin);
+      koff = cbase;
       if (cbase == 0) {
         const int tap = (int)(k0 / a.conv.cin), ky = tap / 3, kx = tap % 3;
         const int Hin = a.conv.up ? 2 * a.conv.Hs : a.conv.Hs, Win = a.conv.up ? 2 * a.conv.Ws : a.conv.Ws;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
           const int iy = rs[i].oy * a.conv.stride + ky - 1, ix = rs[i].ox * a.conv.stride + kx - 1;
-          arow[i] = nullptr;
+          arow[i] = -1;
           if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
             const int sy = a.conv.up ? iy >> 1 : iy, sx = a.conv.up ? ix >> 1 : ix;
-            arow[i] = g.A + (((int64_t)rs[i].img * a.conv.Hs + sy) * a.conv.Ws + sx) * g.lda + 4 * c4;
+            arow[i] = (((int64_t)rs[i].img * a.conv.Hs + sy) * a.conv.Ws + sx) * g.lda;
           }
         }
       }
+    }
 #pragma unroll
-      for (int i = 0; i < NA; ++i)
-        sa[i] = arow[i] ? *reinterpret_cast<const f32x4*>(arow[i] + cbase) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    } else {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) sa[i] = *reinterpret_cast<const f32x4*>(arow[i] + k0 + 4 * c4);
+    for (int i = 0; i < NA; ++i) {
+      const int64_t off = arow[i] + koff + a_col;
+      if (APL) {
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        sah[i] = arow[i] >= 0 ? *reinterpret_cast<const u32x4*>(a.Ah + off) : zero;
+        sal[i] = arow[i] >= 0 ? *reinterpret_cast<const u32x4*>(a.Ah + a.a_plane + off) : zero;
+      } else {
+        sa[i] = arow[i] >= 0 ? *reinterpret_cast<const f32x4*>(g.A + off) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -128,16 +190,21 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
   auto store = [&]() {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      h4 hi, lo;
+      const int off = (ar0 + kARows * i) * kLd + a_col;
+      if (APL) {
+        *reinterpret_cast<u32x4*>(lds + off) = sah[i];
+        *reinterpret_cast<u32x4*>(lds + kArrA + off) = sal[i];
+      } else {
+        h4 hi, lo;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const _Float16 x = (_Float16)sa[i][e];
-        hi[e] = x;
-        lo[e] = (_Float16)(sa[i][e] - (float)x);
+        for (int e = 0; e < 4; ++e) {
+          const _Float16 x = (_Float16)sa[i][e];
+          hi[e] = x;
+          lo[e] = (_Float16)(sa[i][e] - (float)x);
+        }
+        *reinterpret_cast<h4*>(lds + off) = hi;
+        *reinterpret_cast<h4*>(lds + kArrA + off) = lo;
       }
-      const int off = (ar0 + kARows * i) * kLd + 4 * c4;
-      *reinterpret_cast<h4*>(lds + off) = hi;
-      *reinterpret_cast<h4*>(lds + kArrA + off) = lo;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -180,7 +247,8 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
     }
     __syncthreads();
   }
-  gemm_epilogue<kTN>(g, acc, col_on, m0, n0, wm, wn, li, h, tid, 0, bid / n_col_tiles, reinterpret_cast<float*>(lds));
+  if (a.Ch) epilogue_planes<kTN>(a, acc, col_on, m0, n0, wm, wn, li, h);
+  else gemm_epilogue<kTN>(g, acc, col_on, m0, n0, wm, wn, li, h, tid, 0, bid / n_col_tiles, reinterpret_cast<float*>(lds));
 }
 
 }  // namespace
@@ -196,10 +264,19 @@ NSR_INTERNAL int split_f16(const float* w, int64_t n, unsigned short* hi, unsign
 NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   const GemmArgs& g = a.g;
   if (g.M < 0 || g.N <= 0 || g.K <= 0 || (g.K % kTK) != 0 || g.n_valid > g.N) return NSR_ERR_INVALID_ARG;
-  if (!g.A || !a.Bh || !a.Bl || !g.C || g.Ct || g.splits > 1 || g.a_kmajor || g.b_kmajor) return NSR_ERR_INVALID_ARG;
-  if ((g.lda % 4) || (a.ldbh % 8) || (reinterpret_cast<uintptr_t>(g.A) & 15) || (reinterpret_cast<uintptr_t>(a.Bh) & 15) ||
-      (reinterpret_cast<uintptr_t>(a.Bl) & 15))
+  if (!a.Bh || !a.Bl || g.Ct || g.splits > 1 || g.a_kmajor || g.b_kmajor) return NSR_ERR_INVALID_ARG;
+  if ((a.ldbh % 8) || (reinterpret_cast<uintptr_t>(a.Bh) & 15) || (reinterpret_cast<uintptr_t>(a.Bl) & 15)) return NSR_ERR_INVALID_ARG;
+  if (a.Ah) {   // pre-split A: 16-byte chunks of 8 halves
+    if ((g.lda % 8) || (a.a_plane % 8) || (reinterpret_cast<uintptr_t>(a.Ah) & 15)) return NSR_ERR_INVALID_ARG;
+  } else if (!g.A || (g.lda % 4) || (reinterpret_cast<uintptr_t>(g.A) & 15)) {
     return NSR_ERR_INVALID_ARG;
+  }
+  if (a.Ch) {   // plane output: packed pairs of columns
+    if ((g.ldc % 2) || (a.c_plane % 2) || (g.n_valid % 2) || (reinterpret_cast<uintptr_t>(a.Ch) & 3) || g.col_sums || g.mask)
+      return NSR_ERR_INVALID_ARG;
+  } else if (!g.C) {
+    return NSR_ERR_INVALID_ARG;
+  }
   if (a.conv.cin > 0 && ((a.conv.cin % kTK) != 0 || g.K != 9 * a.conv.cin)) return NSR_ERR_INVALID_ARG;
   if (g.M == 0) return NSR_OK;
   const bool wide = g.N >= 256;
@@ -207,8 +284,13 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   const int n_col_tiles = (g.N + tn - 1) / tn;
   const int64_t row_tiles = (g.M + kTM - 1) / kTM;
   const dim3 grid((unsigned)(row_tiles * n_col_tiles));
-  if (wide) hipLaunchKernelGGL(gemm_f16x3_kernel<4>, grid, dim3(512), 0, st, a, n_col_tiles);
-  else hipLaunchKernelGGL(gemm_f16x3_kernel<2>, grid, dim3(256), 0, st, a, n_col_tiles);
+  if (a.Ah) {
+    if (wide) hipLaunchKernelGGL((gemm_f16x3_kernel<4, true>), grid, dim3(512), 0, st, a, n_col_tiles);
+    else hipLaunchKernelGGL((gemm_f16x3_kernel<2, true>), grid, dim3(256), 0, st, a, n_col_tiles);
+  } else {
+    if (wide) hipLaunchKernelGGL((gemm_f16x3_kernel<4, false>), grid, dim3(512), 0, st, a, n_col_tiles);
+    else hipLaunchKernelGGL((gemm_f16x3_kernel<2, false>), grid, dim3(256), 0, st, a, n_col_tiles);
+  }
   if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
   return NSR_OK;
 }

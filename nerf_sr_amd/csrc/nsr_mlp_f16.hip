@@ -392,16 +392,19 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
 
 // Re-split of the pending block: accumulator pair P (registers 2P, 2P+1; P = 0..7) -> activation -> (hi, lo) fp16
 // pairs in the operand registers of the consuming layer: block nb becomes k-steps 2nb (P < 4 -> h0 / l0) and 2nb + 1
-// (P >= 4 -> h1 / l1), element P & 3.  Six VALU instructions per pair:
-//   x0, x1 = max(acc, lower)           (raw v_max: fmaxf() would add a canonicalising v_max per operand)
-//   hi     = RNE_f16(x * 2^-6)         (v_fma_mixlo / mixhi: removes the weight scale)
-//   lo     = RNE_f16(x * 2^-6 - hi)    (v_fma_mixlo / mixhi, f16 source; the fma result is exact in fp32)
-// issued as 17 HALF-STEPS of three instructions in which neighbours never depend on each other -- the lo of pair
-// P - 1 is interleaved with the hi of pair P -- because a wave with the matrix pipe to feed cannot afford to wait for
-// its own VALU results (measured: the same six instructions as two dependent chains cost 8 % of the launch):
-//   half-step 2P     : max x0_P ; max x1_P ; hi_P.lo16 = mix(x0_P)
-//   half-step 2P + 1 : lo_{P-1}.lo16 = mix(x0_{P-1}, hi_{P-1}) ; hi_P.hi16 = mix(x1_P) ; lo_{P-1}.hi16 = mix(x1_{P-1}, hi_{P-1})
-//   half-step 16     : lo_7
+// (P >= 4 -> h1 / l1), element P & 3.  The accumulators hold 64 x the layer output (weight scale, see the header).
+// Six VALU instructions per pair, only two of them on the slow mixed-precision path:
+//   x0, x1 = max(acc, 0)                (raw v_max: fmaxf() would add a canonicalising v_max per operand)
+//   hi64   = RNE_f16(x0), RNE_f16(x1)   (one v_cvt_pk_f16_f32)
+//   hi     = hi64 / 64                  (one v_pk_sub_u16 ... clamp on the two exponent fields: 6 << 10 off each bit
+//                                        pattern, saturating at 0.  Exact whenever the result is a normal number; for
+//                                        |x| < 2^-8 the pattern lands in / below the subnormal encodings and simply
+//                                        means another small number -- harmless, because lo is computed from the bits
+//                                        hi actually holds, so hi + lo is x / 64 either way)
+//   lo     = RNE_f16(x * 2^-6 - hi)     (v_fma_mixlo / mixhi with an f16 source; the fma result is exact in fp32)
+// xyz_encoding_final has no ReLU and negative values do not survive the unsigned exponent trick: there hi comes from
+// two v_fma_mix (RNE_f16(x * 2^-6)) instead of the cvt / sub pair.
+// The work is issued as 17 HALF-STEPS of three instructions; the lo of pair P - 1 is interleaved with the hi of pair P.
 // asm volatile pins each half-step into its k-step (MFMA shadow); LLVM would otherwise sink the work to its first
 // use, i.e. serialise all eight blocks' conversions at the layer end.
 struct PairTmp {
@@ -415,22 +418,30 @@ template <int P>
 __device__ __forceinline__ void put(unsigned v, u32x4& d0, u32x4& d1) {
   if (P < 4) d0[P & 3] = v; else d1[P & 3] = v;
 }
-template <int P>
+template <int P, bool RELU>
 __device__ __forceinline__ void resplit_a(const Acc& p, float lower, Resplit& r) {
   PairTmp& t = r.t[P & 1];
 #ifdef NSR_ABL_NO_CONVERT
   asm volatile("v_max_f32 %0, %2, %4\n\tv_max_f32 %1, %3, %4" : "=&v"(t.x0), "=&v"(t.x1) : "v"(p.m[2 * P]), "v"(p.m[2 * P + 1]), "v"(lower));
   t.hi = __float_as_uint(t.x0);
 #else
-  asm volatile(
-      "v_max_f32 %0, %3, %5\n\t"
-      "v_max_f32 %1, %4, %5\n\t"
-      "v_fma_mixlo_f16 %2, %0, %6, 0 op_sel_hi:[0,0,0]"
-      : "=&v"(t.x0), "=&v"(t.x1), "=&v"(t.hi)
-      : "v"(p.m[2 * P]), "v"(p.m[2 * P + 1]), "v"(lower), "v"(kWInvScale));
+  if (RELU)
+    asm volatile(
+        "v_max_f32 %0, %3, 0\n\t"
+        "v_max_f32 %1, %4, 0\n\t"
+        "v_cvt_pk_f16_f32 %2, %0, %1"
+        : "=&v"(t.x0), "=&v"(t.x1), "=&v"(t.hi)
+        : "v"(p.m[2 * P]), "v"(p.m[2 * P + 1]));
+  else
+    asm volatile(
+        "v_max_f32 %0, %3, %5\n\t"
+        "v_max_f32 %1, %4, %5\n\t"
+        "v_fma_mixlo_f16 %2, %0, %6, 0 op_sel_hi:[0,0,0]"
+        : "=&v"(t.x0), "=&v"(t.x1), "=&v"(t.hi)
+        : "v"(p.m[2 * P]), "v"(p.m[2 * P + 1]), "v"(lower), "v"(kWInvScale));
 #endif
 }
-template <int P>   // P = 0..8: finishes hi of pair P (P < 8) and makes lo of pair P - 1 (P > 0)
+template <int P, bool RELU>   // P = 0..8: finishes hi of pair P (P < 8) and makes lo of pair P - 1 (P > 0)
 __device__ __forceinline__ void resplit_b(Resplit& r, u32x4& h0, u32x4& l0, u32x4& h1, u32x4& l1) {
   PairTmp& cur = r.t[P & 1];
   const PairTmp& prev = r.t[(P & 1) ^ 1];
@@ -438,16 +449,26 @@ __device__ __forceinline__ void resplit_b(Resplit& r, u32x4& h0, u32x4& l0, u32x
   if (P < 8) put<(P < 8 ? P : 0)>(cur.hi, h0, h1);
   if (P > 0) put<(P > 0 ? P - 1 : 0)>(__float_as_uint(prev.x1), l0, l1);
 #else
+  constexpr unsigned kExp6 = 0x18001800u;   // 6 in both fp16 exponent fields
   unsigned lo = 0;
   if (P == 0) {
-    asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(cur.hi) : "v"(cur.x1), "v"(kWInvScale));
+    if (RELU) asm volatile("v_pk_sub_u16 %0, %0, %1 clamp" : "+v"(cur.hi) : "v"(kExp6));
+    else asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(cur.hi) : "v"(cur.x1), "v"(kWInvScale));
   } else if (P < 8) {
-    asm volatile(
-        "v_fma_mixlo_f16 %1, %4, %6, -%3 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %0, %2, %6, 0 op_sel_hi:[0,0,0]\n\t"
-        "v_fma_mixhi_f16 %1, %5, %6, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "+v"(cur.hi), "=&v"(lo)
-        : "v"(cur.x1), "v"(prev.hi), "v"(prev.x0), "v"(prev.x1), "v"(kWInvScale));
+    if (RELU)
+      asm volatile(
+          "v_fma_mixlo_f16 %1, %3, %5, -%2 op_sel_hi:[0,0,1]\n\t"
+          "v_pk_sub_u16 %0, %0, %6 clamp\n\t"
+          "v_fma_mixhi_f16 %1, %4, %5, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+          : "+v"(cur.hi), "=&v"(lo)
+          : "v"(prev.hi), "v"(prev.x0), "v"(prev.x1), "v"(kWInvScale), "v"(kExp6));
+    else
+      asm volatile(
+          "v_fma_mixlo_f16 %1, %4, %6, -%3 op_sel_hi:[0,0,1]\n\t"
+          "v_fma_mixhi_f16 %0, %2, %6, 0 op_sel_hi:[0,0,0]\n\t"
+          "v_fma_mixhi_f16 %1, %5, %6, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+          : "+v"(cur.hi), "=&v"(lo)
+          : "v"(cur.x1), "v"(prev.hi), "v"(prev.x0), "v"(prev.x1), "v"(kWInvScale));
   } else {
     asm volatile(
         "v_fma_mixlo_f16 %0, %2, %4, -%1 op_sel_hi:[0,0,1]\n\t"
@@ -460,27 +481,32 @@ __device__ __forceinline__ void resplit_b(Resplit& r, u32x4& h0, u32x4& l0, u32x
 #endif
 }
 // half-step hs (0..16) of the pending block
-__device__ __forceinline__ void pending_half(int hs, const Acc& p, float lower, Resplit& r, u32x4& h0, u32x4& l0, u32x4& h1,
-                                             u32x4& l1) {
+template <bool RELU>
+__device__ __forceinline__ void pending_half_t(int hs, const Acc& p, float lower, Resplit& r, u32x4& h0, u32x4& l0, u32x4& h1,
+                                               u32x4& l1) {
   switch (hs) {
-#define NSR_HS(P)                                          \
-    case 2 * P: resplit_a<P>(p, lower, r); break;          \
-    case 2 * P + 1: resplit_b<P>(r, h0, l0, h1, l1); break;
+#define NSR_HS(P)                                                  \
+    case 2 * P: resplit_a<P, RELU>(p, lower, r); break;            \
+    case 2 * P + 1: resplit_b<P, RELU>(r, h0, l0, h1, l1); break;
     NSR_HS(0) NSR_HS(1) NSR_HS(2) NSR_HS(3) NSR_HS(4) NSR_HS(5) NSR_HS(6) NSR_HS(7)
 #undef NSR_HS
-    case 16: resplit_b<8>(r, h0, l0, h1, l1); break;
+    case 16: resplit_b<8, RELU>(r, h0, l0, h1, l1); break;
     default: break;
   }
 }
+template <bool RELU>
+__device__ __forceinline__ void pending_half(int hs, const Acc& p, Resplit& r, u32x4& h0, u32x4& l0, u32x4& h1, u32x4& l1) {
+  pending_half_t<RELU>(hs, p, RELU ? 0.0f : -__builtin_inff(), r, h0, l0, h1, l1);
+}
 // Schedule over the k-steps of a 16-step chunk: 17 half-steps in k-steps 0..13 (k-steps 0, 1, 2 take two), so that
 // even the operands of k-steps 14, 15 (block 7 of the previous layer) are complete before they are used.
-__device__ __forceinline__ void pending_step(int s, const Acc& p, float lower, Resplit& r, u32x4& h0, u32x4& l0, u32x4& h1,
-                                             u32x4& l1) {
+template <bool RELU>
+__device__ __forceinline__ void pending_step(int s, const Acc& p, Resplit& r, u32x4& h0, u32x4& l0, u32x4& h1, u32x4& l1) {
   if (s < 3) {
-    pending_half(2 * s, p, lower, r, h0, l0, h1, l1);
-    pending_half(2 * s + 1, p, lower, r, h0, l0, h1, l1);
+    pending_half<RELU>(2 * s, p, r, h0, l0, h1, l1);
+    pending_half<RELU>(2 * s + 1, p, r, h0, l0, h1, l1);
   } else if (s < 14) {
-    pending_half(s + 3, p, lower, r, h0, l0, h1, l1);
+    pending_half<RELU>(s + 3, p, r, h0, l0, h1, l1);
   }
 }
 // colour head: pair P of a finished dir_encoding block (relu) dotted with the three rgb rows
@@ -521,10 +547,10 @@ __device__ __forceinline__ void prefetch_next_chunk(Pre& nxt, int k, const Loade
 // finished last (block 7 of the previous layer on entry; block 7 of this layer on exit): it is
 // activated and re-split in the MFMA shadow of the FOLLOWING block's k-steps 0..13.  `pre` carries the
 // prefetched head of the next chunk across chunk (and layer) boundaries.
+template <bool RELU_OUT>   // relu on L2..L8 (true), none on xyz_encoding_final (L == 8: false)
 __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[16], u32x4 (&oh)[16], u32x4 (&ol)[16],
                                             const u32x4* stash, Loader& ld, int h, Acc& pend, Pre& pre,
                                             const ChunkRef& after0, const ChunkRef& after1) {
-  const float lower = (L < 8) ? 0.0f : -__builtin_inff();   // relu on L1..L8, none on xyz_encoding_final
   const ChunkRef ref0 = layer_ref(L, 0, ld.wave);           // this layer's chunks: piece0 advances by `pieces`
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) {
@@ -564,9 +590,9 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
           if (nb == 0)
             // block 7 of the previous layer (always relu'd: the previous layer is L1..L7) -> k-steps 14, 15
             // of THIS layer's input, needed only at the end of this chunk
-            pending_step(s, pend, 0.0f, ptmp, bh[14], bl[14], bh[15], bl[15]);
+            pending_step<true>(s, pend, ptmp, bh[14], bl[14], bh[15], bl[15]);
           else
-            pending_step(s, pend, lower, ptmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1]);
+            pending_step<RELU_OUT>(s, pend, ptmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1]);
         },
         [&](int k) { prefetch_next_chunk(nxt, k, ld, next_bias, h); });
     pend = cur;
@@ -711,8 +737,8 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
 #pragma unroll
               for (int q4 = 0; q4 < 5; ++q4)
                 if (q4 < 4 || s == 0)
-                  pending_half((s == 0 ? 0 : 4 * s + 1) + q4, pend, 0.0f, ptmp, bh[2 * nb - 2], bl[2 * nb - 2], bh[2 * nb - 1],
-                               bl[2 * nb - 1]);
+                  pending_half<true>((s == 0 ? 0 : 4 * s + 1) + q4, pend, ptmp, bh[2 * nb - 2], bl[2 * nb - 2], bh[2 * nb - 1],
+                                     bl[2 * nb - 1]);
             }
           },
           [&](int k) {
@@ -724,20 +750,21 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     loader_advance(ld);
   }
 
-  // ---- L2..L8 (+ xyz_encoding_final), two layers per trip so the register sets swap roles
-  constexpr int kPairs = SIGMA_ONLY ? 3 : 4;
+  // ---- L2..L8 (+ xyz_encoding_final), two layers per trip so the register sets swap roles.  Three trips of relu
+  // layers (L2..L7); the last pair (L8 + xyz_encoding_final, which has no relu) is peeled so that the activation is a
+  // compile-time property of every re-split.
 #pragma unroll 1
-  for (int pair = 0; pair < kPairs; ++pair) {
+  for (int pair = 0; pair < 3; ++pair) {
     const int L = 1 + 2 * pair;
-    trunk_layer(L, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(L + 1, 0, wave), layer_ref(L + 1, 1, wave));
-    // what follows layer L+1: the next trunk layer, or (after xyz_encoding_final) the density head + dir_encoding
-    const bool last = !SIGMA_ONLY && pair == kPairs - 1;
-    const ChunkRef a0 = last ? sigma_ref(wave) : layer_ref(L + 2, 0, wave);
-    const ChunkRef a1 = last ? dir_ref(0, wave) : layer_ref(L + 2, 1, wave);
-    trunk_layer(L + 1, oh, ol, bh, bl, stash, ld, h, pend, pre, a0, a1);
+    trunk_layer<true>(L, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(L + 1, 0, wave), layer_ref(L + 1, 1, wave));
+    trunk_layer<true>(L + 1, oh, ol, bh, bl, stash, ld, h, pend, pre, layer_ref(L + 2, 0, wave), layer_ref(L + 2, 1, wave));
   }
-  if (SIGMA_ONLY)   // xyz_encoding_final is not evaluated: L8 is followed by the density head, then nothing
-    trunk_layer(7, bh, bl, oh, ol, stash, ld, h, pend, pre, sigma_ref(wave), end_ref(wave));
+  if (SIGMA_ONLY) {   // xyz_encoding_final is not evaluated: L8 is followed by the density head, then nothing
+    trunk_layer<true>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, sigma_ref(wave), end_ref(wave));
+  } else {
+    trunk_layer<true>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave));
+    trunk_layer<false>(8, oh, ol, bh, bl, stash, ld, h, pend, pre, sigma_ref(wave), dir_ref(0, wave));
+  }
 
   // ---- density head: sigma.weight as row 0 of one more 32-row block over h8 (= oh/ol: the input of
   // xyz_encoding_final, still intact).  The pending block is xyz_encoding_final's last one (-> bh, no
@@ -754,9 +781,9 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
         [&](int s, int part) -> u32x4 { return part ? ol[s] : oh[s]; },
         [&](int s) {
           if (SIGMA_ONLY)
-            pending_step(s, pend, 0.0f, ptmp, oh[14], ol[14], oh[15], ol[15]);
+            pending_step<true>(s, pend, ptmp, oh[14], ol[14], oh[15], ol[15]);
           else
-            pending_step(s, pend, -__builtin_inff(), ptmp, bh[14], bl[14], bh[15], bl[15]);
+            pending_step<false>(s, pend, ptmp, bh[14], bl[14], bh[15], bl[15]);
         },
         [&](int k) {
           if (!SIGMA_ONLY) prefetch_next_chunk(nxt, k, ld, next_bias, h);

@@ -9,7 +9,11 @@
 // BatchNorm2d in eval mode is an affine map per channel: folded into the packed weights and bias.
 // Two arithmetic modes (include/nsr_refine.h): NSR_FP32 = explicit im2col + the fp32-MFMA GEMM; NSR_F16X3 = the
 // split-fp16 GEMM with IMPLICIT im2col (the 3 x 3 gather happens while the A tile is staged, no col matrix exists;
-// only the 3-channel first layer still goes through a 32-column col matrix).
+// only the 3-channel first layer still goes through a 32-column col matrix).  In that mode every activation between
+// two convolutions lives PRE-SPLIT in HBM: an fp16 "hi" plane and an fp16 "lo" plane of the same NHWC shape (the
+// same 4 bytes per element as fp32), written by the producing GEMM's epilogue and staged by the consuming GEMM as
+// they are -- a 3 x 3 convolution reads every activation nine times, splitting it once instead of nine times is what
+// the kernel's issue slots were spent on (nsr_gemm.h: GemmF16Args::Ah / Ch).
 #include "nsr_common.h"
 #include "nsr_gemm.h"
 #include "../../include/nsr_refine.h"
@@ -139,6 +143,31 @@ __global__ void __launch_bounds__(256) max_refs_kernel(const float* __restrict__
   *reinterpret_cast<float4*>(dst + bp * ld + 4 * c4) = m;
 }
 
+// the same on pre-split activations: value order = (hi, lo) lexicographic order (|lo| <= ulp(hi) / 2)
+__global__ void __launch_bounds__(256) max_refs_planes_kernel(const unsigned short* __restrict__ src, int64_t src_plane, int C,
+                                                              int R, int64_t px_per_img, int64_t n,
+                                                              unsigned short* __restrict__ dst, int64_t dst_plane, int64_t ld) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B * px * C / 2
+  if (idx >= n) return;
+  const int c2 = (int)(idx % (C / 2));
+  const int64_t bp = idx / (C / 2), b = bp / px_per_img, px = bp % px_per_img;
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const int64_t o0 = ((b * R) * px_per_img + px) * C + 2 * c2;
+  h2 mh = *reinterpret_cast<const h2*>(src + o0), ml = *reinterpret_cast<const h2*>(src + src_plane + o0);
+  for (int r = 1; r < R; ++r) {
+    const int64_t o = ((b * R + r) * px_per_img + px) * C + 2 * c2;
+    const h2 th = *reinterpret_cast<const h2*>(src + o), tl = *reinterpret_cast<const h2*>(src + src_plane + o);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      if (th[e] > mh[e] || (th[e] == mh[e] && tl[e] > ml[e])) {
+        mh[e] = th[e];
+        ml[e] = tl[e];
+      }
+  }
+  *reinterpret_cast<h2*>(dst + bp * ld + 2 * c2) = mh;
+  *reinterpret_cast<h2*>(dst + dst_plane + bp * ld + 2 * c2) = ml;
+}
+
 // (B * H * W, 3) NHWC -> (B, 3, H, W)
 __global__ void nhwc3_to_nchw_kernel(const float* __restrict__ src, int64_t px_per_img, int64_t n, float* __restrict__ dst) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B * 3 * px
@@ -191,26 +220,40 @@ int64_t work_floats(int B, int R, int H, int W, Work* w, float* base) {
     if (rc_ != NSR_OK) return rc_; \
   } while (0)
 
-// one convolution layer: src (NHWC, row stride src_ld; NCHW for layer 0) -> dst (NHWC slice, row stride dst_ld)
-int conv(hipStream_t st, const float* packed, int precision, int l, const float* src, int64_t src_ld, bool nchw, int n_img,
-         int Hs, int Ws, float* col, float* dst, int64_t dst_ld) {
+// An activation tensor between two layers: `p` = start of its buffer, (rows, ld) = the buffer's shape, ch0 = first
+// channel of the slice this layer reads / writes (concatenated buffers).  NSR_FP32: fp32 NHWC.  NSR_F16X3: the buffer
+// holds two fp16 planes of (rows, ld) halves each -- hi at (u16*)p, lo `rows * ld` halves behind it.
+struct Act {
+  float* p;
+  int64_t rows, ld;
+  int ch0;
+};
+inline const float* f32_of(const Act& t) { return t.p + t.ch0; }
+inline unsigned short* hi_of(const Act& t) { return reinterpret_cast<unsigned short*>(t.p) + t.ch0; }
+inline int64_t plane_of(const Act& t) { return t.rows * t.ld; }
+
+// one convolution layer: src (NHWC activation; NCHW fp32 input tensor for layer 0) -> dst (NHWC slice; the last layer
+// writes fp32 in both modes)
+int conv(hipStream_t st, const float* packed, int precision, int l, const Act& src, const float* src_nchw, int n_img, int Hs,
+         int Ws, float* col, const Act& dst) {
   const Layer& L = kLayers[l];
+  const bool nchw = src_nchw != nullptr, f16 = precision == NSR_F16X3, last = l == NSR_REFINE_N_LAYERS - 1;
   const int Hin = L.up ? 2 * Hs : Hs, Win = L.up ? 2 * Ws : Ws;
   const int Ho = (Hin - 1) / L.stride + 1, Wo = (Win - 1) / L.stride + 1;   // k = 3, pad = 1
   const int kp = kpad(l);
   const int64_t M = (int64_t)n_img * Ho * Wo, total = M * (kp / 4);
-  const bool implicit = precision == NSR_F16X3 && !nchw && (L.cin % 32) == 0;
+  const bool implicit = f16 && !nchw && (L.cin % 32) == 0;
   if (!implicit) {
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    if (nchw) hipLaunchKernelGGL(im2col_kernel<true>, grid, block, 0, st, src, src_ld, L.cin, n_img, Hs, Ws, L.stride, L.up, Ho, Wo, kp, col);
-    else hipLaunchKernelGGL(im2col_kernel<false>, grid, block, 0, st, src, src_ld, L.cin, n_img, Hs, Ws, L.stride, L.up, Ho, Wo, kp, col);
+    if (nchw) hipLaunchKernelGGL(im2col_kernel<true>, grid, block, 0, st, src_nchw, (int64_t)0, L.cin, n_img, Hs, Ws, L.stride, L.up, Ho, Wo, kp, col);
+    else hipLaunchKernelGGL(im2col_kernel<false>, grid, block, 0, st, f32_of(src), src.ld, L.cin, n_img, Hs, Ws, L.stride, L.up, Ho, Wo, kp, col);
     NSR_CHECK_LAUNCH();
   }
   const float* wp = packed + layer_offset(l);
   GemmArgs g{};
-  g.A = col; g.lda = kp; g.B = wp; g.ldb = kp; g.C = dst; g.ldc = dst_ld; g.bias = wp + (int64_t)npad(l) * kp;
+  g.A = col; g.lda = kp; g.B = wp; g.ldb = kp; g.C = dst.p + dst.ch0; g.ldc = dst.ld; g.bias = wp + (int64_t)npad(l) * kp;
   g.M = M; g.N = npad(l); g.K = kp; g.n_valid = L.cout; g.act = L.act; g.splits = 1;
-  if (precision != NSR_F16X3) return gemm(g, st);
+  if (!f16) return gemm(g, st);
   GemmF16Args a{};
   a.g = g;
   a.g.acc_scale = kSplitInvScale;
@@ -218,30 +261,46 @@ int conv(hipStream_t st, const float* packed, int precision, int l, const float*
   a.Bh = reinterpret_cast<const unsigned short*>(wp);
   a.Bl = a.Bh + (int64_t)npad(l) * kp;
   a.ldbh = kp;
-  if (implicit) {
-    a.g.A = src;
-    a.g.lda = src_ld;
+  if (implicit) {   // gather from the pre-split NHWC activation
+    a.g.A = nullptr;
+    a.Ah = hi_of(src);
+    a.a_plane = plane_of(src);
+    a.g.lda = src.ld;
     a.conv = ConvGather{L.cin, Hs, Ws, Ho, Wo, L.stride, L.up};
+  }
+  if (!last) {      // ... and leave the result pre-split for the next layer
+    a.g.C = nullptr;
+    a.Ch = hi_of(dst);
+    a.c_plane = plane_of(dst);
   }
   return gemm_f16x3(a, st);
 }
 
-// Model_VNPCAT_Encoder.forward (networks.py:760-774): features x2, x4, x6, x7 into the four (pointer, row stride) slots
-int encoder(hipStream_t st, const float* packed, int prec, const Work& k, const float* x_nchw, int n_img, int H, int W, float* d0,
-            int64_t ld0, float* d1, int64_t ld1, float* d2, int64_t ld2, float* d3, int64_t ld3) {
-  NSR_TRY(conv(st, packed, prec, 0, x_nchw, 0, true, n_img, H, W, k.col, k.a, 128));
-  NSR_TRY(conv(st, packed, prec, 1, k.a, 128, false, n_img, H, W, k.col, d0, ld0));
-  NSR_TRY(conv(st, packed, prec, 2, d0, ld0, false, n_img, H, W, k.col, k.a, 256));
-  NSR_TRY(conv(st, packed, prec, 3, k.a, 256, false, n_img, H / 2, W / 2, k.col, d1, ld1));
-  NSR_TRY(conv(st, packed, prec, 4, d1, ld1, false, n_img, H / 2, W / 2, k.col, k.a, 512));
-  NSR_TRY(conv(st, packed, prec, 5, k.a, 512, false, n_img, H / 4, W / 4, k.col, d2, ld2));
-  NSR_TRY(conv(st, packed, prec, 6, d2, ld2, false, n_img, H / 4, W / 4, k.col, d3, ld3));
+// Model_VNPCAT_Encoder.forward (networks.py:760-774): features x2, x4, x6, x7 into the four destination slots
+int encoder(hipStream_t st, const float* packed, int prec, const Work& k, const float* x_nchw, int n_img, int H, int W,
+            const Act& d0, const Act& d1, const Act& d2, const Act& d3) {
+  const int64_t px0 = (int64_t)H * W;
+  const Act a128{k.a, n_img * px0, 128, 0}, a256{k.a, n_img * px0 / 4, 256, 0}, a512{k.a, n_img * px0 / 16, 512, 0};
+  NSR_TRY(conv(st, packed, prec, 0, Act{}, x_nchw, n_img, H, W, k.col, a128));
+  NSR_TRY(conv(st, packed, prec, 1, a128, nullptr, n_img, H, W, k.col, d0));
+  NSR_TRY(conv(st, packed, prec, 2, d0, nullptr, n_img, H, W, k.col, a256));
+  NSR_TRY(conv(st, packed, prec, 3, a256, nullptr, n_img, H / 2, W / 2, k.col, d1));
+  NSR_TRY(conv(st, packed, prec, 4, d1, nullptr, n_img, H / 2, W / 2, k.col, a512));
+  NSR_TRY(conv(st, packed, prec, 5, a512, nullptr, n_img, H / 4, W / 4, k.col, d2));
+  NSR_TRY(conv(st, packed, prec, 6, d2, nullptr, n_img, H / 4, W / 4, k.col, d3));
   return NSR_OK;
 }
 
-int max_refs(hipStream_t st, const float* src, int C, int B, int R, int64_t px, float* dst, int64_t ld) {
-  const int64_t n = (int64_t)B * px * (C / 4);
-  hipLaunchKernelGGL(max_refs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, C, R, px, n, dst, ld);
+int max_refs(hipStream_t st, int prec, const Act& src, int C, int B, int R, int64_t px, const Act& dst) {
+  if (prec == NSR_F16X3) {
+    const int64_t n = (int64_t)B * px * (C / 2);
+    hipLaunchKernelGGL(max_refs_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hi_of(src), plane_of(src), C,
+                       R, px, n, hi_of(dst), plane_of(dst), dst.ld);
+  } else {
+    const int64_t n = (int64_t)B * px * (C / 4);
+    hipLaunchKernelGGL(max_refs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f32_of(src), C, R, px, n,
+                       dst.p + dst.ch0, dst.ld);
+  }
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
@@ -295,28 +354,33 @@ extern "C" int nsr_refine_forward(const void* packed_v, int prec, const float* x
   Work k;
   work_floats(B, R, H, W, &k, static_cast<float*>(workspace));
   const int64_t px0 = (int64_t)H * W, px1 = px0 / 4, px2 = px0 / 16, px3 = px0 / 64;
+  const int64_t nref = (int64_t)B * R;
+  const Act cat1{k.cat1, B * px3, 1024, 0}, cat3{k.cat3, B * px2, 1536, 0}, cat5{k.cat5, B * px1, 768, 0}, cat7{k.cat7, B * px0, 384, 0};
+  auto slice = [](Act t, int ch0) { t.ch0 = ch0; return t; };
+  const Act fc0{k.fc0, nref * px0, 128, 0}, fc1{k.fc1, nref * px1, 256, 0}, fc2{k.fc2, nref * px2, 512, 0}, fc3{k.fc3, nref * px3, 512, 0};
   // encoder on the synthesised patches: features land in their decoder concat slots (F_synth_i)
-  NSR_TRY(encoder(st, packed, prec, k, x_synth, B, H, W, k.cat7 + 128, 384, k.cat5 + 256, 768, k.cat3 + 512, 1536, k.cat1, 1024));
+  NSR_TRY(encoder(st, packed, prec, k, x_synth, B, H, W, slice(cat7, 128), slice(cat5, 256), slice(cat3, 512), cat1));
   // encoder on the B * R reference patches, then the max over the R references (F_max_i)
-  NSR_TRY(encoder(st, packed, prec, k, x_candi, B * R, H, W, k.fc0, 128, k.fc1, 256, k.fc2, 512, k.fc3, 512));
-  NSR_TRY(max_refs(st, k.fc0, 128, B, R, px0, k.cat7 + 256, 384));
-  NSR_TRY(max_refs(st, k.fc1, 256, B, R, px1, k.cat5 + 512, 768));
-  NSR_TRY(max_refs(st, k.fc2, 512, B, R, px2, k.cat3 + 1024, 1536));
-  NSR_TRY(max_refs(st, k.fc3, 512, B, R, px3, k.cat1 + 512, 1024));
-  // Model_VNPCAT_Decoder.forward (networks.py:827-857)
+  NSR_TRY(encoder(st, packed, prec, k, x_candi, B * R, H, W, fc0, fc1, fc2, fc3));
+  NSR_TRY(max_refs(st, prec, fc0, 128, B, R, px0, slice(cat7, 256)));
+  NSR_TRY(max_refs(st, prec, fc1, 256, B, R, px1, slice(cat5, 512)));
+  NSR_TRY(max_refs(st, prec, fc2, 512, B, R, px2, slice(cat3, 1024)));
+  NSR_TRY(max_refs(st, prec, fc3, 512, B, R, px3, slice(cat1, 512)));
+  // Model_VNPCAT_Decoder.forward (networks.py:827-857); a / b ping-pong, the *_up layers write into the next concat
   const int h3 = H / 8, w3 = W / 8;
-  NSR_TRY(conv(st, packed, prec, 7, k.cat1, 1024, false, B, h3, w3, k.col, k.a, 512));
-  NSR_TRY(conv(st, packed, prec, 8, k.a, 512, false, B, h3, w3, k.col, k.b, 512));
-  NSR_TRY(conv(st, packed, prec, 9, k.b, 512, false, B, h3, w3, k.col, k.cat3, 1536));                 // upsample + conv2_up
-  NSR_TRY(conv(st, packed, prec, 10, k.cat3, 1536, false, B, 2 * h3, 2 * w3, k.col, k.a, 512));
-  NSR_TRY(conv(st, packed, prec, 11, k.a, 512, false, B, 2 * h3, 2 * w3, k.col, k.b, 512));
-  NSR_TRY(conv(st, packed, prec, 12, k.b, 512, false, B, 2 * h3, 2 * w3, k.col, k.cat5, 768));         // upsample + conv4_up
-  NSR_TRY(conv(st, packed, prec, 13, k.cat5, 768, false, B, 4 * h3, 4 * w3, k.col, k.a, 256));
-  NSR_TRY(conv(st, packed, prec, 14, k.a, 256, false, B, 4 * h3, 4 * w3, k.col, k.b, 256));
-  NSR_TRY(conv(st, packed, prec, 15, k.b, 256, false, B, 4 * h3, 4 * w3, k.col, k.cat7, 384));         // upsample + conv6_up
-  NSR_TRY(conv(st, packed, prec, 16, k.cat7, 384, false, B, H, W, k.col, k.a, 128));
-  NSR_TRY(conv(st, packed, prec, 17, k.a, 128, false, B, H, W, k.col, k.b, 128));
-  NSR_TRY(conv(st, packed, prec, 18, k.b, 128, false, B, H, W, k.col, k.rgb, 3));                       // conv9 + tanh
+  auto buf = [](float* p, int64_t rows, int64_t ld) { return Act{p, rows, ld, 0}; };
+  NSR_TRY(conv(st, packed, prec, 7, cat1, nullptr, B, h3, w3, k.col, buf(k.a, B * px3, 512)));
+  NSR_TRY(conv(st, packed, prec, 8, buf(k.a, B * px3, 512), nullptr, B, h3, w3, k.col, buf(k.b, B * px3, 512)));
+  NSR_TRY(conv(st, packed, prec, 9, buf(k.b, B * px3, 512), nullptr, B, h3, w3, k.col, cat3));                  // upsample + conv2_up
+  NSR_TRY(conv(st, packed, prec, 10, cat3, nullptr, B, 2 * h3, 2 * w3, k.col, buf(k.a, B * px2, 512)));
+  NSR_TRY(conv(st, packed, prec, 11, buf(k.a, B * px2, 512), nullptr, B, 2 * h3, 2 * w3, k.col, buf(k.b, B * px2, 512)));
+  NSR_TRY(conv(st, packed, prec, 12, buf(k.b, B * px2, 512), nullptr, B, 2 * h3, 2 * w3, k.col, cat5));          // upsample + conv4_up
+  NSR_TRY(conv(st, packed, prec, 13, cat5, nullptr, B, 4 * h3, 4 * w3, k.col, buf(k.a, B * px1, 256)));
+  NSR_TRY(conv(st, packed, prec, 14, buf(k.a, B * px1, 256), nullptr, B, 4 * h3, 4 * w3, k.col, buf(k.b, B * px1, 256)));
+  NSR_TRY(conv(st, packed, prec, 15, buf(k.b, B * px1, 256), nullptr, B, 4 * h3, 4 * w3, k.col, cat7));          // upsample + conv6_up
+  NSR_TRY(conv(st, packed, prec, 16, cat7, nullptr, B, H, W, k.col, buf(k.a, B * px0, 128)));
+  NSR_TRY(conv(st, packed, prec, 17, buf(k.a, B * px0, 128), nullptr, B, H, W, k.col, buf(k.b, B * px0, 128)));
+  NSR_TRY(conv(st, packed, prec, 18, buf(k.b, B * px0, 128), nullptr, B, H, W, k.col, buf(k.rgb, B * px0, 3)));  // conv9 + tanh
   const int64_t n = (int64_t)B * 3 * px0;
   hipLaunchKernelGGL(nhwc3_to_nchw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, k.rgb, px0, n, out);
   NSR_CHECK_LAUNCH();
