@@ -3,7 +3,8 @@
  * Replaces MaxPoolingModel.forward(x_synth, list_x_candi) in eval mode (models/networks.py:735-990: the
  * Model_VNPCAT encoder on the synthesised patch and on each of its R reference patches, a max over the references
  * at every scale, the Model_VNPCAT decoder), as refine_model.py:99 calls it (`self.netRefine(sr_patch, ref_patches)`).
- * fp32; every 3x3 convolution runs as an im2col + the fp32-MFMA GEMM of the training step (nsr_gemm.hip) with
+ * fp32 in / fp32 out; every 3x3 convolution runs as a GEMM (NSR_FP32: im2col + the fp32-MFMA GEMM of the training step,
+ * nsr_gemm.hip; NSR_F16X3: the split-fp16 GEMM with implicit im2col on pre-split fp16 (hi, lo) activation planes) with
  * bias / ReLU / tanh in its epilogue; BatchNorm (eval: running statistics, eps 1e-5) is folded into the packed
  * weights; activations are NHWC so that channel concatenations and nearest-neighbour upsampling cost nothing
  * (GEMM outputs land directly in the concatenated buffers, the upsampling is an index map of the next im2col).
@@ -32,8 +33,11 @@ size_t nsr_refine_packed_bytes(int precision);
 /* tensors: HOST array of NSR_REFINE_N_TENSORS DEVICE pointers (order above); packed: DEVICE, 16-byte aligned */
 int nsr_refine_pack_weights(const float* const* tensors, void* packed, int precision, void* stream);
 
-/* H and W multiples of 8 (three stride-2 levels); 0 on invalid arguments */
+/* H and W multiples of 8 (three stride-2 levels); 0 on invalid arguments.  The plain form is the NSR_FP32 size (the larger
+ * one: that mode materialises im2col matrices); `_for` gives the size a precision actually needs (NSR_F16X3: activations
+ * + a 32-column im2col matrix of the first layer only, ~21 MB per 64 x 64 patch set with 8 references). */
 size_t nsr_refine_workspace_bytes(int B, int R, int H, int W);
+size_t nsr_refine_workspace_bytes_for(int precision, int B, int R, int H, int W);
 /* x_synth (B, 3, H, W), x_candi (B, R, 3, H, W), out (B, 3, H, W): NCHW fp32 DEVICE (the reference's tensors) */
 int nsr_refine_forward(const void* packed, int precision, const float* x_synth, const float* x_candi, int B, int R, int H,
                        int W, float* out, void* workspace, size_t workspace_bytes, void* stream);

@@ -59,6 +59,7 @@ SIGNATURES = {
     "nsr_refine_packed_bytes": (c_size_t, [c_int]),
     "nsr_refine_pack_weights": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p]),
     "nsr_refine_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "nsr_refine_workspace_bytes_for": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "nsr_refine_forward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                    c_size_t, c_void_p]),
     "nsr_refine_tile": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

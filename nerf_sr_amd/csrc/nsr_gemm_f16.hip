@@ -279,10 +279,13 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   }
   if (a.conv.cin > 0 && ((a.conv.cin % kTK) != 0 || g.K != 9 * a.conv.cin)) return NSR_ERR_INVALID_ARG;
   if (g.M == 0) return NSR_OK;
-  const bool wide = g.N >= 256;
+  // 8-wave 128 x 256 tiles read an A row panel once (activations: HBM traffic); when there are too few of them to
+  // fill the chip (small M: the 8 x 8 decoder layers of the refinement network), twice as many 4-wave 128 x 128
+  // tiles are the better trade -- the panel re-read then comes out of L2
+  const int64_t row_tiles = (g.M + kTM - 1) / kTM;
+  const bool wide = g.N >= 256 && row_tiles * ((g.N + 255) / 256) >= 512;
   const int tn = wide ? 256 : 128;
   const int n_col_tiles = (g.N + tn - 1) / tn;
-  const int64_t row_tiles = (g.M + kTM - 1) / kTM;
   const dim3 grid((unsigned)(row_tiles * n_col_tiles));
   if (a.Ah) {
     if (wide) hipLaunchKernelGGL((gemm_f16x3_kernel<4, true>), grid, dim3(512), 0, st, a, n_col_tiles);

@@ -183,7 +183,8 @@ struct Work {
   float* rgb;                         // NHWC output of conv9
 };
 
-int64_t work_floats(int B, int R, int H, int W, Work* w, float* base) {
+// `implicit`: NSR_F16X3 -- only the 3-channel first layer still materialises an im2col matrix
+int64_t work_floats(int B, int R, int H, int W, Work* w, float* base, bool implicit) {
   const int64_t px0 = (int64_t)H * W, px1 = px0 / 4, px2 = px0 / 16, px3 = px0 / 64, nimg = (int64_t)B * (R > 1 ? R : 1);
   int64_t off = 0;
   auto take = [&](int64_t n) {
@@ -194,10 +195,11 @@ int64_t work_floats(int B, int R, int H, int W, Work* w, float* base) {
   Work tmp;
   Work& k = w ? *w : tmp;
   // largest im2col matrices: encoder conv2 over the reference patches, decoder conv7
-  int64_t col = nimg * px0 * kpad(1);
+  int64_t col = nimg * px0 * kpad(implicit ? 0 : 1);
   const int64_t dec[] = {B * px3 * kpad(7), B * px2 * kpad(9), B * px2 * kpad(10), B * px1 * kpad(12), B * px1 * kpad(13),
                          B * px0 * kpad(15), B * px0 * kpad(16), nimg * px1 * kpad(3), nimg * px2 * kpad(5), nimg * px1 * kpad(2)};
-  for (int64_t d : dec) col = d > col ? d : col;
+  if (!implicit)
+    for (int64_t d : dec) col = d > col ? d : col;
   k.col = take(col);
   const int64_t act = nimg * px0 * 128;   // largest plain activation: conv1 / conv2 outputs of the reference patches
   k.a = take(act);
@@ -336,8 +338,13 @@ extern "C" int nsr_refine_pack_weights(const float* const* t, void* packed, int 
 }
 
 extern "C" size_t nsr_refine_workspace_bytes(int B, int R, int H, int W) {
+  return nsr_refine_workspace_bytes_for(NSR_FP32, B, R, H, W);   // the larger of the two modes
+}
+
+extern "C" size_t nsr_refine_workspace_bytes_for(int precision, int B, int R, int H, int W) {
   if (B <= 0 || R <= 0 || H <= 0 || W <= 0 || (H % 8) || (W % 8)) return 0;
-  return (size_t)work_floats(B, R, H, W, nullptr, nullptr) * sizeof(float);
+  if (precision != NSR_FP32 && precision != NSR_F16X3) return 0;
+  return (size_t)work_floats(B, R, H, W, nullptr, nullptr, precision == NSR_F16X3) * sizeof(float);
 }
 
 extern "C" int nsr_refine_forward(const void* packed_v, int prec, const float* x_synth, const float* x_candi, int B, int R, int H,
@@ -348,11 +355,11 @@ extern "C" int nsr_refine_forward(const void* packed_v, int prec, const float* x
   if (B == 0) return NSR_OK;
   if (!packed_v || !x_synth || !x_candi || !out || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) != 0)
     return NSR_ERR_INVALID_ARG;
-  if (workspace_bytes < nsr_refine_workspace_bytes(B, R, H, W)) return NSR_ERR_WORKSPACE;
+  if (workspace_bytes < nsr_refine_workspace_bytes_for(prec, B, R, H, W)) return NSR_ERR_WORKSPACE;
   const float* packed = static_cast<const float*>(packed_v);
   hipStream_t st = nsr_stream(stream);
   Work k;
-  work_floats(B, R, H, W, &k, static_cast<float*>(workspace));
+  work_floats(B, R, H, W, &k, static_cast<float*>(workspace), prec == NSR_F16X3);
   const int64_t px0 = (int64_t)H * W, px1 = px0 / 4, px2 = px0 / 16, px3 = px0 / 64;
   const int64_t nref = (int64_t)B * R;
   const Act cat1{k.cat1, B * px3, 1024, 0}, cat3{k.cat3, B * px2, 1536, 0}, cat5{k.cat5, B * px1, 768, 0}, cat7{k.cat7, B * px0, 384, 0};

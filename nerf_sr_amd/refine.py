@@ -127,7 +127,7 @@ class MaxPoolingModel:
         if B == 0:
             return out
         lib = _lib.load()
-        need = lib.nsr_refine_workspace_bytes(B, R, H, W)
+        need = lib.nsr_refine_workspace_bytes_for(self._prec, B, R, H, W)
         if need == 0:
             raise ValueError("H and W must be positive multiples of 8 and R >= 1")
         if self._ws is None or self._ws.numel() < need:
@@ -179,9 +179,11 @@ def stitch_patches(patches: torch.Tensor, starts: torch.Tensor, img_wh) -> torch
 
 
 def refine_image(net: MaxPoolingModel, sr_img: torch.Tensor, ref_img: torch.Tensor, locs: torch.Tensor, patch_len: int = 64,
-                 num_ref_patches: int = 8, batch: int = 32) -> torch.Tensor:
+                 num_ref_patches: int = 8, batch: int = 256) -> torch.Tensor:
     """The refinement pass over one synthesised view (config #5 tail): tile -> network on batches of tiles -> stitch.
-    Images are (3, H, W) in [-1, 1] (the dataset's Normalize(0.5, 0.5)); returns the refined (3, H, W) image."""
+    Images are (3, H, W) in [-1, 1] (the dataset's Normalize(0.5, 0.5)); returns the refined (3, H, W) image.
+    ``batch``: tiles per network call.  The default takes the 169 tiles of an 800 x 800 frame in ONE call (3.5 GB of
+    activations): the 8 x 8-pixel decoder layers of a 32-tile batch fill an eighth of the chip (57 vs 45 ms per frame)."""
     starts, refs = tile_refs(locs, patch_len, num_ref_patches)
     sr, ref = gather_patches(sr_img, ref_img, starts, refs, patch_len)
     pred = torch.cat([net(sr[i:i + batch], ref[i:i + batch]) for i in range(0, sr.shape[0], batch)], 0)

@@ -145,6 +145,16 @@ def main():
     ro, rd = ru.get_ndc_rays(H4, W4, f_l, 1.0, ro, rd)
     rays = torch.cat([ro, rd, 0 * torch.ones_like(ro[:, :1]), 1 * torch.ones_like(ro[:, :1])], 1)
     g["llff_rays_lr_s4"] = np32(einops.rearrange(rays.view(H4, W4, -1), '(h s1) (w s2) c -> (h w) (s1 s2) c', s1=4, s2=4))
+    # Blender, s = 4 (BASELINE config #5's regroup): the test path views the rays as (W, H, -1) before the regroup
+    # (data/blender_downX_dataset.py:207-215; the dataset asserts W == H, :63), so the grid is square: 16 x 16 <- 4 x 4
+    Hb = Wb = 16
+    f_b16 = cameras.blender_focal(Wb)
+    dirs = ru.get_ray_directions(Hb, Wb, f_b16, True)
+    ro, rd = ru.get_rays(dirs, torch.FloatTensor(c2w_b))
+    rays = torch.cat([ro, rd, 2.0 * torch.ones_like(ro[:, :1]), 6.0 * torch.ones_like(ro[:, :1])], 1)
+    g["blender_rays_lr_s4"] = np32(einops.rearrange(rays.view(Wb, Hb, -1), '(h s1) (w s2) c -> (h w) (s1 s2) c', s1=4, s2=4))
+    g["blender_s4_hw"] = Hb
+    g["blender_s4_focal"] = np.float64(f_b16)
     np.savez_compressed(os.path.join(HERE, "raygrid.npz"), **g)
 
     # ------------------------------------------------------------------ full path, two families

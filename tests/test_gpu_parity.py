@@ -63,6 +63,9 @@ def test_subpixel_rays_vs_golden(ops, golden_dir):
         _close(rays, g[f"{tag}_rays_lr"], 2e-6)
     rays4 = ops.subpixel_rays(g["llff_c2w"], (W, H), float(g["llff_focal"]), 4, True)
     _close(rays4, g["llff_rays_lr_s4"], 2e-6)
+    hw = int(g["blender_s4_hw"])          # Blender, s = 4: BASELINE config #5's regroup
+    rays_b4 = ops.subpixel_rays(g["blender_c2w"], (hw, hw), float(g["blender_s4_focal"]), 4, False, 2.0, 6.0)
+    _close(rays_b4, g["blender_rays_lr_s4"], 2e-6)
 
 
 def test_subpixel_rays_full_size_vs_oracle(ops):

@@ -45,6 +45,11 @@ def test_raygrid(golden_dir):
         _close(rays, g[f"{tag}_rays_lr"], 1e-6)
     rays4 = oc.subpixel_ray_grid(_t(g["llff_c2w"]), H, W, float(g["llff_focal"]), 4, True, 0.0, 1.0)
     _close(rays4, g["llff_rays_lr_s4"], 1e-6)
+    # Blender 16 x 16 <- 4 x 4, s = 4 (config #5's regroup; data/blender_downX_dataset.py:207-215)
+    hw = int(g["blender_s4_hw"])
+    rays_b4 = oc.subpixel_ray_grid(_t(g["blender_c2w"]), hw, hw, float(g["blender_s4_focal"]), 4, False, 2.0, 6.0)
+    assert rays_b4.shape == (16, 16, 8)
+    _close(rays_b4, g["blender_rays_lr_s4"], 1e-6)
 
 
 def test_posenc_and_sampling(path):
