@@ -251,6 +251,171 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
   else gemm_epilogue<kTN>(g, acc, col_on, m0, n0, wm, wn, li, h, tid, 0, bid / n_col_tiles, reinterpret_cast<float*>(lds));
 }
 
+
+#ifdef NSR_GEMM_DMA
+// ---------------------------------------------------------------------------------------------------------------
+// EXPERIMENT (built only with -DNSR_GEMM_DMA; correct -- the refinement tests pass on it -- but SLOWER than the
+// register-staged kernel above: 48.5 vs 44.5 ms per 800 x 800 refinement pass.  An LDS-DMA costs the issuing wave
+// 60-180 cycles against a handful for a plain global_load_dwordx4, and this kernel has the registers to stage through.)
+// The same product for PRE-SPLIT operands on both sides (A planes, B pre-split weights), fed by LDS-DMA.
+//
+// With both operands already fp16 there is nothing to convert on the way in, so the tiles go global -> LDS directly
+// (global_load_lds_dwordx4: 64 lanes x 16 B per wave-instruction, no staging registers, no ds_write) into a
+// DOUBLE-buffered LDS image: tile t + 1 streams in while tile t is on the matrix pipe, one barrier per K tile.
+// An LDS-DMA lands lane-linear (lane L at base + 16 L), so the image is made of 1 KiB blocks that ARE MFMA fragments:
+// block (32 rows, k-step s, plane) holds at 16 (32 h + li) the 8 halves k = 16 s + 8 h .. + 7 of row li -- what lane
+// (li, h) feeds to v_mfma_f32_32x32x16_f16 -- so every fragment read is a conflict-free ds_read_b128 and every lane's
+// DMA source is one contiguous 16-byte run of a row (the implicit-im2col gather costs nothing extra: each lane computes
+// the address of ITS row under the current tap; rows in the zero padding read a 16-byte zero constant).
+// K tile = 32 (two k-steps, 24 MFMAs per wave); per buffer 16 KiB of A + 16 / 32 KiB of B.
+__device__ __attribute__((aligned(16))) const unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void glds16_gather(const void* src, unsigned lds_dst_uniform) {
+  asm volatile(
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, off"
+      :
+      : "v"(src), "s"(lds_dst_uniform)
+      : "memory");
+}
+
+template <int WN>
+__global__ void __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))
+gemm_f16x3_dma_kernel(GemmF16Args a, int n_col_tiles) {
+  constexpr int NW = 2 * WN;                       // waves per workgroup
+  constexpr int kTN = 64 * WN;
+  constexpr int kABlocks = 16, kBBlocks = (kTN / 32) * 4;          // 1 KiB blocks per K tile: (row block, k-step, plane)
+  constexpr int kBufBytes = (kABlocks + kBBlocks) * 1024;
+  constexpr int kPerWave = (kABlocks + kBBlocks) / NW;             // DMA instructions per wave and K tile (6 / 8)
+  constexpr int kAPerWave = kABlocks / NW;                         // ... of which A blocks (2 / 4)
+  __shared__ __attribute__((aligned(16))) char lds[2 * kBufBytes];
+  const GemmArgs& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1, li = lane & 31, h = lane >> 5;
+  const int64_t bid = blockIdx.x;
+  const int64_t m0 = (bid / n_col_tiles) * kTM;
+  const int n0 = (int)(bid % n_col_tiles) * kTN;
+  const int n_tiles = (int)(g.K / kTK);
+  const bool conv = a.conv.cin > 0;
+  const unsigned lds0 = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)lds);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.0f;
+  bool col_on[2];
+#pragma unroll
+  for (int bj = 0; bj < 2; ++bj) col_on[bj] = (n0 + 64 * wn + 32 * bj) < g.N;
+
+  // ---- this wave's DMA blocks: d = wave + NW i.  d < 16: A block (row block d >> 2, k-step (d >> 1) & 1, plane d & 1);
+  // else B block e = d - 16 (column block e >> 2, k-step, plane).  A lane serves row `li` of the block, halves 8 h ..
+  int64_t a_row[kAPerWave];           // element offset of the lane's A row (conv: under the current tap), -1 = zero row
+  RowSrc rs[kAPerWave];
+  const unsigned short* b_src[kPerWave - kAPerWave];
+#pragma unroll
+  for (int i = 0; i < kAPerWave; ++i) {
+    const int d = wave + NW * i;
+    int64_t m = m0 + 32 * (d >> 2) + li;
+    m = m < g.M ? m : g.M - 1;
+    if (conv) {
+      const int64_t per = (int64_t)a.conv.Ho * a.conv.Wo;
+      rs[i].img = (int)(m / per);
+      rs[i].oy = (int)((m % per) / a.conv.Wo);
+      rs[i].ox = (int)(m % a.conv.Wo);
+      a_row[i] = 0;
+    } else {
+      a_row[i] = m * g.lda;
+    }
+  }
+#pragma unroll
+  for (int i = kAPerWave; i < kPerWave; ++i) {
+    const int e = wave + NW * i - kABlocks;
+    int n = n0 + 32 * (e >> 2) + li;
+    n = n < g.N ? n : g.N - 1;
+    b_src[i - kAPerWave] = ((e & 1) ? a.Bl : a.Bh) + (int64_t)n * a.ldbh + 16 * ((e >> 1) & 1) + 8 * h;
+  }
+
+  auto issue = [&](int t, int buf) {
+    const int64_t k0 = (int64_t)t * kTK;
+    int64_t koff = k0;
+    if (conv) {
+      const int cbase = (int)(k0 % a.conv.cin);
+      koff = cbase;
+      if (cbase == 0) {   // the K tile enters the next tap: new source pixel for every row
+        const int tap = (int)(k0 / a.conv.cin), ky = tap / 3, kx = tap % 3;
+        const int Hin = a.conv.up ? 2 * a.conv.Hs : a.conv.Hs, Win = a.conv.up ? 2 * a.conv.Ws : a.conv.Ws;
+#pragma unroll
+        for (int i = 0; i < kAPerWave; ++i) {
+          const int iy = rs[i].oy * a.conv.stride + ky - 1, ix = rs[i].ox * a.conv.stride + kx - 1;
+          a_row[i] = -1;
+          if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
+            const int sy = a.conv.up ? iy >> 1 : iy, sx = a.conv.up ? ix >> 1 : ix;
+            a_row[i] = (((int64_t)rs[i].img * a.conv.Hs + sy) * a.conv.Ws + sx) * g.lda;
+          }
+        }
+      }
+    }
+    const unsigned base = lds0 + (unsigned)buf * kBufBytes;
+#pragma unroll
+    for (int i = 0; i < kAPerWave; ++i) {
+      const int d = wave + NW * i;
+      const unsigned short* src = a.Ah + ((d & 1) ? a.a_plane : 0) + a_row[i] + koff + 16 * ((d >> 1) & 1) + 8 * h;
+      glds16_gather(a_row[i] >= 0 ? static_cast<const void*>(src) : static_cast<const void*>(g_zero16), base + (unsigned)d * 1024u);
+    }
+#pragma unroll
+    for (int i = kAPerWave; i < kPerWave; ++i) {
+      const int d = wave + NW * i;
+      glds16_gather(b_src[i - kAPerWave] + k0, base + (unsigned)d * 1024u);
+    }
+  };
+
+  if (n_tiles > 0) issue(0, 0);
+  for (int t = 0; t < n_tiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t have landed ...
+    __syncthreads();                                    // ... everyone's have, and everyone is done with tile t - 1
+    if (t + 1 < n_tiles) issue(t + 1, (t + 1) & 1);
+    const char* buf = lds + (t & 1) * kBufBytes + lane * 16;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int bi = 0; bi < 2; ++bi) {
+        const int blk = ((2 * wm + bi) * 2 + s) * 2;
+        ah[bi] = *reinterpret_cast<const h8*>(buf + blk * 1024);
+        al[bi] = *reinterpret_cast<const h8*>(buf + (blk + 1) * 1024);
+      }
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj) {
+        const int blk = kABlocks + ((2 * wn + bj) * 2 + s) * 2;
+        bh[bj] = *reinterpret_cast<const h8*>(buf + blk * 1024);
+        bl[bj] = *reinterpret_cast<const h8*>(buf + (blk + 1) * 1024);
+      }
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj)
+        if (col_on[bj]) {
+#pragma unroll
+          for (int bi = 0; bi < 2; ++bi) {
+            acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[bi], bh[bj], acc[bi][bj], 0, 0, 0);   // small terms first
+            acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[bi], bl[bj], acc[bi][bj], 0, 0, 0);
+            acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[bi], bh[bj], acc[bi][bj], 0, 0, 0);
+          }
+        }
+    }
+  }
+  if (a.Ch) {
+    epilogue_planes<kTN>(a, acc, col_on, m0, n0, wm, wn, li, h);
+  } else {
+    __syncthreads();   // the shared epilogue may use the LDS image for its column sums
+    gemm_epilogue<kTN>(g, acc, col_on, m0, n0, wm, wn, li, h, tid, 0, bid / n_col_tiles, reinterpret_cast<float*>(lds));
+  }
+}
+#endif   // NSR_GEMM_DMA
+
 }  // namespace
 
 NSR_INTERNAL int split_f16(const float* w, int64_t n, unsigned short* hi, unsigned short* lo, hipStream_t st) {
@@ -288,8 +453,13 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   const int n_col_tiles = (g.N + tn - 1) / tn;
   const dim3 grid((unsigned)(row_tiles * n_col_tiles));
   if (a.Ah) {
+#ifdef NSR_GEMM_DMA   // experiment (measured 9 % slower on the refinement pass, see the kernel's header)
+    if (wide) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<4>), grid, dim3(512), 0, st, a, n_col_tiles);
+    else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<2>), grid, dim3(256), 0, st, a, n_col_tiles);
+#else
     if (wide) hipLaunchKernelGGL((gemm_f16x3_kernel<4, true>), grid, dim3(512), 0, st, a, n_col_tiles);
     else hipLaunchKernelGGL((gemm_f16x3_kernel<2, true>), grid, dim3(256), 0, st, a, n_col_tiles);
+#endif
   } else {
     if (wide) hipLaunchKernelGGL((gemm_f16x3_kernel<4, false>), grid, dim3(512), 0, st, a, n_col_tiles);
     else hipLaunchKernelGGL((gemm_f16x3_kernel<2, false>), grid, dim3(256), 0, st, a, n_col_tiles);
