@@ -42,6 +42,15 @@ size_t nsr_refine_workspace_bytes_for(int precision, int B, int R, int H, int W)
 int nsr_refine_forward(const void* packed, int precision, const float* x_synth, const float* x_candi, int B, int R, int H,
                        int W, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- `--not_use_ref` (MaxPoolingModel with Model_VNPCAT_Decoder_NoPooling, networks.py:866-945, 958-969): the encoder
+ * runs on the synthesised patch only and the decoder's concatenations carry no F_max_i channels, i.e. D.conv1, D.conv3,
+ * D.conv5, D.conv7 have 512 / 1024 / 512 / 256 input channels.  Same 106 tensors in the same order (four of them with
+ * those shapes), its own packed blob; workspace: nsr_refine_workspace_bytes_for(precision, B, 1, H, W). */
+size_t nsr_refine_packed_bytes_noref(int precision);
+int nsr_refine_pack_weights_noref(const float* const* tensors, void* packed, int precision, void* stream);
+int nsr_refine_forward_noref(const void* packed, int precision, const float* x_synth, int B, int H, int W, float* out,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- patch tiler / stitcher around the network (the 'test' path of data/llff_refine_dataset.py:303-340 and
  * models/refine_model.py:205-216): an SR image is cut into `patch` x `patch` tiles on a grid (x outer, y inner, starts
  * clamped to size - patch); each tile gets `n_ref` reference patches whose top-left corners are the first `n_ref`

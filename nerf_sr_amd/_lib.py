@@ -62,6 +62,9 @@ SIGNATURES = {
     "nsr_refine_workspace_bytes_for": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "nsr_refine_forward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                    c_size_t, c_void_p]),
+    "nsr_refine_packed_bytes_noref": (c_size_t, [c_int]),
+    "nsr_refine_pack_weights_noref": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p]),
+    "nsr_refine_forward_noref": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nsr_refine_tile": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "nsr_refine_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                   c_void_p, c_void_p]),

@@ -25,8 +25,11 @@ namespace {
 struct Layer {
   int cin, cout, stride, bn, up, act;
 };
-// forward order = state_dict order (E.conv1..7, D.conv1, 2, 2_up, 3, 4, 4_up, 5, 6, 6_up, 7, 8, 9)
-constexpr Layer kLayers[NSR_REFINE_N_LAYERS] = {
+// forward order = state_dict order (E.conv1..7, D.conv1, 2, 2_up, 3, 4, 4_up, 5, 6, 6_up, 7, 8, 9).
+// Variant 0: Model_VNPCAT_Decoder (decoder inputs [.. | F_synth_i | F_max_i]); variant 1: --not_use_ref,
+// Model_VNPCAT_Decoder_NoPooling (networks.py:866-945: the same layers without the F_max_i channels, i.e. D.conv1,
+// D.conv3, D.conv5 and D.conv7 take 512 / 1024 / 512 / 256 input channels).
+constexpr Layer kLayersV[2][NSR_REFINE_N_LAYERS] = {{
     {3, 128, 1, 0, 0, kActRelu},    {128, 128, 1, 1, 0, kActRelu}, {128, 256, 2, 1, 0, kActRelu},
     {256, 256, 1, 1, 0, kActRelu},  {256, 512, 2, 1, 0, kActRelu}, {512, 512, 1, 1, 0, kActRelu},
     {512, 512, 2, 1, 0, kActRelu},
@@ -34,13 +37,21 @@ constexpr Layer kLayers[NSR_REFINE_N_LAYERS] = {
     {1536, 512, 1, 1, 0, kActRelu}, {512, 512, 1, 1, 0, kActRelu}, {512, 256, 1, 1, 1, kActRelu},
     {768, 256, 1, 1, 0, kActRelu},  {256, 256, 1, 1, 0, kActRelu}, {256, 128, 1, 1, 1, kActRelu},
     {384, 128, 1, 1, 0, kActRelu},  {128, 128, 1, 1, 0, kActRelu}, {128, 3, 1, 0, 0, kActTanh},
-};
+}, {
+    {3, 128, 1, 0, 0, kActRelu},    {128, 128, 1, 1, 0, kActRelu}, {128, 256, 2, 1, 0, kActRelu},
+    {256, 256, 1, 1, 0, kActRelu},  {256, 512, 2, 1, 0, kActRelu}, {512, 512, 1, 1, 0, kActRelu},
+    {512, 512, 2, 1, 0, kActRelu},
+    {512, 512, 1, 1, 0, kActRelu},  {512, 512, 1, 1, 0, kActRelu}, {512, 512, 1, 1, 1, kActRelu},
+    {1024, 512, 1, 1, 0, kActRelu}, {512, 512, 1, 1, 0, kActRelu}, {512, 256, 1, 1, 1, kActRelu},
+    {512, 256, 1, 1, 0, kActRelu},  {256, 256, 1, 1, 0, kActRelu}, {256, 128, 1, 1, 1, kActRelu},
+    {256, 128, 1, 1, 0, kActRelu},  {128, 128, 1, 1, 0, kActRelu}, {128, 3, 1, 0, 0, kActTanh},
+}};
 constexpr int pad32(int n) { return (n + 31) & ~31; }
-constexpr int kpad(int l) { return pad32(9 * kLayers[l].cin); }
-constexpr int npad(int l) { return pad32(kLayers[l].cout); }
-constexpr int64_t layer_floats(int l) { return (int64_t)npad(l) * kpad(l) + npad(l); }   // W' (npad x kpad) | b' (npad)
-constexpr int64_t layer_offset(int l) { return l == 0 ? 0 : layer_offset(l - 1) + layer_floats(l - 1); }
-constexpr int64_t kPackFloats = layer_offset(NSR_REFINE_N_LAYERS - 1) + layer_floats(NSR_REFINE_N_LAYERS - 1);
+constexpr int kpad(int v, int l) { return pad32(9 * kLayersV[v][l].cin); }
+constexpr int npad(int v, int l) { return pad32(kLayersV[v][l].cout); }
+constexpr int64_t layer_floats(int v, int l) { return (int64_t)npad(v, l) * kpad(v, l) + npad(v, l); }   // W' (npad x kpad) | b' (npad)
+constexpr int64_t layer_offset(int v, int l) { return l == 0 ? 0 : layer_offset(v, l - 1) + layer_floats(v, l - 1); }
+constexpr int64_t pack_floats(int v) { return layer_offset(v, NSR_REFINE_N_LAYERS - 1) + layer_floats(v, NSR_REFINE_N_LAYERS - 1); }
 constexpr float kBnEps = 1e-5f;   // nn.BatchNorm2d default
 
 inline int64_t align64(int64_t n) { return (n + 63) & ~(int64_t)63; }
@@ -195,9 +206,9 @@ int64_t work_floats(int B, int R, int H, int W, Work* w, float* base, bool impli
   Work tmp;
   Work& k = w ? *w : tmp;
   // largest im2col matrices: encoder conv2 over the reference patches, decoder conv7
-  int64_t col = nimg * px0 * kpad(implicit ? 0 : 1);
-  const int64_t dec[] = {B * px3 * kpad(7), B * px2 * kpad(9), B * px2 * kpad(10), B * px1 * kpad(12), B * px1 * kpad(13),
-                         B * px0 * kpad(15), B * px0 * kpad(16), nimg * px1 * kpad(3), nimg * px2 * kpad(5), nimg * px1 * kpad(2)};
+  int64_t col = nimg * px0 * kpad(0, implicit ? 0 : 1);
+  const int64_t dec[] = {B * px3 * kpad(0, 7), B * px2 * kpad(0, 9), B * px2 * kpad(0, 10), B * px1 * kpad(0, 12), B * px1 * kpad(0, 13),
+                         B * px0 * kpad(0, 15), B * px0 * kpad(0, 16), nimg * px1 * kpad(0, 3), nimg * px2 * kpad(0, 5), nimg * px1 * kpad(0, 2)};
   if (!implicit)
     for (int64_t d : dec) col = d > col ? d : col;
   k.col = take(col);
@@ -236,13 +247,13 @@ inline int64_t plane_of(const Act& t) { return t.rows * t.ld; }
 
 // one convolution layer: src (NHWC activation; NCHW fp32 input tensor for layer 0) -> dst (NHWC slice; the last layer
 // writes fp32 in both modes)
-int conv(hipStream_t st, const float* packed, int precision, int l, const Act& src, const float* src_nchw, int n_img, int Hs,
-         int Ws, float* col, const Act& dst) {
-  const Layer& L = kLayers[l];
+int conv(hipStream_t st, const float* packed, int precision, int v, int l, const Act& src, const float* src_nchw, int n_img,
+         int Hs, int Ws, float* col, const Act& dst) {
+  const Layer& L = kLayersV[v][l];
   const bool nchw = src_nchw != nullptr, f16 = precision == NSR_F16X3, last = l == NSR_REFINE_N_LAYERS - 1;
   const int Hin = L.up ? 2 * Hs : Hs, Win = L.up ? 2 * Ws : Ws;
   const int Ho = (Hin - 1) / L.stride + 1, Wo = (Win - 1) / L.stride + 1;   // k = 3, pad = 1
-  const int kp = kpad(l);
+  const int kp = kpad(v, l);
   const int64_t M = (int64_t)n_img * Ho * Wo, total = M * (kp / 4);
   const bool implicit = f16 && !nchw && (L.cin % 32) == 0;
   if (!implicit) {
@@ -251,17 +262,17 @@ int conv(hipStream_t st, const float* packed, int precision, int l, const Act& s
     else hipLaunchKernelGGL(im2col_kernel<false>, grid, block, 0, st, f32_of(src), src.ld, L.cin, n_img, Hs, Ws, L.stride, L.up, Ho, Wo, kp, col);
     NSR_CHECK_LAUNCH();
   }
-  const float* wp = packed + layer_offset(l);
+  const float* wp = packed + layer_offset(v, l);
   GemmArgs g{};
-  g.A = col; g.lda = kp; g.B = wp; g.ldb = kp; g.C = dst.p + dst.ch0; g.ldc = dst.ld; g.bias = wp + (int64_t)npad(l) * kp;
-  g.M = M; g.N = npad(l); g.K = kp; g.n_valid = L.cout; g.act = L.act; g.splits = 1;
+  g.A = col; g.lda = kp; g.B = wp; g.ldb = kp; g.C = dst.p + dst.ch0; g.ldc = dst.ld; g.bias = wp + (int64_t)npad(v, l) * kp;
+  g.M = M; g.N = npad(v, l); g.K = kp; g.n_valid = L.cout; g.act = L.act; g.splits = 1;
   if (!f16) return gemm(g, st);
   GemmF16Args a{};
   a.g = g;
   a.g.acc_scale = kSplitInvScale;
   a.g.B = nullptr;
   a.Bh = reinterpret_cast<const unsigned short*>(wp);
-  a.Bl = a.Bh + (int64_t)npad(l) * kp;
+  a.Bl = a.Bh + (int64_t)npad(v, l) * kp;
   a.ldbh = kp;
   if (implicit) {   // gather from the pre-split NHWC activation
     a.g.A = nullptr;
@@ -279,17 +290,17 @@ int conv(hipStream_t st, const float* packed, int precision, int l, const Act& s
 }
 
 // Model_VNPCAT_Encoder.forward (networks.py:760-774): features x2, x4, x6, x7 into the four destination slots
-int encoder(hipStream_t st, const float* packed, int prec, const Work& k, const float* x_nchw, int n_img, int H, int W,
+int encoder(hipStream_t st, const float* packed, int prec, int v, const Work& k, const float* x_nchw, int n_img, int H, int W,
             const Act& d0, const Act& d1, const Act& d2, const Act& d3) {
   const int64_t px0 = (int64_t)H * W;
   const Act a128{k.a, n_img * px0, 128, 0}, a256{k.a, n_img * px0 / 4, 256, 0}, a512{k.a, n_img * px0 / 16, 512, 0};
-  NSR_TRY(conv(st, packed, prec, 0, Act{}, x_nchw, n_img, H, W, k.col, a128));
-  NSR_TRY(conv(st, packed, prec, 1, a128, nullptr, n_img, H, W, k.col, d0));
-  NSR_TRY(conv(st, packed, prec, 2, d0, nullptr, n_img, H, W, k.col, a256));
-  NSR_TRY(conv(st, packed, prec, 3, a256, nullptr, n_img, H / 2, W / 2, k.col, d1));
-  NSR_TRY(conv(st, packed, prec, 4, d1, nullptr, n_img, H / 2, W / 2, k.col, a512));
-  NSR_TRY(conv(st, packed, prec, 5, a512, nullptr, n_img, H / 4, W / 4, k.col, d2));
-  NSR_TRY(conv(st, packed, prec, 6, d2, nullptr, n_img, H / 4, W / 4, k.col, d3));
+  NSR_TRY(conv(st, packed, prec, v, 0, Act{}, x_nchw, n_img, H, W, k.col, a128));
+  NSR_TRY(conv(st, packed, prec, v, 1, a128, nullptr, n_img, H, W, k.col, d0));
+  NSR_TRY(conv(st, packed, prec, v, 2, d0, nullptr, n_img, H, W, k.col, a256));
+  NSR_TRY(conv(st, packed, prec, v, 3, a256, nullptr, n_img, H / 2, W / 2, k.col, d1));
+  NSR_TRY(conv(st, packed, prec, v, 4, d1, nullptr, n_img, H / 2, W / 2, k.col, a512));
+  NSR_TRY(conv(st, packed, prec, v, 5, a512, nullptr, n_img, H / 4, W / 4, k.col, d2));
+  NSR_TRY(conv(st, packed, prec, v, 6, d2, nullptr, n_img, H / 4, W / 4, k.col, d3));
   return NSR_OK;
 }
 
@@ -309,11 +320,9 @@ int max_refs(hipStream_t st, int prec, const Act& src, int C, int B, int R, int6
 
 }  // namespace
 
-extern "C" size_t nsr_refine_packed_bytes(int precision) {
-  return (precision == NSR_FP32 || precision == NSR_F16X3) ? (size_t)kPackFloats * sizeof(float) : 0;
-}
+namespace {
 
-extern "C" int nsr_refine_pack_weights(const float* const* t, void* packed, int precision, void* stream) {
+int pack_weights(const float* const* t, void* packed, int precision, int v, void* stream) {
   if (!t || !packed || (reinterpret_cast<uintptr_t>(packed) & 15) != 0) return NSR_ERR_INVALID_ARG;
   if (precision != NSR_FP32 && precision != NSR_F16X3) return NSR_ERR_UNSUPPORTED;
   for (int i = 0; i < NSR_REFINE_N_TENSORS; ++i)
@@ -321,7 +330,7 @@ extern "C" int nsr_refine_pack_weights(const float* const* t, void* packed, int 
   float* dst = static_cast<float*>(packed);
   int ti = 0;
   for (int l = 0; l < NSR_REFINE_N_LAYERS; ++l) {
-    const Layer& L = kLayers[l];
+    const Layer& L = kLayersV[v][l];
     const float *w = t[ti], *b = t[ti + 1];
     const float *gamma = nullptr, *beta = nullptr, *mean = nullptr, *var = nullptr;
     ti += 2;
@@ -329,12 +338,81 @@ extern "C" int nsr_refine_pack_weights(const float* const* t, void* packed, int 
       gamma = t[ti]; beta = t[ti + 1]; mean = t[ti + 2]; var = t[ti + 3];
       ti += 4;
     }
-    const int64_t n = layer_floats(l);
+    const int64_t n = layer_floats(v, l);
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nsr_stream(stream), w, b, gamma, beta,
-                       mean, var, L.cin, L.cout, kpad(l), npad(l), precision == NSR_F16X3, dst + layer_offset(l));
+                       mean, var, L.cin, L.cout, kpad(v, l), npad(v, l), precision == NSR_F16X3, dst + layer_offset(v, l));
     NSR_CHECK_LAUNCH();
   }
   return NSR_OK;
+}
+
+// v = 0: x_candi (B, R, ...) given, decoder inputs [.. | F_synth_i | F_max_i]; v = 1 (--not_use_ref): no references,
+// decoder inputs [.. | F_synth_i] (MaxPoolingModel.forward, networks.py:963-969)
+int forward(const void* packed_v, int prec, int v, const float* x_synth, const float* x_candi, int B, int R, int H, int W, float* out,
+            void* workspace, size_t workspace_bytes, void* stream) {
+  if (B < 0 || R <= 0 || H <= 0 || W <= 0) return NSR_ERR_INVALID_ARG;
+  if (prec != NSR_FP32 && prec != NSR_F16X3) return NSR_ERR_UNSUPPORTED;
+  if ((H % 8) || (W % 8)) return NSR_ERR_UNSUPPORTED;
+  if (B == 0) return NSR_OK;
+  if (!packed_v || !x_synth || (v == 0 && !x_candi) || !out || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) != 0)
+    return NSR_ERR_INVALID_ARG;
+  if (workspace_bytes < nsr_refine_workspace_bytes_for(prec, B, R, H, W)) return NSR_ERR_WORKSPACE;
+  const float* packed = static_cast<const float*>(packed_v);
+  hipStream_t st = nsr_stream(stream);
+  Work k;
+  work_floats(B, R, H, W, &k, static_cast<float*>(workspace), prec == NSR_F16X3);
+  const int64_t px0 = (int64_t)H * W, px1 = px0 / 4, px2 = px0 / 16, px3 = px0 / 64;
+  const int64_t nref = (int64_t)B * R;
+  // concatenated decoder inputs: [x_up | F_synth | F_max] (v = 0) or [x_up | F_synth] (v = 1); level 3 has no x_up
+  const int w1 = v ? 512 : 1024, w3 = v ? 1024 : 1536, w5 = v ? 512 : 768, w7 = v ? 256 : 384;
+  const Act cat1{k.cat1, B * px3, w1, 0}, cat3{k.cat3, B * px2, w3, 0}, cat5{k.cat5, B * px1, w5, 0}, cat7{k.cat7, B * px0, w7, 0};
+  auto slice = [](Act t, int ch0) { t.ch0 = ch0; return t; };
+  // encoder on the synthesised patches: features land in their decoder concat slots (F_synth_i)
+  NSR_TRY(encoder(st, packed, prec, v, k, x_synth, B, H, W, slice(cat7, 128), slice(cat5, 256), slice(cat3, 512), cat1));
+  if (v == 0) {
+    // encoder on the B * R reference patches, then the max over the R references (F_max_i)
+    const Act fc0{k.fc0, nref * px0, 128, 0}, fc1{k.fc1, nref * px1, 256, 0}, fc2{k.fc2, nref * px2, 512, 0}, fc3{k.fc3, nref * px3, 512, 0};
+    NSR_TRY(encoder(st, packed, prec, v, k, x_candi, B * R, H, W, fc0, fc1, fc2, fc3));
+    NSR_TRY(max_refs(st, prec, fc0, 128, B, R, px0, slice(cat7, 256)));
+    NSR_TRY(max_refs(st, prec, fc1, 256, B, R, px1, slice(cat5, 512)));
+    NSR_TRY(max_refs(st, prec, fc2, 512, B, R, px2, slice(cat3, 1024)));
+    NSR_TRY(max_refs(st, prec, fc3, 512, B, R, px3, slice(cat1, 512)));
+  }
+  // Model_VNPCAT_Decoder(_NoPooling).forward (networks.py:827-857, 906-935); a / b ping-pong, the *_up layers write into
+  // the next concatenated buffer
+  const int h3 = H / 8, w3p = W / 8;
+  auto buf = [](float* p, int64_t rows, int64_t ld) { return Act{p, rows, ld, 0}; };
+  NSR_TRY(conv(st, packed, prec, v, 7, cat1, nullptr, B, h3, w3p, k.col, buf(k.a, B * px3, 512)));
+  NSR_TRY(conv(st, packed, prec, v, 8, buf(k.a, B * px3, 512), nullptr, B, h3, w3p, k.col, buf(k.b, B * px3, 512)));
+  NSR_TRY(conv(st, packed, prec, v, 9, buf(k.b, B * px3, 512), nullptr, B, h3, w3p, k.col, cat3));                  // upsample + conv2_up
+  NSR_TRY(conv(st, packed, prec, v, 10, cat3, nullptr, B, 2 * h3, 2 * w3p, k.col, buf(k.a, B * px2, 512)));
+  NSR_TRY(conv(st, packed, prec, v, 11, buf(k.a, B * px2, 512), nullptr, B, 2 * h3, 2 * w3p, k.col, buf(k.b, B * px2, 512)));
+  NSR_TRY(conv(st, packed, prec, v, 12, buf(k.b, B * px2, 512), nullptr, B, 2 * h3, 2 * w3p, k.col, cat5));          // upsample + conv4_up
+  NSR_TRY(conv(st, packed, prec, v, 13, cat5, nullptr, B, 4 * h3, 4 * w3p, k.col, buf(k.a, B * px1, 256)));
+  NSR_TRY(conv(st, packed, prec, v, 14, buf(k.a, B * px1, 256), nullptr, B, 4 * h3, 4 * w3p, k.col, buf(k.b, B * px1, 256)));
+  NSR_TRY(conv(st, packed, prec, v, 15, buf(k.b, B * px1, 256), nullptr, B, 4 * h3, 4 * w3p, k.col, cat7));          // upsample + conv6_up
+  NSR_TRY(conv(st, packed, prec, v, 16, cat7, nullptr, B, H, W, k.col, buf(k.a, B * px0, 128)));
+  NSR_TRY(conv(st, packed, prec, v, 17, buf(k.a, B * px0, 128), nullptr, B, H, W, k.col, buf(k.b, B * px0, 128)));
+  NSR_TRY(conv(st, packed, prec, v, 18, buf(k.b, B * px0, 128), nullptr, B, H, W, k.col, buf(k.rgb, B * px0, 3)));  // conv9 + tanh
+  const int64_t n = (int64_t)B * 3 * px0;
+  hipLaunchKernelGGL(nhwc3_to_nchw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, k.rgb, px0, n, out);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
+}  // namespace
+
+extern "C" size_t nsr_refine_packed_bytes(int precision) {
+  return (precision == NSR_FP32 || precision == NSR_F16X3) ? (size_t)pack_floats(0) * sizeof(float) : 0;
+}
+extern "C" size_t nsr_refine_packed_bytes_noref(int precision) {
+  return (precision == NSR_FP32 || precision == NSR_F16X3) ? (size_t)pack_floats(1) * sizeof(float) : 0;
+}
+extern "C" int nsr_refine_pack_weights(const float* const* t, void* packed, int precision, void* stream) {
+  return pack_weights(t, packed, precision, 0, stream);
+}
+extern "C" int nsr_refine_pack_weights_noref(const float* const* t, void* packed, int precision, void* stream) {
+  return pack_weights(t, packed, precision, 1, stream);
 }
 
 extern "C" size_t nsr_refine_workspace_bytes(int B, int R, int H, int W) {
@@ -349,49 +427,11 @@ extern "C" size_t nsr_refine_workspace_bytes_for(int precision, int B, int R, in
 
 extern "C" int nsr_refine_forward(const void* packed_v, int prec, const float* x_synth, const float* x_candi, int B, int R, int H,
                                   int W, float* out, void* workspace, size_t workspace_bytes, void* stream) {
-  if (B < 0 || R <= 0 || H <= 0 || W <= 0) return NSR_ERR_INVALID_ARG;
-  if (prec != NSR_FP32 && prec != NSR_F16X3) return NSR_ERR_UNSUPPORTED;
-  if ((H % 8) || (W % 8)) return NSR_ERR_UNSUPPORTED;
-  if (B == 0) return NSR_OK;
-  if (!packed_v || !x_synth || !x_candi || !out || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) != 0)
-    return NSR_ERR_INVALID_ARG;
-  if (workspace_bytes < nsr_refine_workspace_bytes_for(prec, B, R, H, W)) return NSR_ERR_WORKSPACE;
-  const float* packed = static_cast<const float*>(packed_v);
-  hipStream_t st = nsr_stream(stream);
-  Work k;
-  work_floats(B, R, H, W, &k, static_cast<float*>(workspace), prec == NSR_F16X3);
-  const int64_t px0 = (int64_t)H * W, px1 = px0 / 4, px2 = px0 / 16, px3 = px0 / 64;
-  const int64_t nref = (int64_t)B * R;
-  const Act cat1{k.cat1, B * px3, 1024, 0}, cat3{k.cat3, B * px2, 1536, 0}, cat5{k.cat5, B * px1, 768, 0}, cat7{k.cat7, B * px0, 384, 0};
-  auto slice = [](Act t, int ch0) { t.ch0 = ch0; return t; };
-  const Act fc0{k.fc0, nref * px0, 128, 0}, fc1{k.fc1, nref * px1, 256, 0}, fc2{k.fc2, nref * px2, 512, 0}, fc3{k.fc3, nref * px3, 512, 0};
-  // encoder on the synthesised patches: features land in their decoder concat slots (F_synth_i)
-  NSR_TRY(encoder(st, packed, prec, k, x_synth, B, H, W, slice(cat7, 128), slice(cat5, 256), slice(cat3, 512), cat1));
-  // encoder on the B * R reference patches, then the max over the R references (F_max_i)
-  NSR_TRY(encoder(st, packed, prec, k, x_candi, B * R, H, W, fc0, fc1, fc2, fc3));
-  NSR_TRY(max_refs(st, prec, fc0, 128, B, R, px0, slice(cat7, 256)));
-  NSR_TRY(max_refs(st, prec, fc1, 256, B, R, px1, slice(cat5, 512)));
-  NSR_TRY(max_refs(st, prec, fc2, 512, B, R, px2, slice(cat3, 1024)));
-  NSR_TRY(max_refs(st, prec, fc3, 512, B, R, px3, slice(cat1, 512)));
-  // Model_VNPCAT_Decoder.forward (networks.py:827-857); a / b ping-pong, the *_up layers write into the next concat
-  const int h3 = H / 8, w3 = W / 8;
-  auto buf = [](float* p, int64_t rows, int64_t ld) { return Act{p, rows, ld, 0}; };
-  NSR_TRY(conv(st, packed, prec, 7, cat1, nullptr, B, h3, w3, k.col, buf(k.a, B * px3, 512)));
-  NSR_TRY(conv(st, packed, prec, 8, buf(k.a, B * px3, 512), nullptr, B, h3, w3, k.col, buf(k.b, B * px3, 512)));
-  NSR_TRY(conv(st, packed, prec, 9, buf(k.b, B * px3, 512), nullptr, B, h3, w3, k.col, cat3));                  // upsample + conv2_up
-  NSR_TRY(conv(st, packed, prec, 10, cat3, nullptr, B, 2 * h3, 2 * w3, k.col, buf(k.a, B * px2, 512)));
-  NSR_TRY(conv(st, packed, prec, 11, buf(k.a, B * px2, 512), nullptr, B, 2 * h3, 2 * w3, k.col, buf(k.b, B * px2, 512)));
-  NSR_TRY(conv(st, packed, prec, 12, buf(k.b, B * px2, 512), nullptr, B, 2 * h3, 2 * w3, k.col, cat5));          // upsample + conv4_up
-  NSR_TRY(conv(st, packed, prec, 13, cat5, nullptr, B, 4 * h3, 4 * w3, k.col, buf(k.a, B * px1, 256)));
-  NSR_TRY(conv(st, packed, prec, 14, buf(k.a, B * px1, 256), nullptr, B, 4 * h3, 4 * w3, k.col, buf(k.b, B * px1, 256)));
-  NSR_TRY(conv(st, packed, prec, 15, buf(k.b, B * px1, 256), nullptr, B, 4 * h3, 4 * w3, k.col, cat7));          // upsample + conv6_up
-  NSR_TRY(conv(st, packed, prec, 16, cat7, nullptr, B, H, W, k.col, buf(k.a, B * px0, 128)));
-  NSR_TRY(conv(st, packed, prec, 17, buf(k.a, B * px0, 128), nullptr, B, H, W, k.col, buf(k.b, B * px0, 128)));
-  NSR_TRY(conv(st, packed, prec, 18, buf(k.b, B * px0, 128), nullptr, B, H, W, k.col, buf(k.rgb, B * px0, 3)));  // conv9 + tanh
-  const int64_t n = (int64_t)B * 3 * px0;
-  hipLaunchKernelGGL(nhwc3_to_nchw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, k.rgb, px0, n, out);
-  NSR_CHECK_LAUNCH();
-  return NSR_OK;
+  return forward(packed_v, prec, 0, x_synth, x_candi, B, R, H, W, out, workspace, workspace_bytes, stream);
+}
+extern "C" int nsr_refine_forward_noref(const void* packed_v, int prec, const float* x_synth, int B, int H, int W, float* out,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+  return forward(packed_v, prec, 1, x_synth, nullptr, B, 1, H, W, out, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -29,9 +29,16 @@ LAYERS = [
 ]
 
 
-def _spec() -> "OrderedDict[str, tuple]":
+# --not_use_ref (Model_VNPCAT_Decoder_NoPooling, networks.py:866-945): the decoder's concatenations carry no F_max_i
+# channels, so four convolutions are narrower
+NOREF_CIN = {"D.conv1": 512, "D.conv3": 1024, "D.conv5": 512, "D.conv7": 256}
+
+
+def _spec(not_use_ref: bool = False) -> "OrderedDict[str, tuple]":
     s = OrderedDict()
     for name, cin, cout, bn in LAYERS:
+        if not_use_ref:
+            cin = NOREF_CIN.get(name, cin)
         s[f"{name}.weight"] = (cout, cin, 3, 3)
         s[f"{name}.bias"] = (cout,)
         if bn:
@@ -40,18 +47,19 @@ def _spec() -> "OrderedDict[str, tuple]":
     return s
 
 
-#: the 106 float tensors of MaxPoolingModel.state_dict(), in order
+#: the 106 float tensors of MaxPoolingModel.state_dict(), in order (and with --not_use_ref)
 REFINE_SPEC = _spec()
-assert len(REFINE_SPEC) == 106
+REFINE_SPEC_NOREF = _spec(True)
+assert len(REFINE_SPEC) == 106 and len(REFINE_SPEC_NOREF) == 106
 
 
-def make_refine_state_dict(seed: int) -> Dict[str, np.ndarray]:
+def make_refine_state_dict(seed: int, not_use_ref: bool = False) -> Dict[str, np.ndarray]:
     """Deterministic synthetic weights (no checkpoint can be downloaded): xavier-normal convolutions
     (``initialize_weight``, networks.py:776-783), BatchNorm weight ~ N(1, 0.02), and NON-trivial running statistics
     (mean ~ N(0, 0.1), var ~ U(0.5, 1.5)) and biases so that the folded affine map is exercised."""
     rng = np.random.default_rng(seed)
     sd = OrderedDict()
-    for k, shape in REFINE_SPEC.items():
+    for k, shape in (REFINE_SPEC_NOREF if not_use_ref else REFINE_SPEC).items():
         if k.endswith("running_var"):
             v = rng.uniform(0.5, 1.5, shape)
         elif k.endswith("running_mean"):
@@ -82,32 +90,37 @@ def refine_macs(H: int = 64, W: int = 64, R: int = 8) -> int:
 
 
 class MaxPoolingModel:
-    """Encoder + max over the reference patches + decoder, eval mode (BatchNorm uses its running statistics)."""
+    """Encoder + max over the reference patches + decoder, eval mode (BatchNorm uses its running statistics).
+    ``opt.not_use_ref`` (or ``not_use_ref=True``) selects the reference's no-pooling decoder: the encoder runs on the
+    synthesised patch only and ``forward`` ignores ``list_x_candi`` (networks.py:958-969)."""
 
-    def __init__(self, opt=None, precision: str = "f16x3", device="cuda"):
-        if opt is not None and getattr(opt, "not_use_ref", False):
-            raise NotImplementedError("not_use_ref (Model_VNPCAT_Decoder_NoPooling) is outside the built path")
+    def __init__(self, opt=None, precision: str = "f16x3", device="cuda", not_use_ref: bool = False):
+        self.not_use_ref = bool(not_use_ref or (opt is not None and getattr(opt, "not_use_ref", False)))
         if precision not in ("fp32", "f16x3"):
             raise ValueError("precision must be 'fp32' or 'f16x3'")
         self.precision, self._prec = precision, _lib.PRECISIONS[precision]
         self.device = torch.device(device)
-        self.packed = torch.empty(_lib.load().nsr_refine_packed_bytes(self._prec), dtype=torch.uint8, device=self.device)
+        self.spec = REFINE_SPEC_NOREF if self.not_use_ref else REFINE_SPEC
+        lib = _lib.load()
+        nbytes = (lib.nsr_refine_packed_bytes_noref if self.not_use_ref else lib.nsr_refine_packed_bytes)(self._prec)
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self._loaded = False
         self._ws = None
 
     def load_state_dict(self, sd):
-        missing = [k for k in REFINE_SPEC if k not in sd]
+        missing = [k for k in self.spec if k not in sd]
         if missing:
             raise KeyError(f"state_dict lacks {missing[:3]}{'...' if len(missing) > 3 else ''}")
         dev = []
-        for k, shape in REFINE_SPEC.items():
+        for k, shape in self.spec.items():
             v = sd[k]
             v = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v.detach()
             if tuple(v.shape) != tuple(shape):
                 raise ValueError(f"{k}: expected shape {shape}, got {tuple(v.shape)}")
             dev.append(v.to(device=self.device, dtype=torch.float32).contiguous())
         ptrs = (c_void_p * len(dev))(*[c_void_p(t.data_ptr()) for t in dev])
-        _lib.check(_lib.load().nsr_refine_pack_weights(ptrs, _p(self.packed), self._prec, _stream()), "nsr_refine_pack_weights")
+        pack = _lib.load().nsr_refine_pack_weights_noref if self.not_use_ref else _lib.load().nsr_refine_pack_weights
+        _lib.check(pack(ptrs, _p(self.packed), self._prec, _stream()), "nsr_refine_pack_weights")
         torch.cuda.current_stream().synchronize()       # `dev` may be freed once the pack kernels have run
         self._loaded = True
         return self
@@ -115,9 +128,11 @@ class MaxPoolingModel:
     def eval(self):
         return self
 
-    def forward(self, x_synth: torch.Tensor, list_x_candi: torch.Tensor) -> torch.Tensor:
+    def forward(self, x_synth: torch.Tensor, list_x_candi: torch.Tensor = None) -> torch.Tensor:
         if not self._loaded:
             raise RuntimeError("MaxPoolingModel.forward called before load_state_dict")
+        if self.not_use_ref:
+            return self._forward_noref(_f32(x_synth, "x_synth"))
         x, c = _f32(x_synth, "x_synth"), _f32(list_x_candi, "list_x_candi")
         if x.ndim != 4 or x.shape[1] != 3 or c.ndim != 5 or c.shape[0] != x.shape[0] or tuple(c.shape[2:]) != tuple(x.shape[1:]):
             raise ValueError("expected x_synth (B, 3, H, W) and list_x_candi (B, R, 3, H, W)")
@@ -134,6 +149,23 @@ class MaxPoolingModel:
             self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
         _lib.check(lib.nsr_refine_forward(_p(self.packed), self._prec, _p(x), _p(c), B, R, H, W, _p(out), _p(self._ws), self._ws.numel(),
                                           _stream()), "nsr_refine_forward")
+        return out
+
+    def _forward_noref(self, x: torch.Tensor) -> torch.Tensor:
+        if x.ndim != 4 or x.shape[1] != 3:
+            raise ValueError("expected x_synth (B, 3, H, W)")
+        B, _, H, W = x.shape
+        out = torch.empty(B, 3, H, W, dtype=torch.float32, device=x.device)
+        if B == 0:
+            return out
+        lib = _lib.load()
+        need = lib.nsr_refine_workspace_bytes_for(self._prec, B, 1, H, W)
+        if need == 0:
+            raise ValueError("H and W must be positive multiples of 8")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        _lib.check(lib.nsr_refine_forward_noref(_p(self.packed), self._prec, _p(x), B, H, W, _p(out), _p(self._ws), self._ws.numel(),
+                                                _stream()), "nsr_refine_forward_noref")
         return out
 
     __call__ = forward

@@ -31,27 +31,37 @@ def encoder(sd, x):
 
 
 def decoder(sd, fs, fm):
+    """``fm = None``: Model_VNPCAT_Decoder_NoPooling (networks.py:906-935, --not_use_ref): no F_max_i in the concats."""
     up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
-    x1 = _cbr(sd, torch.cat((fs[3], fm[3]), 1), "D.conv1", "D.conv1_bnorm")
+    if fm is None:
+        cat = lambda lvl, *xs: torch.cat(xs + (fs[lvl],), 1) if xs else fs[lvl]
+    else:
+        cat = lambda lvl, *xs: torch.cat(xs + (fs[lvl], fm[lvl]), 1)
+    x1 = _cbr(sd, cat(3), "D.conv1", "D.conv1_bnorm")
     x2 = _cbr(sd, x1, "D.conv2", "D.conv2_bnorm")
     x2u = _cbr(sd, up(x2), "D.conv2_up", "D.conv2_up_bnorm")
-    x3 = _cbr(sd, torch.cat((x2u, fs[2], fm[2]), 1), "D.conv3", "D.conv3_bnorm")
+    x3 = _cbr(sd, cat(2, x2u), "D.conv3", "D.conv3_bnorm")
     x4 = _cbr(sd, x3, "D.conv4", "D.conv4_bnorm")
     x4u = _cbr(sd, up(x4), "D.conv4_up", "D.conv4_up_bnorm")
-    x5 = _cbr(sd, torch.cat((x4u, fs[1], fm[1]), 1), "D.conv5", "D.conv5_bnorm")
+    x5 = _cbr(sd, cat(1, x4u), "D.conv5", "D.conv5_bnorm")
     x6 = _cbr(sd, x5, "D.conv6", "D.conv6_bnorm")
     x6u = _cbr(sd, up(x6), "D.conv6_up", "D.conv6_up_bnorm")
-    x7 = _cbr(sd, torch.cat((x6u, fs[0], fm[0]), 1), "D.conv7", "D.conv7_bnorm")
+    x7 = _cbr(sd, cat(0, x6u), "D.conv7", "D.conv7_bnorm")
     x8 = _cbr(sd, x7, "D.conv8", "D.conv8_bnorm")
     return _cbr(sd, x8, "D.conv9", None, 1, "tanh")
 
 
 def forward(sd_np, x_synth, x_candi, dtype=torch.float32, return_features=False):
-    """x_synth (B, 3, H, W), x_candi (B, R, 3, H, W) -> (B, 3, H, W)."""
+    """x_synth (B, 3, H, W), x_candi (B, R, 3, H, W) -> (B, 3, H, W); ``x_candi=None``: the --not_use_ref model
+    (MaxPoolingModel.forward, networks.py:963-969)."""
     sd = {k: torch.as_tensor(v).to(dtype) for k, v in sd_np.items()}
-    x, c = torch.as_tensor(x_synth).to(dtype), torch.as_tensor(x_candi).to(dtype)
-    B, R = c.shape[:2]
+    x = torch.as_tensor(x_synth).to(dtype)
     fs = encoder(sd, x)
+    if x_candi is None:
+        y = decoder(sd, fs, None)
+        return (y, fs, None) if return_features else y
+    c = torch.as_tensor(x_candi).to(dtype)
+    B, R = c.shape[:2]
     fc = encoder(sd, c.reshape(B * R, *c.shape[2:]))
     fm = [f.view(B, R, *f.shape[1:]).max(1)[0] for f in fc]
     y = decoder(sd, fs, fm)

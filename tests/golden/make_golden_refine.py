@@ -41,6 +41,18 @@ def main():
         out[f"x_{tag}"], out[f"c_{tag}"], out[f"y_{tag}"] = mg.np32(x), mg.np32(c), mg.np32(y)
         out[f"f3_{tag}"] = mg.np32(feats[3])
         print(tag, tuple(y.shape), "|y| max", float(y.abs().max()))
+    # --not_use_ref: the reference's own module with the no-pooling decoder (networks.py:866-945, 958-969)
+    net = MaxPoolingModel(types.SimpleNamespace(not_use_ref=True))
+    sd = {k: torch.from_numpy(v) for k, v in make_refine_state_dict(8, not_use_ref=True).items()}
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+    net.eval()
+    out["noref_seed"] = 8
+    out["noref_float_shapes"] = np.array([str(tuple(v.shape)) for v in net.state_dict().values() if v.dtype.is_floating_point])
+    x = torch.rand(2, 3, 24, 16, generator=gen) * 2 - 1
+    y = net(x, None)
+    out["x_noref"], out["y_noref"] = mg.np32(x), mg.np32(y)
+    print("noref", tuple(y.shape), "|y| max", float(y.abs().max()))
     path = os.path.join(HERE, "refine.npz")
     np.savez_compressed(path, **out)
     print("->", path, f"{os.path.getsize(path) / 1024:.0f} KiB")

@@ -47,6 +47,24 @@ def test_refine_patch_64_vs_oracle(net):
     assert net(x[:0].cuda(), c[:0].cuda()).shape == (0, 3, 64, 64)
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "fp32"])
+def test_not_use_ref_vs_reference_fixture_and_oracle(prec, golden_dir):
+    """--not_use_ref (Model_VNPCAT_Decoder_NoPooling, networks.py:866-945): fixture from the reference's own module, and
+    the oracle at the reference's 64 x 64 patch size."""
+    from nerf_sr_amd import refine as _r
+    g = np.load(os.path.join(golden_dir, "refine.npz"))
+    sd = make_refine_state_dict(int(g["noref_seed"]), not_use_ref=True)
+    net = _r.MaxPoolingModel(precision=prec, not_use_ref=True).load_state_dict(sd).eval()
+    y = net(torch.from_numpy(g["x_noref"]).cuda())
+    assert float((y.cpu() - torch.from_numpy(g["y_noref"])).abs().max()) <= TOL
+    x = torch.rand(3, 3, 64, 64, generator=torch.Generator().manual_seed(4)) * 2 - 1
+    want = ro.forward(sd, x, None, dtype=torch.float64)
+    got = net(x.cuda(), None)
+    assert float((got.cpu().double() - want).abs().max()) <= TOL
+    with pytest.raises(ValueError):                      # a with-reference state dict does not fit the narrower layers
+        _r.MaxPoolingModel(precision=prec, not_use_ref=True).load_state_dict(make_refine_state_dict(7))
+
+
 def test_tiler_gather_stitch_vs_reference_fixture(golden_dir):
     """Patch tiler around the network: bit-exact with what the reference's own dataset class and stitching loop
     produced (tests/golden/refine_tiler.npz), and with the oracle on a full-size random case."""

@@ -25,3 +25,13 @@ def test_state_dict_layout_matches_reference(golden_dir):
     g = np.load(os.path.join(golden_dir, "refine.npz"))
     assert list(REFINE_SPEC) == list(g["float_keys"])
     assert [str(tuple(s)) for s in REFINE_SPEC.values()] == list(g["float_shapes"])
+
+
+def test_not_use_ref_matches_reference(golden_dir):
+    """--not_use_ref (Model_VNPCAT_Decoder_NoPooling): fixture from the reference's own module; spec shapes included."""
+    from nerf_sr_amd.refine import REFINE_SPEC_NOREF
+    g = np.load(os.path.join(golden_dir, "refine.npz"))
+    assert [str(tuple(s)) for s in REFINE_SPEC_NOREF.values()] == list(g["noref_float_shapes"])
+    sd = make_refine_state_dict(int(g["noref_seed"]), not_use_ref=True)
+    y = ro.forward(sd, g["x_noref"], None)
+    np.testing.assert_allclose(y.numpy(), g["y_noref"], rtol=0, atol=1e-6)
