@@ -120,6 +120,15 @@ int nsr_mlp_forward(const void* packed_dev, int precision, const float* x, int64
 int nsr_render_rays(const void* packed_dev, int precision, const float* rays, int ray_stride, const float* z,
                     int64_t R, int n_samples, float* out, void* stream);
 
+/* render_rays followed by VolumetricRenderer.forward (models/nerf_downX_model.py:289-291 and :303-305) in ONE launch: a
+ * 128-point tile of the MLP kernel holds whole rays when n_samples is 64 or 128, so the kernel composites them itself
+ * and the (R, N, 4) network output need not go to HBM.  raw (R * N, 4) or NULL; comp_rgb (R, 3), depth (R), opacity (R),
+ * weights (R, N): any may be NULL.  Results are bit-identical to nsr_render_rays + nsr_composite (the same device code).
+ * NSR_ERR_UNSUPPORTED for other sample counts and for the NSR_F16 / NSR_BF16 fast paths (callers fall back to the pair). */
+int nsr_render_rays_composited(const void* packed_dev, int precision, const float* rays, int ray_stride, const float* z,
+                               int64_t R, int n_samples, int white_bkgd, float* raw, float* comp_rgb, float* depth,
+                               float* opacity, float* weights, void* stream);
+
 /* ---- V1: volumetric compositing ------------------------------------------------
  * Replaces VolumetricRenderer.forward (models/rendering.py:75-111).
  * rgb: element (r,k,c) at rgb[(r*N+k)*rgb_stride + c]; sigma: (r,k) at

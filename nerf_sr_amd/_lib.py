@@ -30,6 +30,8 @@ SIGNATURES = {
     "nsr_sample_along_rays": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsr_mlp_forward": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "nsr_render_rays": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "nsr_render_rays_composited": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsr_composite": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nsr_resample_along_rays": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,

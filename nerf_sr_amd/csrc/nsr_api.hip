@@ -82,14 +82,21 @@ extern "C" int nsr_forward_rays_profiled(const void* packed_coarse, const void* 
   // S1: coarse depths
   rc = nsr_sample_along_rays(rays, ray_stride, R, n_coarse, lindisp, nullptr, z_c, nullptr, stream);
   if (rc != NSR_OK) return rc;
-  // D2+M1: coarse network at every sample
-  mark(0);
-  rc = nsr_render_rays(packed_coarse, precision, rays, ray_stride, z_c, R, n_coarse, raw_c, stream);
-  mark(1);
-  if (rc != NSR_OK) return rc;
-  // V1: coarse compositing (weights are needed by the resampler even if the caller does not want them)
+  // D2+M1+V1: coarse network at every sample, composited by the same launch when the tile shape allows it (64 or 128
+  // samples per ray, contract-grade precisions): the (R, N, 4) network output then never goes to HBM.  The coarse weights
+  // are needed by the resampler even if the caller does not want them.
   float* w_c = outs[3] ? outs[3] : w_c_ws;
-  rc = nsr_composite(raw_c, 4, raw_c + 3, 4, z_c, R, n_coarse, white_bkgd, outs[0], outs[1], outs[2], w_c, stream);
+  mark(0);
+  rc = nsr_render_rays_composited(packed_coarse, precision, rays, ray_stride, z_c, R, n_coarse, white_bkgd, nullptr, outs[0],
+                                  outs[1], outs[2], w_c, stream);
+  if (rc == NSR_ERR_UNSUPPORTED) {   // other sample counts / the single-operand fast paths: network, then compositor
+    rc = nsr_render_rays(packed_coarse, precision, rays, ray_stride, z_c, R, n_coarse, raw_c, stream);
+    mark(1);
+    if (rc != NSR_OK) return rc;
+    rc = nsr_composite(raw_c, 4, raw_c + 3, 4, z_c, R, n_coarse, white_bkgd, outs[0], outs[1], outs[2], w_c, stream);
+  } else {
+    mark(1);
+  }
   if (rc != NSR_OK) return rc;
   if (n_importance == 0) return NSR_OK;
   // S2: importance resampling + merge
@@ -97,6 +104,12 @@ extern "C" int nsr_forward_rays_profiled(const void* packed_coarse, const void* 
   if (rc != NSR_OK) return rc;
   // fine network + compositing
   mark(2);
+  rc = nsr_render_rays_composited(packed_fine, precision, rays, ray_stride, z_f, R, n_coarse + n_importance, white_bkgd, nullptr,
+                                  outs[4], outs[5], outs[6], outs[7], stream);
+  if (rc != NSR_ERR_UNSUPPORTED) {
+    mark(3);
+    return rc;
+  }
   rc = nsr_render_rays(packed_fine, precision, rays, ray_stride, z_f, R, n_coarse + n_importance, raw_f, stream);
   mark(3);
   if (rc != NSR_OK) return rc;

@@ -15,6 +15,7 @@
 //     register-resident activations; bias enters as the accumulator init.
 #include "nsr_common.h"
 #include "nsr_mlp_layout.h"
+#include "nsr_composite.h"
 
 using namespace nsr;
 
@@ -237,10 +238,12 @@ __device__ __forceinline__ float half_dot(const float (&v)[16 * NB], const float
 }
 
 // MODE 0: x is (P, 90) embedded rows.  MODE 1: x is rays (R, 8), z (R, N) given.
-template <int MODE, bool SIGMA_ONLY>
+// NSC > 0 (64 or 128 = samples per ray, MODE 1): the tile's points are whole rays and the kernel composites them itself
+// (nsr_composite.h); `out` may then be null.
+template <int MODE, bool SIGMA_ONLY, int NSC = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ zv,
-                int64_t P, int N, int stride, float* __restrict__ out) {
+                int64_t P, int N, int stride, float* __restrict__ out, NsrCompOut co = NsrCompOut{}) {
   __shared__ __attribute__((aligned(16))) float ring[2 * kChunkBytes / 4];   // 64 KiB
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -365,7 +368,11 @@ mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, c
     s += aux[kAuxRgbB + k];
     rgb[k] = 1.0f / (1.0f + expf(-s));
   }
-  if (h == 0 && p < P) reinterpret_cast<float4*>(out)[p] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
+  if (out && h == 0 && p < P) reinterpret_cast<float4*>(out)[p] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
+  if (NSC > 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no weight DMA may still be landing in the ring that is re-used below
+    composite_tile<(NSC > 0 ? NSC : 64)>(ring, h == 0, wave, m, lane, make_float4(rgb[0], rgb[1], rgb[2], sigma), zv[pc], P / (NSC > 0 ? NSC : 1), co);
+  }
 }
 
 extern "C" int nsr_mlp_forward(const void* packed_dev, int precision, const float* x, int64_t P, int sigma_only,
@@ -402,6 +409,33 @@ extern "C" int nsr_render_rays(const void* packed_dev, int precision, const floa
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   hipLaunchKernelGGL((mlp_fp32_kernel<1, false>), grid, block, 0, nsr_stream(stream),
                      static_cast<const float*>(packed_dev), rays, z, P, n_samples, ray_stride, out);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
+/* D2 + V1 in one launch, see include/nsr.h */
+extern "C" NSR_INTERNAL int nsr_f16x3_render_composite(const void* packed, const float* rays, int ray_stride, const float* z,
+                                                       int64_t R, int N, float* raw, const NsrCompOut* co, void* stream);
+
+extern "C" int nsr_render_rays_composited(const void* packed_dev, int precision, const float* rays, int ray_stride, const float* z,
+                                          int64_t R, int n_samples, int white_bkgd, float* raw, float* comp_rgb, float* depth,
+                                          float* opacity, float* weights, void* stream) {
+  if (!packed_dev || R < 0 || n_samples <= 0 || !nsr_ray_stride_ok(ray_stride)) return NSR_ERR_INVALID_ARG;
+  if (!precision_built(precision)) return NSR_ERR_UNSUPPORTED;
+  if ((precision != NSR_FP32 && precision != NSR_F16X3) || (n_samples != 64 && n_samples != 128)) return NSR_ERR_UNSUPPORTED;
+  if (R == 0) return NSR_OK;
+  if (!rays || !z) return NSR_ERR_INVALID_ARG;
+  if ((raw && (reinterpret_cast<uintptr_t>(raw) & 15) != 0) || (ray_stride == 8 && (reinterpret_cast<uintptr_t>(rays) & 15) != 0))
+    return NSR_ERR_INVALID_ARG;
+  const NsrCompOut co{comp_rgb, depth, opacity, weights, white_bkgd};
+  if (precision == NSR_F16X3) return nsr_f16x3_render_composite(packed_dev, rays, ray_stride, z, R, n_samples, raw, &co, stream);
+  const int64_t P = R * n_samples;
+  const dim3 grid((unsigned)((P + 127) / 128)), block(256);
+  const float* pk = static_cast<const float*>(packed_dev);
+  if (n_samples == 64)
+    hipLaunchKernelGGL((mlp_fp32_kernel<1, false, 64>), grid, block, 0, nsr_stream(stream), pk, rays, z, P, n_samples, ray_stride, raw, co);
+  else
+    hipLaunchKernelGGL((mlp_fp32_kernel<1, false, 128>), grid, block, 0, nsr_stream(stream), pk, rays, z, P, n_samples, ray_stride, raw, co);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }

@@ -19,6 +19,7 @@
 // matrix pipe; two register sets alternate roles layer by layer.
 #include "nsr_common.h"
 #include "nsr_mlp_layout.h"
+#include "nsr_composite.h"
 #include <utility>
 
 using namespace nsr;
@@ -601,10 +602,12 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
   }
 }
 
-template <int MODE, bool SIGMA_ONLY, int NS>
+// COMP: the tile's points are whole rays (MODE 1, NS = 64 or 128) and the kernel composites them itself (V1 fused into
+// D2 + M1: the (R, N, 4) network output never goes to HBM); `out` may then be null.
+template <int MODE, bool SIGMA_ONLY, int NS, bool COMP = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ zv,
-                 int64_t P, int N, int stride, float* __restrict__ out) {
+                 int64_t P, int N, int stride, float* __restrict__ out, NsrCompOut co = NsrCompOut{}) {
   // 3 x 41 KiB weight ring + per-wave stash of the encoded position (8 fragments x 64 lanes x 16 B = 8 KiB
   // per wave) + the colour-head block (rgb weights and bias, 448 floats): 160,512 B of the CU's 160 KiB
   constexpr int kStash0 = 3 * kSlotFloats, kAux0 = kStash0 + 4 * 8 * 256;
@@ -830,8 +833,10 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     s += aux[hx::kAuxRgbB + k];
     rgb[k] = 1.0f / (1.0f + expf(-s));
   }
-  if (h == 0 && p < P) reinterpret_cast<float4*>(out)[p] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
-  dma_drain();     // no LDS-DMA may be in flight when the workgroup's LDS is released
+  if (out && h == 0 && p < P) reinterpret_cast<float4*>(out)[p] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
+  dma_drain();     // no LDS-DMA may be in flight when the workgroup's LDS is released (or re-used just below)
+  if (COMP) composite_tile<(COMP ? NS : 64)>(ring, h == 0, wave, m, lane, make_float4(rgb[0], rgb[1], rgb[2], sigma), zv[pc],
+                                            P / NS, co);
 }
 
 template <int MODE, bool SIGMA_ONLY>
@@ -853,6 +858,22 @@ extern "C" NSR_INTERNAL int nsr_f16x3_mlp_forward(const void* packed, const floa
                                      void* stream) {
   return sigma_only ? launch_f16x3<0, true>(packed, x, nullptr, P, 1, 8, out, nsr_stream(stream))
                     : launch_f16x3<0, false>(packed, x, nullptr, P, 1, 8, out, nsr_stream(stream));
+}
+
+// render_rays + VolumetricRenderer.forward in one launch (n_samples 64 or 128); raw (R * N, 4) optional
+extern "C" NSR_INTERNAL int nsr_f16x3_render_composite(const void* packed, const float* rays, int ray_stride, const float* z,
+                                                       int64_t R, int N, float* raw, const NsrCompOut* co, void* stream) {
+  const int64_t P = R * N;
+  const dim3 grid((unsigned)((P + 127) / 128)), block(256);
+  const float* pk = static_cast<const float*>(packed);
+  if (N == 64)
+    hipLaunchKernelGGL((mlp_f16x3_kernel<1, false, 64, true>), grid, block, 0, nsr_stream(stream), pk, rays, z, P, N, ray_stride, raw, *co);
+  else if (N == 128)
+    hipLaunchKernelGGL((mlp_f16x3_kernel<1, false, 128, true>), grid, block, 0, nsr_stream(stream), pk, rays, z, P, N, ray_stride, raw, *co);
+  else
+    return NSR_ERR_UNSUPPORTED;
+  if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
+  return NSR_OK;
 }
 
 extern "C" NSR_INTERNAL int nsr_f16x3_render_rays(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,

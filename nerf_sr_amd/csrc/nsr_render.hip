@@ -9,12 +9,13 @@
 // (ATen cpu_cum_base_kernel, acc_type<float,false> = double), so the scans here
 // run in double and round per element as well.
 #include "nsr_common.h"
+#include "nsr_composite.h"
 
 #define NSR_MAX_SAMPLES 512   // composite: N <= 512 (8 samples per lane)
 #define NSR_RS_MAX 256        // resample: Nc <= 256, Ni <= 256
 
 // ---------------------------------------------------------------------------
-// V1  (reference: models/rendering.py:75-111)
+// V1  (reference: models/rendering.py:75-111): one wavefront per ray, nsr_composite.h
 // ---------------------------------------------------------------------------
 template <int K>   // samples per lane, lane l owns samples l*K .. l*K+K-1
 __global__ void __launch_bounds__(256) composite_kernel(const float* __restrict__ rgb, int rgb_stride,
@@ -26,67 +27,8 @@ __global__ void __launch_bounds__(256) composite_kernel(const float* __restrict_
   const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r >= R) return;   // whole wave exits together
   const int64_t base = r * N;
-  float zk[K], sg[K], cr[K], cg[K], cb[K];
-#pragma unroll
-  for (int i = 0; i < K; ++i) {
-    const int k = lane * K + i;
-    const bool ok = k < N;
-    const int64_t p = base + (ok ? k : N - 1);
-    zk[i] = z[p];
-    sg[i] = sigma[p * sigma_stride];
-    cr[i] = rgb[p * rgb_stride + 0];
-    cg[i] = rgb[p * rgb_stride + 1];
-    cb[i] = rgb[p * rgb_stride + 2];
-  }
-  const float z_next_lane = __shfl_down(zk[0], 1, 64);
-  float alpha[K];
-  double pl[K];   // lane-local inclusive products of (1 - alpha + 1e-10)
-  double run = 1.0;
-#pragma unroll
-  for (int i = 0; i < K; ++i) {
-    const int k = lane * K + i;
-    const float zn = (i + 1 < K) ? zk[(i + 1 < K) ? i + 1 : i] : z_next_lane;
-    const float delta = (k >= N - 1) ? 1e10f : __fsub_rn(zn, zk[i]);
-    const float s = fmaxf(sg[i], 0.0f);
-    float a = __fsub_rn(1.0f, expf(__fmul_rn(-delta, s)));
-    if (k >= N) a = 0.0f;
-    alpha[i] = a;
-    const float f = (k < N) ? __fadd_rn(__fsub_rn(1.0f, a), 1e-10f) : 1.0f;
-    run *= (double)f;
-    pl[i] = run;
-  }
-  // exclusive prefix over lanes of the lane totals
-  const double incl = wave_scan_mul_d(run, lane);
-  double excl = __shfl_up(incl, 1, 64);
-  if (lane == 0) excl = 1.0;
-  float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_o = 0.f;
-#pragma unroll
-  for (int i = 0; i < K; ++i) {
-    const int k = lane * K + i;
-    // T_k = fp32( prod_{j<k} f_j ), T_0 = 1 exactly
-    const double t_d = (i == 0) ? excl : excl * pl[(i > 0) ? i - 1 : 0];
-    const float T = (k == 0) ? 1.0f : (float)t_d;
-    const float w = __fmul_rn(alpha[i], T);
-    if (k < N) {
-      if (weights) weights[base + k] = w;
-      acc_r = __fadd_rn(acc_r, __fmul_rn(w, cr[i]));
-      acc_g = __fadd_rn(acc_g, __fmul_rn(w, cg[i]));
-      acc_b = __fadd_rn(acc_b, __fmul_rn(w, cb[i]));
-      acc_d = __fadd_rn(acc_d, __fmul_rn(w, zk[i]));
-      acc_o = __fadd_rn(acc_o, w);
-    }
-  }
-  acc_r = wave_sum(acc_r); acc_g = wave_sum(acc_g); acc_b = wave_sum(acc_b);
-  acc_d = wave_sum(acc_d); acc_o = wave_sum(acc_o);
-  if (lane == 0) {
-    if (white) {
-      const float bg = __fsub_rn(1.0f, acc_o);
-      acc_r = __fadd_rn(acc_r, bg); acc_g = __fadd_rn(acc_g, bg); acc_b = __fadd_rn(acc_b, bg);
-    }
-    if (comp_rgb) { comp_rgb[r * 3 + 0] = acc_r; comp_rgb[r * 3 + 1] = acc_g; comp_rgb[r * 3 + 2] = acc_b; }
-    if (depth) depth[r] = acc_d;
-    if (opacity) opacity[r] = acc_o;
-  }
+  composite_ray<K>(rgb + base * rgb_stride, rgb_stride, sigma + base * sigma_stride, sigma_stride, z + base, N, white, lane, r,
+                   comp_rgb, depth, opacity, weights);
 }
 
 extern "C" int nsr_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z,

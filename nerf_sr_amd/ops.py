@@ -19,7 +19,7 @@ from .weights import STATE_DICT_SPEC, check_state_dict, IN_CH
 
 __all__ = [
     "subpixel_rays", "PositionalEncoding", "sample_along_rays", "resample_along_rays", "cast_rays",
-    "VanillaMLP", "VolumetricRenderer", "render_rays", "forward_rays", "sr_mean", "unflatten_reshape",
+    "VanillaMLP", "VolumetricRenderer", "render_rays", "render_rays_composited", "forward_rays", "sr_mean", "unflatten_reshape",
 ]
 
 
@@ -255,6 +255,25 @@ def render_rays(model: VanillaMLP, rays: torch.Tensor, z_vals: torch.Tensor):
     _lib.check(_lib.load().nsr_render_rays(_p(model.packed), model._prec, _p(rays), stride, _p(z_vals), R, N, _p(raw),
                                            _stream()), "nsr_render_rays")
     return raw[..., :3], raw[..., 3]
+
+
+def render_rays_composited(model: VanillaMLP, rays: torch.Tensor, z_vals: torch.Tensor, white_bkgd: bool,
+                           want_raw: bool = False):
+    """``render_rays`` + ``VolumetricRenderer.forward`` in one launch (models/nerf_downX_model.py:289-291): 64 or 128
+    samples per ray, fp32 / f16x3.  Returns ``(comp_rgb (R,3), depth (R), opacity (R), weights (R,N))`` and, if
+    ``want_raw``, the (R, N, 4) network output as a fifth element.  Bit-identical to the two-call route."""
+    rays, z_vals = _f32(rays, "rays"), _f32(z_vals, "z_vals")
+    R, N = z_vals.shape
+    dev = rays.device
+    comp = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    depth = torch.empty(R, dtype=torch.float32, device=dev)
+    opac = torch.empty(R, dtype=torch.float32, device=dev)
+    w = torch.empty(R, N, dtype=torch.float32, device=dev)
+    raw = torch.empty(R, N, 4, dtype=torch.float32, device=dev) if want_raw else None
+    _lib.check(_lib.load().nsr_render_rays_composited(_p(model.packed), model._prec, _p(rays), _ray_stride(rays), _p(z_vals), R, N,
+                                                      int(bool(white_bkgd)), _p(raw), _p(comp), _p(depth), _p(opac), _p(w),
+                                                      _stream()), "nsr_render_rays_composited")
+    return (comp, depth, opac, w, raw) if want_raw else (comp, depth, opac, w)
 
 
 OUT_KEYS = ("coarse_comp_rgbs", "coarse_depth", "coarse_opacity", "coarse_weights",

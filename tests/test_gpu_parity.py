@@ -508,3 +508,34 @@ def test_full_size_properties_config2(ops):
     p_ref = oc.psnr(want["fine_comp_rgbs"], want["coarse_comp_rgbs"])
     p_hip = oc.psnr(out["fine_comp_rgbs"][lo:lo + 1024].cpu(), want["coarse_comp_rgbs"])
     assert abs(p_ref - p_hip) < PSNR_TOL, (p_ref, p_hip, err)
+
+
+# ------------------------------------------------------------------- D2 + V1 in one launch
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
+def test_render_rays_composited_is_bit_identical_to_the_two_call_route(ops, fam, prec):
+    """nsr_render_rays_composited (the MLP kernel composites the rays of its own tile) vs nsr_render_rays followed by
+    nsr_composite: the same device code on the same values -> every output bit-identical; 64 and 128 samples, an odd
+    ray count (half-filled last tile), white background on / off, 11-wide rays, optional raw output."""
+    g, _, _, sd_c, sd_f = fam
+    net = ops.VanillaMLP(precision=prec).load_state_dict(sd_c)
+    rend = ops.VolumetricRenderer()
+    rays = _cu(g["rays"])[:77].contiguous()
+    gen = torch.Generator().manual_seed(11)
+    for N in (64, 128):
+        z = (torch.sort(torch.rand(77, N, generator=gen), -1)[0] * (rays[:, 7:8].cpu() - rays[:, 6:7].cpu()) + rays[:, 6:7].cpu()).cuda()
+        for white in (False, True):
+            rgb, sig = ops.render_rays(net, rays, z)
+            want = rend(rgb.contiguous(), sig.contiguous(), z, white)
+            got = ops.render_rays_composited(net, rays, z, white, want_raw=True)
+            for a, b in zip(got[:4], want):
+                assert torch.equal(a, b)
+            assert torch.equal(got[4][..., :3], rgb) and torch.equal(got[4][..., 3], sig)
+    rays11 = torch.cat([rays, rays[:, 3:6].flip(0)], 1).contiguous()
+    z = torch.sort(torch.rand(77, 64, generator=gen), -1)[0].cuda()
+    rgb, sig = ops.render_rays(net, rays11, z)
+    want = rend(rgb.contiguous(), sig.contiguous(), z, False)
+    for a, b in zip(ops.render_rays_composited(net, rays11, z, False), want):
+        assert torch.equal(a, b)
+    with pytest.raises(Exception):      # 96 samples: tiles would straddle rays -> NSR_ERR_UNSUPPORTED (forward_rays falls back)
+        ops.render_rays_composited(net, rays, torch.sort(torch.rand(77, 96, generator=gen), -1)[0].cuda(), False)
+    assert ops.render_rays_composited(net, rays[:0], z[:0], False)[3].shape == (0, 64)
