@@ -100,6 +100,24 @@ def test_next_row_entry_points_validate_before_any_launch(lib):
     assert lib.nsr_train_loss_and_grads(*args(64, 4, 64, 300, 0, ws)) == -2          # sample count outside the path
     assert lib.nsr_train_loss_and_grads(*args(64, 4, 64, 64, 6, ws)) == -1           # chunk not a multiple of s2
     assert lib.nsr_train_loss_and_grads(*args(0, 4, 64, 64, 0, 0)) == 0              # empty batch
+    # every pass must hold a multiple of 32 sample points (K tiles of the weight-gradient GEMM): rejected up front,
+    # for the whole batch (12 rays x 5 samples) and for a shorter LAST chunk (36 rays in chunks of 32: 32 x 4 is fine,
+    # the last 4 x 4 is not) -- before anything is enqueued
+    big = 1 << 40
+    assert lib.nsr_train_loss_and_grads(*args(12, 1, 5, 3, 0, big)) == -2
+    assert lib.nsr_train_loss_and_grads(*args(36, 1, 4, 8, 32, big)) == -2
+    # depth kinds, the no-reference refinement variant, the fused render + composite launch
+    assert lib.nsr_refine_packed_bytes_noref(2) < lib.nsr_refine_packed_bytes(2) and lib.nsr_refine_packed_bytes_noref(1) == 0
+    assert lib.nsr_refine_forward_noref(one, 2, one, 1, 64, 60, one, one, big, null) == -2
+    assert lib.nsr_refine_workspace_bytes_for(2, 4, 8, 64, 64) < lib.nsr_refine_workspace_bytes_for(0, 4, 8, 64, 64) == lib.nsr_refine_workspace_bytes(4, 8, 64, 64)
+    assert lib.nsr_render_rays_composited(one, 2, c_void_p(32), 8, one, 10, 96, 0, null, null, null, null, null, null) == -2   # 96 samples
+    assert lib.nsr_render_rays_composited(one, 3, c_void_p(32), 8, one, 10, 64, 0, null, null, null, null, null, null) == -2   # fast path
+    assert lib.nsr_render_rays_composited(one, 2, c_void_p(32), 8, one, 0, 64, 0, null, null, null, null, null, null) == 0
+    assert lib.nsr_gen_rays_range((c_float * 12)(), 8, 8, 10.0, 2, 0, 2.0, 6.0, 3, 17, one, null) == -1     # 16 LR pixels only
+    assert lib.nsr_gen_rays_range((c_float * 12)(), 8, 8, 10.0, 2, 0, 2.0, 6.0, 5, 5, null, null) == 0      # empty shard
+    assert lib.nsr_lanczos_ksize(504, 252) == 13 and lib.nsr_lanczos_ksize(100, 250) == 7 and lib.nsr_lanczos_ksize(0, 4) == 0
+    assert lib.nsr_resample_pass_u8(one, 4, 4, 3, 2, 2, one, one, 7, one, null) == -1                       # axis
+    assert lib.nsr_image_to_targets(one, 6, 6, 4, one, null) == -1                                          # H % s
     assert lib.nsr_adam_step(p24, p24, p24, p24, 0, 5e-4, 0.9, 0.999, 1e-8, null) == -1   # steps count from 1
     assert lib.nsr_linear(one, 64, one, 64, null, 7, one, 32, null, 0, 4, 64, 32, null) == -1
     assert lib.nsr_linear(one, 64, one, 64, null, 0, one, 32, null, 0, 4, 48, 32, null) == -1   # K % 32
