@@ -1,7 +1,9 @@
 #!/bin/bash
+# One GPU session through gpurun (development aid): the whole GPU suite, smoke, every bench line, rocprofv3 stats and
+# the PMC passes profiles/r2_pmc.json is derived from.  Output: gpurun_out/session/.
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
-O=$R/gpurun_out/r2c7
+O=$R/gpurun_out/session
 mkdir -p $O
 cd $R
 echo "== GPU suite" | tee $O/summary.txt
@@ -22,7 +24,7 @@ head -8 $O/trace/run_kernel_stats.csv | cut -c1-200 | tee -a $O/summary.txt
 echo "== PMC" | tee -a $O/summary.txt
 C1="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES"
 C2="SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES"
-timeout 300 bash scripts/pmc.sh r2c7/pmc_a f16x3 $C1 2>&1 | tail -2 | tee -a $O/summary.txt
-timeout 300 bash scripts/pmc.sh r2c7/pmc_b f16x3 $C2 2>&1 | tail -2 | tee -a $O/summary.txt
-timeout 300 bash scripts/pmc.sh r2c7/pmc_fetch f16x3 FETCH_SIZE 2>&1 | tail -2 | tee -a $O/summary.txt
-timeout 300 bash scripts/pmc.sh r2c7/pmc_write f16x3 WRITE_SIZE 2>&1 | tail -2 | tee -a $O/summary.txt
+timeout 300 bash scripts/pmc.sh session/pmc_a f16x3 $C1 2>&1 | tail -2 | tee -a $O/summary.txt
+timeout 300 bash scripts/pmc.sh session/pmc_b f16x3 $C2 2>&1 | tail -2 | tee -a $O/summary.txt
+timeout 300 bash scripts/pmc.sh session/pmc_fetch f16x3 FETCH_SIZE 2>&1 | tail -2 | tee -a $O/summary.txt
+timeout 300 bash scripts/pmc.sh session/pmc_write f16x3 WRITE_SIZE 2>&1 | tail -2 | tee -a $O/summary.txt
