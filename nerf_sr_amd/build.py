@@ -34,7 +34,7 @@ UNITS = [
 ]
 # experiment kernels: compiled (and dispatched, see the #ifdef in nsr_mlp.hip) only in a variant build that defines the flag
 VARIANT_UNITS = {
-    "-DNSR_F16X3_PAIR": ("nsr_mlp_f16p.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    "-DNSR_F16X3_PAIR": ("experiments/nsr_mlp_f16p.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
 }
 
 
@@ -69,7 +69,7 @@ def build(force: bool = False, verbose: bool = True, variant: str = "", defines=
     common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", *defines]
     objs = []
     for src, extra in UNITS + [VARIANT_UNITS[d] for d in defines if d in VARIANT_UNITS]:
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
         srcp = os.path.join(CSRC, src)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < _newest_source_mtime():
             cmd = [hipcc, *common, *extra, "-c", srcp, "-o", obj]

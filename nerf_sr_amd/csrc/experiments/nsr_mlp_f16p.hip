@@ -23,10 +23,10 @@
 // three dependent MFMAs per k-step, kept the matrix pipe 66 % busy), and the VALU re-split of a finished pair
 // rides between the MFMAs of the following pair.  The bias enters through the matrix pipe (one fragment
 // holding (hi, lo) of both blocks' biases against a constant ones-operand).
-#include "nsr_common.h"
-#include "nsr_mlp_layout.h"
-#include "nsr_mlp_stream.h"
-#include "nsr_mlp_encode.h"
+#include "../nsr_common.h"
+#include "../nsr_mlp_layout.h"
+#include "../nsr_mlp_stream.h"
+#include "../nsr_mlp_encode.h"
 
 using namespace nsr;
 using namespace nsr::stream;

@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) pack_fp32_kernel(PackPtrs w, float* __res
 
 // split-fp16 path (nsr_mlp_f16.hip)
 // split-fp16 kernels: nsr_mlp_f16.hip (the product) -- or, in a -DNSR_F16X3_PAIR ablation build, the block-pair
-// schedule of nsr_mlp_f16p.hip (measured slower, profiles/r2_f16x3_pair_experiment.md)
+// schedule of experiments/nsr_mlp_f16p.hip (measured slower, profiles/r2_f16x3_pair_experiment.md)
 #ifdef NSR_F16X3_PAIR
 #define nsr_f16x3_packed_bytes nsr_f16x3p_packed_bytes
 #define nsr_f16x3_pack nsr_f16x3p_pack
