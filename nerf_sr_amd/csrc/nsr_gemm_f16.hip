@@ -87,15 +87,30 @@ __device__ __forceinline__ void epilogue_planes(const GemmF16Args& a, f32x16 (&a
   }
 }
 
+// launch index -> tile index, see the kernel
+__device__ __forceinline__ int64_t xcd_tile(int64_t launch_idx, int64_t n_blocks) {
+#ifdef NSR_GEMM_NO_XCD
+  return launch_idx;
+#else
+  const int64_t per_xcd = (n_blocks + 7) / 8;
+  return (launch_idx % 8) * per_xcd + launch_idx / 8;
+#endif
+}
+
 template <int WN, bool APL>   // APL: A comes as (hi, lo) fp16 planes
 __global__ void __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))   // <= 256 registers
-gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles) {
+gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
   constexpr int NT = 128 * WN, kTN = 64 * WN, kArrB = kTN * kLd;
   __shared__ __attribute__((aligned(16))) _Float16 lds[2 * kArrA + 2 * kArrB];   // A hi | A lo | B hi | B lo
   const GemmArgs& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1, li = lane & 31, h = lane >> 5;
-  const int64_t bid = blockIdx.x;
+  // XCD-aware tile order: the hardware deals consecutive workgroups round-robin to the 8 XCDs (private L2s), so the
+  // launch index is remapped such that each XCD works through ONE contiguous run of tiles: the column tiles that share an
+  // A row panel, and the neighbouring row tiles whose 3 x 3 gathers overlap, then hit the same L2.  (Measured neutral
+  // on the refinement pass, 44.4-45.3 ms either way: the 256 MB Infinity Cache already serves those re-reads.)
+  const int64_t bid = xcd_tile(blockIdx.x, n_blocks);
+  if (bid >= n_blocks) return;                     // padding of the launch to a multiple of 8 (whole workgroup)
   const int64_t m0 = (bid / n_col_tiles) * kTM;
   const int n0 = (int)(bid % n_col_tiles) * kTN;
   const int n_tiles = (int)(g.K / kTK);
@@ -451,18 +466,19 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   const bool wide = g.N >= 256 && row_tiles * ((g.N + 255) / 256) >= 512;
   const int tn = wide ? 256 : 128;
   const int n_col_tiles = (g.N + tn - 1) / tn;
-  const dim3 grid((unsigned)(row_tiles * n_col_tiles));
+  const int64_t n_blocks = row_tiles * n_col_tiles;
+  const dim3 grid((unsigned)(((n_blocks + 7) / 8) * 8));
   if (a.Ah) {
 #ifdef NSR_GEMM_DMA   // experiment (measured 9 % slower on the refinement pass, see the kernel's header)
-    if (wide) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<4>), grid, dim3(512), 0, st, a, n_col_tiles);
-    else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<2>), grid, dim3(256), 0, st, a, n_col_tiles);
+    if (wide) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<4>), dim3((unsigned)n_blocks), dim3(512), 0, st, a, n_col_tiles);
+    else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<2>), dim3((unsigned)n_blocks), dim3(256), 0, st, a, n_col_tiles);
 #else
-    if (wide) hipLaunchKernelGGL((gemm_f16x3_kernel<4, true>), grid, dim3(512), 0, st, a, n_col_tiles);
-    else hipLaunchKernelGGL((gemm_f16x3_kernel<2, true>), grid, dim3(256), 0, st, a, n_col_tiles);
+    if (wide) hipLaunchKernelGGL((gemm_f16x3_kernel<4, true>), grid, dim3(512), 0, st, a, n_col_tiles, n_blocks);
+    else hipLaunchKernelGGL((gemm_f16x3_kernel<2, true>), grid, dim3(256), 0, st, a, n_col_tiles, n_blocks);
 #endif
   } else {
-    if (wide) hipLaunchKernelGGL((gemm_f16x3_kernel<4, false>), grid, dim3(512), 0, st, a, n_col_tiles);
-    else hipLaunchKernelGGL((gemm_f16x3_kernel<2, false>), grid, dim3(256), 0, st, a, n_col_tiles);
+    if (wide) hipLaunchKernelGGL((gemm_f16x3_kernel<4, false>), grid, dim3(512), 0, st, a, n_col_tiles, n_blocks);
+    else hipLaunchKernelGGL((gemm_f16x3_kernel<2, false>), grid, dim3(256), 0, st, a, n_col_tiles, n_blocks);
   }
   if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
   return NSR_OK;
