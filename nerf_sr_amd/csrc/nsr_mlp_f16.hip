@@ -3,13 +3,14 @@
 // formed as a_hi*b_hi + (a_hi*b_lo + a_lo*b_hi) on v_mfma_f32_32x32x16_f16 with fp32
 // accumulation, at 3/16 of the fp32-MFMA cycle cost.  Two details keep the split at its full
 // 22 bits, which is what puts the rendered colours as close to the fp32 oracle as the fp32-MFMA
-// kernel is (median |dRGB| 9e-8, worst non-exempt ray of 65,536 7e-5; round 1, without them: 5e-7 / 1.3e-4):
+// kernel is (262,144 rays of the four BASELINE geometries: median |dRGB| 1e-7, worst non-exempt ray
+// 8.3e-5; round 1, without them: 5e-7 / 1.3e-4):
 //   * weights and biases are multiplied by 2^6 before they are split (exact): the lo part of a
 //     typical weight (|w| ~ 0.05 -> lo ~ 2^-16) otherwise sits on fp16's subnormal floor (2^-24)
 //     and loses three bits.  Accumulators therefore hold 64 x the layer output; the factor is
-//     removed, exactly, inside the conversion of a finished block (v_fma_mix: f16(x * 2^-6));
-//   * hi is rounded to nearest by that same v_fma_mix, so |lo| <= 2^-12 |v| (round 1: cvt_pkrtz,
-//     2^-11 |v|).
+//     removed, exactly, inside the re-split of a finished block (an exponent subtract on the packed
+//     fp16 pair, see "Re-split" below);
+//   * hi is rounded to nearest (v_cvt_pk_f16_f32), so |lo| <= 2^-12 |v| (round 1: cvt_pkrtz, 2^-11 |v|).
 //
 // Same register algebra as the fp32 kernel (nsr_mlp_layout.h): a wave owns 32 sample
 // points, activations never leave registers, weights stream global -> LDS by DMA.
@@ -165,19 +166,6 @@ __device__ __forceinline__ void glds16x2_asm(const char* base_uniform, unsigned 
       : "v"(lane_off), "s"(base_uniform), "s"(lds_dst_uniform), "i"(OFF), "i"(OFF + 1024)
       : "memory");
 }
-// four consecutive pieces with ONE M0 write (6 issue slots instead of 12)
-__device__ __forceinline__ void glds16x4_asm(const char* base_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
-  asm volatile(
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %0, %1\n\t"
-      "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
-      "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
-      "global_load_lds_dwordx4 %0, %1 offset:3072"
-      :
-      : "v"(lane_off), "s"(base_uniform), "s"(lds_dst_uniform)
-      : "memory");
-}
 __device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---------------------------------------------------------------------------
@@ -265,14 +253,6 @@ __device__ __forceinline__ void loader_issue2(const Loader& ld, int j) {
   const unsigned dst = ld.dma_lds + (unsigned)(j >> 1) * 4096u;
   if (j & 1) glds16x2_asm<2048>(base, ld.lane_off, dst);
   else glds16x2_asm<0>(base, ld.lane_off, dst);
-}
-
-// pieces 4g .. 4g+3 of the chunk being fetched, g = 0, 1 (always present)
-__device__ __forceinline__ void loader_issue4(const Loader& ld, int g) {
-#ifdef NSR_ABL_NO_DMA
-  return;
-#endif
-  glds16x4_asm(ld.dma_base + g * 4096, ld.lane_off, ld.dma_lds + (unsigned)g * 4096u);
 }
 
 __device__ __forceinline__ void loader_advance(Loader& ld) {
