@@ -539,3 +539,38 @@ def test_render_rays_composited_is_bit_identical_to_the_two_call_route(ops, fam,
     with pytest.raises(Exception):      # 96 samples: tiles would straddle rays -> NSR_ERR_UNSUPPORTED (forward_rays falls back)
         ops.render_rays_composited(net, rays, torch.sort(torch.rand(77, 96, generator=gen), -1)[0].cuda(), False)
     assert ops.render_rays_composited(net, rays[:0], z[:0], False)[3].shape == (0, 64)
+
+
+def _scaled_trunk(sd_c, scale):
+    """The coarse network with its trunk activations multiplied by `scale` (ReLU layers are positively homogeneous: scale
+    the first layer, the skip layer's encoded-position columns and every trunk bias)."""
+    sd = {k: v.copy() for k, v in sd_c.items()}
+    f = np.float32(scale)
+    sd["xyz_encoding_1.0.weight"] = sd["xyz_encoding_1.0.weight"] * f
+    sd["xyz_encoding_5.0.weight"][:, :63] *= f
+    for i in range(1, 9):
+        sd[f"xyz_encoding_{i}.0.bias"] = sd[f"xyz_encoding_{i}.0.bias"] * f
+    return sd
+
+
+def test_f16x3_activation_range_edges(ops, fam):
+    """The split-fp16 re-split scales by an exponent subtract on packed fp16 values (csrc/nsr_mlp_f16.hip): check both
+    ends of its range against the fp64 oracle -- tiny activations (|h| ~ 1e-5: the subtract lands in / below fp16's
+    subnormal encodings and lo carries the value) and large ones (|h| of several hundred: 64 |h| close to the fp16
+    maximum 65,504) -- next to the fp32-MFMA kernel on the same inputs."""
+    g, _, _, sd_c, _ = fam
+    x = _cu(g["mlp_in_512"])
+    for scale in (1e-5, 1.0, 300.0):
+        sd = _scaled_trunk(sd_c, scale)
+        want = oc.mlp_forward(oc.to_torch_sd(sd, torch.float64), torch.from_numpy(g["mlp_in_512"]).double())
+        smax = float(want[:, 3].abs().max())
+        errs = {}
+        for prec in ("f16x3", "fp32"):
+            got = ops.VanillaMLP(precision=prec).load_state_dict(sd)(x).cpu().double()
+            assert torch.isfinite(got).all(), (prec, scale)
+            errs[prec] = (float((got[:, 3] - want[:, 3]).abs().max()), float((got[:, :3] - want[:, :3]).abs().max()))
+        print(f"[trunk x{scale:g}] max|sigma| {smax:.3g}; sigma / rgb error  f16x3 {errs['f16x3'][0]:.2e} / {errs['f16x3'][1]:.2e}   "
+              f"fp32 {errs['fp32'][0]:.2e} / {errs['fp32'][1]:.2e}")
+        # fp32-grade: a few 1e-6 of the density's magnitude (the fp32 oracle itself is ~2e-6 of it away from fp64)
+        assert errs["f16x3"][0] <= 1e-5 * (smax + 1e-3), scale
+        assert errs["f16x3"][0] <= 4.0 * errs["fp32"][0] + 1e-9 and errs["f16x3"][1] <= 4.0 * errs["fp32"][1] + 5e-6, scale
