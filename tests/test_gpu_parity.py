@@ -573,4 +573,7 @@ def test_f16x3_activation_range_edges(ops, fam):
               f"fp32 {errs['fp32'][0]:.2e} / {errs['fp32'][1]:.2e}")
         # fp32-grade: a few 1e-6 of the density's magnitude (the fp32 oracle itself is ~2e-6 of it away from fp64)
         assert errs["f16x3"][0] <= 1e-5 * (smax + 1e-3), scale
-        assert errs["f16x3"][0] <= 4.0 * errs["fp32"][0] + 1e-9 and errs["f16x3"][1] <= 4.0 * errs["fp32"][1] + 5e-6, scale
+        if scale >= 1.0:    # fp32-grade next to the fp32-MFMA kernel
+            assert errs["f16x3"][0] <= 4.0 * errs["fp32"][0] + 1e-9 and errs["f16x3"][1] <= 4.0 * errs["fp32"][1] + 5e-6, scale
+        else:               # activations below fp16's normal range (2^-14) keep an ABSOLUTE floor of 2^-25 each (their lo
+            assert errs["f16x3"][0] <= 5e-6 and errs["f16x3"][1] <= 2e-6, scale    # part is subnormal): 1e-6-level density error
