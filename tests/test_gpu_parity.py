@@ -577,3 +577,25 @@ def test_f16x3_activation_range_edges(ops, fam):
             assert errs["f16x3"][0] <= 4.0 * errs["fp32"][0] + 1e-9 and errs["f16x3"][1] <= 4.0 * errs["fp32"][1] + 5e-6, scale
         else:               # activations below fp16's normal range (2^-14) keep an ABSOLUTE floor of 2^-25 each (their lo
             assert errs["f16x3"][0] <= 5e-6 and errs["f16x3"][1] <= 2e-6, scale    # part is subnormal): 1e-6-level density error
+
+
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
+def test_forward_rays_other_sample_counts(ops, fam, prec):
+    """forward_rays away from the 64 + 64 default: the fused network + compositing launch only exists for 64 or 128
+    samples per ray, every other count goes through network then compositor inside the same call -- (32, 32): coarse
+    un-fused, fine fused; (48, 16): fine fused only; (40, 24) and (128, 72): nothing / coarse only fused -- against the
+    oracle; and the want_weights = False / NULL-output forms."""
+    g, _, _, sd_c, sd_f = fam
+    white = bool(g["white_bkgd"])
+    net_c = ops.VanillaMLP(precision=prec).load_state_dict(sd_c)
+    net_f = ops.VanillaMLP(precision=prec).load_state_dict(sd_f)
+    rays = _cu(g["rays"])[:96].contiguous()
+    for nc, ni in ((32, 32), (48, 16), (40, 24), (128, 72)):
+        want = oc.forward_rays(oc.to_torch_sd(sd_c), oc.to_torch_sd(sd_f), rays.cpu(), nc, ni, white)
+        got = ops.forward_rays(net_c, net_f, rays, nc, ni, white)
+        assert got["coarse_weights"].shape == (96, nc) and got["fine_weights"].shape == (96, nc + ni)
+        _close(got["coarse_comp_rgbs"], want["coarse_comp_rgbs"], 1e-5)
+        _close(got["coarse_weights"], want["coarse_weights"], 1e-5)
+        _close(got["fine_comp_rgbs"], want["fine_comp_rgbs"], 3e-4)     # coarser sampling: larger bins, more amplification
+        noweights = ops.forward_rays(net_c, net_f, rays, nc, ni, white, want_weights=False)
+        assert "fine_weights" not in noweights and torch.equal(noweights["fine_comp_rgbs"], got["fine_comp_rgbs"])
