@@ -18,29 +18,9 @@
 // all k-steps of that block + its bias), so that a finished block is re-split into the
 // next layer's hi/lo operand registers on the VALU while the next block occupies the
 // matrix pipe; two register sets alternate roles layer by layer.
-#include "nsr_common.h"
-#include "nsr_mlp_layout.h"
+#include "nsr_f16x3_core.h"
 #include "nsr_composite.h"
 #include <utility>
-
-using namespace nsr;
-using namespace nsr::hx;
-
-// NSR_ABL_*: ablation switches for the measurement ladder in profiles/r1_f16x3_pmc.txt (scripts/ablate.sh builds
-// variant libraries with them); never defined in the product build.
-#ifdef NSR_ABL_NO_BARRIER
-#define NSR_SYNC() ((void)0)
-#else
-#define NSR_SYNC() do { dma_drain(); __syncthreads(); } while (0)
-#endif
-
-// weights and biases enter the stream multiplied by 2^6 (see the header); |w| < 1023 stays inside fp16
-constexpr float kWScale = 64.0f, kWInvScale = 1.0f / 64.0f;
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------
 // packing
@@ -58,14 +38,6 @@ __device__ __forceinline__ int tensor_ld_h(int tensor) {
   }
 }
 
-__device__ __forceinline__ unsigned pack_hl(float a, float b, int part) {
-  _Float16 ha = (_Float16)a, hb = (_Float16)b;               // round to nearest even
-  if (part) {
-    ha = (_Float16)(a - (float)ha);
-    hb = (_Float16)(b - (float)hb);
-  }
-  return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
-}
 
 // one thread per 32-bit word of the blob
 __global__ void __launch_bounds__(256) pack_f16x3_kernel(PackPtrsH w, unsigned* __restrict__ out) {
@@ -125,78 +97,6 @@ extern "C" NSR_INTERNAL int nsr_f16x3_pack(const float* const* w, void* packed_d
   return NSR_OK;
 }
 
-// ---------------------------------------------------------------------------
-// kernel
-// ---------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-
-// LDS byte address (32-bit) of a __shared__ object
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-  return (unsigned)(size_t)((const __attribute__((address_space(3))) char*)p);
-}
-
-// Weight DMA (global -> LDS, 64 lanes x 16 B) issued from inline asm: wave-uniform 64-bit base in SGPRs
-// + one 32-bit lane offset.  Why not __builtin_amdgcn_global_load_lds: hipcc's waitcnt insertion treats
-// an in-flight LDS-DMA as a FLAT-like event and from then on waits lgkmcnt(0) — i.e. for the fragment
-// loads issued two instructions earlier — before every MFMA group.  The asm form is invisible to that
-// pass; its completion is waited for by hand (dma_drain) right before the barrier that publishes the
-// chunk.  OFF (0..3072) is added to BOTH the global and the LDS address, so one (base, M0) pair serves
-// four consecutive 1 KiB pieces.  M0 is written in the same statement that consumes it (hipcc reserves
-// M0 and uses it nowhere else in this kernel).
-template <int OFF>
-__device__ __forceinline__ void glds16_asm(const char* base_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
-  asm volatile(
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %0, %1 offset:%3"
-      :
-      : "v"(lane_off), "s"(base_uniform), "s"(lds_dst_uniform), "i"(OFF)
-      : "memory");
-}
-// two consecutive pieces (OFF, OFF + 1024) with ONE M0 write
-template <int OFF>
-__device__ __forceinline__ void glds16x2_asm(const char* base_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
-  asm volatile(
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %0, %1 offset:%3\n\t"
-      "global_load_lds_dwordx4 %0, %1 offset:%4"
-      :
-      : "v"(lane_off), "s"(base_uniform), "s"(lds_dst_uniform), "i"(OFF), "i"(OFF + 1024)
-      : "memory");
-}
-__device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// ---------------------------------------------------------------------------
-// weight-stream loader: 3-slot LDS ring, the chunk at sequence position j lives in slot j % 3.
-//
-// Protocol (per wave, chunk j being consumed):
-//   * entering chunk j: its data is PUBLISHED (every wave's DMA landed and a barrier passed), chunk
-//     j+1's DMA has been issued by every wave, and the first k-steps' fragments + bias of chunk j are
-//     already in registers (prefetched at the end of chunk j-1) — no bubble at the chunk boundary;
-//   * at k-step kBar of chunk j: wait for the own DMA of chunk j+1 (issued half a chunk ago), barrier
-//     => chunk j+1 is published and every wave has left chunk j-1, whose slot is therefore free;
-//   * k-steps kBar..kBar+5: issue the DMA of chunk j+2 into that slot (two pieces per k-step);
-//   * last three k-steps: prefetch chunk j+1's first fragments and bias.
-// ---------------------------------------------------------------------------
-constexpr int kSlotBytes = kSlotFloats * 4;
-constexpr int kBar = 8;
-
-// a chunk of the stream as this wave sees it: where it starts, how many 1 KiB pieces it has, and the
-// contiguous quarter of it this wave moves (all wave-uniform, SGPRs)
-struct ChunkRef {
-  int piece0, pieces;
-  int first, count;
-};
-__device__ __forceinline__ ChunkRef make_ref(int piece0, int pieces, int wave) {
-  ChunkRef c;
-  c.piece0 = piece0;
-  c.pieces = pieces;
-  c.first = (wave * pieces) >> 2;
-  c.count = (((wave + 1) * pieces) >> 2) - c.first;
-  return c;
-}
 // trunk layer L (1..8: L2..L8, xyz_encoding_final), output block nb: chunk ids 2 + 8(L-1) + nb (see chunk_info)
 __device__ __forceinline__ ChunkRef layer_ref(int L, int nb, int wave) {
   const int pieces = (L == 4) ? 41 : 33;
@@ -209,167 +109,6 @@ __device__ __forceinline__ ChunkRef dir_ref(int nb, int wave) { return make_ref(
 // tile) so that the first eight DMA issues of every chunk need no bounds test; the kernel drains before exit
 __device__ __forceinline__ ChunkRef end_ref(int wave) { return make_ref(0, 32, wave); }
 
-struct Loader {
-  const float* stream;   // packed blob viewed as 32-bit words
-  int wave;
-  unsigned lane_off;     // lane * 16
-  unsigned slot_cur, slot_next, slot_free;   // LDS byte addresses of the slots of chunks j, j+1, j+2
-  // DMA descriptor of the chunk being fetched: wave-uniform byte address of this wave's first piece, the
-  // matching LDS byte address, its piece count
-  const char* dma_base;
-  unsigned dma_lds;
-  int dma_count;
-};
-
-__device__ __forceinline__ void loader_prepare_dma(Loader& ld, const ChunkRef& c, unsigned slot_lds) {
-  ld.dma_count = c.count;
-  ld.dma_base = reinterpret_cast<const char*>(ld.stream) + (size_t)(c.piece0 + c.first) * 1024;
-  ld.dma_lds = slot_lds + (unsigned)c.first * 1024u;
-}
-
-// issue this wave's DMA piece number i of the chunk being fetched (no-op past its end)
-__device__ __forceinline__ void loader_issue(const Loader& ld, int i) {
-#ifdef NSR_ABL_NO_DMA
-  return;
-#endif
-  if (i < 8 || i < ld.dma_count) {   // every wave owns at least 8 pieces of every chunk
-    const char* base = ld.dma_base + (i >> 2) * 4096;
-    const unsigned dst = ld.dma_lds + (unsigned)(i >> 2) * 4096u;
-    switch (i & 3) {
-      case 0: glds16_asm<0>(base, ld.lane_off, dst); break;
-      case 1: glds16_asm<1024>(base, ld.lane_off, dst); break;
-      case 2: glds16_asm<2048>(base, ld.lane_off, dst); break;
-      default: glds16_asm<3072>(base, ld.lane_off, dst); break;
-    }
-  }
-}
-
-// pieces 2j, 2j + 1 (j = 0..3: always present) with one M0 write
-__device__ __forceinline__ void loader_issue2(const Loader& ld, int j) {
-#ifdef NSR_ABL_NO_DMA
-  return;
-#endif
-  const char* base = ld.dma_base + (j >> 1) * 4096;
-  const unsigned dst = ld.dma_lds + (unsigned)(j >> 1) * 4096u;
-  if (j & 1) glds16x2_asm<2048>(base, ld.lane_off, dst);
-  else glds16x2_asm<0>(base, ld.lane_off, dst);
-}
-
-__device__ __forceinline__ void loader_advance(Loader& ld) {
-  const unsigned t = ld.slot_cur;
-  ld.slot_cur = ld.slot_next;
-  ld.slot_next = ld.slot_free;
-  ld.slot_free = t;
-}
-
-// the publish point of chunk j+1 (see protocol above), then start fetching chunk j+2
-__device__ __forceinline__ void loader_publish(Loader& ld, const ChunkRef& c2) {
-#ifndef NSR_ABL_NO_DRAIN
-  dma_drain();
-#endif
-#ifndef NSR_ABL_NO_BARRIER
-  __syncthreads();
-#endif
-  loader_prepare_dma(ld, c2, ld.slot_free);
-}
-
-__device__ __forceinline__ h8 as_h8(const u32x4& v) { return __builtin_bit_cast(h8, v); }
-__device__ __forceinline__ const u32x4* lds_vec(unsigned byte_addr) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return (const u32x4*)(const __attribute__((address_space(3))) u32x4*)(size_t)byte_addr;
-#else
-  (void)byte_addr;
-  return nullptr;   // host pass of the single-source compile; never executed
-#endif
-}
-
-struct Acc {
-  f32x16 m;   // bias + sum (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi), fp32.  (A separate accumulator for the
-              // two correction terms was measured: it removes the dependent MFMA issue (-5 % on a bare
-              // MFMA+LDS loop) but its 16 extra adds per block cost more in the full kernel.)
-};
-
-// what a k-step sequence needs before its first MFMA: the A fragments of its first kPF k-steps (and, for
-// a new chunk, the accumulator init = bias).  Filled during the last k-steps of the preceding sequence.
-#ifndef NSR_F16X3_KPF
-#define NSR_F16X3_KPF 3
-#endif
-constexpr int kPF = NSR_F16X3_KPF;
-struct Pre {
-  u32x4 ah[kPF], al[kPF];
-  f32x16 bias;
-};
-
-// fragments of k-step k (< kPF) of the sequence whose pieces start at LDS byte address `seq_addr` (+ lane*16)
-__device__ __forceinline__ void prefetch_frag(Pre& pre, int k, unsigned seq_addr) {
-  const u32x4* a = lds_vec(seq_addr);
-  pre.ah[k] = a[(2 * k) * 64];
-  pre.al[k] = a[(2 * k + 1) * 64];
-}
-// accumulator init of a chunk from its bias piece (fp32, D-fragment order; broadcast reads)
-__device__ __forceinline__ void prefetch_bias(Pre& pre, unsigned bias_addr, int h) {
-  const f32x4* b = reinterpret_cast<const f32x4*>(lds_vec(bias_addr + 16u * (unsigned)h));
-#pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
-    const f32x4 b4 = b[2 * qd];                    // floats 8*qd + 4*h .. +3
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pre.bias[4 * qd + i] = b4[i];
-  }
-}
-
-// NSTEP k-steps of one output block, fragments software-pipelined kPF k-steps ahead (the first kPF come
-// in through `pre`), order pinned by sched_barrier.  a_addr: LDS byte address (+ lane*16) of the
-// sequence's first piece.  b_of(s, part) yields the k-step's activation operands; hook(s) runs in the MFMA
-// shadow of k-step s; BAR >= 0 places the chunk's publish point + DMA issue (k-steps BAR..BAR+5);
-// next(k), k = 0..2, runs in the last three k-steps and prefetches the following sequence into `nxt`.
-template <int NSTEP, int BAR, class BOf, class Hook, class Next>
-__device__ __forceinline__ void block_mma(Acc& acc, const Pre& pre, unsigned a_addr, Loader& ld, const ChunkRef& c2,
-                                          BOf&& b_of, Hook&& hook, Next&& next) {
-  static_assert(NSTEP >= kPF, "sequence shorter than the prefetch depth");
-  const u32x4* a_pieces = lds_vec(a_addr);
-  u32x4 ah[NSTEP], al[NSTEP];
-#pragma unroll
-  for (int s = 0; s < kPF; ++s) {
-    ah[s] = pre.ah[s];
-    al[s] = pre.al[s];
-  }
-#pragma unroll
-  for (int s = 0; s < NSTEP; ++s) {
-    if (s == BAR) loader_publish(ld, c2);
-    if (s + kPF < NSTEP) {
-      ah[s + kPF] = a_pieces[(2 * (s + kPF)) * 64];
-      al[s + kPF] = a_pieces[(2 * (s + kPF) + 1) * 64];
-    } else {
-      next(s + kPF - NSTEP);
-    }
-    const u32x4 bh = b_of(s, 0), bl = b_of(s, 1);
-    // a_lo first: it is the younger of the step's two fragment loads, so ONE lgkmcnt wait serves all three
-    acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(al[s]), as_h8(bh), acc.m, 0, 0, 0);
-    acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bl), acc.m, 0, 0, 0);
-    acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bh), acc.m, 0, 0, 0);
-    hook(s);
-    // DMA of chunk j+2: two pieces per k-step over six k-steps.  (Measured alternatives: bursts of four pieces
-    // sharing one M0 write -7 %: back-to-back LDS-DMA issues hold the wave longer than one MFMA; one piece per
-    // k-step from an earlier publish point (k-step 5) -3 %.)
-    if (BAR >= 0 && s >= BAR && s < BAR + 6) {
-      if (s - BAR < 4) {
-        loader_issue2(ld, s - BAR);   // pieces 0..7: every wave owns them, one M0 write per pair
-      } else {
-        loader_issue(ld, 2 * (s - BAR));
-        loader_issue(ld, 2 * (s - BAR) + 1);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// v -> (hi, lo) fp16 pairs packed two per 32-bit register, both rounded to nearest (prologue only)
-__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
-  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-  const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
-  hi = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-  lo = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
-}
 
 // Re-split of the pending block: accumulator pair P (registers 2P, 2P+1; P = 0..7) -> activation -> (hi, lo) fp16
 // pairs in the operand registers of the consuming layer: block nb becomes k-steps 2nb (P < 4 -> h0 / l0) and 2nb + 1
