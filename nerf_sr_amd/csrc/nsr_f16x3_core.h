@@ -75,6 +75,10 @@ __device__ __forceinline__ void glds16x2_asm(const char* base_uniform, unsigned 
       : "memory");
 }
 __device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// vector memory operations complete in issue order: with N younger operations (loads / stores issued AFTER the last DMA
+// piece that must have landed) allowed to stay in flight
+template <int N>
+__device__ __forceinline__ void dma_drain_but() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
 // ---------------------------------------------------------------------------
 // weight-stream loader: 3-slot LDS ring, the chunk at sequence position j lives in slot j % 3.
@@ -160,9 +164,10 @@ __device__ __forceinline__ void loader_advance(Loader& ld) {
 }
 
 // the publish point of chunk j+1 (see protocol above), then start fetching chunk j+2
+template <int YOUNGER = 0>
 __device__ __forceinline__ void loader_publish(Loader& ld, const ChunkRef& c2) {
 #ifndef NSR_ABL_NO_DRAIN
-  dma_drain();
+  dma_drain_but<YOUNGER>();
 #endif
 #ifndef NSR_ABL_NO_BARRIER
   __syncthreads();
@@ -219,7 +224,7 @@ __device__ __forceinline__ void prefetch_bias(Pre& pre, unsigned bias_addr, int 
 // sequence's first piece.  b_of(s, part) yields the k-step's activation operands; hook(s) runs in the MFMA
 // shadow of k-step s; BAR >= 0 places the chunk's publish point + DMA issue (k-steps BAR..BAR+5);
 // next(k), k = 0..2, runs in the last three k-steps and prefetches the following sequence into `nxt`.
-template <int NSTEP, int BAR, class BOf, class Hook, class Next>
+template <int NSTEP, int BAR, int YOUNGER = 0, class BOf, class Hook, class Next>
 __device__ __forceinline__ void block_mma(Acc& acc, const Pre& pre, unsigned a_addr, Loader& ld, const ChunkRef& c2,
                                           BOf&& b_of, Hook&& hook, Next&& next) {
   static_assert(NSTEP >= kPF, "sequence shorter than the prefetch depth");
@@ -232,7 +237,7 @@ __device__ __forceinline__ void block_mma(Acc& acc, const Pre& pre, unsigned a_a
   }
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
-    if (s == BAR) loader_publish(ld, c2);
+    if (s == BAR) loader_publish<YOUNGER>(ld, c2);
     if (s + kPF < NSTEP) {
       ah[s + kPF] = a_pieces[(2 * (s + kPF)) * 64];
       al[s + kPF] = a_pieces[(2 * (s + kPF) + 1) * 64];
@@ -266,4 +271,40 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
   const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
   hi = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
   lo = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+}
+
+// ---------------------------------------------------------------------------
+// Training panels.  The chain kernels of the training step (the TRAIN instantiation of the inference kernel and
+// nsr_train_chain.hip) keep per-layer tensors as "blocked transposed" panels: [group of 32 points][feature][32 points]
+// floats.  The 32 points of a wave are one group, so an accumulator register -- one feature of 32 points per lane half
+// -- goes out as one dword store that fills two whole 128 B lines, and the 32 features of an output block sit within
+// the 4 KiB the instruction's immediate offset reaches (one scalar base per block).  The weight-gradient GEMM reads
+// the same panels as K-contiguous operands (nsr_gemm.h, a_blk / b_blk).
+// A panel set is ten panels back to back: 0..7 = trunk layers 1..8, 8 = xyz_encoding_final, 9 = dir_encoding (128 rows).
+// ---------------------------------------------------------------------------
+constexpr int64_t kPanelGroupFloats = 256 * 32;   // a 256-row panel's stride between point groups
+__device__ __host__ __forceinline__ int64_t panel_offset(int64_t n_groups, int panel) { return panel * n_groups * kPanelGroupFloats; }
+__device__ __host__ __forceinline__ int panel_rows(int panel) { return panel == 9 ? 128 : 256; }
+struct PanelRef {
+  float* base;        // panel set
+  int64_t n_groups;   // ceil(P / 128) * 4
+  int64_t group;      // this wave's point group (wave-uniform)
+};
+// first float of output block `blk` of `panel` for this wave's points
+__device__ __forceinline__ float* panel_block(const PanelRef& t, int panel, int blk) {
+  return t.base + panel_offset(t.n_groups, panel) + (t.group * panel_rows(panel) + 32 * blk) * 32;
+}
+// accumulator register R of a lane (m, h) holds feature 8 (R >> 2) + (R & 3) + 4 h of the block; voff = 4 (m + 128 h) bytes
+template <int R>
+__device__ __forceinline__ void panel_store_r(float v, const float* blk, unsigned voff) {
+  asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(voff), "v"(v), "s"(blk), "n"((8 * (R >> 2) + (R & 3)) * 128) : "memory");
+}
+__device__ __forceinline__ void panel_store(int r, const Acc& p, const float* blk, unsigned voff) {
+  switch (r) {
+#define NSR_PS(R) case R: panel_store_r<R>(p.m[R], blk, voff); break;
+    NSR_PS(0) NSR_PS(1) NSR_PS(2) NSR_PS(3) NSR_PS(4) NSR_PS(5) NSR_PS(6) NSR_PS(7)
+    NSR_PS(8) NSR_PS(9) NSR_PS(10) NSR_PS(11) NSR_PS(12) NSR_PS(13) NSR_PS(14) NSR_PS(15)
+#undef NSR_PS
+    default: break;
+  }
 }

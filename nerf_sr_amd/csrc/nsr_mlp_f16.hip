@@ -267,10 +267,14 @@ __device__ __forceinline__ void prefetch_next_chunk(Pre& nxt, int k, const Loade
 // finished last (block 7 of the previous layer on entry; block 7 of this layer on exit): it is
 // activated and re-split in the MFMA shadow of the FOLLOWING block's k-steps 0..13.  `pre` carries the
 // prefetched head of the next chunk across chunk (and layer) boundaries.
-template <bool RELU_OUT>   // relu on L2..L8 (true), none on xyz_encoding_final (L == 8: false)
+// TRAIN: the pending block's raw accumulators (64 x the pre-activation) are also written to the training panels
+// (panel L - 1 holds trunk layer L's output, see nsr_f16x3_core.h): two dword stores per k-step in k-steps 8..15, i.e.
+// AFTER the chunk's publish point, so that the vmcnt(0) of the next publish finds them a whole chunk old.
+template <bool RELU_OUT, bool TRAIN = false>   // relu on L2..L8 (true), none on xyz_encoding_final (L == 8: false)
 __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[16], u32x4 (&oh)[16], u32x4 (&ol)[16],
                                             const u32x4* stash, Loader& ld, int h, Acc& pend, Pre& pre,
-                                            const ChunkRef& after0, const ChunkRef& after1) {
+                                            const ChunkRef& after0, const ChunkRef& after1,
+                                            const PanelRef& tr = PanelRef{}, unsigned voff = 0) {
   const ChunkRef ref0 = layer_ref(L, 0, ld.wave);           // this layer's chunks: piece0 advances by `pieces`
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) {
@@ -313,6 +317,11 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
             pending_step<true>(s, pend, ptmp, bh[14], bl[14], bh[15], bl[15]);
           else
             pending_step<RELU_OUT>(s, pend, ptmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1]);
+          if (TRAIN && s >= 8) {
+            const float* blk = (nb == 0) ? panel_block(tr, L - 1, 7) : panel_block(tr, L, nb - 1);
+            panel_store(2 * (s - 8), pend, blk, voff);
+            panel_store(2 * (s - 8) + 1, pend, blk, voff);
+          }
         },
         [&](int k) { prefetch_next_chunk(nxt, k, ld, next_bias, h); });
     pend = cur;
@@ -323,10 +332,12 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
 
 // COMP: the tile's points are whole rays (MODE 1, NS = 64 or 128) and the kernel composites them itself (V1 fused into
 // D2 + M1: the (R, N, 4) network output never goes to HBM); `out` may then be null.
-template <int MODE, bool SIGMA_ONLY, int NS, bool COMP = false>
+// TRAIN: the forward pass of the training step (nsr_train.hip): additionally keeps every layer's pre-activations for the
+// backward pass in the training panels `pan` (n_groups = 4 * gridDim.x point groups).
+template <int MODE, bool SIGMA_ONLY, int NS, bool COMP = false, bool TRAIN = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ zv,
-                 int64_t P, int N, int stride, float* __restrict__ out, NsrCompOut co = NsrCompOut{}) {
+                 int64_t P, int N, int stride, float* __restrict__ out, NsrCompOut co = NsrCompOut{}, float* pan = nullptr) {
   // 3 x 41 KiB weight ring + per-wave stash of the encoded position (8 fragments x 64 lanes x 16 B = 8 KiB
   // per wave) + the colour-head block (rgb weights and bias, 448 floats): 160,512 B of the CU's 160 KiB
   constexpr int kStash0 = 3 * kSlotFloats, kAux0 = kStash0 + 4 * 8 * 256;
@@ -354,6 +365,13 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
 
   const int64_t p = (int64_t)blockIdx.x * 128 + wave * 32 + m;
   const int64_t pc = p < P ? p : P - 1;
+  PanelRef tr{};
+  if (TRAIN) {
+    tr.base = pan;
+    tr.n_groups = (int64_t)gridDim.x * 4;
+    tr.group = (int64_t)blockIdx.x * 4 + wave;
+  }
+  const unsigned voff = 4u * (unsigned)(m + 128 * h);   // panel stores: point m of the group, lane half h = 4 rows on
 
   float pe[32], de[16];
   if (MODE == 0) {
@@ -461,6 +479,11 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
                 if (q4 < 4 || s == 0)
                   pending_half<true>((s == 0 ? 0 : 4 * s + 1) + q4, pend, ptmp, bh[2 * nb - 2], bl[2 * nb - 2], bh[2 * nb - 1],
                                      bl[2 * nb - 1]);
+              if (TRAIN) {
+                const float* blk = panel_block(tr, 0, nb - 1);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) panel_store(4 * s + q4, pend, blk, voff);
+              }
             }
           },
           [&](int k) {
@@ -478,14 +501,15 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
 #pragma unroll 1
   for (int pair = 0; pair < 3; ++pair) {
     const int L = 1 + 2 * pair;
-    trunk_layer<true>(L, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(L + 1, 0, wave), layer_ref(L + 1, 1, wave));
-    trunk_layer<true>(L + 1, oh, ol, bh, bl, stash, ld, h, pend, pre, layer_ref(L + 2, 0, wave), layer_ref(L + 2, 1, wave));
+    trunk_layer<true, TRAIN>(L, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(L + 1, 0, wave), layer_ref(L + 1, 1, wave), tr, voff);
+    trunk_layer<true, TRAIN>(L + 1, oh, ol, bh, bl, stash, ld, h, pend, pre, layer_ref(L + 2, 0, wave), layer_ref(L + 2, 1, wave), tr,
+                             voff);
   }
   if (SIGMA_ONLY) {   // xyz_encoding_final is not evaluated: L8 is followed by the density head, then nothing
     trunk_layer<true>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, sigma_ref(wave), end_ref(wave));
   } else {
-    trunk_layer<true>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave));
-    trunk_layer<false>(8, oh, ol, bh, bl, stash, ld, h, pend, pre, sigma_ref(wave), dir_ref(0, wave));
+    trunk_layer<true, TRAIN>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave), tr, voff);
+    trunk_layer<false, TRAIN>(8, oh, ol, bh, bl, stash, ld, h, pend, pre, sigma_ref(wave), dir_ref(0, wave), tr, voff);
   }
 
   // ---- density head: sigma.weight as row 0 of one more 32-row block over h8 (= oh/ol: the input of
@@ -506,6 +530,11 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
             pending_step<true>(s, pend, ptmp, oh[14], ol[14], oh[15], ol[15]);
           else
             pending_step<false>(s, pend, ptmp, bh[14], bl[14], bh[15], bl[15]);
+          if (TRAIN && s >= 8) {   // xyz_encoding_final's last block
+            const float* blk = panel_block(tr, 8, 7);
+            panel_store(2 * (s - 8), pend, blk, voff);
+            panel_store(2 * (s - 8) + 1, pend, blk, voff);
+          }
         },
         [&](int k) {
           if (!SIGMA_ONLY) prefetch_next_chunk(nxt, k, ld, next_bias, h);
@@ -535,6 +564,11 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
         },
         [&](int s) {
           if (nb > 0) rgb_step<kConvStep0>(s, pend, aux + hx::kAuxRgbW + 32 * (nb - 1), h, rgb);
+          if (TRAIN && nb > 0 && s >= 8 && s < 16) {
+            const float* blk = panel_block(tr, 9, nb - 1);
+            panel_store(2 * (s - 8), pend, blk, voff);
+            panel_store(2 * (s - 8) + 1, pend, blk, voff);
+          }
         },
         [&](int k) {
           if (nb < 3) prefetch_next_chunk(nxt, k, ld, next_bias, h);
@@ -545,6 +579,11 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   }
 #pragma unroll
   for (int s = 0; s < 8; ++s) rgb_step<0>(s, pend, aux + hx::kAuxRgbW + 32 * 3, h, rgb);
+  if (TRAIN) {
+    const float* blk = panel_block(tr, 9, 3);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) panel_store(r, pend, blk, voff);
+  }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     float s = rgb[k];
@@ -591,6 +630,22 @@ extern "C" NSR_INTERNAL int nsr_f16x3_render_composite(const void* packed, const
     hipLaunchKernelGGL((mlp_f16x3_kernel<1, false, 128, true>), grid, block, 0, nsr_stream(stream), pk, rays, z, P, N, ray_stride, raw, *co);
   else
     return NSR_ERR_UNSUPPORTED;
+  if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
+  return NSR_OK;
+}
+
+// forward pass of the training step: raw (R * N, 4) network outputs + the training panels (see nsr_f16x3_core.h);
+// `pan` holds 10 panels of ceil(R N / 128) * 4 point groups (nsr_f16x3_train_panel_floats)
+extern "C" NSR_INTERNAL int64_t nsr_f16x3_train_panel_floats(int64_t P) {
+  const int64_t n_groups = ((P + 127) / 128) * 4;
+  return panel_offset(n_groups, 9) + n_groups * 128 * 32;
+}
+extern "C" NSR_INTERNAL int nsr_f16x3_train_forward(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
+                                                    int N, float* raw, float* pan, void* stream) {
+  const int64_t P = R * N;
+  const dim3 grid((unsigned)((P + 127) / 128)), block(256);
+  hipLaunchKernelGGL((mlp_f16x3_kernel<1, false, 0, false, true>), grid, block, 0, nsr_stream(stream),
+                     static_cast<const float*>(packed), rays, z, P, N, ray_stride, raw, NsrCompOut{}, pan);
   if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
   return NSR_OK;
 }

@@ -14,11 +14,21 @@
 // Layers are padded to MFMA-friendly shapes once per step (63 -> 64 input channels, the skip concat as
 // [pe64 | h4], the density head stacked under xyz_encoding_final as one 288-row layer, the colour head as 32 rows);
 // the gradients are scattered back to the nn.Linear shapes by the reduction kernel.
+//
+// CHAIN path (precision NSR_F16X3, the default there): the network is a per-point chain, so its forward pass and its
+// input gradients do not need per-layer GEMMs at all.  The forward pass is the inference kernel (nsr_mlp_f16.hip, TRAIN)
+// that additionally keeps every layer's pre-activations; the input gradients are one launch of the backward chain
+// (nsr_train_chain.hip).  Both write "panels" ([group of 32 points][feature][32 points], nsr_f16x3_core.h) that the
+// weight-gradient GEMMs read as K-contiguous operands; those GEMMs also sum the bias gradients while they stage the
+// pre-activation gradients.  Only the weight gradients stay on the fp32 MFMA.  NSR_TRAIN_PATH=gemm selects the
+// layer-by-layer path above for NSR_F16X3 as well (the A/B switch of profiles/; NSR_FP32 always takes it).
 // Per-ray stages (sampling, compositing, resampling) are the inference kernels (nsr_rays.hip / nsr_render.hip);
 // the compositing backward is a one-wave-per-ray kernel like its forward.
 #include "nsr_common.h"
 #include "nsr_gemm.h"
+#include "nsr_train_chain.h"
 #include "../../include/nsr_train.h"
+#include <cstdlib>
 
 using namespace nsr;
 
@@ -97,11 +107,11 @@ __global__ void __launch_bounds__(256) encode_train_kernel(const float* __restri
 }
 
 // N1: sigma + noise * std (models/utils.py:199-212); noise == nullptr copies
-__global__ void sigma_noise_kernel(const float* __restrict__ gs, const float* __restrict__ noise, float std_,
-                                   int64_t P, float* __restrict__ out) {
+__global__ void sigma_noise_kernel(const float* __restrict__ sigma, int sigma_stride, const float* __restrict__ noise,
+                                   float std_, int64_t P, float* __restrict__ out) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
-  const float s = gs[p * kGs + kSigmaCol];
+  const float s = sigma[p * sigma_stride];
   out[p] = noise ? __fadd_rn(s, __fmul_rn(noise[p], std_)) : s;
 }
 
@@ -295,7 +305,7 @@ __global__ void __launch_bounds__(256) sum_finish_kernel(const double* __restric
 // dst[i * dst_ld + dc0 + j] (+)= sum_z partial[z * stride + (pr0 + i) * p_ld + pc0 + j]
 __global__ void __launch_bounds__(256) reduce_place_kernel(float* __restrict__ dst, int dst_ld, int dc0, int rows, int cols,
                                                            const float* __restrict__ partial, int splits, int64_t stride,
-                                                           int p_ld, int pr0, int pc0, int accumulate) {
+                                                           int p_ld, int pr0, int pc0, int accumulate, float scale) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * cols) return;
   const int i = idx / cols, j = idx % cols;
@@ -311,7 +321,23 @@ __global__ void __launch_bounds__(256) reduce_place_kernel(float* __restrict__ d
   for (; zc < splits; ++zc) s0 += (double)src[zc * stride];
   const double s = (s0 + s1) + (s2 + s3);
   float* d = dst + (int64_t)i * dst_ld + dc0 + j;
-  *d = (accumulate ? *d : 0.0f) + (float)s;
+  *d = (accumulate ? *d : 0.0f) + (float)(s * (double)scale);   // scale: a power of two (pre-scaled operands)
+}
+// bias gradient from the row sums a weight-gradient GEMM left per split-K slice: dst[i] (+)= sum_z partial[z * rows + i]
+__global__ void __launch_bounds__(256) rowsum_finish_kernel(const float* __restrict__ partial, int splits, int rows,
+                                                            float* __restrict__ dst, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int zc = 0;
+  for (; zc + 4 <= splits; zc += 4) {
+    s0 += (double)partial[(zc + 0) * rows + i];
+    s1 += (double)partial[(zc + 1) * rows + i];
+    s2 += (double)partial[(zc + 2) * rows + i];
+    s3 += (double)partial[(zc + 3) * rows + i];
+  }
+  for (; zc < splits; ++zc) s0 += (double)partial[zc * rows + i];
+  dst[i] = (accumulate ? dst[i] : 0.0f) + (float)((s0 + s1) + (s2 + s3));
 }
 
 struct AdamPtrs {
@@ -355,6 +381,10 @@ struct Work {   // per-pass buffers, sized for P_max = chunk * (Nc + Ni) sample 
   float *z_c, *z_f, *w_c, *comp, *g_comp, *partial, *scratch_out;
   double *block_sums, *carry;
   WeightPack pack[2];
+  // chain path (NSR_F16X3): pre-activation panels of the forward pass, gradient panels of the backward chain
+  // (nsr_f16x3_core.h), the two weight streams per network, per-slice row sums of the weight-gradient GEMMs
+  float *zpan, *dpan, *row_part;
+  float *stream_f[2], *stream_b[2];
 };
 
 int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base) {
@@ -386,6 +416,13 @@ int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base) {
     q.w1p = take(256 * 64);   q.w5p = take(256 * 320);   q.w9p = take(288 * 256);   q.wdirp = take(128 * 288);
     q.wrgbp = take(32 * 128);   q.b9p = take(320);   q.brgbp = take(64);
     q.split = reinterpret_cast<unsigned short*>(take((kSplitHalves + 1) / 2));
+  }
+  const int64_t pan = nsr_f16x3_train_panel_floats(P);
+  k.zpan = take(pan);   k.dpan = take(pan);
+  k.row_part = take(kMaxSplits * 256);
+  for (int n = 0; n < 2; ++n) {
+    k.stream_f[n] = take((int64_t)(nsr_f16x3_packed_bytes() / 4));
+    k.stream_b[n] = take((int64_t)(nsr_chain_bwd_packed_bytes() / 4));
   }
   return off;
 }
@@ -478,10 +515,10 @@ int lin_wgrad(hipStream_t st, const float* dy, int64_t lddy, int M, const float*
   return gemm(g, st);
 }
 int reduce_place(hipStream_t st, float* dst, int dst_ld, int dc0, int rows, int cols, const float* partial, int splits,
-                 int p_ld, int pr0, int pc0, int accumulate) {
+                 int p_ld, int pr0, int pc0, int accumulate, float scale = 1.0f) {
   const int n = rows * cols;
   hipLaunchKernelGGL(reduce_place_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dst, dst_ld, dc0, rows, cols, partial,
-                     splits, kPartialFloats, p_ld, pr0, pc0, accumulate);
+                     splits, kPartialFloats, p_ld, pr0, pc0, accumulate, scale);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
@@ -568,6 +605,90 @@ int net_backward(hipStream_t st, const float* const* w, const WeightPack& q, con
   return NSR_OK;
 }
 
+// ---- chain path ------------------------------------------------------------------------------------------
+int64_t n_groups_of(int64_t P) { return ((P + 127) / 128) * 4; }
+float* panel_of(float* set, int64_t P, int panel) { return set + panel * n_groups_of(P) * 256 * 32; }
+
+// partial[z] (M x N) = sum over slice z of the points of A[p][0..M) B[p][0..N)^T.  Each operand is either a panel
+// (blk: rows x 32 floats per point group, K-contiguous) or a row-major (P, ld) buffer (K-major)
+struct Operand {
+  const float* p;
+  int64_t ld;
+  int blk;      // panel (ld = 32 x panel rows) / row-major
+  int relu;     // B only: read max(x, 0)
+};
+int chain_wgrad(hipStream_t st, const Operand& a, int M, const Operand& b, int N, int64_t P, float* partial, int splits,
+                float* row_sums) {
+  GemmArgs g{};
+  g.A = a.p; g.lda = a.ld; g.a_kmajor = !a.blk; g.a_blk = a.blk;
+  g.B = b.p; g.ldb = b.ld; g.b_kmajor = !b.blk; g.b_blk = b.blk; g.b_relu = b.relu;
+  g.C = partial; g.ldc = N; g.M = M; g.N = N; g.K = P; g.n_valid = N; g.act = kActNone;
+  g.splits = splits; g.split_stride = kPartialFloats; g.row_sums = row_sums;
+  return gemm(g, st);
+}
+int rowsum_finish(hipStream_t st, const float* partial, int splits, int rows, float* dst, int acc) {
+  hipLaunchKernelGGL(rowsum_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, partial, splits, rows, dst, acc);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
+// weight and bias gradients from the panels: zpan = forward pre-activations x 2^6 (kWScale), dpan = true-scale
+// gradients of the pre-activations; d_rgb_pre in k.drgb (P, 32), d_sigma in column 256 of k.g1 (P, 288)
+int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g, int acc) {
+  const int sp = n_splits(P);
+  float* part = k.partial;
+  float* rs = k.row_part;
+  constexpr float kInv = 1.0f / 64.0f;
+  auto zp = [&](int panel, int relu) { return Operand{panel_of(k.zpan, P, panel), panel == 9 ? 128 * 32 : 256 * 32, 1, relu}; };
+  auto dp = [&](int panel) { return Operand{panel_of(k.dpan, P, panel), panel == 9 ? 128 * 32 : 256 * 32, 1, 0}; };
+  const Operand pe{k.x5, kX5, 0, 0};                      // [pe63 | 0] in columns 0..63
+  const Operand de{k.gs + kSigmaCol, kGs, 0, 0};          // [. 0 0 0 de27 0]: 32 columns from 256
+  const Operand drgb{k.drgb, kRgbPad, 0, 0};
+  const Operand dsig{k.g1 + kSigmaCol, kGs, 0, 0};
+  // rgb head: d_rgb_pre^T relu(zcc)
+  NSR_TRY(chain_wgrad(st, drgb, kRgbPad, zp(9, 1), kDirOut, P, part, sp, nullptr));
+  NSR_TRY(reduce_place(st, g[kRgbW], 128, 0, 3, 128, part, sp, kDirOut, 0, 0, acc, kInv));
+  NSR_TRY(colsum(st, k.drgb, kRgbPad, P, 0, 3, g[kRgbB], acc, part));
+  // dir_encoding: dzc^T [g | de]
+  NSR_TRY(chain_wgrad(st, dp(9), kDirOut, zp(8, 0), kW, P, part, sp, rs));
+  NSR_TRY(reduce_place(st, g[kDirW], 283, 0, 128, 256, part, sp, kW, 0, 0, acc, kInv));
+  NSR_TRY(rowsum_finish(st, rs, sp, kDirOut, g[kDirB], acc));
+  NSR_TRY(chain_wgrad(st, dp(9), kDirOut, de, 32, P, part, sp, nullptr));
+  NSR_TRY(reduce_place(st, g[kDirW], 283, 256, 128, 27, part, sp, 32, 0, kDeCol - kSigmaCol, acc));
+  // xyz_encoding_final: dg^T relu(z8); sigma: d_sigma^T relu(z8)
+  NSR_TRY(chain_wgrad(st, dp(8), kW, zp(7, 1), kW, P, part, sp, rs));
+  NSR_TRY(reduce_place(st, g[kFinalW], 256, 0, 256, 256, part, sp, kW, 0, 0, acc, kInv));
+  NSR_TRY(rowsum_finish(st, rs, sp, kW, g[kFinalB], acc));
+  NSR_TRY(chain_wgrad(st, dsig, 32, zp(7, 1), kW, P, part, sp, nullptr));
+  NSR_TRY(reduce_place(st, g[kSigmaW], 256, 0, 1, 256, part, sp, kW, 0, 0, acc, kInv));
+  NSR_TRY(colsum(st, k.g1, kGs, P, 256, 1, g[kSigmaB], acc, part));
+  // trunk layers 8..1: dz_L^T (input of layer L)
+  for (int L = 8; L >= 1; --L) {
+    float* gw = g[2 * (L - 1)];
+    const Operand dz = dp(L - 1);
+    if (L == 1 || L == 5) {
+      NSR_TRY(chain_wgrad(st, dz, kW, pe, kPe, P, part, sp, rs));
+      NSR_TRY(reduce_place(st, gw, L == 1 ? 63 : 319, 0, 256, 63, part, sp, kPe, 0, 0, acc));
+      NSR_TRY(rowsum_finish(st, rs, sp, kW, g[2 * (L - 1) + 1], acc));
+      if (L == 5) {
+        NSR_TRY(chain_wgrad(st, dz, kW, zp(3, 1), kW, P, part, sp, nullptr));
+        NSR_TRY(reduce_place(st, gw, 319, 63, 256, 256, part, sp, kW, 0, 0, acc, kInv));
+      }
+    } else {
+      NSR_TRY(chain_wgrad(st, dz, kW, zp(L - 2, 1), kW, P, part, sp, rs));
+      NSR_TRY(reduce_place(st, gw, 256, 0, 256, 256, part, sp, kW, 0, 0, acc, kInv));
+      NSR_TRY(rowsum_finish(st, rs, sp, kW, g[2 * (L - 1) + 1], acc));
+    }
+  }
+  return NSR_OK;
+}
+
+bool chain_selected(int precision) {
+  if (precision != NSR_F16X3) return false;
+  const char* e = getenv("NSR_TRAIN_PATH");
+  return !(e && e[0] == 'g');   // "gemm": the layer-by-layer path
+}
+
 int composite_bwd(hipStream_t st, const Work& k, const float* z, int64_t R, int N, int white) {
   const dim3 block(256), grid((unsigned)((R + 3) / 4));
   const int K = (N + 63) / 64;
@@ -629,8 +750,16 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
   const int64_t n_lr_total = R / s2;
   const double mse_scale = 1.0 / (3.0 * (double)n_lr_total);
 
-  NSR_TRY(prepare_weights(st, w_coarse, k.pack[0], precision));
-  NSR_TRY(prepare_weights(st, w_fine, k.pack[1], precision));
+  const bool chain = chain_selected(precision);
+  if (chain) {
+    for (int net = 0; net < 2; ++net) {
+      NSR_TRY(nsr_f16x3_pack(net ? w_fine : w_coarse, k.stream_f[net], stream));
+      NSR_TRY(nsr_chain_bwd_pack(net ? w_fine : w_coarse, k.stream_b[net], stream));
+    }
+  } else {
+    NSR_TRY(prepare_weights(st, w_coarse, k.pack[0], precision));
+    NSR_TRY(prepare_weights(st, w_fine, k.pack[1], precision));
+  }
   if (hipMemsetAsync(k.carry, 0, 4 * sizeof(double), st) != hipSuccess) return NSR_ERR_LAUNCH;
 
   for (int64_t r0 = 0; r0 < R; r0 += ray_chunk) {
@@ -655,10 +784,12 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
       hipLaunchKernelGGL(encode_train_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, rays_c, ray_stride, z,
                          P, N, k.x5, k.gs);
       NSR_CHECK_LAUNCH();
-      NSR_TRY(net_forward(st, w, k.pack[net], k, P, precision));
+      if (chain) NSR_TRY(nsr_f16x3_train_forward(k.stream_f[net], rays_c, ray_stride, z, rc, N, k.rgb, k.zpan, stream));
+      else NSR_TRY(net_forward(st, w, k.pack[net], k, P, precision));
       const float* noise = net ? noise_fine : noise_coarse;
-      hipLaunchKernelGGL(sigma_noise_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, k.gs,
-                         (noisy && noise) ? noise + r0 * N : nullptr, noise_std, P, k.sig);
+      hipLaunchKernelGGL(sigma_noise_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st,
+                         chain ? k.rgb + 3 : k.gs + kSigmaCol, chain ? 4 : kGs, (noisy && noise) ? noise + r0 * N : nullptr,
+                         noise_std, P, k.sig);
       NSR_CHECK_LAUNCH();
       float* comp = outs[4 * net + 0] + r0 * 3;
       float* depth = outs[4 * net + 1] ? outs[4 * net + 1] + r0 : nullptr;
@@ -675,7 +806,12 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
                          k.carry);
       NSR_CHECK_LAUNCH();
       NSR_TRY(composite_bwd(st, k, z, rc, N, white_bkgd));
-      NSR_TRY(net_backward(st, w, k.pack[net], k, P, g, acc));
+      if (chain) {
+        NSR_TRY(nsr_chain_bwd(k.stream_b[net], k.zpan, k.dpan, k.drgb, kRgbPad, k.g1 + kSigmaCol, kGs, P, stream));
+        NSR_TRY(chain_weight_grads(st, k, P, g, acc));
+      } else {
+        NSR_TRY(net_backward(st, w, k.pack[net], k, P, g, acc));
+      }
     }
   }
   return NSR_OK;

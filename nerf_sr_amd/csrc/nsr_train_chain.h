@@ -1,0 +1,16 @@
+// Chain kernels of the training step (internal; see nsr_mlp_f16.hip TRAIN and nsr_train_chain.hip).
+#pragma once
+#include "nsr_common.h"
+
+// floats of one panel set (10 panels, see nsr_f16x3_core.h) for P sample points
+extern "C" NSR_INTERNAL int64_t nsr_f16x3_train_panel_floats(int64_t P);
+// forward pass: raw (R N, 4) = (rgb, sigma) + the pre-activation panels; `packed` = nsr_f16x3_pack of the weights
+extern "C" NSR_INTERNAL int nsr_f16x3_train_forward(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
+                                                    int N, float* raw, float* pan, void* stream);
+extern "C" NSR_INTERNAL size_t nsr_f16x3_packed_bytes(void);
+extern "C" NSR_INTERNAL int nsr_f16x3_pack(const float* const* w, void* packed_dev, void* stream);
+// backward chain: transposed weight stream, then d(rgb_pre) (P, stride) / d(sigma) (P, stride) -> gradient panels
+extern "C" NSR_INTERNAL size_t nsr_chain_bwd_packed_bytes(void);
+extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* packed_dev, void* stream);
+extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const float* zpan, float* dpan, const float* d_rgb, int d_rgb_stride,
+                                          const float* d_sigma, int d_sigma_stride, int64_t P, void* stream);

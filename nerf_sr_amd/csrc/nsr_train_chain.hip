@@ -1,0 +1,507 @@
+// Backward CHAIN of the training step on the split-fp16 matrix pipe (the reference's counterpart is
+// autograd through models/networks.py:130-213, driven by nerf_downX_model.py:398-408).
+//
+// The input gradients of the network -- d(rgb_pre), d(sigma) from the compositing backward, down to the first trunk
+// layer -- are a per-point chain exactly like the forward pass: dz_{l-1} = (W_l^T dz_l) * [z_{l-1} > 0].  This kernel
+// runs it with the machinery of the inference kernel (nsr_f16x3_core.h): W^T streams through the LDS ring as split-fp16
+// A fragments, a wave owns 32 points, the gradient of a finished 32-feature block is masked, written out and re-split
+// into the next layer's B operand in the MFMA shadow of the following block.  It replaces the ten input-gradient GEMMs
+// of the step (each of which read and wrote a (P, 256) fp32 panel through a store-bound epilogue).
+//
+//   prologue (VALU)  dzc = (Wrgb^T d_rgb_pre) * [zcc > 0]                  128 features, K = 3
+//   layer 0          dg  = Wdir[:, :256]^T dzc                             K = 128 (zero-padded to 16 k-steps)
+//   layer 1          dz8 = (Wfinal^T dg + wsigma d_sigma) * [z8 > 0]       K = 256 + 4 prepended k-steps (sigma)
+//   layers 2..8      dz_{l-1} = (W_l^T dz_l) * [z_{l-1} > 0], l = 8..2     (l = 5: the h4 columns of the skip layer)
+//
+// Inputs: the forward panels (pre-activations, nsr_f16x3_core.h); outputs: gradient panels of the same layout, TRUE
+// scale fp32 -- the operands of the weight-gradient GEMMs (nsr_gemm.h, a_blk), whose staging also sums them into the
+// bias gradients.
+//
+// Range: gradients sit far below fp16's range and differ by orders of magnitude from point to point, so every point
+// (lane pair) carries its own power-of-two scale: the prologue scales the point's inputs to max 2^1..2^2, and each
+// layer's outputs are re-normalised by a factor chosen from the measured maximum of the layer before (gains of real
+// layers stay far inside the 2^7 of headroom this leaves below fp16's overflow).  All factors are powers of two, and
+// the stored gradients are multiplied back to true scale in fp32, so the scaling itself is exact.
+#include "nsr_f16x3_core.h"
+#include "nsr_train_chain.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// stream: 9 layers x 8 chunks (one 32-feature output block each), no bias pieces
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kBwdLayers = 9;
+__device__ __host__ __forceinline__ int bwd_chunk_pieces(int lam) { return lam == 1 ? 40 : 32; }
+__device__ __host__ __forceinline__ int bwd_piece0(int lam, int nb) {
+  if (lam == 0) return 32 * nb;
+  if (lam == 1) return 256 + 40 * nb;
+  return 576 + 256 * (lam - 2) + 32 * nb;
+}
+constexpr int kBwdPieces = 576 + 256 * 7;      // 2368 pieces of 1 KiB
+constexpr int kBwdAuxFloats = 512;             // rgb.weight as [feature][4] (fp32, true scale)
+
+struct BwdPackPtrs {
+  const float* p[NSR_N_STATE_TENSORS];
+};
+
+// one thread per 32-bit word.  Piece (layer lam, block nb, k-step s, part): lane (i, h), halves j = 0..7 hold
+// 64 W[k = act_feature(8 s + j, h)][column 32 nb + i] of the layer's nn.Linear weight (out, in) -- its transpose as the
+// MFMA A operand.
+__global__ void __launch_bounds__(256) pack_bwd_kernel(BwdPackPtrs w, unsigned* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int stream_words = kBwdPieces * 256;
+  if (idx >= stream_words + kBwdAuxFloats) return;
+  unsigned v = 0u;
+  if (idx < stream_words) {
+    const int piece = idx >> 8, word = idx & 255;
+    int lam, local;
+    if (piece < 256) { lam = 0; local = piece; }
+    else if (piece < 576) { lam = 1; local = piece - 256; }
+    else { lam = 2 + (piece - 576) / 256; local = (piece - 576) % 256; }
+    const int cp = bwd_chunk_pieces(lam);
+    const int nb = local / cp, rem = local % cp;
+    const int s = rem >> 1, part = rem & 1;
+    const int lane = word >> 2, jj = word & 3;
+    const int n = 32 * nb + (lane & 31), h = lane >> 5;
+    float f[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int j = 2 * jj + e;
+      float x = 0.0f;
+      if (lam == 0) {                                   // dir_encoding.weight (128, 283): columns 0..255 = g
+        const int k = act_feature(8 * s + j, h);
+        if (k < 128) x = w.p[18][k * 283 + n];
+      } else if (lam == 1) {                            // sigma.weight (1, 256) in slot 0 of the prepended k-steps,
+        if (s < 4) {                                    // then xyz_encoding_final.weight (256, 256)
+          if (s == 0 && j == 0 && h == 0) x = w.p[20][n];
+        } else {
+          x = w.p[16][act_feature(8 * (s - 4) + j, h) * 256 + n];
+        }
+      } else {                                          // trunk layer l = 10 - lam (8..2), tensor 2 (l - 1)
+        const int l = 10 - lam;
+        const int k = act_feature(8 * s + j, h);
+        x = (l == 5) ? w.p[8][k * 319 + 63 + n] : w.p[2 * (l - 1)][k * 256 + n];
+      }
+      f[e] = kWScale * x;
+    }
+    v = pack_hl(f[0], f[1], part);
+  } else {
+    const int a = idx - stream_words, feat = a >> 2, c = a & 3;
+    v = __float_as_uint(c < 3 ? w.p[22][c * 128 + feat] : 0.0f);
+  }
+  out[idx] = v;
+}
+
+__device__ __forceinline__ ChunkRef bwd_ref(int lam, int nb, int wave) {
+  return make_ref(bwd_piece0(lam, nb), bwd_chunk_pieces(lam), wave);
+}
+// chunk number q = 8 lam + nb of the stream; past the end chunk 0 is re-fetched into the idle slot (as in the forward)
+__device__ __forceinline__ ChunkRef bwd_seq(int q, int wave) {
+  return q < 8 * kBwdLayers ? bwd_ref(q >> 3, q & 7, wave) : make_ref(0, 32, wave);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-point scale bookkeeping (all powers of two, identical in the two lanes of a point)
+// ---------------------------------------------------------------------------------------------------------
+struct Scale {
+  float cinv;      // 1 / (accumulator scale of the stage): accumulator x cinv = true gradient
+  float phi;       // accumulator -> next operand factor
+  unsigned phi2;   // the same as a packed fp16 pair
+  float mx;        // running max |accumulator| (masked) of the stage
+};
+__device__ __forceinline__ float pow2f(int e) {          // 2^e, e clamped to the normal range
+  e = e < -120 ? -120 : (e > 120 ? 120 : e);
+  return __uint_as_float((unsigned)(e + 127) << 23);
+}
+__device__ __forceinline__ int floor_log2(float x) {     // x > 0; denormals count as 2^-127
+  return (int)((__float_as_uint(x) >> 23) & 255u) - 127;
+}
+__device__ __forceinline__ unsigned pack_h2(float x) {
+  const _Float16 hx_ = (_Float16)x;
+  const unsigned b = __builtin_bit_cast(unsigned short, hx_);
+  return b | (b << 16);
+}
+// the stage that consumes operands of magnitude `o_max` (already combined over the point's two lanes): factors of its
+// outputs, given the scale 1 / cinv_in ... of its accumulators
+__device__ __forceinline__ void stage_factors(Scale& cur, const Scale& prev) {
+  cur.cinv = prev.cinv * (1.0f / 64.0f) / prev.phi;      // accumulators of this stage = 64 x (operand scale) x truth
+  float o = prev.mx * prev.phi;
+  o = fmaxf(o, __shfl_xor(o, 32, 64));
+  // operands below 2^E: outputs of a gain-1 layer land in [2, 4) x 64 before phi
+  const int E = (o > 0.0f) ? floor_log2(o) + 1 : 2;
+  int e = -4 - E;
+  e = e < -14 ? -14 : (e > 0 ? 0 : e);                   // phi must be a normal fp16
+  cur.phi = pow2f(e);
+  cur.phi2 = pack_h2(cur.phi);
+  cur.mx = 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// re-split of a finished gradient block (in place in its accumulator registers)
+//   MASK:  x = acc * [z > 0]                         (v_cmp + v_cndmask per element)
+//   CONV:  hi = RNE_f16(x) * phi (v_cvt_pk, v_pk_mul), lo = RNE_f16(x phi - hi) (v_fma_mix), max |x| tracked
+//   then   acc = x * cinv  (true scale), stored to the gradient panel by the caller
+// 17 half-steps as in the forward kernel: half-step 2P = first part of pair P, 2P + 1 = second part of pair P and the
+// lo of pair P - 1.
+// ---------------------------------------------------------------------------------------------------------
+struct BwdTmp {
+  unsigned hi[2];
+};
+template <int P, bool MASK, bool CONV>
+__device__ __forceinline__ void bsplit_a(Acc& p, const float (&mz)[16], Scale& sc, BwdTmp& t) {
+  unsigned& hi = t.hi[P & 1];
+  if (MASK && CONV)
+    asm volatile(
+        "v_cmp_lt_f32 vcc, 0, %4\n\t"
+        "v_cndmask_b32 %0, 0, %0, vcc\n\t"
+        "v_cmp_lt_f32 vcc, 0, %5\n\t"
+        "v_cndmask_b32 %1, 0, %1, vcc\n\t"
+        "v_cvt_pk_f16_f32 %2, %0, %1\n\t"
+        "v_max3_f32 %3, |%0|, |%1|, %3"
+        : "+v"(p.m[2 * P]), "+v"(p.m[2 * P + 1]), "=&v"(hi), "+v"(sc.mx)
+        : "v"(mz[2 * P]), "v"(mz[2 * P + 1])
+        : "vcc");
+  else if (CONV)
+    asm volatile(
+        "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_max3_f32 %1, |%2|, |%3|, %1"
+        : "=&v"(hi), "+v"(sc.mx)
+        : "v"(p.m[2 * P]), "v"(p.m[2 * P + 1]));
+  else   // last layer: mask and scale only
+    asm volatile(
+        "v_cmp_lt_f32 vcc, 0, %2\n\t"
+        "v_cndmask_b32 %0, 0, %0, vcc\n\t"
+        "v_cmp_lt_f32 vcc, 0, %3\n\t"
+        "v_cndmask_b32 %1, 0, %1, vcc\n\t"
+        "v_mul_f32 %0, %0, %4\n\t"
+        "v_mul_f32 %1, %1, %4"
+        : "+v"(p.m[2 * P]), "+v"(p.m[2 * P + 1])
+        : "v"(mz[2 * P]), "v"(mz[2 * P + 1]), "v"(sc.cinv)
+        : "vcc");
+}
+template <int P>
+__device__ __forceinline__ void bput(unsigned v, u32x4& d0, u32x4& d1) {
+  if (P < 4) d0[P & 3] = v; else d1[P & 3] = v;
+}
+template <int P, bool CONV>   // P = 0..8
+__device__ __forceinline__ void bsplit_b(Acc& p, const Scale& sc, BwdTmp& t, u32x4& h0, u32x4& l0, u32x4& h1, u32x4& l1) {
+  if (!CONV) return;
+  unsigned& cur = t.hi[P & 1];
+  const unsigned prev = t.hi[(P & 1) ^ 1];
+  unsigned lo = 0;
+  constexpr int Q = P > 0 ? P - 1 : 0;   // the pair whose lo is made here
+  if (P == 0) {
+    asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(cur) : "v"(sc.phi2));
+  } else if (P < 8) {
+    asm volatile(
+        "v_fma_mixlo_f16 %1, %2, %4, -%5 op_sel_hi:[0,0,1]\n\t"
+        "v_pk_mul_f16 %0, %0, %6\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%5 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_mul_f32 %2, %2, %7\n\t"
+        "v_mul_f32 %3, %3, %7"
+        : "+v"(cur), "=&v"(lo), "+v"(p.m[2 * Q]), "+v"(p.m[2 * Q + 1])
+        : "v"(sc.phi), "v"(prev), "v"(sc.phi2), "v"(sc.cinv));
+  } else {
+    asm volatile(
+        "v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_mul_f32 %1, %1, %5\n\t"
+        "v_mul_f32 %2, %2, %5"
+        : "=&v"(lo), "+v"(p.m[2 * Q]), "+v"(p.m[2 * Q + 1])
+        : "v"(sc.phi), "v"(prev), "v"(sc.cinv));
+  }
+  if (P < 8) bput<(P < 8 ? P : 0)>(cur, h0, h1);
+  if (P > 0) bput<Q>(lo, l0, l1);
+}
+template <bool MASK, bool CONV>
+__device__ __forceinline__ void bwd_half(int hs, Acc& p, const float (&mz)[16], Scale& sc, BwdTmp& t, u32x4& h0, u32x4& l0,
+                                         u32x4& h1, u32x4& l1) {
+  switch (hs) {
+#define NSR_HS(P)                                                         \
+    case 2 * P: bsplit_a<P, MASK, CONV>(p, mz, sc, t); break;             \
+    case 2 * P + 1: bsplit_b<P, CONV>(p, sc, t, h0, l0, h1, l1); break;
+    NSR_HS(0) NSR_HS(1) NSR_HS(2) NSR_HS(3) NSR_HS(4) NSR_HS(5) NSR_HS(6) NSR_HS(7)
+#undef NSR_HS
+    case 16: bsplit_b<8, CONV>(p, sc, t, h0, l0, h1, l1); break;
+    default: break;
+  }
+}
+// the forward kernel's schedule: 17 half-steps in k-steps 0..13 (k-steps 0, 1, 2 take two)
+template <bool MASK, bool CONV>
+__device__ __forceinline__ void bwd_step(int s, Acc& p, const float (&mz)[16], Scale& sc, BwdTmp& t, u32x4& h0, u32x4& l0,
+                                         u32x4& h1, u32x4& l1) {
+  if (s < 3) {
+    bwd_half<MASK, CONV>(2 * s, p, mz, sc, t, h0, l0, h1, l1);
+    bwd_half<MASK, CONV>(2 * s + 1, p, mz, sc, t, h0, l0, h1, l1);
+  } else if (s < 14) {
+    bwd_half<MASK, CONV>(s + 3, p, mz, sc, t, h0, l0, h1, l1);
+  }
+}
+// Stores of the pending block in k-steps 8..13, i.e. after the chunk's publish point and before the mask loads.  Pair P
+// is final (true scale) after half-step 2P + 3 = k-steps 1, 2, 4, 6, 8, 10, 12, 13 for P = 0..7 (non-CONV: after half-step
+// 2P), and a k-step's store follows its half-step inside the same hook.
+__device__ __forceinline__ void bwd_store_step(int s, const Acc& p, const float* blk, unsigned voff) {
+  if (s == 8 || s == 9) {          // pairs 0, 1 | 2, 3
+#pragma unroll
+    for (int r = 0; r < 4; ++r) panel_store(4 * (s - 8) + r, p, blk, voff);
+  } else if (s >= 10 && s <= 13) { // pairs 4..7
+    panel_store(2 * (s - 6), p, blk, voff);
+    panel_store(2 * (s - 6) + 1, p, blk, voff);
+  }
+}
+
+// Mask loads: the 16 pre-activations this lane needs to mask block X are fetched during block X - 1, k-steps 14 and 15
+// -- a whole block before their first use (the re-split of X runs in the shadow of block X + 1) and as the YOUNGEST
+// vector-memory operations of their block, behind its DMA and stores.  Plain loads: the compiler's own vmcnt bookkeeping
+// guards their use; the asm DMA / stores it cannot see only make its waits stricter, and by then they are a block old.
+__device__ __forceinline__ void mask_load_step(int s, float (&mz)[16], const float* blk, unsigned voff) {
+  if (s >= 14) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = 8 * (s - 14) + i;
+      mz[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(blk) + voff + (8 * (r >> 2) + (r & 3)) * 128);
+    }
+  }
+}
+
+struct BwdCtx {
+  PanelRef zp;        // forward panels (masks)
+  PanelRef dp;        // gradient panels
+  unsigned voff;
+};
+
+// One layer `lam` of the chain: operands (bh, bl) -> eight output blocks.
+//   PREV_MASK / PREV_PANEL: the layer before (whose block 7 is still pending on entry): its mask flag and gradient panel
+//   MASK: this layer's outputs are masked by forward panel `panel` (and written to gradient panel `panel`)
+//   PREPEND: 4 extra k-steps ahead of the 16 (sigma operand in slot 0)
+//   LAST: outputs are not converted (nothing consumes them in this kernel)
+//   NEXT_MASK / next_panel: the layer after this one, whose first block's masks are fetched during this layer's last block
+template <bool PREV_MASK, bool MASK, bool PREPEND, bool LAST, bool NEXT_MASK>
+__device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, int next_panel, u32x4 (&bh)[16], u32x4 (&bl)[16], u32x4 (&oh)[16],
+                                          u32x4 (&ol)[16], const u32x4& sig_h, const u32x4& sig_l, Loader& ld, Acc& pend,
+                                          Pre& pre, float (&mz)[2][16], Scale& prev, const BwdCtx& cx) {
+  Scale cur{};
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) {
+    const int q = 8 * lam + nb;
+    const ChunkRef c2 = bwd_seq(q + 2, ld.wave);
+    Acc acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc.m[r] = 0.0f;
+    BwdTmp tmp;
+    unsigned a_addr = ld.slot_cur + ld.lane_off;
+    Pre nxt;
+    if (nb == 1) stage_factors(cur, prev);     // the previous layer's last block was measured during block 0
+    if (PREPEND) {
+      const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
+      Pre mid;
+      block_mma<4, -1>(
+          acc, pre, a_addr, ld, c2, [&](int s, int part) -> u32x4 { return s == 0 ? (part ? sig_l : sig_h) : zero4; },
+          [&](int) {}, [&](int k) { prefetch_frag(mid, k, a_addr + 8 * 1024); });
+#pragma unroll
+      for (int k = 0; k < kPF; ++k) {
+        pre.ah[k] = mid.ah[k];
+        pre.al[k] = mid.al[k];
+      }
+      a_addr += 8 * 1024;
+    }
+    // masks of the block AFTER this one (loaded here), of the PENDING block (loaded two blocks ago, same buffer parity)
+    const bool load_next = (nb < 7) ? MASK : NEXT_MASK;
+    const float* next_blk = !load_next ? nullptr : (nb < 7 ? panel_block(cx.zp, panel, nb + 1) : panel_block(cx.zp, next_panel, 0));
+    float (&mz_pend)[16] = mz[(nb + 1) & 1];
+    float (&mz_next)[16] = mz[(nb + 1) & 1];   // block nb + 1; free again once the pending block (nb - 1) is done (k-step 13)
+    // younger than the DMA this chunk's publish point waits for: the 16 mask loads the block before issued for THIS
+    // block in its k-steps 14, 15 -- behind the last DMA piece (k-step 13) -- if this layer is masked at all
+    block_mma<16, kBar, (MASK ? 16 : 0)>(
+        acc, pre, a_addr, ld, c2, [&](int s, int part) -> u32x4 { return part ? bl[s] : bh[s]; },
+        [&](int s) {
+          if (nb == 0) {
+            // block 7 of the layer before -> k-steps 14, 15 of THIS layer's input
+            bwd_step<PREV_MASK, true>(s, pend, mz_pend, prev, tmp, bh[14], bl[14], bh[15], bl[15]);
+            if (prev_panel >= 0) bwd_store_step(s, pend, panel_block(cx.dp, prev_panel, 7), cx.voff);
+          } else {
+            bwd_step<MASK, !LAST>(s, pend, mz_pend, cur, tmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1]);
+            bwd_store_step(s, pend, panel_block(cx.dp, panel, nb - 1), cx.voff);
+          }
+          if (load_next) mask_load_step(s, mz_next, next_blk, cx.voff);
+        },
+        [&](int k) { prefetch_frag(nxt, k, ld.slot_next + ld.lane_off); });
+    pend = acc;
+    pre = nxt;
+    loader_advance(ld);
+  }
+  prev = cur;
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+chain_bwd_kernel(const float* __restrict__ packed, const float* __restrict__ zpan, float* __restrict__ dpan,
+                 const float* __restrict__ d_rgb, int d_rgb_stride, const float* __restrict__ d_sigma, int d_sigma_stride,
+                 int64_t P) {
+  constexpr int kAux0 = 3 * kSlotFloats;
+  __shared__ __attribute__((aligned(16))) float ring[kAux0 + kBwdAuxFloats];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  for (int i = threadIdx.x; i < kBwdAuxFloats; i += 256) ring[kAux0 + i] = packed[kBwdPieces * 256 + i];
+
+  Loader ld;
+  ld.stream = packed;
+  ld.wave = wave;
+  ld.lane_off = (unsigned)lane * 16u;
+  ld.slot_cur = lds_addr(ring);
+  ld.slot_next = ld.slot_cur + kSlotBytes;
+  ld.slot_free = ld.slot_cur + 2 * kSlotBytes;
+  // chunks 0 and 1 stream in behind the prologue
+  loader_prepare_dma(ld, bwd_seq(0, wave), ld.slot_cur);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) loader_issue(ld, i);
+  loader_prepare_dma(ld, bwd_seq(1, wave), ld.slot_next);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) loader_issue(ld, i);
+
+  const int64_t p = (int64_t)blockIdx.x * 128 + wave * 32 + m;
+  const int64_t pc = p < P ? p : P - 1;
+  BwdCtx cx;
+  cx.zp.base = const_cast<float*>(zpan);
+  cx.dp.base = dpan;
+  cx.zp.n_groups = cx.dp.n_groups = (int64_t)gridDim.x * 4;
+  cx.zp.group = cx.dp.group = (int64_t)blockIdx.x * 4 + wave;
+  cx.voff = 4u * (unsigned)(m + 128 * h);
+
+  // ---- prologue: the colour head's input gradient on the VALU (K = 3), masked by dir_encoding's ReLU
+  const float g0 = d_rgb[pc * d_rgb_stride + 0], g1 = d_rgb[pc * d_rgb_stride + 1], g2 = d_rgb[pc * d_rgb_stride + 2];
+  const float gs = d_sigma[pc * d_sigma_stride];
+  float zc[64];
+#pragma unroll
+  for (int t = 0; t < 64; ++t) {
+    const float* blk = panel_block(cx.zp, 9, t >> 4);
+    const int r = t & 15;
+    zc[t] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(blk) + cx.voff + (8 * (r >> 2) + (r & 3)) * 128);
+  }
+  __syncthreads();   // aux visible
+  float dz[64];
+  float mxin = fabsf(gs);
+#pragma unroll
+  for (int t = 0; t < 64; ++t) {
+    const int feat = act_feature(t, h);
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(ring + kAux0 + 4 * feat);
+    float v = __fmaf_rn(w4[2], g2, __fmaf_rn(w4[1], g1, __fmul_rn(w4[0], g0)));
+    v = zc[t] > 0.0f ? v : 0.0f;
+    dz[t] = v;
+    mxin = fmaxf(mxin, fabsf(v));
+  }
+  mxin = fmaxf(mxin, __shfl_xor(mxin, 32, 64));
+  // the point's scale: its largest input lands in [2, 4)
+  const float S = mxin > 0.0f ? pow2f(1 - floor_log2(mxin)) : 1.0f;
+  {
+    Acc tmp;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmp.m[r] = dz[16 * b + r];
+      const float* blk = panel_block(cx.dp, 9, b);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) panel_store(r, tmp, blk, cx.voff);
+    }
+  }
+  u32x4 bh[16], bl[16], oh[16], ol[16];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    unsigned a[4], b[4];
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) split2(dz[8 * s + 2 * pr] * S, dz[8 * s + 2 * pr + 1] * S, a[pr], b[pr]);
+    bh[s] = u32x4{a[0], a[1], a[2], a[3]};
+    bl[s] = u32x4{b[0], b[1], b[2], b[3]};
+  }
+#pragma unroll
+  for (int s = 8; s < 16; ++s) {
+    bh[s] = u32x4{0u, 0u, 0u, 0u};
+    bl[s] = u32x4{0u, 0u, 0u, 0u};
+  }
+  // d_sigma joins at layer 1 with the scale of layer 0's converted outputs (phi of layer 0 is fixed: S x 64 x 2^-6 = S)
+  u32x4 sig_h = u32x4{0u, 0u, 0u, 0u}, sig_l = u32x4{0u, 0u, 0u, 0u};
+  {
+    unsigned a, b;
+    split2(h == 0 ? gs * S : 0.0f, 0.0f, a, b);
+    sig_h[0] = a;
+    sig_l[0] = b;
+  }
+  // "previous stage" of layer 0 = the prologue: operands at scale S with max in [2, 4)
+  Scale prev;
+  prev.cinv = 1.0f / S;      // so that stage_factors() gives layer 0 the accumulator scale 64 S
+  prev.phi = 1.0f;
+  prev.phi2 = 0u;
+  prev.mx = 3.0f;            // E = 2 -> phi of layer 0 = 2^-6
+
+  // chunk 0 published, first fragments in registers
+  dma_drain();
+  __syncthreads();
+  Pre pre;
+#pragma unroll
+  for (int k = 0; k < kPF; ++k) prefetch_frag(pre, k, ld.slot_cur + ld.lane_off);
+  loader_prepare_dma(ld, bwd_seq(2, wave), ld.slot_free);   // replaced at the first publish point; keeps the descriptor defined
+
+  Acc pend;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) pend.m[r] = 0.0f;
+  float mz[2][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mz[0][r] = mz[1][r] = 0.0f;
+
+  // layer 0: dg (no mask) -> gradient panel 8.  Its block-0 hook sees a dummy pending block (zeros, converted into the
+  // zero padding of its own input, stored nowhere)
+  bwd_layer<false, false, false, false, true>(0, -1, 8, 7, bh, bl, oh, ol, sig_h, sig_l, ld, pend, pre, mz, prev, cx);
+  bwd_layer<false, true, true, false, true>(1, 8, 7, 6, oh, ol, bh, bl, sig_h, sig_l, ld, pend, pre, mz, prev, cx);
+  // layers 2..8: trunk layers 8..2; outputs dz7..dz1 -> panels 6..0
+#pragma unroll 1
+  for (int pair = 0; pair < 3; ++pair) {
+    const int lam = 2 + 2 * pair;
+    bwd_layer<true, true, false, false, true>(lam, 9 - lam, 8 - lam, 7 - lam, bh, bl, oh, ol, sig_h, sig_l, ld, pend, pre, mz, prev,
+                                              cx);
+    bwd_layer<true, true, false, false, true>(lam + 1, 8 - lam, 7 - lam, 6 - lam, oh, ol, bh, bl, sig_h, sig_l, ld, pend, pre, mz,
+                                              prev, cx);
+  }
+  bwd_layer<true, true, false, true, false>(8, 1, 0, -1, bh, bl, oh, ol, sig_h, sig_l, ld, pend, pre, mz, prev, cx);
+  // the last block of dz1: mask, true scale, store
+  {
+    Scale last{};
+    last.cinv = prev.cinv;
+    BwdTmp tmp;
+    // the accumulators were written by the MFMA just issued, and the hazard recognizer does not look inside inline asm:
+    // give the matrix pipe its write-back latency (18 wait states for a 16-pass MFMA) before the asm below reads them
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int hs = 0; hs < 16; hs += 2) bwd_half<true, false>(hs, pend, mz[1], last, tmp, bh[0], bl[0], bh[1], bl[1]);
+    const float* blk = panel_block(cx.dp, 0, 7);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) panel_store(r, pend, blk, cx.voff);
+  }
+  dma_drain();   // no LDS-DMA may be in flight when the workgroup's LDS is released
+}
+
+}  // namespace
+
+extern "C" NSR_INTERNAL size_t nsr_chain_bwd_packed_bytes(void) { return 4 * (size_t)(kBwdPieces * 256 + kBwdAuxFloats); }
+
+extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* packed_dev, void* stream) {
+  BwdPackPtrs pp;
+  for (int i = 0; i < NSR_N_STATE_TENSORS; ++i) {
+    if (!w[i]) return NSR_ERR_INVALID_ARG;
+    pp.p[i] = w[i];
+  }
+  const int total = kBwdPieces * 256 + kBwdAuxFloats;
+  hipLaunchKernelGGL(pack_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, nsr_stream(stream), pp,
+                     static_cast<unsigned*>(packed_dev));
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
+extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const float* zpan, float* dpan, const float* d_rgb, int d_rgb_stride,
+                                          const float* d_sigma, int d_sigma_stride, int64_t P, void* stream) {
+  if (P <= 0) return NSR_OK;
+  const dim3 grid((unsigned)((P + 127) / 128)), block(256);
+  hipLaunchKernelGGL(chain_bwd_kernel, grid, block, 0, nsr_stream(stream), static_cast<const float*>(packed), zpan, dpan, d_rgb,
+                     d_rgb_stride, d_sigma, d_sigma_stride, P);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
