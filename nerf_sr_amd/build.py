@@ -26,6 +26,7 @@ UNITS = [
     ("nsr_mlp_h1.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("nsr_gemm.hip", ["-ffp-contract=off"]),
     ("nsr_gemm_f16.hip", ["-ffp-contract=off"]),
+    ("nsr_wgrad_f16.hip", ["-ffp-contract=off"]),
     ("nsr_train.hip", ["-ffp-contract=off"]),
     ("nsr_train_chain.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("nsr_warp.hip", ["-ffp-contract=off"]),

@@ -76,4 +76,20 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st);
 // v = kSplitScale * w[i];  hi[i] = fp16(v), lo[i] = fp16(v - hi[i])   (round to nearest)
 NSR_INTERNAL int split_f16(const float* w, int64_t n, unsigned short* hi, unsigned short* lo, hipStream_t st);
 
+// ---- weight gradient from two training panels on the split-fp16 MFMA (nsr_wgrad_f16.hip): partial[z] (M x 256) =
+// out_scale * sum over slice z of the points of A[p][0..M) max(B[p][0..256), lower)^T, M = 256 or 128, both operands
+// "blocked transposed" fp32 panels (nsr_f16x3_core.h).  A is pre-scaled by a power of two derived from *a_max_bits
+// (float bits of the panel's largest magnitude, device memory); the scale is removed again before the store.
+struct WgradArgs {
+  const float* A; int64_t a_gstride; int M;   // gradient panel, floats between two point groups (32 M)
+  const float* B; int64_t b_gstride; int N;   // forward panel (N = 256)
+  int b_relu;
+  int64_t P;                                  // points, multiple of 32
+  const unsigned* a_max_bits;
+  float out_scale;
+  float* partial; int64_t split_stride; int splits;
+  float* row_sums;                            // may be null: (splits, M) sums of A's rows over the slice (fp32, true scale)
+};
+NSR_INTERNAL int wgrad_f16x3(const WgradArgs& w, hipStream_t st);
+
 }  // namespace nsr

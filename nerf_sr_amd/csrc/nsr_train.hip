@@ -385,6 +385,7 @@ struct Work {   // per-pass buffers, sized for P_max = chunk * (Nc + Ni) sample 
   // (nsr_f16x3_core.h), the two weight streams per network, per-slice row sums of the weight-gradient GEMMs
   float *zpan, *dpan, *row_part;
   float *stream_f[2], *stream_b[2];
+  unsigned* gmax;   // float bits of the largest magnitude in each gradient panel (written by the backward chain)
 };
 
 int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base) {
@@ -420,6 +421,7 @@ int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base) {
   const int64_t pan = nsr_f16x3_train_panel_floats(P);
   k.zpan = take(pan);   k.dpan = take(pan);
   k.row_part = take(kMaxSplits * 256);
+  k.gmax = reinterpret_cast<unsigned*>(take(64));
   for (int n = 0; n < 2; ++n) {
     k.stream_f[n] = take((int64_t)(nsr_f16x3_packed_bytes() / 4));
     k.stream_b[n] = take((int64_t)(nsr_chain_bwd_packed_bytes() / 4));
@@ -626,6 +628,16 @@ int chain_wgrad(hipStream_t st, const Operand& a, int M, const Operand& b, int N
   g.splits = splits; g.split_stride = kPartialFloats; g.row_sums = row_sums;
   return gemm(g, st);
 }
+// both operands panels: the split-fp16 kernel (nsr_wgrad_f16.hip).  a_panel / b_panel: panel numbers of dpan / zpan
+int panel_wgrad(hipStream_t st, const Work& k, int64_t P, int a_panel, int b_panel, int b_relu, float* partial, int splits,
+                float* row_sums) {
+  WgradArgs w{};
+  w.A = panel_of(k.dpan, P, a_panel); w.M = a_panel == 9 ? 128 : 256; w.a_gstride = 32 * w.M;
+  w.B = panel_of(k.zpan, P, b_panel); w.N = 256; w.b_gstride = 32 * 256; w.b_relu = b_relu;
+  w.P = P; w.a_max_bits = k.gmax + a_panel; w.out_scale = 1.0f / 64.0f;
+  w.partial = partial; w.split_stride = kPartialFloats; w.splits = splits; w.row_sums = row_sums;
+  return wgrad_f16x3(w, st);
+}
 int rowsum_finish(hipStream_t st, const float* partial, int splits, int rows, float* dst, int acc) {
   hipLaunchKernelGGL(rowsum_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, partial, splits, rows, dst, acc);
   NSR_CHECK_LAUNCH();
@@ -650,14 +662,14 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
   NSR_TRY(reduce_place(st, g[kRgbW], 128, 0, 3, 128, part, sp, kDirOut, 0, 0, acc, kInv));
   NSR_TRY(colsum(st, k.drgb, kRgbPad, P, 0, 3, g[kRgbB], acc, part));
   // dir_encoding: dzc^T [g | de]
-  NSR_TRY(chain_wgrad(st, dp(9), kDirOut, zp(8, 0), kW, P, part, sp, rs));
-  NSR_TRY(reduce_place(st, g[kDirW], 283, 0, 128, 256, part, sp, kW, 0, 0, acc, kInv));
+  NSR_TRY(panel_wgrad(st, k, P, 9, 8, 0, part, sp, rs));
+  NSR_TRY(reduce_place(st, g[kDirW], 283, 0, 128, 256, part, sp, kW, 0, 0, acc));
   NSR_TRY(rowsum_finish(st, rs, sp, kDirOut, g[kDirB], acc));
   NSR_TRY(chain_wgrad(st, dp(9), kDirOut, de, 32, P, part, sp, nullptr));
   NSR_TRY(reduce_place(st, g[kDirW], 283, 256, 128, 27, part, sp, 32, 0, kDeCol - kSigmaCol, acc));
   // xyz_encoding_final: dg^T relu(z8); sigma: d_sigma^T relu(z8)
-  NSR_TRY(chain_wgrad(st, dp(8), kW, zp(7, 1), kW, P, part, sp, rs));
-  NSR_TRY(reduce_place(st, g[kFinalW], 256, 0, 256, 256, part, sp, kW, 0, 0, acc, kInv));
+  NSR_TRY(panel_wgrad(st, k, P, 8, 7, 1, part, sp, rs));
+  NSR_TRY(reduce_place(st, g[kFinalW], 256, 0, 256, 256, part, sp, kW, 0, 0, acc));
   NSR_TRY(rowsum_finish(st, rs, sp, kW, g[kFinalB], acc));
   NSR_TRY(chain_wgrad(st, dsig, 32, zp(7, 1), kW, P, part, sp, nullptr));
   NSR_TRY(reduce_place(st, g[kSigmaW], 256, 0, 1, 256, part, sp, kW, 0, 0, acc, kInv));
@@ -666,19 +678,15 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
   for (int L = 8; L >= 1; --L) {
     float* gw = g[2 * (L - 1)];
     const Operand dz = dp(L - 1);
-    if (L == 1 || L == 5) {
-      NSR_TRY(chain_wgrad(st, dz, kW, pe, kPe, P, part, sp, rs));
+    if (L == 1 || L == 5) {   // the encoded position is a row-major buffer: fp32 GEMM
+      NSR_TRY(chain_wgrad(st, dz, kW, pe, kPe, P, part, sp, L == 1 ? rs : nullptr));
       NSR_TRY(reduce_place(st, gw, L == 1 ? 63 : 319, 0, 256, 63, part, sp, kPe, 0, 0, acc));
-      NSR_TRY(rowsum_finish(st, rs, sp, kW, g[2 * (L - 1) + 1], acc));
-      if (L == 5) {
-        NSR_TRY(chain_wgrad(st, dz, kW, zp(3, 1), kW, P, part, sp, nullptr));
-        NSR_TRY(reduce_place(st, gw, 319, 63, 256, 256, part, sp, kW, 0, 0, acc, kInv));
-      }
-    } else {
-      NSR_TRY(chain_wgrad(st, dz, kW, zp(L - 2, 1), kW, P, part, sp, rs));
-      NSR_TRY(reduce_place(st, gw, 256, 0, 256, 256, part, sp, kW, 0, 0, acc, kInv));
-      NSR_TRY(rowsum_finish(st, rs, sp, kW, g[2 * (L - 1) + 1], acc));
     }
+    if (L > 1) {
+      NSR_TRY(panel_wgrad(st, k, P, L - 1, L - 2, 1, part, sp, rs));
+      NSR_TRY(reduce_place(st, gw, L == 5 ? 319 : 256, L == 5 ? 63 : 0, 256, 256, part, sp, kW, 0, 0, acc));
+    }
+    NSR_TRY(rowsum_finish(st, rs, sp, kW, g[2 * (L - 1) + 1], acc));
   }
   return NSR_OK;
 }
@@ -807,7 +815,7 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
       NSR_CHECK_LAUNCH();
       NSR_TRY(composite_bwd(st, k, z, rc, N, white_bkgd));
       if (chain) {
-        NSR_TRY(nsr_chain_bwd(k.stream_b[net], k.zpan, k.dpan, k.drgb, kRgbPad, k.g1 + kSigmaCol, kGs, P, stream));
+        NSR_TRY(nsr_chain_bwd(k.stream_b[net], k.zpan, k.dpan, k.drgb, kRgbPad, k.g1 + kSigmaCol, kGs, P, k.gmax, stream));
         NSR_TRY(chain_weight_grads(st, k, P, g, acc));
       } else {
         NSR_TRY(net_backward(st, w, k.pack[net], k, P, g, acc));

@@ -9,8 +9,10 @@ extern "C" NSR_INTERNAL int nsr_f16x3_train_forward(const void* packed, const fl
                                                     int N, float* raw, float* pan, void* stream);
 extern "C" NSR_INTERNAL size_t nsr_f16x3_packed_bytes(void);
 extern "C" NSR_INTERNAL int nsr_f16x3_pack(const float* const* w, void* packed_dev, void* stream);
-// backward chain: transposed weight stream, then d(rgb_pre) (P, stride) / d(sigma) (P, stride) -> gradient panels
+// backward chain: transposed weight stream, then d(rgb_pre) (P, stride) / d(sigma) (P, stride) -> gradient panels;
+// gmax[10] (device): float bits of the largest magnitude written to each gradient panel (zeroed, then atomicMax)
 extern "C" NSR_INTERNAL size_t nsr_chain_bwd_packed_bytes(void);
 extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* packed_dev, void* stream);
 extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const float* zpan, float* dpan, const float* d_rgb, int d_rgb_stride,
-                                          const float* d_sigma, int d_sigma_stride, int64_t P, void* stream);
+                                          const float* d_sigma, int d_sigma_stride, int64_t P, unsigned* gmax,
+                                          void* stream);

@@ -169,13 +169,14 @@ __device__ __forceinline__ void bsplit_a(Acc& p, const float (&mz)[16], Scale& s
         : "v"(p.m[2 * P]), "v"(p.m[2 * P + 1]));
   else   // last layer: mask and scale only
     asm volatile(
-        "v_cmp_lt_f32 vcc, 0, %2\n\t"
-        "v_cndmask_b32 %0, 0, %0, vcc\n\t"
         "v_cmp_lt_f32 vcc, 0, %3\n\t"
+        "v_cndmask_b32 %0, 0, %0, vcc\n\t"
+        "v_cmp_lt_f32 vcc, 0, %4\n\t"
         "v_cndmask_b32 %1, 0, %1, vcc\n\t"
-        "v_mul_f32 %0, %0, %4\n\t"
-        "v_mul_f32 %1, %1, %4"
-        : "+v"(p.m[2 * P]), "+v"(p.m[2 * P + 1])
+        "v_max3_f32 %2, |%0|, |%1|, %2\n\t"
+        "v_mul_f32 %0, %0, %5\n\t"
+        "v_mul_f32 %1, %1, %5"
+        : "+v"(p.m[2 * P]), "+v"(p.m[2 * P + 1]), "+v"(sc.mx)
         : "v"(mz[2 * P]), "v"(mz[2 * P + 1]), "v"(sc.cinv)
         : "vcc");
 }
@@ -268,7 +269,14 @@ struct BwdCtx {
   PanelRef zp;        // forward panels (masks)
   PanelRef dp;        // gradient panels
   unsigned voff;
+  unsigned* gmax;     // per gradient panel: float bits of the largest magnitude written (atomicMax over the launch)
 };
+// largest true-scale magnitude a wave wrote to gradient panel `panel` (the weight-gradient GEMM scales by it)
+__device__ __forceinline__ void publish_max(const BwdCtx& cx, int panel, float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(cx.gmax + panel, __float_as_uint(v));
+}
 
 // One layer `lam` of the chain: operands (bh, bl) -> eight output blocks.
 //   PREV_MASK / PREV_PANEL: the layer before (whose block 7 is still pending on entry): its mask flag and gradient panel
@@ -291,7 +299,10 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
     BwdTmp tmp;
     unsigned a_addr = ld.slot_cur + ld.lane_off;
     Pre nxt;
-    if (nb == 1) stage_factors(cur, prev);     // the previous layer's last block was measured during block 0
+    if (nb == 1) {                             // the previous layer's last block was measured during block 0
+      if (prev_panel >= 0) publish_max(cx, prev_panel, prev.mx * prev.cinv);
+      stage_factors(cur, prev);
+    }
     if (PREPEND) {
       const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
       Pre mid;
@@ -336,7 +347,7 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 chain_bwd_kernel(const float* __restrict__ packed, const float* __restrict__ zpan, float* __restrict__ dpan,
                  const float* __restrict__ d_rgb, int d_rgb_stride, const float* __restrict__ d_sigma, int d_sigma_stride,
-                 int64_t P) {
+                 int64_t P, unsigned* __restrict__ gmax) {
   constexpr int kAux0 = 3 * kSlotFloats;
   __shared__ __attribute__((aligned(16))) float ring[kAux0 + kBwdAuxFloats];
   const int lane = threadIdx.x & 63;
@@ -367,6 +378,7 @@ chain_bwd_kernel(const float* __restrict__ packed, const float* __restrict__ zpa
   cx.zp.n_groups = cx.dp.n_groups = (int64_t)gridDim.x * 4;
   cx.zp.group = cx.dp.group = (int64_t)blockIdx.x * 4 + wave;
   cx.voff = 4u * (unsigned)(m + 128 * h);
+  cx.gmax = gmax;
 
   // ---- prologue: the colour head's input gradient on the VALU (K = 3), masked by dir_encoding's ReLU
   const float g0 = d_rgb[pc * d_rgb_stride + 0], g1 = d_rgb[pc * d_rgb_stride + 1], g2 = d_rgb[pc * d_rgb_stride + 2];
@@ -389,6 +401,12 @@ chain_bwd_kernel(const float* __restrict__ packed, const float* __restrict__ zpa
     v = zc[t] > 0.0f ? v : 0.0f;
     dz[t] = v;
     mxin = fmaxf(mxin, fabsf(v));
+  }
+  {
+    float mdz = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 64; ++t) mdz = fmaxf(mdz, fabsf(dz[t]));
+    publish_max(cx, 9, mdz);
   }
   mxin = fmaxf(mxin, __shfl_xor(mxin, 32, 64));
   // the point's scale: its largest input lands in [2, 4)
@@ -470,8 +488,10 @@ chain_bwd_kernel(const float* __restrict__ packed, const float* __restrict__ zpa
     // the accumulators were written by the MFMA just issued, and the hazard recognizer does not look inside inline asm:
     // give the matrix pipe its write-back latency (18 wait states for a 16-pass MFMA) before the asm below reads them
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    last.mx = prev.mx;
 #pragma unroll
     for (int hs = 0; hs < 16; hs += 2) bwd_half<true, false>(hs, pend, mz[1], last, tmp, bh[0], bl[0], bh[1], bl[1]);
+    publish_max(cx, 0, last.mx * last.cinv);
     const float* blk = panel_block(cx.dp, 0, 7);
 #pragma unroll
     for (int r = 0; r < 16; ++r) panel_store(r, pend, blk, cx.voff);
@@ -497,11 +517,13 @@ extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* pack
 }
 
 extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const float* zpan, float* dpan, const float* d_rgb, int d_rgb_stride,
-                                          const float* d_sigma, int d_sigma_stride, int64_t P, void* stream) {
+                                          const float* d_sigma, int d_sigma_stride, int64_t P, unsigned* gmax,
+                                          void* stream) {
   if (P <= 0) return NSR_OK;
+  if (hipMemsetAsync(gmax, 0, 10 * sizeof(unsigned), nsr_stream(stream)) != hipSuccess) return NSR_ERR_LAUNCH;
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   hipLaunchKernelGGL(chain_bwd_kernel, grid, block, 0, nsr_stream(stream), static_cast<const float*>(packed), zpan, dpan, d_rgb,
-                     d_rgb_stride, d_sigma, d_sigma_stride, P);
+                     d_rgb_stride, d_sigma, d_sigma_stride, P, gmax);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }

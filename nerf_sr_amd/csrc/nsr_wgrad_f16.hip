@@ -1,0 +1,173 @@
+// Weight gradient of a linear layer from two training panels on the split-fp16 matrix pipe (nsr_gemm.h: wgrad_f16x3).
+//
+//   partial[z] (M x N) = mult * sum over slice z of the points p of  A[p][0..M) B[p][0..N)^T
+//
+// A = a gradient panel (true-scale fp32, nsr_train_chain.hip), B = a forward panel (pre-activations x 2^6, read through
+// max(., 0) when the consumer saw them behind a ReLU).  Both are "blocked transposed" ([group of 32 points][row][32],
+// nsr_f16x3_core.h), so the K tile of one point group is ONE contiguous rows x 128 B run of each panel: the staging
+// loads are perfectly coalesced float4 streams and every byte of both panels is read exactly once by exactly one
+// workgroup (tile = all M x all 256 columns).  Each value is split into fp16 (hi, lo) on its way from registers to LDS
+// and each product is a_hi b_hi + a_hi b_lo + a_lo b_hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation: 3/16 of the
+// fp32-MFMA cycles, which turns the product from matrix-pipe bound (68 % of the fp32 peak, 0.32 ms per fine-pass layer)
+// into HBM bound (two panels of P KiB each).
+// Range: gradients are tiny (1e-8 .. 1e-3), so A is multiplied by a power of two S that puts the panel's largest
+// magnitude (kept by the backward chain, one atomicMax per wave and layer) at 2^13..2^14; elements far below the
+// maximum lose relative precision against fp16's subnormal floor (2^-24 / S absolute), which is 2^-38 of the panel's
+// maximum -- nothing a sum over the points can see.  S and B's 2^6 are removed from the accumulators (exactly) before
+// the partial sums are written; the split-K reduction is the deterministic second pass of the fp32 path.
+// While a thread stages its A values it also sums them per row in fp32: the bias gradient of the layer.
+#include "nsr_gemm.h"
+
+namespace nsr {
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTK = 32, kLd = kTK + 8;   // one point group per K tile; LDS row stride in halves (80 B: conflict-free b128 reads)
+constexpr int kTN = 256, kNT = 512;      // 8 waves: 2 (rows) x 4 (columns), wave tile (32 BM) x 64
+
+template <int BM>   // 32-row blocks per wave: 4 -> 256-row tile, 2 -> 128-row tile
+__global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wgrad_f16x3_kernel(WgradArgs w, int64_t groups_per_slice) {
+  constexpr int TM = 64 * BM;
+  constexpr int kArrA = TM * kLd, kArrB = kTN * kLd;
+  constexpr int NA = TM * kTK / 4 / kNT, NB = kTN * kTK / 4 / kNT;   // float4 per thread and K tile: 4 (2) and 4
+  __shared__ __attribute__((aligned(16))) _Float16 lds[2 * kArrA + 2 * kArrB];   // A hi | A lo | B hi | B lo
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1, li = lane & 31, h = lane >> 5;
+  const int z = blockIdx.x;
+  const int64_t n_groups = w.P / 32;
+  const int64_t g_begin = (int64_t)z * groups_per_slice;
+  const int64_t g_end = (g_begin + groups_per_slice < n_groups) ? g_begin + groups_per_slice : n_groups;
+
+  // power-of-two pre-scale of A from the panel's maximum magnitude
+  const float amax = __uint_as_float(*w.a_max_bits);
+  int e = 13 - ((int)((__float_as_uint(amax) >> 23) & 255u) - 127);
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  const float S = amax > 0.0f ? __uint_as_float((unsigned)(e + 127) << 23) : 1.0f;
+  const float b_lower = w.b_relu ? 0.0f : -__builtin_inff();
+
+  f32x16 acc[BM][2];
+#pragma unroll
+  for (int bi = 0; bi < BM; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.0f;
+
+  // staging: float4 number tid + 512 i of the group's contiguous (rows x 32) run = row (tid >> 3) + 64 i, k = 4 (tid & 7)
+  f32x4 sa[NA], sb[NB];
+  float rs[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) rs[i] = 0.0f;
+  auto load = [&](int64_t g) {
+    const f32x4* ap = reinterpret_cast<const f32x4*>(w.A + g * w.a_gstride);
+    const f32x4* bp = reinterpret_cast<const f32x4*>(w.B + g * w.b_gstride);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) sa[i] = ap[tid + kNT * i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) sb[i] = bp[tid + kNT * i];
+  };
+  auto split_store = [&](const f32x4& v, _Float16* hi_arr, _Float16* lo_arr, int row) {
+    h4 hi, lo;
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+      const _Float16 x = (_Float16)v[e4];
+      hi[e4] = x;
+      lo[e4] = (_Float16)(v[e4] - (float)x);
+    }
+    const int off = row * kLd + 4 * (tid & 7);
+    *reinterpret_cast<h4*>(hi_arr + off) = hi;
+    *reinterpret_cast<h4*>(lo_arr + off) = lo;
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      rs[i] += (sa[i][0] + sa[i][1]) + (sa[i][2] + sa[i][3]);
+      split_store(sa[i] * S, lds, lds + kArrA, (tid >> 3) + 64 * i);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      f32x4 v = sb[i];
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) v[e4] = fmaxf(v[e4], b_lower);
+      split_store(v, lds + 2 * kArrA, lds + 2 * kArrA + kArrB, (tid >> 3) + 64 * i);
+    }
+  };
+
+  if (g_begin < g_end) load(g_begin);
+  for (int64_t g = g_begin; g < g_end; ++g) {
+    store();
+    __syncthreads();
+    if (g + 1 < g_end) load(g + 1);
+    const _Float16* ap = lds + (32 * BM * wm + li) * kLd + 8 * h;
+    const _Float16* bp = lds + 2 * kArrA + (64 * wn + li) * kLd + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      h8 bh[2], bl[2];
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj) {
+        bh[bj] = *reinterpret_cast<const h8*>(bp + 32 * bj * kLd + 16 * s);
+        bl[bj] = *reinterpret_cast<const h8*>(bp + kArrB + 32 * bj * kLd + 16 * s);
+      }
+#pragma unroll
+      for (int bi = 0; bi < BM; ++bi) {
+        const h8 ah = *reinterpret_cast<const h8*>(ap + 32 * bi * kLd + 16 * s);
+        const h8 al = *reinterpret_cast<const h8*>(ap + kArrA + 32 * bi * kLd + 16 * s);
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj) {
+          acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[bj], acc[bi][bj], 0, 0, 0);   // small terms first
+          acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[bj], acc[bi][bj], 0, 0, 0);
+          acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[bj], acc[bi][bj], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // partial sums at true scale: D lane (column li, half h) of block (bi, bj) holds rows 8 (r >> 2) + 4 h + (r & 3)
+  const float mult = w.out_scale / S;
+  float* C = w.partial + (int64_t)z * w.split_stride;
+#pragma unroll
+  for (int bi = 0; bi < BM; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+      const int n = 64 * wn + 32 * bj + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * BM * wm + 32 * bi + 8 * (r >> 2) + 4 * h + (r & 3);
+        C[(int64_t)m * kTN + n] = acc[bi][bj][r] * mult;
+      }
+    }
+  if (w.row_sums) {   // the 8 threads that stage one row are neighbours
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      float s = rs[i];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      if ((tid & 7) == 0) w.row_sums[(int64_t)z * TM + (tid >> 3) + 64 * i] = s;
+    }
+  }
+}
+
+}  // namespace
+
+NSR_INTERNAL int wgrad_f16x3(const WgradArgs& w, hipStream_t st) {
+  if (!w.A || !w.B || !w.partial || !w.a_max_bits || w.splits < 1 || w.N != kTN || (w.M != 256 && w.M != 128))
+    return NSR_ERR_INVALID_ARG;
+  if (w.P < 0 || w.P % 32 != 0 || w.a_gstride % 4 || w.b_gstride % 4) return NSR_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(w.A) & 15) || (reinterpret_cast<uintptr_t>(w.B) & 15)) return NSR_ERR_INVALID_ARG;
+  if (w.P == 0) return NSR_OK;
+  const int64_t n_groups = w.P / 32;
+  const int64_t per = (n_groups + w.splits - 1) / w.splits;
+  if (w.M == 256) hipLaunchKernelGGL(wgrad_f16x3_kernel<4>, dim3((unsigned)w.splits), dim3(kNT), 0, st, w, per);
+  else hipLaunchKernelGGL(wgrad_f16x3_kernel<2>, dim3((unsigned)w.splits), dim3(kNT), 0, st, w, per);
+  if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
+  return NSR_OK;
+}
+
+}  // namespace nsr
