@@ -324,20 +324,62 @@ __global__ void __launch_bounds__(256) reduce_place_kernel(float* __restrict__ d
   *d = (accumulate ? *d : 0.0f) + (float)(s * (double)scale);   // scale: a power of two (pre-scaled operands)
 }
 // bias gradient from the row sums a weight-gradient GEMM left per split-K slice: dst[i] (+)= sum_z partial[z * rows + i]
+// One wavefront per row (4 rows per block): the slices of a row are loaded in parallel and combined by shuffles in a
+// fixed order.
 __global__ void __launch_bounds__(256) rowsum_finish_kernel(const float* __restrict__ partial, int splits, int rows,
                                                             float* __restrict__ dst, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows) return;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int zc = 0;
-  for (; zc + 4 <= splits; zc += 4) {
-    s0 += (double)partial[(zc + 0) * rows + i];
-    s1 += (double)partial[(zc + 1) * rows + i];
-    s2 += (double)partial[(zc + 2) * rows + i];
-    s3 += (double)partial[(zc + 3) * rows + i];
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= rows) return;   // wave-uniform
+  double s = 0.0;
+  for (int zc = lane; zc < splits; zc += 64) s += (double)partial[(int64_t)zc * rows + i];
+  s = wave_sum_d(s);
+  if (lane == 0) dst[i] = (accumulate ? dst[i] : 0.0f) + (float)s;
+}
+
+// sums over the points of  w[p][c] * max(panel[p][row], lower)  for c < NW weights per point -- the weight gradients of
+// the 1- and 3-row heads (sigma over h8, rgb over dir_encoding's output), whose "GEMM" is a stream over one panel:
+// partial[z][c * R + row] = scale * sum over slice z.  The panel run of a point group is contiguous (R x 32 floats);
+// thread t takes its float4 number t + 256 i = row (t >> 3) + 32 i, points 4 (t & 7) ..+3.
+template <int R, int NW>
+__global__ void __launch_bounds__(256) panel_wsums_kernel(const float* __restrict__ panel, int64_t P, const float* __restrict__ w,
+                                                          int w_stride, float lower, float scale, int64_t groups_per_slice,
+                                                          float* __restrict__ partial) {
+  constexpr int NI = R * 8 / 256;
+  const int tid = threadIdx.x, c4 = tid & 7, z = blockIdx.x;
+  const int64_t n_groups = P / 32;
+  const int64_t g0 = (int64_t)z * groups_per_slice;
+  const int64_t g1 = (g0 + groups_per_slice < n_groups) ? g0 + groups_per_slice : n_groups;
+  float acc[NI][NW];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int c = 0; c < NW; ++c) acc[i][c] = 0.0f;
+  for (int64_t g = g0; g < g1; ++g) {
+    const float4* run = reinterpret_cast<const float4*>(panel + g * (int64_t)(R * 32));
+    float wk[4][NW];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < NW; ++c) wk[e][c] = w[(g * 32 + 4 * c4 + e) * w_stride + c];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float4 v = run[tid + 256 * i];
+      const float x[4] = {fmaxf(v.x, lower), fmaxf(v.y, lower), fmaxf(v.z, lower), fmaxf(v.w, lower)};
+#pragma unroll
+      for (int c = 0; c < NW; ++c)
+        acc[i][c] += (x[0] * wk[0][c] + x[1] * wk[1][c]) + (x[2] * wk[2][c] + x[3] * wk[3][c]);
+    }
   }
-  for (; zc < splits; ++zc) s0 += (double)partial[zc * rows + i];
-  dst[i] = (accumulate ? dst[i] : 0.0f) + (float)((s0 + s1) + (s2 + s3));
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int c = 0; c < NW; ++c) {
+      float s = acc[i][c];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      if (c4 == 0) partial[(int64_t)z * (NW * R) + c * R + (tid >> 3) + 32 * i] = s * scale;
+    }
 }
 
 struct AdamPtrs {
@@ -639,7 +681,7 @@ int panel_wgrad(hipStream_t st, const Work& k, int64_t P, int a_panel, int b_pan
   return wgrad_f16x3(w, st);
 }
 int rowsum_finish(hipStream_t st, const float* partial, int splits, int rows, float* dst, int acc) {
-  hipLaunchKernelGGL(rowsum_finish_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, partial, splits, rows, dst, acc);
+  hipLaunchKernelGGL(rowsum_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, partial, splits, rows, dst, acc);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
@@ -651,15 +693,15 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
   float* part = k.partial;
   float* rs = k.row_part;
   constexpr float kInv = 1.0f / 64.0f;
-  auto zp = [&](int panel, int relu) { return Operand{panel_of(k.zpan, P, panel), panel == 9 ? 128 * 32 : 256 * 32, 1, relu}; };
   auto dp = [&](int panel) { return Operand{panel_of(k.dpan, P, panel), panel == 9 ? 128 * 32 : 256 * 32, 1, 0}; };
   const Operand pe{k.x5, kX5, 0, 0};                      // [pe63 | 0] in columns 0..63
   const Operand de{k.gs + kSigmaCol, kGs, 0, 0};          // [. 0 0 0 de27 0]: 32 columns from 256
-  const Operand drgb{k.drgb, kRgbPad, 0, 0};
-  const Operand dsig{k.g1 + kSigmaCol, kGs, 0, 0};
   // rgb head: d_rgb_pre^T relu(zcc)
-  NSR_TRY(chain_wgrad(st, drgb, kRgbPad, zp(9, 1), kDirOut, P, part, sp, nullptr));
-  NSR_TRY(reduce_place(st, g[kRgbW], 128, 0, 3, 128, part, sp, kDirOut, 0, 0, acc, kInv));
+  const int64_t per = (P / 32 + sp - 1) / sp;
+  hipLaunchKernelGGL((panel_wsums_kernel<128, 3>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 9), P, k.drgb, kRgbPad, 0.0f,
+                     kInv, per, part);
+  NSR_CHECK_LAUNCH();
+  NSR_TRY(rowsum_finish(st, part, sp, 3 * 128, g[kRgbW], acc));
   NSR_TRY(colsum(st, k.drgb, kRgbPad, P, 0, 3, g[kRgbB], acc, part));
   // dir_encoding: dzc^T [g | de]
   NSR_TRY(panel_wgrad(st, k, P, 9, 8, 0, part, sp, rs));
@@ -671,8 +713,10 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
   NSR_TRY(panel_wgrad(st, k, P, 8, 7, 1, part, sp, rs));
   NSR_TRY(reduce_place(st, g[kFinalW], 256, 0, 256, 256, part, sp, kW, 0, 0, acc));
   NSR_TRY(rowsum_finish(st, rs, sp, kW, g[kFinalB], acc));
-  NSR_TRY(chain_wgrad(st, dsig, 32, zp(7, 1), kW, P, part, sp, nullptr));
-  NSR_TRY(reduce_place(st, g[kSigmaW], 256, 0, 1, 256, part, sp, kW, 0, 0, acc, kInv));
+  hipLaunchKernelGGL((panel_wsums_kernel<256, 1>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 7), P, k.g1 + kSigmaCol, kGs,
+                     0.0f, kInv, per, part);
+  NSR_CHECK_LAUNCH();
+  NSR_TRY(rowsum_finish(st, part, sp, 256, g[kSigmaW], acc));
   NSR_TRY(colsum(st, k.g1, kGs, P, 256, 1, g[kSigmaB], acc, part));
   // trunk layers 8..1: dz_L^T (input of layer L)
   for (int L = 8; L >= 1; --L) {

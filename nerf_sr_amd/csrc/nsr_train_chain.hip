@@ -269,13 +269,12 @@ struct BwdCtx {
   PanelRef zp;        // forward panels (masks)
   PanelRef dp;        // gradient panels
   unsigned voff;
-  unsigned* gmax;     // per gradient panel: float bits of the largest magnitude written (atomicMax over the launch)
+  unsigned* lmax;     // LDS, 16 words: per gradient panel, float bits of the largest magnitude this workgroup wrote
 };
-// largest true-scale magnitude a wave wrote to gradient panel `panel` (the weight-gradient GEMM scales by it)
+// largest true-scale magnitude written to gradient panel `panel` (the weight-gradient kernel scales by it): a no-return
+// LDS atomic per lane now, one global atomicMax per workgroup and panel at the end of the kernel
 __device__ __forceinline__ void publish_max(const BwdCtx& cx, int panel, float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(cx.gmax + panel, __float_as_uint(v));
+  atomicMax(cx.lmax + panel, __float_as_uint(v));
 }
 
 // One layer `lam` of the chain: operands (bh, bl) -> eight output blocks.
@@ -349,7 +348,9 @@ chain_bwd_kernel(const float* __restrict__ packed, const float* __restrict__ zpa
                  const float* __restrict__ d_rgb, int d_rgb_stride, const float* __restrict__ d_sigma, int d_sigma_stride,
                  int64_t P, unsigned* __restrict__ gmax) {
   constexpr int kAux0 = 3 * kSlotFloats;
-  __shared__ __attribute__((aligned(16))) float ring[kAux0 + kBwdAuxFloats];
+  __shared__ __attribute__((aligned(16))) float ring[kAux0 + kBwdAuxFloats + 16];
+  unsigned* lmax = reinterpret_cast<unsigned*>(ring + kAux0 + kBwdAuxFloats);
+  if (threadIdx.x < 16) lmax[threadIdx.x] = 0u;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 31, h = lane >> 5;
@@ -378,7 +379,7 @@ chain_bwd_kernel(const float* __restrict__ packed, const float* __restrict__ zpa
   cx.zp.n_groups = cx.dp.n_groups = (int64_t)gridDim.x * 4;
   cx.zp.group = cx.dp.group = (int64_t)blockIdx.x * 4 + wave;
   cx.voff = 4u * (unsigned)(m + 128 * h);
-  cx.gmax = gmax;
+  cx.lmax = lmax;
 
   // ---- prologue: the colour head's input gradient on the VALU (K = 3), masked by dir_encoding's ReLU
   const float g0 = d_rgb[pc * d_rgb_stride + 0], g1 = d_rgb[pc * d_rgb_stride + 1], g2 = d_rgb[pc * d_rgb_stride + 2];
@@ -497,6 +498,8 @@ chain_bwd_kernel(const float* __restrict__ packed, const float* __restrict__ zpa
     for (int r = 0; r < 16; ++r) panel_store(r, pend, blk, cx.voff);
   }
   dma_drain();   // no LDS-DMA may be in flight when the workgroup's LDS is released
+  __syncthreads();
+  if (threadIdx.x < 10) atomicMax(gmax + threadIdx.x, lmax[threadIdx.x]);
 }
 
 }  // namespace
