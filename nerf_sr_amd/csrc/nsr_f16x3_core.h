@@ -289,6 +289,7 @@ struct PanelRef {
   float* base;        // panel set
   int64_t n_groups;   // ceil(P / 128) * 4
   int64_t group;      // this wave's point group (wave-uniform)
+  unsigned* sgn;      // sign panels (see below)
 };
 // first float of output block `blk` of `panel` for this wave's points
 __device__ __forceinline__ float* panel_block(const PanelRef& t, int panel, int blk) {
@@ -307,4 +308,20 @@ __device__ __forceinline__ void panel_store(int r, const Acc& p, const float* bl
 #undef NSR_PS
     default: break;
   }
+}
+
+// Sign panels: one bit per pre-activation ([z < 0], i.e. "the ReLU zeroes it"; +0.0 counts as active), the only thing the
+// backward chain needs from the forward pass.  Per point group 76 blocks (8 per 256-row panel, 4 for panel 9) of 64 dwords:
+// lane (m, h) keeps the 16 bits of its 16 accumulator registers of a block, register r in bit 15 - r.
+constexpr int kSignBlocks = 76;
+__device__ __host__ __forceinline__ int64_t sign_panel_words(int64_t n_groups) { return n_groups * kSignBlocks * 64; }
+__device__ __forceinline__ unsigned* sign_block(unsigned* base, int64_t group, int panel, int blk) {
+  return base + (group * kSignBlocks + 8 * panel + blk) * 64;
+}
+// bits = (bits << 1) | sign(v)
+__device__ __forceinline__ void sign_push(unsigned& bits, float v) {
+  asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(bits) : "v"(v));
+}
+__device__ __forceinline__ void sign_store(unsigned bits, const unsigned* blk, unsigned lane4) {
+  asm volatile("global_store_dword %0, %1, %2" : : "v"(lane4), "v"(bits), "s"(blk) : "memory");
 }

@@ -288,6 +288,7 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
     Acc cur;
     cur.m = pre.bias;
     Resplit ptmp;
+    unsigned sbits = 0u;
     unsigned a_addr = ld.slot_cur + ld.lane_off;
     const unsigned next_bias = (unsigned)(c1.pieces - 1) * 1024u;
     Pre nxt;
@@ -321,6 +322,11 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
             const float* blk = (nb == 0) ? panel_block(tr, L - 1, 7) : panel_block(tr, L, nb - 1);
             panel_store(2 * (s - 8), pend, blk, voff);
             panel_store(2 * (s - 8) + 1, pend, blk, voff);
+            sign_push(sbits, pend.m[2 * (s - 8)]);
+            sign_push(sbits, pend.m[2 * (s - 8) + 1]);
+            if (s == 15)
+              sign_store(sbits, (nb == 0) ? sign_block(tr.sgn, tr.group, L - 1, 7) : sign_block(tr.sgn, tr.group, L, nb - 1),
+                         ld.lane_off >> 2);
           }
         },
         [&](int k) { prefetch_next_chunk(nxt, k, ld, next_bias, h); });
@@ -337,7 +343,8 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
 template <int MODE, bool SIGMA_ONLY, int NS, bool COMP = false, bool TRAIN = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ zv,
-                 int64_t P, int N, int stride, float* __restrict__ out, NsrCompOut co = NsrCompOut{}, float* pan = nullptr) {
+                 int64_t P, int N, int stride, float* __restrict__ out, NsrCompOut co = NsrCompOut{}, float* pan = nullptr,
+                 unsigned* sgn = nullptr) {
   // 3 x 41 KiB weight ring + per-wave stash of the encoded position (8 fragments x 64 lanes x 16 B = 8 KiB
   // per wave) + the colour-head block (rgb weights and bias, 448 floats): 160,512 B of the CU's 160 KiB
   constexpr int kStash0 = 3 * kSlotFloats, kAux0 = kStash0 + 4 * 8 * 256;
@@ -370,6 +377,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     tr.base = pan;
     tr.n_groups = (int64_t)gridDim.x * 4;
     tr.group = (int64_t)blockIdx.x * 4 + wave;
+    tr.sgn = sgn;
   }
   const unsigned voff = 4u * (unsigned)(m + 128 * h);   // panel stores: point m of the group, lane half h = 4 rows on
 
@@ -468,6 +476,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
       Acc cur;
       cur.m = mine.bias;
       Resplit ptmp;
+      unsigned sbits = 0u;
       block_mma<4, -1>(
           cur, mine, a_addr, ld, end_ref(wave), [&](int s, int part) -> u32x4 { return part ? pel[s] : peh[s]; },
           [&](int s) {
@@ -483,6 +492,9 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
                 const float* blk = panel_block(tr, 0, nb - 1);
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) panel_store(4 * s + q4, pend, blk, voff);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) sign_push(sbits, pend.m[4 * s + q4]);
+                if (s == 3) sign_store(sbits, sign_block(tr.sgn, tr.group, 0, nb - 1), ld.lane_off >> 2);
               }
             }
           },
@@ -534,6 +546,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
             const float* blk = panel_block(tr, 8, 7);
             panel_store(2 * (s - 8), pend, blk, voff);
             panel_store(2 * (s - 8) + 1, pend, blk, voff);
+            // (no sign bits: nothing is masked by xyz_encoding_final's output)
           }
         },
         [&](int k) {
@@ -555,6 +568,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   for (int nb = 0; nb < 4; ++nb) {
     Acc cur;
     cur.m = pre.bias;
+    unsigned sbits = 0u;
     const unsigned next_bias = 36u * 1024u;
     Pre nxt;
     block_mma<18, kBar>(
@@ -568,6 +582,9 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
             const float* blk = panel_block(tr, 9, nb - 1);
             panel_store(2 * (s - 8), pend, blk, voff);
             panel_store(2 * (s - 8) + 1, pend, blk, voff);
+            sign_push(sbits, pend.m[2 * (s - 8)]);
+            sign_push(sbits, pend.m[2 * (s - 8) + 1]);
+            if (s == 15) sign_store(sbits, sign_block(tr.sgn, tr.group, 9, nb - 1), ld.lane_off >> 2);
           }
         },
         [&](int k) {
@@ -581,8 +598,13 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   for (int s = 0; s < 8; ++s) rgb_step<0>(s, pend, aux + hx::kAuxRgbW + 32 * 3, h, rgb);
   if (TRAIN) {
     const float* blk = panel_block(tr, 9, 3);
+    unsigned sbits = 0u;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) panel_store(r, pend, blk, voff);
+    for (int r = 0; r < 16; ++r) {
+      panel_store(r, pend, blk, voff);
+      sign_push(sbits, pend.m[r]);
+    }
+    sign_store(sbits, sign_block(tr.sgn, tr.group, 9, 3), ld.lane_off >> 2);
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -640,12 +662,13 @@ extern "C" NSR_INTERNAL int64_t nsr_f16x3_train_panel_floats(int64_t P) {
   const int64_t n_groups = ((P + 127) / 128) * 4;
   return panel_offset(n_groups, 9) + n_groups * 128 * 32;
 }
+extern "C" NSR_INTERNAL int64_t nsr_f16x3_train_sign_words(int64_t P) { return sign_panel_words(((P + 127) / 128) * 4); }
 extern "C" NSR_INTERNAL int nsr_f16x3_train_forward(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
-                                                    int N, float* raw, float* pan, void* stream) {
+                                                    int N, float* raw, float* pan, unsigned* sgn, void* stream) {
   const int64_t P = R * N;
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   hipLaunchKernelGGL((mlp_f16x3_kernel<1, false, 0, false, true>), grid, block, 0, nsr_stream(stream),
-                     static_cast<const float*>(packed), rays, z, P, N, ray_stride, raw, NsrCompOut{}, pan);
+                     static_cast<const float*>(packed), rays, z, P, N, ray_stride, raw, NsrCompOut{}, pan, sgn);
   if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
   return NSR_OK;
 }

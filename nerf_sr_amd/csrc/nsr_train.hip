@@ -427,6 +427,7 @@ struct Work {   // per-pass buffers, sized for P_max = chunk * (Nc + Ni) sample 
   // (nsr_f16x3_core.h), the two weight streams per network, per-slice row sums of the weight-gradient GEMMs
   float *zpan, *dpan, *row_part;
   float *stream_f[2], *stream_b[2];
+  unsigned* sgn;    // sign panels of the forward pass (nsr_f16x3_core.h)
   unsigned* gmax;   // float bits of the largest magnitude in each gradient panel (written by the backward chain)
 };
 
@@ -464,6 +465,7 @@ int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base) {
   k.zpan = take(pan);   k.dpan = take(pan);
   k.row_part = take(kMaxSplits * 256);
   k.gmax = reinterpret_cast<unsigned*>(take(64));
+  k.sgn = reinterpret_cast<unsigned*>(take(nsr_f16x3_train_sign_words(P)));
   for (int n = 0; n < 2; ++n) {
     k.stream_f[n] = take((int64_t)(nsr_f16x3_packed_bytes() / 4));
     k.stream_b[n] = take((int64_t)(nsr_chain_bwd_packed_bytes() / 4));
@@ -836,7 +838,7 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
       hipLaunchKernelGGL(encode_train_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, rays_c, ray_stride, z,
                          P, N, k.x5, k.gs);
       NSR_CHECK_LAUNCH();
-      if (chain) NSR_TRY(nsr_f16x3_train_forward(k.stream_f[net], rays_c, ray_stride, z, rc, N, k.rgb, k.zpan, stream));
+      if (chain) NSR_TRY(nsr_f16x3_train_forward(k.stream_f[net], rays_c, ray_stride, z, rc, N, k.rgb, k.zpan, k.sgn, stream));
       else NSR_TRY(net_forward(st, w, k.pack[net], k, P, precision));
       const float* noise = net ? noise_fine : noise_coarse;
       hipLaunchKernelGGL(sigma_noise_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st,
@@ -859,7 +861,7 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
       NSR_CHECK_LAUNCH();
       NSR_TRY(composite_bwd(st, k, z, rc, N, white_bkgd));
       if (chain) {
-        NSR_TRY(nsr_chain_bwd(k.stream_b[net], k.zpan, k.dpan, k.drgb, kRgbPad, k.g1 + kSigmaCol, kGs, P, k.gmax, stream));
+        NSR_TRY(nsr_chain_bwd(k.stream_b[net], k.sgn, k.dpan, k.drgb, kRgbPad, k.g1 + kSigmaCol, kGs, P, k.gmax, stream));
         NSR_TRY(chain_weight_grads(st, k, P, g, acc));
       } else {
         NSR_TRY(net_backward(st, w, k.pack[net], k, P, g, acc));

@@ -6,13 +6,15 @@
 extern "C" NSR_INTERNAL int64_t nsr_f16x3_train_panel_floats(int64_t P);
 // forward pass: raw (R N, 4) = (rgb, sigma) + the pre-activation panels; `packed` = nsr_f16x3_pack of the weights
 extern "C" NSR_INTERNAL int nsr_f16x3_train_forward(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
-                                                    int N, float* raw, float* pan, void* stream);
+                                                    int N, float* raw, float* pan, unsigned* sgn, void* stream);
+// dwords of the sign panels (one bit per pre-activation) for P sample points
+extern "C" NSR_INTERNAL int64_t nsr_f16x3_train_sign_words(int64_t P);
 extern "C" NSR_INTERNAL size_t nsr_f16x3_packed_bytes(void);
 extern "C" NSR_INTERNAL int nsr_f16x3_pack(const float* const* w, void* packed_dev, void* stream);
 // backward chain: transposed weight stream, then d(rgb_pre) (P, stride) / d(sigma) (P, stride) -> gradient panels;
 // gmax[10] (device): float bits of the largest magnitude written to each gradient panel (zeroed, then atomicMax)
 extern "C" NSR_INTERNAL size_t nsr_chain_bwd_packed_bytes(void);
 extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* packed_dev, void* stream);
-extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const float* zpan, float* dpan, const float* d_rgb, int d_rgb_stride,
+extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const unsigned* sgn, float* dpan, const float* d_rgb, int d_rgb_stride,
                                           const float* d_sigma, int d_sigma_stride, int64_t P, unsigned* gmax,
                                           void* stream);

@@ -147,20 +147,22 @@ __device__ __forceinline__ void stage_factors(Scale& cur, const Scale& prev) {
 struct BwdTmp {
   unsigned hi[2];
 };
+// mask: the block's sign word (register r in bit 15 - r, set = the ReLU zeroed it): v_bfe_i32 spreads the bit over a
+// register, v_bfi_b32 keeps the accumulator where it is clear
 template <int P, bool MASK, bool CONV>
-__device__ __forceinline__ void bsplit_a(Acc& p, const float (&mz)[16], Scale& sc, BwdTmp& t) {
+__device__ __forceinline__ void bsplit_a(Acc& p, unsigned mz, Scale& sc, BwdTmp& t) {
   unsigned& hi = t.hi[P & 1];
+  unsigned t0, t1;
   if (MASK && CONV)
     asm volatile(
-        "v_cmp_lt_f32 vcc, 0, %4\n\t"
-        "v_cndmask_b32 %0, 0, %0, vcc\n\t"
-        "v_cmp_lt_f32 vcc, 0, %5\n\t"
-        "v_cndmask_b32 %1, 0, %1, vcc\n\t"
+        "v_bfe_i32 %4, %6, %7, 1\n\t"
+        "v_bfe_i32 %5, %6, %8, 1\n\t"
+        "v_bfi_b32 %0, %4, 0, %0\n\t"
+        "v_bfi_b32 %1, %5, 0, %1\n\t"
         "v_cvt_pk_f16_f32 %2, %0, %1\n\t"
         "v_max3_f32 %3, |%0|, |%1|, %3"
-        : "+v"(p.m[2 * P]), "+v"(p.m[2 * P + 1]), "=&v"(hi), "+v"(sc.mx)
-        : "v"(mz[2 * P]), "v"(mz[2 * P + 1])
-        : "vcc");
+        : "+v"(p.m[2 * P]), "+v"(p.m[2 * P + 1]), "=&v"(hi), "+v"(sc.mx), "=&v"(t0), "=&v"(t1)
+        : "v"(mz), "n"(15 - 2 * P), "n"(14 - 2 * P));
   else if (CONV)
     asm volatile(
         "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
@@ -169,16 +171,15 @@ __device__ __forceinline__ void bsplit_a(Acc& p, const float (&mz)[16], Scale& s
         : "v"(p.m[2 * P]), "v"(p.m[2 * P + 1]));
   else   // last layer: mask and scale only
     asm volatile(
-        "v_cmp_lt_f32 vcc, 0, %3\n\t"
-        "v_cndmask_b32 %0, 0, %0, vcc\n\t"
-        "v_cmp_lt_f32 vcc, 0, %4\n\t"
-        "v_cndmask_b32 %1, 0, %1, vcc\n\t"
+        "v_bfe_i32 %3, %5, %7, 1\n\t"
+        "v_bfe_i32 %4, %5, %8, 1\n\t"
+        "v_bfi_b32 %0, %3, 0, %0\n\t"
+        "v_bfi_b32 %1, %4, 0, %1\n\t"
         "v_max3_f32 %2, |%0|, |%1|, %2\n\t"
-        "v_mul_f32 %0, %0, %5\n\t"
-        "v_mul_f32 %1, %1, %5"
-        : "+v"(p.m[2 * P]), "+v"(p.m[2 * P + 1]), "+v"(sc.mx)
-        : "v"(mz[2 * P]), "v"(mz[2 * P + 1]), "v"(sc.cinv)
-        : "vcc");
+        "v_mul_f32 %0, %0, %6\n\t"
+        "v_mul_f32 %1, %1, %6"
+        : "+v"(p.m[2 * P]), "+v"(p.m[2 * P + 1]), "+v"(sc.mx), "=&v"(t0), "=&v"(t1)
+        : "v"(mz), "v"(sc.cinv), "n"(15 - 2 * P), "n"(14 - 2 * P));
 }
 template <int P>
 __device__ __forceinline__ void bput(unsigned v, u32x4& d0, u32x4& d1) {
@@ -215,7 +216,7 @@ __device__ __forceinline__ void bsplit_b(Acc& p, const Scale& sc, BwdTmp& t, u32
   if (P > 0) bput<Q>(lo, l0, l1);
 }
 template <bool MASK, bool CONV>
-__device__ __forceinline__ void bwd_half(int hs, Acc& p, const float (&mz)[16], Scale& sc, BwdTmp& t, u32x4& h0, u32x4& l0,
+__device__ __forceinline__ void bwd_half(int hs, Acc& p, unsigned mz, Scale& sc, BwdTmp& t, u32x4& h0, u32x4& l0,
                                          u32x4& h1, u32x4& l1) {
   switch (hs) {
 #define NSR_HS(P)                                                         \
@@ -229,7 +230,7 @@ __device__ __forceinline__ void bwd_half(int hs, Acc& p, const float (&mz)[16], 
 }
 // the forward kernel's schedule: 17 half-steps in k-steps 0..13 (k-steps 0, 1, 2 take two)
 template <bool MASK, bool CONV>
-__device__ __forceinline__ void bwd_step(int s, Acc& p, const float (&mz)[16], Scale& sc, BwdTmp& t, u32x4& h0, u32x4& l0,
+__device__ __forceinline__ void bwd_step(int s, Acc& p, unsigned mz, Scale& sc, BwdTmp& t, u32x4& h0, u32x4& l0,
                                          u32x4& h1, u32x4& l1) {
   if (s < 3) {
     bwd_half<MASK, CONV>(2 * s, p, mz, sc, t, h0, l0, h1, l1);
@@ -251,24 +252,19 @@ __device__ __forceinline__ void bwd_store_step(int s, const Acc& p, const float*
   }
 }
 
-// Mask loads: the 16 pre-activations this lane needs to mask block X are fetched during block X - 1, k-steps 14 and 15
-// -- a whole block before their first use (the re-split of X runs in the shadow of block X + 1) and as the YOUNGEST
-// vector-memory operations of their block, behind its DMA and stores.  Plain loads: the compiler's own vmcnt bookkeeping
-// guards their use; the asm DMA / stores it cannot see only make its waits stricter, and by then they are a block old.
-__device__ __forceinline__ void mask_load_step(int s, float (&mz)[16], const float* blk, unsigned voff) {
-  if (s >= 14) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = 8 * (s - 14) + i;
-      mz[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(blk) + voff + (8 * (r >> 2) + (r & 3)) * 128);
-    }
-  }
+// Mask load: the sign word this lane needs to mask block X is fetched during block X - 1, k-step 14 -- a whole block
+// before its first use (the re-split of X runs in the shadow of block X + 1) and as the YOUNGEST vector-memory operation
+// of its block, behind its DMA and stores.  A plain load: the compiler's own vmcnt bookkeeping guards its use; the asm
+// DMA / stores it cannot see only make its waits stricter, and by then they are a block old.
+__device__ __forceinline__ void mask_load_step(int s, unsigned& mz, const unsigned* blk, int lane) {
+  if (s == 14) mz = blk[lane];
 }
 
 struct BwdCtx {
-  PanelRef zp;        // forward panels (masks)
-  PanelRef dp;        // gradient panels
+  const unsigned* sgn;   // sign panels of the forward pass (masks)
+  PanelRef dp;           // gradient panels
   unsigned voff;
+  int lane;
   unsigned* lmax;     // LDS, 16 words: per gradient panel, float bits of the largest magnitude this workgroup wrote
 };
 // largest true-scale magnitude written to gradient panel `panel` (the weight-gradient kernel scales by it): a no-return
@@ -286,7 +282,7 @@ __device__ __forceinline__ void publish_max(const BwdCtx& cx, int panel, float v
 template <bool PREV_MASK, bool MASK, bool PREPEND, bool LAST, bool NEXT_MASK>
 __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, int next_panel, u32x4 (&bh)[16], u32x4 (&bl)[16], u32x4 (&oh)[16],
                                           u32x4 (&ol)[16], const u32x4& sig_h, const u32x4& sig_l, Loader& ld, Acc& pend,
-                                          Pre& pre, float (&mz)[2][16], Scale& prev, const BwdCtx& cx) {
+                                          Pre& pre, unsigned (&mz)[2], Scale& prev, const BwdCtx& cx) {
   Scale cur{};
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) {
@@ -317,12 +313,15 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
     }
     // masks of the block AFTER this one (loaded here), of the PENDING block (loaded two blocks ago, same buffer parity)
     const bool load_next = (nb < 7) ? MASK : NEXT_MASK;
-    const float* next_blk = !load_next ? nullptr : (nb < 7 ? panel_block(cx.zp, panel, nb + 1) : panel_block(cx.zp, next_panel, 0));
-    float (&mz_pend)[16] = mz[(nb + 1) & 1];
-    float (&mz_next)[16] = mz[(nb + 1) & 1];   // block nb + 1; free again once the pending block (nb - 1) is done (k-step 13)
-    // younger than the DMA this chunk's publish point waits for: the 16 mask loads the block before issued for THIS
-    // block in its k-steps 14, 15 -- behind the last DMA piece (k-step 13) -- if this layer is masked at all
-    block_mma<16, kBar, (MASK ? 16 : 0)>(
+    const unsigned* next_blk =
+        !load_next ? nullptr
+                   : (nb < 7 ? sign_block(const_cast<unsigned*>(cx.sgn), cx.dp.group, panel, nb + 1)
+                             : sign_block(const_cast<unsigned*>(cx.sgn), cx.dp.group, next_panel, 0));
+    const unsigned mz_pend = mz[(nb + 1) & 1];
+    unsigned& mz_next = mz[(nb + 1) & 1];   // block nb + 1; free again once the pending block (nb - 1) is done (k-step 13)
+    // younger than the DMA this chunk's publish point waits for: the mask load the block before issued for THIS block
+    // in its k-step 14 -- behind the last DMA piece (k-step 13) -- if this layer is masked at all
+    block_mma<16, kBar, (MASK ? 1 : 0)>(
         acc, pre, a_addr, ld, c2, [&](int s, int part) -> u32x4 { return part ? bl[s] : bh[s]; },
         [&](int s) {
           if (nb == 0) {
@@ -333,7 +332,7 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
             bwd_step<MASK, !LAST>(s, pend, mz_pend, cur, tmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1]);
             bwd_store_step(s, pend, panel_block(cx.dp, panel, nb - 1), cx.voff);
           }
-          if (load_next) mask_load_step(s, mz_next, next_blk, cx.voff);
+          if (load_next) mask_load_step(s, mz_next, next_blk, cx.lane);
         },
         [&](int k) { prefetch_frag(nxt, k, ld.slot_next + ld.lane_off); });
     pend = acc;
@@ -344,7 +343,7 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
 }
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-chain_bwd_kernel(const float* __restrict__ packed, const float* __restrict__ zpan, float* __restrict__ dpan,
+chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ sgn, float* __restrict__ dpan,
                  const float* __restrict__ d_rgb, int d_rgb_stride, const float* __restrict__ d_sigma, int d_sigma_stride,
                  int64_t P, unsigned* __restrict__ gmax) {
   constexpr int kAux0 = 3 * kSlotFloats;
@@ -374,23 +373,21 @@ chain_bwd_kernel(const float* __restrict__ packed, const float* __restrict__ zpa
   const int64_t p = (int64_t)blockIdx.x * 128 + wave * 32 + m;
   const int64_t pc = p < P ? p : P - 1;
   BwdCtx cx;
-  cx.zp.base = const_cast<float*>(zpan);
+  cx.sgn = sgn;
   cx.dp.base = dpan;
-  cx.zp.n_groups = cx.dp.n_groups = (int64_t)gridDim.x * 4;
-  cx.zp.group = cx.dp.group = (int64_t)blockIdx.x * 4 + wave;
+  cx.dp.n_groups = (int64_t)gridDim.x * 4;
+  cx.dp.group = (int64_t)blockIdx.x * 4 + wave;
+  cx.dp.sgn = nullptr;
   cx.voff = 4u * (unsigned)(m + 128 * h);
+  cx.lane = lane;
   cx.lmax = lmax;
 
   // ---- prologue: the colour head's input gradient on the VALU (K = 3), masked by dir_encoding's ReLU
   const float g0 = d_rgb[pc * d_rgb_stride + 0], g1 = d_rgb[pc * d_rgb_stride + 1], g2 = d_rgb[pc * d_rgb_stride + 2];
   const float gs = d_sigma[pc * d_sigma_stride];
-  float zc[64];
+  unsigned zc[4];   // sign words of dir_encoding's four output blocks
 #pragma unroll
-  for (int t = 0; t < 64; ++t) {
-    const float* blk = panel_block(cx.zp, 9, t >> 4);
-    const int r = t & 15;
-    zc[t] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(blk) + cx.voff + (8 * (r >> 2) + (r & 3)) * 128);
-  }
+  for (int b = 0; b < 4; ++b) zc[b] = sign_block(const_cast<unsigned*>(sgn), cx.dp.group, 9, b)[lane];
   __syncthreads();   // aux visible
   float dz[64];
   float mxin = fabsf(gs);
@@ -399,7 +396,7 @@ chain_bwd_kernel(const float* __restrict__ packed, const float* __restrict__ zpa
     const int feat = act_feature(t, h);
     const f32x4 w4 = *reinterpret_cast<const f32x4*>(ring + kAux0 + 4 * feat);
     float v = __fmaf_rn(w4[2], g2, __fmaf_rn(w4[1], g1, __fmul_rn(w4[0], g0)));
-    v = zc[t] > 0.0f ? v : 0.0f;
+    v = ((zc[t >> 4] >> (15 - (t & 15))) & 1u) ? 0.0f : v;
     dz[t] = v;
     mxin = fmaxf(mxin, fabsf(v));
   }
@@ -463,9 +460,7 @@ chain_bwd_kernel(const float* __restrict__ packed, const float* __restrict__ zpa
   Acc pend;
 #pragma unroll
   for (int r = 0; r < 16; ++r) pend.m[r] = 0.0f;
-  float mz[2][16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) mz[0][r] = mz[1][r] = 0.0f;
+  unsigned mz[2] = {0u, 0u};
 
   // layer 0: dg (no mask) -> gradient panel 8.  Its block-0 hook sees a dummy pending block (zeros, converted into the
   // zero padding of its own input, stored nowhere)
@@ -519,13 +514,13 @@ extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* pack
   return NSR_OK;
 }
 
-extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const float* zpan, float* dpan, const float* d_rgb, int d_rgb_stride,
+extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const unsigned* sgn, float* dpan, const float* d_rgb, int d_rgb_stride,
                                           const float* d_sigma, int d_sigma_stride, int64_t P, unsigned* gmax,
                                           void* stream) {
   if (P <= 0) return NSR_OK;
   if (hipMemsetAsync(gmax, 0, 10 * sizeof(unsigned), nsr_stream(stream)) != hipSuccess) return NSR_ERR_LAUNCH;
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
-  hipLaunchKernelGGL(chain_bwd_kernel, grid, block, 0, nsr_stream(stream), static_cast<const float*>(packed), zpan, dpan, d_rgb,
+  hipLaunchKernelGGL(chain_bwd_kernel, grid, block, 0, nsr_stream(stream), static_cast<const float*>(packed), sgn, dpan, d_rgb,
                      d_rgb_stride, d_sigma, d_sigma_stride, P, gmax);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
