@@ -164,10 +164,13 @@ __device__ __forceinline__ void loader_advance(Loader& ld) {
 }
 
 // the publish point of chunk j+1 (see protocol above), then start fetching chunk j+2
+// YOUNGER: vector-memory operations known to have been issued AFTER the last DMA piece this publish point waits for
+// (they may stay in flight); strict: ... unless this call site cannot vouch for them (runtime, wave-uniform)
 template <int YOUNGER = 0>
-__device__ __forceinline__ void loader_publish(Loader& ld, const ChunkRef& c2) {
+__device__ __forceinline__ void loader_publish(Loader& ld, const ChunkRef& c2, bool strict = false) {
 #ifndef NSR_ABL_NO_DRAIN
-  dma_drain_but<YOUNGER>();
+  if (YOUNGER > 0 && strict) dma_drain();
+  else dma_drain_but<YOUNGER>();
 #endif
 #ifndef NSR_ABL_NO_BARRIER
   __syncthreads();
@@ -226,7 +229,7 @@ __device__ __forceinline__ void prefetch_bias(Pre& pre, unsigned bias_addr, int 
 // next(k), k = 0..2, runs in the last three k-steps and prefetches the following sequence into `nxt`.
 template <int NSTEP, int BAR, int YOUNGER = 0, class BOf, class Hook, class Next>
 __device__ __forceinline__ void block_mma(Acc& acc, const Pre& pre, unsigned a_addr, Loader& ld, const ChunkRef& c2,
-                                          BOf&& b_of, Hook&& hook, Next&& next) {
+                                          BOf&& b_of, Hook&& hook, Next&& next, bool strict = false) {
   static_assert(NSTEP >= kPF, "sequence shorter than the prefetch depth");
   const u32x4* a_pieces = lds_vec(a_addr);
   u32x4 ah[NSTEP], al[NSTEP];
@@ -237,7 +240,7 @@ __device__ __forceinline__ void block_mma(Acc& acc, const Pre& pre, unsigned a_a
   }
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
-    if (s == BAR) loader_publish<YOUNGER>(ld, c2);
+    if (s == BAR) loader_publish<YOUNGER>(ld, c2, strict);
     if (s + kPF < NSTEP) {
       ah[s + kPF] = a_pieces[(2 * (s + kPF)) * 64];
       al[s + kPF] = a_pieces[(2 * (s + kPF) + 1) * 64];

@@ -20,6 +20,7 @@
 // matrix pipe; two register sets alternate roles layer by layer.
 #include "nsr_f16x3_core.h"
 #include "nsr_composite.h"
+#include <type_traits>
 #include <utility>
 
 // ---------------------------------------------------------------------------
@@ -268,8 +269,11 @@ __device__ __forceinline__ void prefetch_next_chunk(Pre& nxt, int k, const Loade
 // activated and re-split in the MFMA shadow of the FOLLOWING block's k-steps 0..13.  `pre` carries the
 // prefetched head of the next chunk across chunk (and layer) boundaries.
 // TRAIN: the pending block's raw accumulators (64 x the pre-activation) are also written to the training panels
-// (panel L - 1 holds trunk layer L's output, see nsr_f16x3_core.h): two dword stores per k-step in k-steps 8..15, i.e.
-// AFTER the chunk's publish point, so that the vmcnt(0) of the next publish finds them a whole chunk old.
+// (panel L - 1 holds trunk layer L's output, see nsr_f16x3_core.h): 16 dword stores in k-steps 14 and 15 (+ the block's
+// sign word), i.e. BEHIND the chunk's last DMA piece (k-step 13).  Vector-memory operations complete in issue order, so
+// the next publish point -- which must see that DMA landed -- may leave those 17 stores in flight (block_mma's YOUNGER);
+// they have a whole further chunk to reach HBM.  (Spread over k-steps 8..15 and covered by the publish point's
+// vmcnt(0), they stalled the wave on write latency every chunk.)
 template <bool RELU_OUT, bool TRAIN = false>   // relu on L2..L8 (true), none on xyz_encoding_final (L == 8: false)
 __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[16], u32x4 (&oh)[16], u32x4 (&ol)[16],
                                             const u32x4* stash, Loader& ld, int h, Acc& pend, Pre& pre,
@@ -309,7 +313,7 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
       }
       a_addr += 8 * 1024;
     }
-    block_mma<16, kBar>(
+    block_mma<16, kBar, (TRAIN ? 17 : 0)>(
         cur, pre, a_addr, ld, c2, [&](int s, int part) -> u32x4 { return part ? bl[s] : bh[s]; },
         [&](int s) {
           if (nb == 0)
@@ -320,8 +324,10 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
             pending_step<RELU_OUT>(s, pend, ptmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1]);
           if (TRAIN && s >= 8) {
             const float* blk = (nb == 0) ? panel_block(tr, L - 1, 7) : panel_block(tr, L, nb - 1);
-            panel_store(2 * (s - 8), pend, blk, voff);
-            panel_store(2 * (s - 8) + 1, pend, blk, voff);
+            if (s >= 14) {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) panel_store(8 * (s - 14) + r, pend, blk, voff);
+            }
             sign_push(sbits, pend.m[2 * (s - 8)]);
             sign_push(sbits, pend.m[2 * (s - 8) + 1]);
             if (s == 15)
@@ -329,7 +335,9 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
                          ld.lane_off >> 2);
           }
         },
-        [&](int k) { prefetch_next_chunk(nxt, k, ld, next_bias, h); });
+        [&](int k) { prefetch_next_chunk(nxt, k, ld, next_bias, h); },
+        // the block before the first trunk block is L1's last one, whose stores interleave with its DMA
+        TRAIN && L == 1 && nb == 0);
     pend = cur;
     pre = nxt;
     loader_advance(ld);
@@ -534,7 +542,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     Resplit ptmp;
     const unsigned next_bias = 36u * 1024u;       // dir_encoding chunks: 36 weight pieces, then the bias
     Pre nxt;
-    block_mma<16, kBar>(
+    block_mma<16, kBar, (TRAIN ? 17 : 0)>(
         cur, pre, ld.slot_cur + ld.lane_off, ld, SIGMA_ONLY ? end_ref(wave) : dir_ref(1, wave),
         [&](int s, int part) -> u32x4 { return part ? ol[s] : oh[s]; },
         [&](int s) {
@@ -542,11 +550,10 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
             pending_step<true>(s, pend, ptmp, oh[14], ol[14], oh[15], ol[15]);
           else
             pending_step<false>(s, pend, ptmp, bh[14], bl[14], bh[15], bl[15]);
-          if (TRAIN && s >= 8) {   // xyz_encoding_final's last block
+          if (TRAIN && s >= 14) {   // xyz_encoding_final's last block (no sign bits: nothing is masked by it)
             const float* blk = panel_block(tr, 8, 7);
-            panel_store(2 * (s - 8), pend, blk, voff);
-            panel_store(2 * (s - 8) + 1, pend, blk, voff);
-            // (no sign bits: nothing is masked by xyz_encoding_final's output)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) panel_store(8 * (s - 14) + r, pend, blk, voff);
           }
         },
         [&](int k) {
@@ -571,25 +578,31 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     unsigned sbits = 0u;
     const unsigned next_bias = 36u * 1024u;
     Pre nxt;
-    block_mma<18, kBar>(
-        cur, pre, ld.slot_cur + ld.lane_off, ld, nb < 2 ? dir_ref(nb + 2, wave) : end_ref(wave),
-        [&](int s, int part) -> u32x4 {
-          return (s < 16) ? (part ? bl[s & 15] : bh[s & 15]) : (part ? del[s & 1] : deh[s & 1]);
-        },
-        [&](int s) {
-          if (nb > 0) rgb_step<kConvStep0>(s, pend, aux + hx::kAuxRgbW + 32 * (nb - 1), h, rgb);
-          if (TRAIN && nb > 0 && s >= 8 && s < 16) {
-            const float* blk = panel_block(tr, 9, nb - 1);
-            panel_store(2 * (s - 8), pend, blk, voff);
-            panel_store(2 * (s - 8) + 1, pend, blk, voff);
-            sign_push(sbits, pend.m[2 * (s - 8)]);
-            sign_push(sbits, pend.m[2 * (s - 8) + 1]);
-            if (s == 15) sign_store(sbits, sign_block(tr.sgn, tr.group, 9, nb - 1), ld.lane_off >> 2);
-          }
-        },
-        [&](int k) {
-          if (nb < 3) prefetch_next_chunk(nxt, k, ld, next_bias, h);
-        });
+    // in flight behind the previous block's DMA: the density block's 16 stores | nothing | a dir block's 16 + sign word
+    const unsigned a_seq = ld.slot_cur + ld.lane_off;
+    const ChunkRef c2 = nb < 2 ? dir_ref(nb + 2, wave) : end_ref(wave);
+    auto b_of = [&](int s, int part) -> u32x4 {
+      return (s < 16) ? (part ? bl[s & 15] : bh[s & 15]) : (part ? del[s & 1] : deh[s & 1]);
+    };
+    auto hook = [&](int s) {
+      if (nb > 0) rgb_step<kConvStep0>(s, pend, aux + hx::kAuxRgbW + 32 * (nb - 1), h, rgb);
+      if (TRAIN && nb > 0 && s >= 8 && s < 16) {
+        const float* blk = panel_block(tr, 9, nb - 1);
+        if (s >= 14) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) panel_store(8 * (s - 14) + r, pend, blk, voff);
+        }
+        sign_push(sbits, pend.m[2 * (s - 8)]);
+        sign_push(sbits, pend.m[2 * (s - 8) + 1]);
+        if (s == 15) sign_store(sbits, sign_block(tr.sgn, tr.group, 9, nb - 1), ld.lane_off >> 2);
+      }
+    };
+    auto next = [&](int k) {
+      if (nb < 3) prefetch_next_chunk(nxt, k, ld, next_bias, h);
+    };
+    if (!TRAIN || nb == 1) block_mma<18, kBar>(cur, pre, a_seq, ld, c2, b_of, hook, next);
+    else if (nb == 0) block_mma<18, kBar, 16>(cur, pre, a_seq, ld, c2, b_of, hook, next);
+    else block_mma<18, kBar, 17>(cur, pre, a_seq, ld, c2, b_of, hook, next);
     pend = cur;
     pre = nxt;
     loader_advance(ld);

@@ -24,6 +24,7 @@
 // the stored gradients are multiplied back to true scale in fp32, so the scaling itself is exact.
 #include "nsr_f16x3_core.h"
 #include "nsr_train_chain.h"
+#include <type_traits>
 
 namespace {
 
@@ -239,16 +240,22 @@ __device__ __forceinline__ void bwd_step(int s, Acc& p, unsigned mz, Scale& sc, 
     bwd_half<MASK, CONV>(s + 3, p, mz, sc, t, h0, l0, h1, l1);
   }
 }
-// Stores of the pending block in k-steps 8..13, i.e. after the chunk's publish point and before the mask loads.  Pair P
-// is final (true scale) after half-step 2P + 3 = k-steps 1, 2, 4, 6, 8, 10, 12, 13 for P = 0..7 (non-CONV: after half-step
-// 2P), and a k-step's store follows its half-step inside the same hook.
+// Stores of the pending block: all 16 in k-steps 14 and 15 (the block is final, true scale, after half-step 16 =
+// k-step 13), i.e. BEHIND the chunk's last DMA piece (k-step 13).  Vector-memory operations complete in issue order, so
+// the next publish point -- which must see that DMA landed -- can leave these stores in flight (block_mma's YOUNGER
+// count); they only have to be done one block later.  (With the stores spread over k-steps 8..13 the publish point's
+// wait covered them too and the wave stalled on HBM write latency every block.)
+// These are PLAIN (compiler-visible, non-temporal) stores, unlike the forward kernel's asm ones: the kernel also has
+// compiler-visible loads (the mask words), and the compiler's vmcnt for a load only counts the younger operations it
+// can see -- with invisible stores behind the load its wait would cover them as well.
+__device__ __forceinline__ void bwd_panel_store(int r, const Acc& p, const float* blk, unsigned voff) {
+  float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(const_cast<float*>(blk)) + voff + (8 * (r >> 2) + (r & 3)) * 128);
+  __builtin_nontemporal_store(p.m[r], dst);
+}
 __device__ __forceinline__ void bwd_store_step(int s, const Acc& p, const float* blk, unsigned voff) {
-  if (s == 8 || s == 9) {          // pairs 0, 1 | 2, 3
+  if (s >= 14) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) panel_store(4 * (s - 8) + r, p, blk, voff);
-  } else if (s >= 10 && s <= 13) { // pairs 4..7
-    panel_store(2 * (s - 6), p, blk, voff);
-    panel_store(2 * (s - 6) + 1, p, blk, voff);
+    for (int r = 0; r < 8; ++r) bwd_panel_store(8 * (s - 14) + r, p, blk, voff);
   }
 }
 
@@ -279,7 +286,8 @@ __device__ __forceinline__ void publish_max(const BwdCtx& cx, int panel, float v
 //   PREPEND: 4 extra k-steps ahead of the 16 (sigma operand in slot 0)
 //   LAST: outputs are not converted (nothing consumes them in this kernel)
 //   NEXT_MASK / next_panel: the layer after this one, whose first block's masks are fetched during this layer's last block
-template <bool PREV_MASK, bool MASK, bool PREPEND, bool LAST, bool NEXT_MASK>
+//   FIRST: no layer before this one (layer 0): block 0 has nothing pending to convert or store
+template <bool PREV_MASK, bool MASK, bool PREPEND, bool LAST, bool NEXT_MASK, bool FIRST = false>
 __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, int next_panel, u32x4 (&bh)[16], u32x4 (&bl)[16], u32x4 (&oh)[16],
                                           u32x4 (&ol)[16], const u32x4& sig_h, const u32x4& sig_l, Loader& ld, Acc& pend,
                                           Pre& pre, unsigned (&mz)[2], Scale& prev, const BwdCtx& cx) {
@@ -319,9 +327,11 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
                              : sign_block(const_cast<unsigned*>(cx.sgn), cx.dp.group, next_panel, 0));
     const unsigned mz_pend = mz[(nb + 1) & 1];
     unsigned& mz_next = mz[(nb + 1) & 1];   // block nb + 1; free again once the pending block (nb - 1) is done (k-step 13)
-    // younger than the DMA this chunk's publish point waits for: the mask load the block before issued for THIS block
-    // in its k-step 14 -- behind the last DMA piece (k-step 13) -- if this layer is masked at all
-    block_mma<16, kBar, (MASK ? 1 : 0)>(
+    // younger than the DMA this chunk's publish point waits for: what the block before issued in its k-steps 14, 15,
+    // behind its last DMA piece (k-step 13): the 16 stores of ITS pending block and the mask load for THIS block
+    const int kYoung = ((FIRST && nb <= 1) ? 0 : 16) + ((MASK && !(FIRST && nb == 0)) ? 1 : 0);
+    auto mma = [&](auto young) {
+    block_mma<16, kBar, decltype(young)::value>(
         acc, pre, a_addr, ld, c2, [&](int s, int part) -> u32x4 { return part ? bl[s] : bh[s]; },
         [&](int s) {
           if (nb == 0) {
@@ -335,6 +345,11 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
           if (load_next) mask_load_step(s, mz_next, next_blk, cx.lane);
         },
         [&](int k) { prefetch_frag(nxt, k, ld.slot_next + ld.lane_off); });
+    };
+    if (kYoung == 17) mma(std::integral_constant<int, 17>{});
+    else if (kYoung == 16) mma(std::integral_constant<int, 16>{});
+    else if (kYoung == 1) mma(std::integral_constant<int, 1>{});
+    else mma(std::integral_constant<int, 0>{});
     pend = acc;
     pre = nxt;
     loader_advance(ld);
@@ -464,7 +479,7 @@ chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ 
 
   // layer 0: dg (no mask) -> gradient panel 8.  Its block-0 hook sees a dummy pending block (zeros, converted into the
   // zero padding of its own input, stored nowhere)
-  bwd_layer<false, false, false, false, true>(0, -1, 8, 7, bh, bl, oh, ol, sig_h, sig_l, ld, pend, pre, mz, prev, cx);
+  bwd_layer<false, false, false, false, true, true>(0, -1, 8, 7, bh, bl, oh, ol, sig_h, sig_l, ld, pend, pre, mz, prev, cx);
   bwd_layer<false, true, true, false, true>(1, 8, 7, 6, oh, ol, bh, bl, sig_h, sig_l, ld, pend, pre, mz, prev, cx);
   // layers 2..8: trunk layers 8..2; outputs dz7..dz1 -> panels 6..0
 #pragma unroll 1
