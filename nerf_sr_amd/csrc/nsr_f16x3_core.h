@@ -283,11 +283,18 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
 // -- goes out as one dword store that fills two whole 128 B lines, and the 32 features of an output block sit within
 // the 4 KiB the instruction's immediate offset reaches (one scalar base per block).  The weight-gradient GEMM reads
 // the same panels as K-contiguous operands (nsr_gemm.h, a_blk / b_blk).
-// A panel set is ten panels back to back: 0..7 = trunk layers 1..8, 8 = xyz_encoding_final, 9 = dir_encoding (128 rows).
+// A panel set is twelve panels back to back: 0..7 = trunk layers 1..8, 8 = xyz_encoding_final, 9 = dir_encoding (128
+// rows); forward sets only: 10 = the encoded position (64 rows: register t of lane half h in row t + 32 h, i.e. column
+// pecol(t, h) of the 63), 11 = the encoded direction (64 rows of which 32 are written: row t + 16 h = column
+// dircol(t, h) of the 27; the rest pads the panel to the weight-gradient kernel's narrowest tile), both at true scale.
 // ---------------------------------------------------------------------------
 constexpr int64_t kPanelGroupFloats = 256 * 32;   // a 256-row panel's stride between point groups
-__device__ __host__ __forceinline__ int64_t panel_offset(int64_t n_groups, int panel) { return panel * n_groups * kPanelGroupFloats; }
-__device__ __host__ __forceinline__ int panel_rows(int panel) { return panel == 9 ? 128 : 256; }
+__device__ __host__ __forceinline__ int panel_rows(int panel) { return panel < 9 ? 256 : (panel == 9 ? 128 : 64); }
+__device__ __host__ __forceinline__ int64_t panel_offset(int64_t n_groups, int panel) {   // floats
+  const int64_t rows_before = panel <= 9 ? 256 * (int64_t)panel : (panel == 10 ? 2304 + 128 : (panel == 11 ? 2304 + 192 : 2304 + 256));
+  return rows_before * 32 * n_groups;
+}
+__device__ __host__ __forceinline__ int64_t panel_set_floats(int64_t n_groups) { return panel_offset(n_groups, 12); }
 struct PanelRef {
   float* base;        // panel set
   int64_t n_groups;   // ceil(P / 128) * 4
@@ -332,4 +339,21 @@ __device__ __forceinline__ void sign_push(unsigned& bits, float v) {
 }
 __device__ __forceinline__ void sign_store(unsigned bits, const unsigned* blk, unsigned lane4) {
   asm volatile("global_store_dword %0, %1, %2" : : "v"(lane4), "v"(bits), "s"(blk) : "memory");
+}
+
+// value v of this lane into row T (0..31) of a panel block: row pitch 128 B, voff = this lane's byte offset inside the block
+template <int T>
+__device__ __forceinline__ void row_store_t(float v, const float* blk, unsigned voff) {
+  asm volatile("global_store_dword %0, %1, %2 offset:%3" NSR_PANEL_STORE_POLICY : : "v"(voff), "v"(v), "s"(blk), "n"(T * 128) : "memory");
+}
+__device__ __forceinline__ void row_store(int t, float v, const float* blk, unsigned voff) {
+  switch (t) {
+#define NSR_RS(T) case T: row_store_t<T>(v, blk, voff); break;
+    NSR_RS(0) NSR_RS(1) NSR_RS(2) NSR_RS(3) NSR_RS(4) NSR_RS(5) NSR_RS(6) NSR_RS(7)
+    NSR_RS(8) NSR_RS(9) NSR_RS(10) NSR_RS(11) NSR_RS(12) NSR_RS(13) NSR_RS(14) NSR_RS(15)
+    NSR_RS(16) NSR_RS(17) NSR_RS(18) NSR_RS(19) NSR_RS(20) NSR_RS(21) NSR_RS(22) NSR_RS(23)
+    NSR_RS(24) NSR_RS(25) NSR_RS(26) NSR_RS(27) NSR_RS(28) NSR_RS(29) NSR_RS(30) NSR_RS(31)
+#undef NSR_RS
+    default: break;
+  }
 }

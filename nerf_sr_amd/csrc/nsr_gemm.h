@@ -28,13 +28,6 @@ struct GemmArgs {
                                     // (the bias gradient of the layer whose pre-activation gradient this GEMM makes)
   float acc_scale;                  // 0 or 1: off; else the accumulator is multiplied by it before the bias (removes the
                                     // power-of-two scale of pre-scaled split-fp16 weights, kSplitScale)
-  // Training panels (nsr_f16x3_core.h) as K-contiguous operands: a_blk / b_blk != 0 means element (i, k) of that operand
-  // lies at p[(k >> 5) * ld + i * 32 + (k & 31)] (ld = floats between two groups of 32 points = 32 x the panel's rows);
-  // the operand's *_kmajor flag must be 0.
-  int a_blk, b_blk;
-  int b_relu;                       // B is read as max(B, 0): the panels hold PRE-activations
-  float* row_sums;                  // may be null: (splits, M) sums over this slice's k of A's rows (A K-contiguous),
-                                    // i.e. the bias gradient when A is a layer's pre-activation gradient
 };
 
 // Weights handed to gemm_f16x3 are multiplied by 2^6 before they are split into fp16 (hi, lo) halves (exact), and the

@@ -27,11 +27,9 @@ template <int ROWS, int TK>   // floats of one staged operand tile (either orien
 constexpr int tile_floats() { return (ROWS * (TK + 4) > TK * (ROWS + 4)) ? ROWS * (TK + 4) : TK * (ROWS + 4); }
 
 // global -> registers: tile of ROWS x 32 of an operand, NT threads, VEC float4 per thread
-// blk: the operand is a training panel (see nsr_gemm.h); lower: -inf, or 0 to read max(x, 0)
 template <int KMAJOR, int ROWS, int NT, int TK>
 __device__ __forceinline__ void load_tile(f32x4 (&v)[ROWS * TK / 4 / NT], const float* __restrict__ p, int64_t ld,
-                                          int64_t r0, int64_t extent, int64_t k0, int tid, int blk = 0,
-                                          float lower = -__builtin_inff()) {
+                                          int64_t r0, int64_t extent, int64_t k0, int tid) {
 #pragma unroll
   for (int i = 0; i < ROWS * TK / 4 / NT; ++i) {
     const int idx = tid + NT * i;
@@ -44,21 +42,9 @@ __device__ __forceinline__ void load_tile(f32x4 (&v)[ROWS * TK / 4 / NT], const 
       const int row = idx / (TK / 4), c4 = idx % (TK / 4);
       int64_t r = r0 + row;
       r = r < extent ? r : extent - 1;
-      const int64_t k = k0 + 4 * c4;
-      const int64_t off = blk ? (k >> 5) * ld + r * 32 + (k & 31) : r * ld + k;
-      v[i] = *reinterpret_cast<const f32x4*>(p + off);
-    }
-    if (lower == 0.0f) {   // wave-uniform
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], 0.0f);
+      v[i] = *reinterpret_cast<const f32x4*>(p + r * ld + k0 + 4 * c4);
     }
   }
-}
-// running sums of the K-contiguous A rows a thread stages (thread <-> rows is the same for every K tile)
-template <int ROWS, int NT, int TK>
-__device__ __forceinline__ void add_rows(float (&rs)[ROWS * TK / 4 / NT], const f32x4 (&v)[ROWS * TK / 4 / NT]) {
-#pragma unroll
-  for (int i = 0; i < ROWS * TK / 4 / NT; ++i) rs[i] += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
 }
 template <int KMAJOR, int ROWS, int NT, int TK>
 __device__ __forceinline__ void store_tile(const f32x4 (&v)[ROWS * TK / 4 / NT], float* s, int tid) {
@@ -114,15 +100,9 @@ gemm_kernel(GemmArgs g, int n_col_tiles, int64_t k_chunk) {
   for (int bj = 0; bj < 2; ++bj) col_on[bj] = (n0 + 64 * wn + 32 * bj) < g.N;
 
   f32x4 sa[kTM * TK / 4 / NT], sb[TN * TK / 4 / NT];
-  float rs[kTM * TK / 4 / NT];
-#pragma unroll
-  for (int i = 0; i < kTM * TK / 4 / NT; ++i) rs[i] = 0.0f;
-  const bool sum_rows = !AK && g.row_sums != nullptr && n0 == 0;
-  const float b_lower = g.b_relu ? 0.0f : -__builtin_inff();
   if (n_tiles > 0) {
-    load_tile<AK, kTM, NT, TK>(sa, g.A, g.lda, m0, g.M, k_begin, tid, g.a_blk);
-    load_tile<BK, TN, NT, TK>(sb, g.B, g.ldb, n0, g.N, k_begin, tid, g.b_blk, b_lower);
-    if (sum_rows) add_rows<kTM, NT, TK>(rs, sa);
+    load_tile<AK, kTM, NT, TK>(sa, g.A, g.lda, m0, g.M, k_begin, tid);
+    load_tile<BK, TN, NT, TK>(sb, g.B, g.ldb, n0, g.N, k_begin, tid);
     store_tile<AK, kTM, NT, TK>(sa, lds, tid);
     store_tile<BK, TN, NT, TK>(sb, lds + kAF, tid);
   }
@@ -131,8 +111,8 @@ gemm_kernel(GemmArgs g, int n_col_tiles, int64_t k_chunk) {
     const float* As = lds + (t & 1) * (kAF + kBF);
     const float* Bs = As + kAF;
     if (t + 1 < n_tiles) {
-      load_tile<AK, kTM, NT, TK>(sa, g.A, g.lda, m0, g.M, k_begin + (int64_t)(t + 1) * TK, tid, g.a_blk);
-      load_tile<BK, TN, NT, TK>(sb, g.B, g.ldb, n0, g.N, k_begin + (int64_t)(t + 1) * TK, tid, g.b_blk, b_lower);
+      load_tile<AK, kTM, NT, TK>(sa, g.A, g.lda, m0, g.M, k_begin + (int64_t)(t + 1) * TK, tid);
+      load_tile<BK, TN, NT, TK>(sb, g.B, g.ldb, n0, g.N, k_begin + (int64_t)(t + 1) * TK, tid);
     }
 #pragma unroll
     for (int q = 0; q < TK / 8; ++q) {
@@ -155,20 +135,8 @@ gemm_kernel(GemmArgs g, int n_col_tiles, int64_t k_chunk) {
       float* An = lds + ((t + 1) & 1) * (kAF + kBF);
       store_tile<AK, kTM, NT, TK>(sa, An, tid);
       store_tile<BK, TN, NT, TK>(sb, An + kAF, tid);
-      if (sum_rows) add_rows<kTM, NT, TK>(rs, sa);
     }
     __syncthreads();
-  }
-  if (sum_rows) {   // the TK / 4 threads that stage one row are neighbours: combine, the first one writes
-#pragma unroll
-    for (int i = 0; i < kTM * TK / 4 / NT; ++i) {
-      float s = rs[i];
-#pragma unroll
-      for (int o = 1; o < TK / 4; o <<= 1) s += __shfl_xor(s, o, 64);
-      const int idx = tid + NT * i;
-      const int64_t row = m0 + idx / (TK / 4);
-      if (idx % (TK / 4) == 0 && row < g.M) g.row_sums[(int64_t)z * g.M + row] = s;
-    }
   }
 
   gemm_epilogue<TN>(g, acc, col_on, m0, n0, wm, wn, li, h, tid, z, bid / n_col_tiles, lds);
@@ -200,20 +168,17 @@ NSR_INTERNAL int gemm(const GemmArgs& g, hipStream_t st) {
   if ((reinterpret_cast<uintptr_t>(g.A) & 15) || (reinterpret_cast<uintptr_t>(g.B) & 15) ||
       (g.Ct && (reinterpret_cast<uintptr_t>(g.Ct) & 15)))
     return NSR_ERR_INVALID_ARG;
-  if ((g.a_blk && g.a_kmajor) || (g.b_blk && g.b_kmajor) || (g.row_sums && g.a_kmajor)) return NSR_ERR_INVALID_ARG;
-  if ((g.a_blk && g.lda % 32) || (g.b_blk && g.ldb % 32)) return NSR_ERR_INVALID_ARG;
   if (g.a_kmajor && (g.M % 4 != 0 || g.M < 4)) return NSR_ERR_INVALID_ARG;
   if (g.b_kmajor && (g.N % 4 != 0 || g.N < 4)) return NSR_ERR_INVALID_ARG;
   const int splits = g.splits > 1 ? g.splits : 1;
   if (splits > 1 && (g.bias || g.mask || g.act != kActNone || g.Ct || !g.C || g.col_sums)) return NSR_ERR_INVALID_ARG;
-  if (g.row_sums && g.K / 32 < splits) return NSR_ERR_INVALID_ARG;   // every slice must own at least one K tile
   if (g.M == 0) return NSR_OK;
   GemmArgs a = g;
   a.splits = splits;
   if (!g.a_kmajor && !g.b_kmajor) return launch<0, 0>(a, splits, st);
   if (!g.a_kmajor && g.b_kmajor) return launch<0, 1>(a, splits, st);
   if (g.a_kmajor && g.b_kmajor) return launch<1, 1>(a, splits, st);
-  return launch<1, 0>(a, splits, st);
+  return NSR_ERR_UNSUPPORTED;
 }
 
 }  // namespace nsr

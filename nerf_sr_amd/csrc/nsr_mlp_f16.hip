@@ -453,6 +453,16 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   }
 
 
+  if (TRAIN) {   // the encodings themselves: operands of the weight gradients of L1, L5 (skip part) and dir_encoding
+    const float* pblk = tr.base + panel_offset(tr.n_groups, 10) + tr.group * (64 * 32);
+    const float* dblk = tr.base + panel_offset(tr.n_groups, 11) + tr.group * (64 * 32);
+    const unsigned voff_pe = 4u * (unsigned)(m + 1024 * h), voff_de = 4u * (unsigned)(m + 512 * h);
+#pragma unroll
+    for (int t = 0; t < 32; ++t) row_store(t, pe[t], pblk, voff_pe);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) row_store(t, de[t], dblk, voff_de);
+  }
+
   // park the split position encoding in LDS: L5 (skip) re-reads it, which frees 32 registers in the loop
   u32x4* stash = reinterpret_cast<u32x4*>(ring + kStash0) + wave * 8 * 64 + lane;
 #pragma unroll
@@ -673,7 +683,7 @@ extern "C" NSR_INTERNAL int nsr_f16x3_render_composite(const void* packed, const
 // `pan` holds 10 panels of ceil(R N / 128) * 4 point groups (nsr_f16x3_train_panel_floats)
 extern "C" NSR_INTERNAL int64_t nsr_f16x3_train_panel_floats(int64_t P) {
   const int64_t n_groups = ((P + 127) / 128) * 4;
-  return panel_offset(n_groups, 9) + n_groups * 128 * 32;
+  return panel_set_floats(n_groups);
 }
 extern "C" NSR_INTERNAL int64_t nsr_f16x3_train_sign_words(int64_t P) { return sign_panel_words(((P + 127) / 128) * 4); }
 extern "C" NSR_INTERNAL int nsr_f16x3_train_forward(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,

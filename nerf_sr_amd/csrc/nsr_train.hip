@@ -305,11 +305,18 @@ __global__ void __launch_bounds__(256) sum_finish_kernel(const double* __restric
 // dst[i * dst_ld + dc0 + j] (+)= sum_z partial[z * stride + (pr0 + i) * p_ld + pc0 + j]
 __global__ void __launch_bounds__(256) reduce_place_kernel(float* __restrict__ dst, int dst_ld, int dc0, int rows, int cols,
                                                            const float* __restrict__ partial, int splits, int64_t stride,
-                                                           int p_ld, int pr0, int pc0, int accumulate, float scale) {
+                                                           int p_ld, int pr0, int pc0, int accumulate, float scale,
+                                                           int enc_rows) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * cols) return;
   const int i = idx / cols, j = idx % cols;
-  const float* src = partial + (int64_t)(pr0 + i) * p_ld + pc0 + j;
+  // enc_rows: the partial's columns are rows of an encoding panel, i.e. in register order (nsr_f16x3_core.h).
+  // 1: encoded position, register t of lane half h in row t + 32 h = column pecol(t, h): column j of the 63 sits at
+  //    0, 1, 32 (x, y, z), j - 1 (j < 33) or j + 1;   2: encoded direction, row t + 16 h = column dircol(t, h): column j of
+  //    the 27 sits at 0, 1, 16, j - 1 (j < 15) or j + 3
+  const int js = enc_rows == 1 ? (j < 2 ? j : (j == 2 ? 32 : (j < 33 ? j - 1 : j + 1)))
+               : enc_rows == 2 ? (j < 2 ? j : (j == 2 ? 16 : (j < 15 ? j - 1 : j + 3))) : j;
+  const float* src = partial + (int64_t)(pr0 + i) * p_ld + pc0 + js;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four independent chains: the loads of a round are all in flight
   int zc = 0;
   for (; zc + 4 <= splits; zc += 4) {
@@ -561,10 +568,10 @@ int lin_wgrad(hipStream_t st, const float* dy, int64_t lddy, int M, const float*
   return gemm(g, st);
 }
 int reduce_place(hipStream_t st, float* dst, int dst_ld, int dc0, int rows, int cols, const float* partial, int splits,
-                 int p_ld, int pr0, int pc0, int accumulate, float scale = 1.0f) {
+                 int p_ld, int pr0, int pc0, int accumulate, float scale = 1.0f, int enc_rows = 0) {
   const int n = rows * cols;
   hipLaunchKernelGGL(reduce_place_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dst, dst_ld, dc0, rows, cols, partial,
-                     splits, kPartialFloats, p_ld, pr0, pc0, accumulate, scale);
+                     splits, kPartialFloats, p_ld, pr0, pc0, accumulate, scale, enc_rows);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
@@ -653,32 +660,19 @@ int net_backward(hipStream_t st, const float* const* w, const WeightPack& q, con
 
 // ---- chain path ------------------------------------------------------------------------------------------
 int64_t n_groups_of(int64_t P) { return ((P + 127) / 128) * 4; }
-float* panel_of(float* set, int64_t P, int panel) { return set + panel * n_groups_of(P) * 256 * 32; }
-
-// partial[z] (M x N) = sum over slice z of the points of A[p][0..M) B[p][0..N)^T.  Each operand is either a panel
-// (blk: rows x 32 floats per point group, K-contiguous) or a row-major (P, ld) buffer (K-major)
-struct Operand {
-  const float* p;
-  int64_t ld;
-  int blk;      // panel (ld = 32 x panel rows) / row-major
-  int relu;     // B only: read max(x, 0)
-};
-int chain_wgrad(hipStream_t st, const Operand& a, int M, const Operand& b, int N, int64_t P, float* partial, int splits,
-                float* row_sums) {
-  GemmArgs g{};
-  g.A = a.p; g.lda = a.ld; g.a_kmajor = !a.blk; g.a_blk = a.blk;
-  g.B = b.p; g.ldb = b.ld; g.b_kmajor = !b.blk; g.b_blk = b.blk; g.b_relu = b.relu;
-  g.C = partial; g.ldc = N; g.M = M; g.N = N; g.K = P; g.n_valid = N; g.act = kActNone;
-  g.splits = splits; g.split_stride = kPartialFloats; g.row_sums = row_sums;
-  return gemm(g, st);
+float* panel_of(float* set, int64_t P, int panel) {   // nsr_f16x3_core.h: panel_offset
+  const int64_t rows_before = panel <= 9 ? 256 * (int64_t)panel : (panel == 10 ? 2304 + 128 : 2304 + 192);
+  return set + rows_before * 32 * n_groups_of(P);
 }
+
 // both operands panels: the split-fp16 kernel (nsr_wgrad_f16.hip).  a_panel / b_panel: panel numbers of dpan / zpan
 int panel_wgrad(hipStream_t st, const Work& k, int64_t P, int a_panel, int b_panel, int b_relu, float* partial, int splits,
                 float* row_sums) {
   WgradArgs w{};
   w.A = panel_of(k.dpan, P, a_panel); w.M = a_panel == 9 ? 128 : 256; w.a_gstride = 32 * w.M;
-  w.B = panel_of(k.zpan, P, b_panel); w.N = 256; w.b_gstride = 32 * 256; w.b_relu = b_relu;
-  w.P = P; w.a_max_bits = k.gmax + a_panel; w.out_scale = 1.0f / 64.0f;
+  w.B = panel_of(k.zpan, P, b_panel); w.N = b_panel >= 10 ? 64 : 256; w.b_gstride = 32 * w.N; w.b_relu = b_relu;
+  w.P = P; w.a_max_bits = k.gmax + a_panel;
+  w.out_scale = b_panel >= 10 ? 1.0f : 1.0f / 64.0f;    // the encodings are stored at true scale
   w.partial = partial; w.split_stride = kPartialFloats; w.splits = splits; w.row_sums = row_sums;
   return wgrad_f16x3(w, st);
 }
@@ -695,9 +689,6 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
   float* part = k.partial;
   float* rs = k.row_part;
   constexpr float kInv = 1.0f / 64.0f;
-  auto dp = [&](int panel) { return Operand{panel_of(k.dpan, P, panel), panel == 9 ? 128 * 32 : 256 * 32, 1, 0}; };
-  const Operand pe{k.x5, kX5, 0, 0};                      // [pe63 | 0] in columns 0..63
-  const Operand de{k.gs + kSigmaCol, kGs, 0, 0};          // [. 0 0 0 de27 0]: 32 columns from 256
   // rgb head: d_rgb_pre^T relu(zcc)
   const int64_t per = (P / 32 + sp - 1) / sp;
   hipLaunchKernelGGL((panel_wsums_kernel<128, 3>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 9), P, k.drgb, kRgbPad, 0.0f,
@@ -709,8 +700,8 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
   NSR_TRY(panel_wgrad(st, k, P, 9, 8, 0, part, sp, rs));
   NSR_TRY(reduce_place(st, g[kDirW], 283, 0, 128, 256, part, sp, kW, 0, 0, acc));
   NSR_TRY(rowsum_finish(st, rs, sp, kDirOut, g[kDirB], acc));
-  NSR_TRY(chain_wgrad(st, dp(9), kDirOut, de, 32, P, part, sp, nullptr));
-  NSR_TRY(reduce_place(st, g[kDirW], 283, 256, 128, 27, part, sp, 32, 0, kDeCol - kSigmaCol, acc));
+  NSR_TRY(panel_wgrad(st, k, P, 9, 11, 0, part, sp, nullptr));
+  NSR_TRY(reduce_place(st, g[kDirW], 283, 256, 128, 27, part, sp, kPe, 0, 0, acc, 1.0f, 2));
   // xyz_encoding_final: dg^T relu(z8); sigma: d_sigma^T relu(z8)
   NSR_TRY(panel_wgrad(st, k, P, 8, 7, 1, part, sp, rs));
   NSR_TRY(reduce_place(st, g[kFinalW], 256, 0, 256, 256, part, sp, kW, 0, 0, acc));
@@ -723,10 +714,9 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
   // trunk layers 8..1: dz_L^T (input of layer L)
   for (int L = 8; L >= 1; --L) {
     float* gw = g[2 * (L - 1)];
-    const Operand dz = dp(L - 1);
-    if (L == 1 || L == 5) {   // the encoded position is a row-major buffer: fp32 GEMM
-      NSR_TRY(chain_wgrad(st, dz, kW, pe, kPe, P, part, sp, L == 1 ? rs : nullptr));
-      NSR_TRY(reduce_place(st, gw, L == 1 ? 63 : 319, 0, 256, 63, part, sp, kPe, 0, 0, acc));
+    if (L == 1 || L == 5) {   // over the encoded position (panel 10, 64 rows in register order)
+      NSR_TRY(panel_wgrad(st, k, P, L - 1, 10, 0, part, sp, L == 1 ? rs : nullptr));
+      NSR_TRY(reduce_place(st, gw, L == 1 ? 63 : 319, 0, 256, 63, part, sp, kPe, 0, 0, acc, 1.0f, 1));
     }
     if (L > 1) {
       NSR_TRY(panel_wgrad(st, k, P, L - 1, L - 2, 1, part, sp, rs));
@@ -835,9 +825,11 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
         NSR_TRY(nsr_resample_along_rays(rays_c, ray_stride, k.z_c, wc, rc, nc, n_importance,
                                         u_fine ? u_fine + r0 * n_importance : nullptr, z, nullptr, stream));
       }
-      hipLaunchKernelGGL(encode_train_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, rays_c, ray_stride, z,
-                         P, N, k.x5, k.gs);
-      NSR_CHECK_LAUNCH();
+      if (!chain) {   // the chain path encodes inside its forward kernel
+        hipLaunchKernelGGL(encode_train_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, rays_c, ray_stride, z,
+                           P, N, k.x5, k.gs);
+        NSR_CHECK_LAUNCH();
+      }
       if (chain) NSR_TRY(nsr_f16x3_train_forward(k.stream_f[net], rays_c, ray_stride, z, rc, N, k.rgb, k.zpan, k.sgn, stream));
       else NSR_TRY(net_forward(st, w, k.pack[net], k, P, precision));
       const float* noise = net ? noise_fine : noise_coarse;

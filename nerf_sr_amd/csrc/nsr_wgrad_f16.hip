@@ -35,17 +35,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 constexpr int kTK = 32, kLd = kTK + 8;   // one point group per K tile; LDS row stride in halves (80 B: conflict-free b128 reads)
-constexpr int kTN = 256, kNT = 512;      // 8 waves: 2 (rows) x 4 (columns), wave tile (32 BM) x 64
+constexpr int kNT = 512;                 // 8 waves, each a (32 BM) x (32 BN) tile of the TM x TN product
 
-template <int BM>   // 32-row blocks per wave: 4 -> 256-row tile, 2 -> 128-row tile
+// TM x TN (BM, BN) = 256 x 256 (4, 2): trunk layers; 128 x 256 (2, 2): dir_encoding over g; 256 x 64 (1, 2): a trunk
+// layer over the encoded position; 128 x 64 (1, 1): dir_encoding over the encoded direction
+template <int TM, int kTN, int BM, int BN>
 __global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wgrad_f16x3_kernel(WgradArgs w, int64_t groups_per_slice) {
-  constexpr int TM = 64 * BM;
+  constexpr int WM = TM / (32 * BM), WN = kTN / (32 * BN);   // wave grid
+  static_assert(WM * WN == 8, "tile does not split over 8 waves");
   constexpr int kArrA = TM * kLd, kArrB = kTN * kLd;
   constexpr int NA = TM * kTK / 4 / kNT, NB = kTN * kTK / 4 / kNT;   // float4 per thread and K tile: 4 (2) and 4
   __shared__ __attribute__((aligned(16))) _Float16 lds[2 * kArrA + 2 * kArrB];   // A hi | A lo | B hi | B lo
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1, li = lane & 31, h = lane >> 5;
+  const int wm = wave % WM, wn = wave / WM, li = lane & 31, h = lane >> 5;
   const int z = blockIdx.x;
   const int64_t n_groups = w.P / 32;
   const int64_t g_begin = (int64_t)z * groups_per_slice;
@@ -58,11 +61,11 @@ wgrad_f16x3_kernel(WgradArgs w, int64_t groups_per_slice) {
   const float S = amax > 0.0f ? __uint_as_float((unsigned)(e + 127) << 23) : 1.0f;
   const float b_lower = w.b_relu ? 0.0f : -__builtin_inff();
 
-  f32x16 acc[BM][2];
+  f32x16 acc[BM][BN];
 #pragma unroll
   for (int bi = 0; bi < BM; ++bi)
 #pragma unroll
-    for (int bj = 0; bj < 2; ++bj)
+    for (int bj = 0; bj < BN; ++bj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.0f;
 
@@ -112,12 +115,12 @@ wgrad_f16x3_kernel(WgradArgs w, int64_t groups_per_slice) {
     __syncthreads();
     if (g + 1 < g_end) load(g + 1);
     const _Float16* ap = lds + (32 * BM * wm + li) * kLd + 8 * h;
-    const _Float16* bp = lds + 2 * kArrA + (64 * wn + li) * kLd + 8 * h;
+    const _Float16* bp = lds + 2 * kArrA + (32 * BN * wn + li) * kLd + 8 * h;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      h8 bh[2], bl[2];
+      h8 bh[BN], bl[BN];
 #pragma unroll
-      for (int bj = 0; bj < 2; ++bj) {
+      for (int bj = 0; bj < BN; ++bj) {
         bh[bj] = *reinterpret_cast<const h8*>(bp + 32 * bj * kLd + 16 * s);
         bl[bj] = *reinterpret_cast<const h8*>(bp + kArrB + 32 * bj * kLd + 16 * s);
       }
@@ -126,7 +129,7 @@ wgrad_f16x3_kernel(WgradArgs w, int64_t groups_per_slice) {
         const h8 ah = *reinterpret_cast<const h8*>(ap + 32 * bi * kLd + 16 * s);
         const h8 al = *reinterpret_cast<const h8*>(ap + kArrA + 32 * bi * kLd + 16 * s);
 #pragma unroll
-        for (int bj = 0; bj < 2; ++bj) {
+        for (int bj = 0; bj < BN; ++bj) {
           acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[bj], acc[bi][bj], 0, 0, 0);   // small terms first
           acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[bj], acc[bi][bj], 0, 0, 0);
           acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[bj], acc[bi][bj], 0, 0, 0);
@@ -142,8 +145,8 @@ wgrad_f16x3_kernel(WgradArgs w, int64_t groups_per_slice) {
 #pragma unroll
   for (int bi = 0; bi < BM; ++bi)
 #pragma unroll
-    for (int bj = 0; bj < 2; ++bj) {
-      const int n = 64 * wn + 32 * bj + li;
+    for (int bj = 0; bj < BN; ++bj) {
+      const int n = 32 * BN * wn + 32 * bj + li;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = 32 * BM * wm + 32 * bi + 8 * (r >> 2) + 4 * h + (r & 3);
@@ -165,15 +168,18 @@ wgrad_f16x3_kernel(WgradArgs w, int64_t groups_per_slice) {
 }  // namespace
 
 NSR_INTERNAL int wgrad_f16x3(const WgradArgs& w, hipStream_t st) {
-  if (!w.A || !w.B || !w.partial || !w.a_max_bits || w.splits < 1 || w.N != kTN || (w.M != 256 && w.M != 128))
-    return NSR_ERR_INVALID_ARG;
+  const int shape = (w.N == 256 ? 0 : (w.N == 64 ? 2 : -8)) + (w.M == 256 ? 0 : (w.M == 128 ? 1 : -8));
+  if (!w.A || !w.B || !w.partial || !w.a_max_bits || w.splits < 1 || shape < 0) return NSR_ERR_INVALID_ARG;
   if (w.P < 0 || w.P % 32 != 0 || w.a_gstride % 4 || w.b_gstride % 4) return NSR_ERR_INVALID_ARG;
   if ((reinterpret_cast<uintptr_t>(w.A) & 15) || (reinterpret_cast<uintptr_t>(w.B) & 15)) return NSR_ERR_INVALID_ARG;
   if (w.P == 0) return NSR_OK;
   const int64_t n_groups = w.P / 32;
   const int64_t per = (n_groups + w.splits - 1) / w.splits;
-  if (w.M == 256) hipLaunchKernelGGL(wgrad_f16x3_kernel<4>, dim3((unsigned)w.splits), dim3(kNT), 0, st, w, per);
-  else hipLaunchKernelGGL(wgrad_f16x3_kernel<2>, dim3((unsigned)w.splits), dim3(kNT), 0, st, w, per);
+  const dim3 grid((unsigned)w.splits), block(kNT);
+  if (shape == 0) hipLaunchKernelGGL((wgrad_f16x3_kernel<256, 256, 4, 2>), grid, block, 0, st, w, per);
+  else if (shape == 1) hipLaunchKernelGGL((wgrad_f16x3_kernel<128, 256, 2, 2>), grid, block, 0, st, w, per);
+  else if (shape == 2) hipLaunchKernelGGL((wgrad_f16x3_kernel<256, 64, 1, 2>), grid, block, 0, st, w, per);
+  else hipLaunchKernelGGL((wgrad_f16x3_kernel<128, 64, 1, 1>), grid, block, 0, st, w, per);
   if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
   return NSR_OK;
 }
