@@ -167,6 +167,22 @@ def main_train(args):
                          "note": "algorithmic flops = 3 x 593,408 MAC x 2 per sample point x 192 points per ray"},
             "losses": [float(x) for x in t.losses.tolist()],
         }
+        if args.train_precision == "f16x3" and not os.environ.get("NSR_TRAIN_PATH", "").startswith("g"):
+            # chain path: every product runs on the split-fp16 MFMA and the step is bound by the panels it
+            # moves through HBM.  Rows of 4-byte values per sample point: the forward kernel writes 2,816 (ten
+            # pre-activation panels + the two encodings), the backward chain writes 2,688, the weight-gradient kernels
+            # read 5,696 (each product reads its gradient panel and its input panel once).
+            rows = 2816 + 2688 + 5696
+            gb = 4.0 * rows * R * (N_COARSE + N_COARSE + N_IMPORTANCE) / 1e9
+            res["dtype"] = "f32 results from split-fp16 x3 MFMA products (forward, input and weight gradients; fp32-grade)"
+            res["roofline"] = {"bound": "hbm", "kernel": "whole training step, chain path (mlp_f16x3_kernel TRAIN, "
+                                                          "chain_bwd_kernel, wgrad_f16x3_kernel)",
+                               "achieved": gb / (dt / args.steps), "peak": 8000.0, "unit": "GB/s",
+                               "frac": gb / (dt / args.steps) / 8000.0, "traffic": None, "gbytes_per_step": gb,
+                               "mfma_tflops_issued": 3 * achieved,
+                               "note": "algorithmic bytes = 44,800 B of panel traffic per sample point x 192 points per ray "
+                                       "(split-K partial sums, weight streams and per-ray arrays excluded); "
+                                       "mfma_tflops_issued = 3 fp16 MFMAs per product x 3 x the forward MACs"}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import train_oracle as to     # checker/baseline only; never on the product path
             n = 256
