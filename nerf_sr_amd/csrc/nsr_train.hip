@@ -38,6 +38,9 @@ constexpr int kW = 256, kPe = 64, kX5 = 320, kGs = 288, kDirOut = 128, kRgbPad =
 constexpr int kSigmaCol = 256, kDeCol = 260;     // columns of the [g | sigma | 0 0 0 | de27 | 0] buffer
 constexpr int kMaxSplits = 256;
 constexpr int64_t kPartialFloats = (int64_t)kGs * kX5;   // >= every padded weight-gradient shape
+constexpr int kChainSlots = 14, kChainRowSlots = 12;     // chain path: partial sums of a network's 14 weight-gradient
+constexpr int64_t kSlotFloats = (int64_t)kMaxSplits * 256 * 256;   // products and of its bias row sums, all alive until
+constexpr int64_t kRowSlotFloats = (int64_t)kMaxSplits * 256;      // ONE finishing launch
 
 // state_dict indices (nsr.h): layer i (1..8) weight = 2 (i - 1), bias = 2 (i - 1) + 1
 constexpr int kFinalW = 16, kFinalB = 17, kDirW = 18, kDirB = 19, kSigmaW = 20, kSigmaB = 21, kRgbW = 22, kRgbB = 23;
@@ -330,19 +333,6 @@ __global__ void __launch_bounds__(256) reduce_place_kernel(float* __restrict__ d
   float* d = dst + (int64_t)i * dst_ld + dc0 + j;
   *d = (accumulate ? *d : 0.0f) + (float)(s * (double)scale);   // scale: a power of two (pre-scaled operands)
 }
-// bias gradient from the row sums a weight-gradient GEMM left per split-K slice: dst[i] (+)= sum_z partial[z * rows + i]
-// One wavefront per row (4 rows per block): the slices of a row are loaded in parallel and combined by shuffles in a
-// fixed order.
-__global__ void __launch_bounds__(256) rowsum_finish_kernel(const float* __restrict__ partial, int splits, int rows,
-                                                            float* __restrict__ dst, int accumulate) {
-  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= rows) return;   // wave-uniform
-  double s = 0.0;
-  for (int zc = lane; zc < splits; zc += 64) s += (double)partial[(int64_t)zc * rows + i];
-  s = wave_sum_d(s);
-  if (lane == 0) dst[i] = (accumulate ? dst[i] : 0.0f) + (float)s;
-}
-
 // sums over the points of  w[p][c] * max(panel[p][row], lower)  for c < NW weights per point -- the weight gradients of
 // the 1- and 3-row heads (sigma over h8, rgb over dir_encoding's output), whose "GEMM" is a stream over one panel:
 // partial[z][c * R + row] = scale * sum over slice z.  The panel run of a point group is contiguous (R x 32 floats);
@@ -389,6 +379,55 @@ __global__ void __launch_bounds__(256) panel_wsums_kernel(const float* __restric
     }
 }
 
+// All second passes of one network's weight / bias gradients in ONE launch (chain path): blockIdx.y = job.
+//   kind 0: dst[i * dst_ld + dc0 + j] (+)= scale * sum_z partial[z * stride + i * p_ld + col(j)]   (reduce_place_kernel)
+//   kind 1: dst[i] (+)= sum_z partial[z * rows + i]                                                 (rowsum_finish_kernel)
+// Twenty-odd launches of a few microseconds of work each (one wave of latency-bound workgroups) became the tail of
+// the step once the GEMMs before them had shrunk; together they keep the memory system busy.
+struct FinishJob {
+  float* dst;
+  const float* partial;
+  int64_t stride;
+  int kind, dst_ld, dc0, rows, cols, splits, p_ld, accumulate, enc_rows;
+  float scale;
+};
+constexpr int kMaxFinishJobs = 32;
+struct FinishJobs {
+  FinishJob j[kMaxFinishJobs];
+  int n;
+};
+__global__ void __launch_bounds__(256) finish_jobs_kernel(FinishJobs jobs) {
+  const FinishJob& q = jobs.j[blockIdx.y];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= q.rows * q.cols) return;
+  const float* src;
+  int64_t stride;
+  float* d;
+  if (q.kind == 0) {
+    const int i = idx / q.cols, j = idx % q.cols;
+    const int js = q.enc_rows == 1 ? (j < 2 ? j : (j == 2 ? 32 : (j < 33 ? j - 1 : j + 1)))
+                 : q.enc_rows == 2 ? (j < 2 ? j : (j == 2 ? 16 : (j < 15 ? j - 1 : j + 3))) : j;   // see reduce_place_kernel
+    src = q.partial + (int64_t)i * q.p_ld + js;
+    stride = q.stride;
+    d = q.dst + (int64_t)i * q.dst_ld + q.dc0 + j;
+  } else {
+    src = q.partial + idx;
+    stride = q.rows;
+    d = q.dst + idx;
+  }
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four independent chains: the loads of a round are all in flight
+  int zc = 0;
+  for (; zc + 4 <= q.splits; zc += 4) {
+    s0 += (double)src[(zc + 0) * stride];
+    s1 += (double)src[(zc + 1) * stride];
+    s2 += (double)src[(zc + 2) * stride];
+    s3 += (double)src[(zc + 3) * stride];
+  }
+  for (; zc < q.splits; ++zc) s0 += (double)src[zc * stride];
+  const double sum = (s0 + s1) + (s2 + s3);
+  *d = (q.accumulate ? *d : 0.0f) + (float)(sum * (double)q.scale);
+}
+
 struct AdamPtrs {
   float* w[NSR_N_STATE_TENSORS];
   const float* g[NSR_N_STATE_TENSORS];
@@ -432,7 +471,7 @@ struct Work {   // per-pass buffers, sized for P_max = chunk * (Nc + Ni) sample 
   WeightPack pack[2];
   // chain path (NSR_F16X3): pre-activation panels of the forward pass, gradient panels of the backward chain
   // (nsr_f16x3_core.h), the two weight streams per network, per-slice row sums of the weight-gradient GEMMs
-  float *zpan, *dpan, *row_part;
+  float *zpan, *dpan, *row_part, *slots;
   float *stream_f[2], *stream_b[2];
   unsigned* sgn;    // sign panels of the forward pass (nsr_f16x3_core.h)
   unsigned* gmax;   // float bits of the largest magnitude in each gradient panel (written by the backward chain)
@@ -460,6 +499,7 @@ int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base) {
   k.comp = take(chunk * 3);   k.g_comp = take(chunk * 3);
   k.scratch_out = take(chunk * (nf + 8));
   k.partial = take(kMaxSplits * kPartialFloats);           // also scratch of the small bias sums
+  k.slots = take(kChainSlots * kSlotFloats);               // chain path: every second pass of a network waits for one launch
   k.block_sums = reinterpret_cast<double*>(take(2 * (chunk / 256 + 2)));
   k.carry = reinterpret_cast<double*>(take(8));
   for (int n = 0; n < 2; ++n) {
@@ -470,7 +510,7 @@ int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base) {
   }
   const int64_t pan = nsr_f16x3_train_panel_floats(P);
   k.zpan = take(pan);   k.dpan = take(pan);
-  k.row_part = take(kMaxSplits * 256);
+  k.row_part = take(kChainRowSlots * kRowSlotFloats);
   k.gmax = reinterpret_cast<unsigned*>(take(64));
   k.sgn = reinterpret_cast<unsigned*>(take(nsr_f16x3_train_sign_words(P)));
   for (int n = 0; n < 2; ++n) {
@@ -665,65 +705,80 @@ float* panel_of(float* set, int64_t P, int panel) {   // nsr_f16x3_core.h: panel
   return set + rows_before * 32 * n_groups_of(P);
 }
 
-// both operands panels: the split-fp16 kernel (nsr_wgrad_f16.hip).  a_panel / b_panel: panel numbers of dpan / zpan
-int panel_wgrad(hipStream_t st, const Work& k, int64_t P, int a_panel, int b_panel, int b_relu, float* partial, int splits,
-                float* row_sums) {
-  WgradArgs w{};
-  w.A = panel_of(k.dpan, P, a_panel); w.M = a_panel == 9 ? 128 : 256; w.a_gstride = 32 * w.M;
-  w.B = panel_of(k.zpan, P, b_panel); w.N = b_panel >= 10 ? 64 : 256; w.b_gstride = 32 * w.N; w.b_relu = b_relu;
-  w.P = P; w.a_max_bits = k.gmax + a_panel;
-  w.out_scale = b_panel >= 10 ? 1.0f : 1.0f / 64.0f;    // the encodings are stored at true scale
-  w.partial = partial; w.split_stride = kPartialFloats; w.splits = splits; w.row_sums = row_sums;
-  return wgrad_f16x3(w, st);
-}
-int rowsum_finish(hipStream_t st, const float* partial, int splits, int rows, float* dst, int acc) {
-  hipLaunchKernelGGL(rowsum_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, partial, splits, rows, dst, acc);
-  NSR_CHECK_LAUNCH();
-  return NSR_OK;
-}
-
 // weight and bias gradients from the panels: zpan = forward pre-activations x 2^6 (kWScale), dpan = true-scale
 // gradients of the pre-activations; d_rgb_pre in k.drgb (P, 32), d_sigma in column 256 of k.g1 (P, 288)
 int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g, int acc) {
   const int sp = n_splits(P);
-  float* part = k.partial;
-  float* rs = k.row_part;
   constexpr float kInv = 1.0f / 64.0f;
-  // rgb head: d_rgb_pre^T relu(zcc)
+  FinishJobs jobs{};
+  int n_big = 0, n_row = 0;
+  auto big_slot = [&]() { return k.slots + (int64_t)(n_big++) * kSlotFloats; };
+  auto row_slot = [&]() { return k.row_part + (int64_t)(n_row++) * kRowSlotFloats; };
+  // second passes, executed by finish_jobs_kernel at the end
+  auto place = [&](float* dst, int dst_ld, int dc0, int rows, int cols, const float* partial, int p_ld, int enc_rows) {
+    FinishJob& q = jobs.j[jobs.n++];
+    q.kind = 0; q.dst = dst; q.dst_ld = dst_ld; q.dc0 = dc0; q.rows = rows; q.cols = cols; q.partial = partial;
+    q.stride = (int64_t)256 * 256; q.splits = sp; q.p_ld = p_ld; q.accumulate = acc; q.enc_rows = enc_rows; q.scale = 1.0f;
+  };
+  auto sum_rows = [&](float* dst, int rows, const float* partial) {
+    FinishJob& q = jobs.j[jobs.n++];
+    q.kind = 1; q.dst = dst; q.rows = rows; q.cols = 1; q.partial = partial; q.splits = sp; q.accumulate = acc; q.scale = 1.0f;
+  };
+  // product of gradient panel a with forward panel b -> a fresh slot (+ the bias row sums of a)
+  auto product = [&](int a_panel, int b_panel, int b_relu, float** part, float** rs) {
+    *part = big_slot();
+    float* r = rs ? row_slot() : nullptr;
+    if (rs) *rs = r;
+    WgradArgs w{};
+    w.A = panel_of(k.dpan, P, a_panel); w.M = a_panel == 9 ? 128 : 256; w.a_gstride = 32 * w.M;
+    w.B = panel_of(k.zpan, P, b_panel); w.N = b_panel >= 10 ? 64 : 256; w.b_gstride = 32 * w.N; w.b_relu = b_relu;
+    w.P = P; w.a_max_bits = k.gmax + a_panel;
+    w.out_scale = b_panel >= 10 ? 1.0f : kInv;    // the encodings are stored at true scale, the pre-activations x 2^6
+    w.partial = *part; w.split_stride = (int64_t)256 * 256; w.splits = sp; w.row_sums = r;
+    return wgrad_f16x3(w, st);
+  };
+  float *part, *rs;
   const int64_t per = (P / 32 + sp - 1) / sp;
+  // rgb head: d_rgb_pre^T relu(zcc), a stream over the panel
+  part = big_slot();
   hipLaunchKernelGGL((panel_wsums_kernel<128, 3>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 9), P, k.drgb, kRgbPad, 0.0f,
                      kInv, per, part);
   NSR_CHECK_LAUNCH();
-  NSR_TRY(rowsum_finish(st, part, sp, 3 * 128, g[kRgbW], acc));
-  NSR_TRY(colsum(st, k.drgb, kRgbPad, P, 0, 3, g[kRgbB], acc, part));
+  sum_rows(g[kRgbW], 3 * 128, part);
+  NSR_TRY(colsum(st, k.drgb, kRgbPad, P, 0, 3, g[kRgbB], acc, k.partial));
   // dir_encoding: dzc^T [g | de]
-  NSR_TRY(panel_wgrad(st, k, P, 9, 8, 0, part, sp, rs));
-  NSR_TRY(reduce_place(st, g[kDirW], 283, 0, 128, 256, part, sp, kW, 0, 0, acc));
-  NSR_TRY(rowsum_finish(st, rs, sp, kDirOut, g[kDirB], acc));
-  NSR_TRY(panel_wgrad(st, k, P, 9, 11, 0, part, sp, nullptr));
-  NSR_TRY(reduce_place(st, g[kDirW], 283, 256, 128, 27, part, sp, kPe, 0, 0, acc, 1.0f, 2));
+  NSR_TRY(product(9, 8, 0, &part, &rs));
+  place(g[kDirW], 283, 0, 128, 256, part, kW, 0);
+  sum_rows(g[kDirB], kDirOut, rs);
+  NSR_TRY(product(9, 11, 0, &part, nullptr));
+  place(g[kDirW], 283, 256, 128, 27, part, kPe, 2);
   // xyz_encoding_final: dg^T relu(z8); sigma: d_sigma^T relu(z8)
-  NSR_TRY(panel_wgrad(st, k, P, 8, 7, 1, part, sp, rs));
-  NSR_TRY(reduce_place(st, g[kFinalW], 256, 0, 256, 256, part, sp, kW, 0, 0, acc));
-  NSR_TRY(rowsum_finish(st, rs, sp, kW, g[kFinalB], acc));
+  NSR_TRY(product(8, 7, 1, &part, &rs));
+  place(g[kFinalW], 256, 0, 256, 256, part, kW, 0);
+  sum_rows(g[kFinalB], kW, rs);
+  part = big_slot();
   hipLaunchKernelGGL((panel_wsums_kernel<256, 1>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 7), P, k.g1 + kSigmaCol, kGs,
                      0.0f, kInv, per, part);
   NSR_CHECK_LAUNCH();
-  NSR_TRY(rowsum_finish(st, part, sp, 256, g[kSigmaW], acc));
-  NSR_TRY(colsum(st, k.g1, kGs, P, 256, 1, g[kSigmaB], acc, part));
+  sum_rows(g[kSigmaW], 256, part);
+  NSR_TRY(colsum(st, k.g1, kGs, P, 256, 1, g[kSigmaB], acc, k.partial));
   // trunk layers 8..1: dz_L^T (input of layer L)
   for (int L = 8; L >= 1; --L) {
     float* gw = g[2 * (L - 1)];
-    if (L == 1 || L == 5) {   // over the encoded position (panel 10, 64 rows in register order)
-      NSR_TRY(panel_wgrad(st, k, P, L - 1, 10, 0, part, sp, L == 1 ? rs : nullptr));
-      NSR_TRY(reduce_place(st, gw, L == 1 ? 63 : 319, 0, 256, 63, part, sp, kPe, 0, 0, acc, 1.0f, 1));
-    }
+    rs = nullptr;
     if (L > 1) {
-      NSR_TRY(panel_wgrad(st, k, P, L - 1, L - 2, 1, part, sp, rs));
-      NSR_TRY(reduce_place(st, gw, L == 5 ? 319 : 256, L == 5 ? 63 : 0, 256, 256, part, sp, kW, 0, 0, acc));
+      NSR_TRY(product(L - 1, L - 2, 1, &part, &rs));
+      place(gw, L == 5 ? 319 : 256, L == 5 ? 63 : 0, 256, 256, part, kW, 0);
     }
-    NSR_TRY(rowsum_finish(st, rs, sp, kW, g[2 * (L - 1) + 1], acc));
+    if (L == 1 || L == 5) {   // over the encoded position (panel 10, 64 rows in register order)
+      NSR_TRY(product(L - 1, 10, 0, &part, L == 1 ? &rs : nullptr));
+      place(gw, L == 1 ? 63 : 319, 0, 256, 63, part, kPe, 1);
+    }
+    sum_rows(g[2 * (L - 1) + 1], kW, rs);
   }
+  if (n_big > kChainSlots || n_row > kChainRowSlots || jobs.n > kMaxFinishJobs) return NSR_ERR_UNSUPPORTED;   // cannot happen
+  hipLaunchKernelGGL(finish_jobs_kernel, dim3(256, jobs.n), dim3(256), 0, st, jobs);
+  NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
 
