@@ -39,8 +39,7 @@ constexpr int kSigmaCol = 256, kDeCol = 260;     // columns of the [g | sigma | 
 constexpr int kMaxSplits = 256;
 constexpr int64_t kPartialFloats = (int64_t)kGs * kX5;   // >= every padded weight-gradient shape
 constexpr int kChainSlots = 14, kChainRowSlots = 12;     // chain path: partial sums of a network's 14 weight-gradient
-constexpr int64_t kSlotFloats = (int64_t)kMaxSplits * 256 * 256;   // products and of its bias row sums, all alive until
-constexpr int64_t kRowSlotFloats = (int64_t)kMaxSplits * 256;      // ONE finishing launch
+                                                        // products and of its bias row sums, all alive until ONE finishing launch
 
 // state_dict indices (nsr.h): layer i (1..8) weight = 2 (i - 1), bias = 2 (i - 1) + 1
 constexpr int kFinalW = 16, kFinalB = 17, kDirW = 18, kDirB = 19, kSigmaW = 20, kSigmaB = 21, kRgbW = 22, kRgbB = 23;
@@ -499,7 +498,9 @@ int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base) {
   k.comp = take(chunk * 3);   k.g_comp = take(chunk * 3);
   k.scratch_out = take(chunk * (nf + 8));
   k.partial = take(kMaxSplits * kPartialFloats);           // also scratch of the small bias sums
-  k.slots = take(kChainSlots * kSlotFloats);               // chain path: every second pass of a network waits for one launch
+  // chain path: every second pass of a network waits for one launch; sized by the split-K factor of the larger pass
+  const int64_t sp_max = (P + 511) / 512 < 1 ? 1 : ((P + 511) / 512 > kMaxSplits ? kMaxSplits : (P + 511) / 512);
+  k.slots = take(kChainSlots * sp_max * 256 * 256);
   k.block_sums = reinterpret_cast<double*>(take(2 * (chunk / 256 + 2)));
   k.carry = reinterpret_cast<double*>(take(8));
   for (int n = 0; n < 2; ++n) {
@@ -510,7 +511,7 @@ int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base) {
   }
   const int64_t pan = nsr_f16x3_train_panel_floats(P);
   k.zpan = take(pan);   k.dpan = take(pan);
-  k.row_part = take(kChainRowSlots * kRowSlotFloats);
+  k.row_part = take(kChainRowSlots * sp_max * 256);
   k.gmax = reinterpret_cast<unsigned*>(take(64));
   k.sgn = reinterpret_cast<unsigned*>(take(nsr_f16x3_train_sign_words(P)));
   for (int n = 0; n < 2; ++n) {
@@ -712,8 +713,8 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
   constexpr float kInv = 1.0f / 64.0f;
   FinishJobs jobs{};
   int n_big = 0, n_row = 0;
-  auto big_slot = [&]() { return k.slots + (int64_t)(n_big++) * kSlotFloats; };
-  auto row_slot = [&]() { return k.row_part + (int64_t)(n_row++) * kRowSlotFloats; };
+  auto big_slot = [&]() { return k.slots + (int64_t)(n_big++) * sp * 256 * 256; };     // sp <= the workspace's sp_max
+  auto row_slot = [&]() { return k.row_part + (int64_t)(n_row++) * sp * 256; };
   // second passes, executed by finish_jobs_kernel at the end
   auto place = [&](float* dst, int dst_ld, int dc0, int rows, int cols, const float* partial, int p_ld, int enc_rows) {
     FinishJob& q = jobs.j[jobs.n++];
