@@ -18,8 +18,11 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kTM = 128, kTK = 32, kLd = kTK + 8;   // LDS row stride in halves
-constexpr int kArrA = kTM * kLd;                    // halves per staged A array
+// development switch: -DNSR_GEMM_K32_ONLY=1 keeps every launch on K tiles of 32 (A/B in profiles/)
+#ifndef NSR_GEMM_K32_ONLY
+#define NSR_GEMM_K32_ONLY 0
+#endif
+constexpr int kTM = 128, kTK = 32;   // row tile; default K tile (the kernels pad LDS rows by 8 halves)
 
 __global__ void split_f16_kernel(const float* __restrict__ w, int64_t n, unsigned short* __restrict__ hi,
                                  unsigned short* __restrict__ lo) {
@@ -97,9 +100,14 @@ __device__ __forceinline__ int64_t xcd_tile(int64_t launch_idx, int64_t n_blocks
 #endif
 }
 
-template <int WN, bool APL>   // APL: A comes as (hi, lo) fp16 planes
+// APL: A comes as (hi, lo) fp16 planes.  TK: K tile, 32 or (plane A only) 64 halves -- twice the MFMAs between two
+// barriers for the same staging overhead, 110 KB of LDS on the 8-wave tile
+template <int WN, bool APL, int TK = 32>
 __global__ void __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))   // <= 256 registers
 gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
+  static_assert(TK == 32 || (APL && TK == 64), "K tiles of 64 are built for pre-split A only");
+  constexpr int kLd = TK + 8, kArrA = kTM * kLd;            // shadow the 32-wide constants of the file
+  constexpr int kCh = TK / 8;                               // 16-byte chunks (8 halves) per row and plane
   constexpr int NT = 128 * WN, kTN = 64 * WN, kArrB = kTN * kLd;
   __shared__ __attribute__((aligned(16))) _Float16 lds[2 * kArrA + 2 * kArrB];   // A hi | A lo | B hi | B lo
   const GemmArgs& g = a.g;
@@ -113,7 +121,7 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
   if (bid >= n_blocks) return;                     // padding of the launch to a multiple of 8 (whole workgroup)
   const int64_t m0 = (bid / n_col_tiles) * kTM;
   const int n0 = (int)(bid % n_col_tiles) * kTN;
-  const int n_tiles = (int)(g.K / kTK);
+  const int n_tiles = (int)(g.K / TK);
   const bool conv = a.conv.cin > 0;
 
   f32x16 acc[2][2];
@@ -130,9 +138,11 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
   // ---- staging assignment.  fp32 A: NA x (row = (tid >> 3) + (NT / 8) i, float4 column c4 = tid & 7), split on the way
   // to LDS; plane A: NP x (row = (tid >> 2) + (NT / 4) i, 8-half chunk c8 = tid & 3) of each plane, copied as it is.
   // B: 2 x 2 x (row = (tid >> 2) + (NT / 4) i, 8-half chunk c8 = tid & 3)
-  constexpr int NA = APL ? 512 / NT : 1024 / NT, kARows = APL ? NT / 4 : NT / 8, kBRows = NT / 4;
-  const int c4 = tid & 7, c8 = tid & 3, br0 = tid >> 2;
-  const int ar0 = APL ? (tid >> 2) : (tid >> 3);
+  // (with K tiles of 64: eight chunks per row, rows (tid >> 3) + (NT / 8) i)
+  constexpr int NA = APL ? kTM * kCh / NT : 1024 / NT, kARows = APL ? NT / kCh : NT / 8, kBRows = NT / kCh;
+  constexpr int NBP = kTN * kCh / NT;                       // B chunks per thread and plane
+  const int c4 = tid & 7, c8 = tid % kCh, br0 = tid / kCh;
+  const int ar0 = APL ? (tid / kCh) : (tid >> 3);
   const int a_col = APL ? 8 * c8 : 4 * c4;                  // column offset inside the K tile, in elements
   // row base of the A operand in ELEMENTS from its base pointer (fp32: g.A floats; planes: a.Ah halves); -1 = zero row
   int64_t arow[NA];
@@ -151,10 +161,10 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
       arow[i] = m * g.lda;
     }
   }
-  const unsigned short* bh_row[2];
-  const unsigned short* bl_row[2];
+  const unsigned short* bh_row[NBP];
+  const unsigned short* bl_row[NBP];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NBP; ++i) {
     int n = n0 + br0 + kBRows * i;
     n = n < g.N ? n : g.N - 1;
     bh_row[i] = a.Bh + (int64_t)n * a.ldbh;
@@ -162,9 +172,9 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
   }
   f32x4 sa[APL ? 1 : NA];
   u32x4 sah[APL ? NA : 1], sal[APL ? NA : 1];
-  u32x4 sbh[2], sbl[2];
+  u32x4 sbh[NBP], sbl[NBP];
   auto load = [&](int t) {
-    const int64_t k0 = (int64_t)t * kTK;
+    const int64_t k0 = (int64_t)t * TK;
     int64_t koff = k0;
     if (conv) {
       // the gather address of a row changes only when the K tile enters the next tap (every cin / 32 tiles):
@@ -197,7 +207,7 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NBP; ++i) {
       sbh[i] = *reinterpret_cast<const u32x4*>(bh_row[i] + k0 + 8 * c8);
       sbl[i] = *reinterpret_cast<const u32x4*>(bl_row[i] + k0 + 8 * c8);
     }
@@ -222,7 +232,7 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NBP; ++i) {
       const int off = (br0 + kBRows * i) * kLd + 8 * c8;
       *reinterpret_cast<u32x4*>(lds + 2 * kArrA + off) = sbh[i];
       *reinterpret_cast<u32x4*>(lds + 2 * kArrA + kArrB + off) = sbl[i];
@@ -237,7 +247,7 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
     const _Float16* ap = lds + (64 * wm + li) * kLd + 8 * h;
     const _Float16* bp = lds + 2 * kArrA + (64 * wn + li) * kLd + 8 * h;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < TK / 16; ++s) {
       h8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int bi = 0; bi < 2; ++bi) {
@@ -473,7 +483,10 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
     if (wide) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<4>), dim3((unsigned)n_blocks), dim3(512), 0, st, a, n_col_tiles);
     else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<2>), dim3((unsigned)n_blocks), dim3(256), 0, st, a, n_col_tiles);
 #else
-    if (wide) hipLaunchKernelGGL((gemm_f16x3_kernel<4, true>), grid, dim3(512), 0, st, a, n_col_tiles, n_blocks);
+    const bool k64 = (g.K % 64) == 0 && (a.conv.cin <= 0 || (a.conv.cin % 64) == 0) && !NSR_GEMM_K32_ONLY;
+    if (wide && k64) hipLaunchKernelGGL((gemm_f16x3_kernel<4, true, 64>), grid, dim3(512), 0, st, a, n_col_tiles, n_blocks);
+    else if (wide) hipLaunchKernelGGL((gemm_f16x3_kernel<4, true>), grid, dim3(512), 0, st, a, n_col_tiles, n_blocks);
+    else if (k64) hipLaunchKernelGGL((gemm_f16x3_kernel<2, true, 64>), grid, dim3(256), 0, st, a, n_col_tiles, n_blocks);
     else hipLaunchKernelGGL((gemm_f16x3_kernel<2, true>), grid, dim3(256), 0, st, a, n_col_tiles, n_blocks);
 #endif
   } else {
