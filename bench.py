@@ -104,6 +104,15 @@ def committed_pmc(precision: str) -> dict:
         return {}
 
 
+def committed_train_traffic(R):
+    """HBM bytes per training step from the committed PMC run (profiles/r2_train_traffic.json, measured at 2,048 rays)."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r2_train_traffic.json")) as f:
+            return int(json.load(f)["hbm_bytes_per_step"] * (R / 2048.0))
+    except Exception:
+        return None
+
+
 def main_train(args):
     """Training-step benchmark (not the headline): scripts/train_llff_downX.sh's batch -- 512 LR pixels x 4
     sub-rays = 2,048 rays per GPU per step, 64 + 128 samples, randomized sampling, noise_std 1 -- through
@@ -178,10 +187,12 @@ def main_train(args):
             res["roofline"] = {"bound": "hbm", "kernel": "whole training step, chain path (mlp_f16x3_kernel TRAIN, "
                                                           "chain_bwd_kernel, wgrad_f16x3_kernel)",
                                "achieved": gb / (dt / args.steps), "peak": 8000.0, "unit": "GB/s",
-                               "frac": gb / (dt / args.steps) / 8000.0, "traffic": None, "gbytes_per_step": gb,
+                               "frac": gb / (dt / args.steps) / 8000.0, "traffic": committed_train_traffic(R),
+                               "gbytes_per_step": gb,
                                "mfma_tflops_issued": 3 * achieved,
                                "note": "algorithmic bytes = 44,800 B of panel traffic per sample point x 192 points per ray "
-                                       "(split-K partial sums, weight streams and per-ray arrays excluded); "
+                                       "(split-K partial sums, weight streams and per-ray arrays excluded; traffic = PMC-measured HBM bytes of all kernels "
+                                       "of a step, profiles/r2_train_traffic.json); "
                                        "mfma_tflops_issued = 3 fp16 MFMAs per product x 3 x the forward MACs"}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import train_oracle as to     # checker/baseline only; never on the product path
