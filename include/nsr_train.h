@@ -10,8 +10,10 @@
  * (see NSR_N_STATE_TENSORS in nsr.h), handed over as HOST arrays of 24 DEVICE pointers, so a binding can
  * pass `p.data_ptr()` / `p.grad.data_ptr()` of the reference's own parameters.
  *
- * Arithmetic: fp32 storage and accumulation throughout, like the reference; contractions on v_mfma_f32_32x32x2_f32,
- * optionally (precision = NSR_F16X3) the forward ones on split-fp16 v_mfma_f32_32x32x16_f16 with fp32-grade products.
+ * Arithmetic: fp32 storage and accumulation throughout, like the reference.  precision = NSR_FP32: every contraction on
+ * v_mfma_f32_32x32x2_f32, layer by layer.  precision = NSR_F16X3: every contraction (forward, input and weight gradients)
+ * on split-fp16 v_mfma_f32_32x32x16_f16 with fp32-grade products (hi/lo operands, three MFMAs per product; gradients
+ * scaled by exact powers of two per point / per tensor), the network as two fused chain launches per pass -- DESIGN 7.1.
  */
 #ifndef NSR_TRAIN_H_
 #define NSR_TRAIN_H_
@@ -22,8 +24,9 @@
 extern "C" {
 #endif
 
-/* Workspace for one pass over `ray_chunk` rays (activations of one network in both orientations, gradient
- * ping-pong buffers, padded / transposed weight copies, split-K partials).  0 on invalid arguments. */
+/* Workspace for one pass over `ray_chunk` rays (activations of one network, gradient buffers, padded weight copies,
+ * split-K partials; for NSR_F16X3 the pre-activation / gradient panels, ~35 KB per sample point in all).  0 on invalid
+ * arguments. */
 size_t nsr_train_workspace_bytes(int64_t ray_chunk, int n_coarse, int n_importance);
 
 /* Losses and d(loss_tot)/d(weights) of one batch.
@@ -36,8 +39,9 @@ size_t nsr_train_workspace_bytes(int64_t ray_chunk, int n_coarse, int n_importan
  * (R, Nc), noise_fine (R, Nc + Ni) standard normal, scaled by noise_std.  NULL selects the deterministic
  * branch of the corresponding stage (randomized = False / noise off).
  * g_coarse / g_fine: 24 gradient tensors each, OVERWRITTEN.
- * precision: NSR_FP32 = every product on the fp32 MFMA; NSR_F16X3 = the forward products of both networks on the
- * split-fp16 MFMA (exact to ~2^-21, the inference path's scheme), gradients on the fp32 MFMA.
+ * precision: NSR_FP32 = every product on the fp32 MFMA; NSR_F16X3 = every product on the split-fp16 MFMA (exact to
+ * ~2^-21, the inference path's scheme; the environment variable NSR_TRAIN_PATH=gemm selects round 1's variant of it:
+ * per-layer GEMMs, forward products split-fp16, gradients on the fp32 MFMA).
  * ray_chunk: rays per pass (bounds the workspace; multiple of s2; 0 = R); gradients and losses of the passes
  * are accumulated, the result does not depend on the chunking beyond fp32 summation order.  Every pass -- the
  * shorter last one included -- must hold a multiple of 32 sample points in both networks
