@@ -1,0 +1,25 @@
+#!/bin/bash
+# SQ / GRBM counters of the training step's kernels (one --pmc pass; 1 warm-up + 2 timed steps, sums / 3).
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$PWD}
+mkdir -p $R/gpurun_out/train_traffic
+rm -rf /tmp/tsq
+(cd /tmp && rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/tsq -o run -- python $R/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline > /tmp/tsq.log 2>&1)
+python - <<PY
+import csv, collections, glob, json
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+for f in glob.glob("/tmp/tsq/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0].split("::")[-1].strip()[:40]
+        acc[n][r["Counter_Name"]] += float(r["Counter_Value"]) / 3.0
+out = {}
+for n, c in acc.items():
+    if c.get("GRBM_GUI_ACTIVE", 0) < 1e5: continue
+    wc = c["SQ_WAVE_CYCLES"]
+    out[n] = {"gui_active_cycles_per_step": int(c["GRBM_GUI_ACTIVE"]),
+              "mfma_busy": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (128.0 * c["GRBM_GUI_ACTIVE"]), 4),
+              "wave_cycles_split": {"active": round(c["SQ_ACTIVE_INST_ANY"] / wc, 3), "issue_wait": round(c["SQ_WAIT_INST_ANY"] / wc, 3),
+                                    "parked": round(c["SQ_WAIT_ANY"] / wc, 3)}}
+json.dump(out, open("$R/gpurun_out/train_traffic/SQ.json", "w"), indent=1)
+print(json.dumps(out, indent=1)[:2500])
+PY
