@@ -69,16 +69,24 @@ def build(force: bool = False, verbose: bool = True, variant: str = "", defines=
     objdir = os.path.join(HERE, "build", variant) if variant else os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", *defines]
-    objs = []
+    objs, jobs = [], []
+    newest = _newest_source_mtime()
     for src, extra in UNITS + [VARIANT_UNITS[d] for d in defines if d in VARIANT_UNITS]:
         obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
         srcp = os.path.join(CSRC, src)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < _newest_source_mtime():
-            cmd = [hipcc, *common, *extra, "-c", srcp, "-o", obj]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+            jobs.append([hipcc, *common, *extra, "-c", srcp, "-o", obj])
         objs.append(obj)
+    # the units are independent: compile them side by side (the three MFMA chain kernels take 30-40 s each)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def _compile(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs) or 1, os.cpu_count() or 1))) as pool:
+        list(pool.map(_compile, jobs))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
