@@ -13,9 +13,13 @@
 //   layer 1          dz8 = (Wfinal^T dg + wsigma d_sigma) * [z8 > 0]       K = 256 + 4 prepended k-steps (sigma)
 //   layers 2..8      dz_{l-1} = (W_l^T dz_l) * [z_{l-1} > 0], l = 8..2     (l = 5: the h4 columns of the skip layer)
 //
-// Inputs: the forward panels (pre-activations, nsr_f16x3_core.h); outputs: gradient panels of the same layout, TRUE
-// scale fp32 -- the operands of the weight-gradient GEMMs (nsr_gemm.h, a_blk), whose staging also sums them into the
-// bias gradients.
+// Inputs: the sign panels of the forward pass (one bit per pre-activation, nsr_f16x3_core.h) for the ReLU masks;
+// outputs: gradient panels in the forward panels' layout, TRUE scale fp32 -- the A operands of the weight-gradient
+// kernel (nsr_wgrad_f16.hip), whose staging also sums them into the bias gradients -- and, per panel, the largest
+// magnitude written (that kernel's fp16 pre-scale).
+// Vector-memory choreography per 16-k-step block: weight DMA of the chunk after next in k-steps 8..13, then the 16
+// stores of the pending block and the sign-word load of the next one in k-steps 14, 15 -- behind the DMA, so the next
+// publish point (s_waitcnt vmcnt(17)) does not have to wait for them.
 //
 // Range: gradients sit far below fp16's range and differ by orders of magnitude from point to point, so every point
 // (lane pair) carries its own power-of-two scale: the prologue scales the point's inputs to max 2^1..2^2, and each

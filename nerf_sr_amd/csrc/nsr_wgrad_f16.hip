@@ -6,12 +6,13 @@
 // max(., 0) when the consumer saw them behind a ReLU).  Both are "blocked transposed" ([group of 32 points][row][32],
 // nsr_f16x3_core.h), so the K tile of one point group is ONE contiguous rows x 128 B run of each panel: the staging
 // loads are perfectly coalesced float4 streams and every byte of both panels is read exactly once by exactly one
-// workgroup (tile = all M x all 256 columns).  Each value is split into fp16 (hi, lo) on its way from registers to LDS
+// workgroup (tile = all M x all N columns; PMC: 8.36 GB fetched per 2,048-ray step against 8.36 GB of panels,
+// profiles/r2_train_traffic.json).  Each value is split into fp16 (hi, lo) on its way from registers to LDS
 // and each product is a_hi b_hi + a_hi b_lo + a_lo b_hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation: 3/16 of the
 // fp32-MFMA cycles, which turns the product from matrix-pipe bound (68 % of the fp32 peak, 0.32 ms per fine-pass layer)
 // into HBM bound (two panels of P KiB each).
 // Range: gradients are tiny (1e-8 .. 1e-3), so A is multiplied by a power of two S that puts the panel's largest
-// magnitude (kept by the backward chain, one atomicMax per wave and layer) at 2^13..2^14; elements far below the
+// magnitude (kept by the backward chain: an LDS atomicMax per lane and layer, a global one per workgroup) at 2^13..2^14; elements far below the
 // maximum lose relative precision against fp16's subnormal floor (2^-24 / S absolute), which is 2^-38 of the panel's
 // maximum -- nothing a sum over the points can see.  S and B's 2^6 are removed from the accumulators (exactly) before
 // the partial sums are written; the split-K reduction is the deterministic second pass of the fp32 path.
