@@ -120,11 +120,6 @@ struct Loader {
   const char* dma_base;
   unsigned dma_lds;
   int dma_count;
-#ifdef NSR_F16X3_STAGED
-  // EXPERIMENT (-DNSR_F16X3_STAGED): the weight stream goes global -> registers -> LDS instead of by LDS-DMA: pieces are
-  // loaded in the k-steps the DMA would be issued in and written to the slot in k-steps 0..5 of the following chunk
-  u32x4 st[12];
-#endif
 };
 
 __device__ __forceinline__ void loader_prepare_dma(Loader& ld, const ChunkRef& c, unsigned slot_lds) {
@@ -133,27 +128,6 @@ __device__ __forceinline__ void loader_prepare_dma(Loader& ld, const ChunkRef& c
   ld.dma_lds = slot_lds + (unsigned)c.first * 1024u;
 }
 
-#ifdef NSR_F16X3_STAGED
-__device__ __forceinline__ void loader_issue(Loader& ld, int i) {
-  if (i < 8 || i < ld.dma_count) ld.st[i] = *reinterpret_cast<const u32x4*>(ld.dma_base + i * 1024 + ld.lane_off);
-}
-__device__ __forceinline__ void loader_issue2(Loader& ld, int j) {
-  loader_issue(ld, 2 * j);
-  loader_issue(ld, 2 * j + 1);
-}
-__device__ __forceinline__ void stage_write(const u32x4& v, unsigned lds_byte_addr) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  *(__attribute__((address_space(3))) u32x4*)(size_t)lds_byte_addr = v;
-#else
-  (void)v; (void)lds_byte_addr;
-#endif
-}
-// second half of the staged transfer of piece i (the descriptor is the one the loads were issued under)
-__device__ __forceinline__ void loader_commit(Loader& ld, int i) {
-  if (i < 8 || i < ld.dma_count) stage_write(ld.st[i], ld.dma_lds + (unsigned)i * 1024u + ld.lane_off);
-}
-#else
-__device__ __forceinline__ void loader_commit(Loader&, int) {}
 // issue this wave's DMA piece number i of the chunk being fetched (no-op past its end)
 __device__ __forceinline__ void loader_issue(const Loader& ld, int i) {
 #ifdef NSR_ABL_NO_DMA
@@ -181,7 +155,6 @@ __device__ __forceinline__ void loader_issue2(const Loader& ld, int j) {
   if (j & 1) glds16x2_asm<2048>(base, ld.lane_off, dst);
   else glds16x2_asm<0>(base, ld.lane_off, dst);
 }
-#endif   // NSR_F16X3_STAGED
 
 __device__ __forceinline__ void loader_advance(Loader& ld) {
   const unsigned t = ld.slot_cur;
@@ -267,10 +240,6 @@ __device__ __forceinline__ void block_mma(Acc& acc, const Pre& pre, unsigned a_a
   }
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
-    if (BAR >= 0 && s < 6) {   // staged-loader experiment only (no-ops otherwise): land the pieces loaded one chunk ago
-      loader_commit(ld, 2 * s);
-      loader_commit(ld, 2 * s + 1);
-    }
     if (s == BAR) loader_publish<YOUNGER>(ld, c2, strict);
     if (s + kPF < NSTEP) {
       ah[s + kPF] = a_pieces[(2 * (s + kPF)) * 64];

@@ -374,9 +374,6 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   loader_prepare_dma(ld, make_ref(0, 33, wave), ld.slot_cur);
 #pragma unroll
   for (int i = 0; i < 11; ++i) loader_issue(ld, i);
-#ifdef NSR_F16X3_STAGED
-  Loader ld0 = ld;   // chunk 0's pieces and descriptor: committed behind the encoding prologue, like chunk 1's
-#endif
   loader_prepare_dma(ld, make_ref(33, 33, wave), ld.slot_next);
 #pragma unroll
   for (int i = 0; i < 11; ++i) loader_issue(ld, i);
@@ -466,12 +463,6 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     for (int t = 0; t < 16; ++t) row_store(t, de[t], dblk, voff_de);
   }
 
-#ifdef NSR_F16X3_STAGED
-#pragma unroll
-  for (int i = 0; i < 11; ++i) loader_commit(ld0, i);
-#pragma unroll
-  for (int i = 0; i < 11; ++i) loader_commit(ld, i);
-#endif
   // park the split position encoding in LDS: L5 (skip) re-reads it, which frees 32 registers in the loop
   u32x4* stash = reinterpret_cast<u32x4*>(ring + kStash0) + wave * 8 * 64 + lane;
 #pragma unroll
@@ -531,10 +522,6 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
       pend = cur;
     }
     if (c == 1) pre = nxt;
-    if (c == 0) {   // staged-loader experiment only: chunk 2 must be in LDS before the publish point of the second L1 chunk
-#pragma unroll
-      for (int i = 0; i < 11; ++i) loader_commit(ld, i);
-    }
     loader_advance(ld);
   }
 
