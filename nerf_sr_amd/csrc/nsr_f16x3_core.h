@@ -316,6 +316,9 @@ __device__ __forceinline__ void panel_store_r(float v, const float* blk, unsigne
   asm volatile("global_store_dword %0, %1, %2 offset:%3" NSR_PANEL_STORE_POLICY : : "v"(voff), "v"(v), "s"(blk), "n"((8 * (R >> 2) + (R & 3)) * 128) : "memory");
 }
 __device__ __forceinline__ void panel_store(int r, const Acc& p, const float* blk, unsigned voff) {
+#ifdef NSR_ABL_FWD_NO_STORE   // ablation (scripts/): how much of the TRAIN forward kernel is its panel writes
+  if (voff != 0xffffffffu) return;
+#endif
   switch (r) {
 #define NSR_PS(R) case R: panel_store_r<R>(p.m[R], blk, voff); break;
     NSR_PS(0) NSR_PS(1) NSR_PS(2) NSR_PS(3) NSR_PS(4) NSR_PS(5) NSR_PS(6) NSR_PS(7)

@@ -253,6 +253,9 @@ __device__ __forceinline__ void bwd_step(int s, Acc& p, unsigned mz, Scale& sc, 
 // compiler-visible loads (the mask words), and the compiler's vmcnt for a load only counts the younger operations it
 // can see -- with invisible stores behind the load its wait would cover them as well.
 __device__ __forceinline__ void bwd_panel_store(int r, const Acc& p, const float* blk, unsigned voff) {
+#ifdef NSR_ABL_BWD_NO_STORE   // ablation (scripts/): how much of the kernel is its panel writes
+  if (voff != 0xffffffffu) return;
+#endif
   float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(const_cast<float*>(blk)) + voff + (8 * (r >> 2) + (r & 3)) * 128);
   __builtin_nontemporal_store(p.m[r], dst);
 }
