@@ -79,6 +79,7 @@ struct WgradArgs {
   int b_relu;
   int64_t P;                                  // points, multiple of 32
   const unsigned* a_max_bits;
+  const float* a_pscale;                      // may be null: per point, A's stored values x a_pscale = the true values
   float out_scale;
   float* partial; int64_t split_stride; int splits;
   float* row_sums;                            // may be null: (splits, M) sums of A's rows over the slice (fp32, true scale)

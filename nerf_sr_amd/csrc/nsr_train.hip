@@ -473,6 +473,7 @@ struct Work {   // per-pass buffers, sized for P_max = chunk * (Nc + Ni) sample 
   float *zpan, *dpan, *row_part, *slots;
   float *stream_f[2], *stream_b[2];
   unsigned* sgn;    // sign panels of the forward pass (nsr_f16x3_core.h)
+  float* pscale;    // per gradient panel and point: stored value x pscale = true gradient (written by the backward chain)
   unsigned* gmax;   // float bits of the largest magnitude in each gradient panel (written by the backward chain)
 };
 
@@ -513,6 +514,7 @@ int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base) {
   k.zpan = take(pan);   k.dpan = take(pan);
   k.row_part = take(kChainRowSlots * sp_max * 256);
   k.gmax = reinterpret_cast<unsigned*>(take(64));
+  k.pscale = take(10 * ((P + 127) / 128) * 128);
   k.sgn = reinterpret_cast<unsigned*>(take(nsr_f16x3_train_sign_words(P)));
   for (int n = 0; n < 2; ++n) {
     k.stream_f[n] = take((int64_t)(nsr_f16x3_packed_bytes() / 4));
@@ -734,6 +736,7 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
     w.A = panel_of(k.dpan, P, a_panel); w.M = a_panel == 9 ? 128 : 256; w.a_gstride = 32 * w.M;
     w.B = panel_of(k.zpan, P, b_panel); w.N = b_panel >= 10 ? 64 : 256; w.b_gstride = 32 * w.N; w.b_relu = b_relu;
     w.P = P; w.a_max_bits = k.gmax + a_panel;
+    w.a_pscale = k.pscale + (int64_t)a_panel * n_groups_of(P) * 32;
     w.out_scale = b_panel >= 10 ? 1.0f : kInv;    // the encodings are stored at true scale, the pre-activations x 2^6
     w.partial = *part; w.split_stride = (int64_t)256 * 256; w.splits = sp; w.row_sums = r;
     return wgrad_f16x3(w, st);
@@ -909,7 +912,7 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
       NSR_CHECK_LAUNCH();
       NSR_TRY(composite_bwd(st, k, z, rc, N, white_bkgd));
       if (chain) {
-        NSR_TRY(nsr_chain_bwd(k.stream_b[net], k.sgn, k.dpan, k.drgb, kRgbPad, k.g1 + kSigmaCol, kGs, P, k.gmax, stream));
+        NSR_TRY(nsr_chain_bwd(k.stream_b[net], k.sgn, k.dpan, k.drgb, kRgbPad, k.g1 + kSigmaCol, kGs, P, k.gmax, k.pscale, stream));
         NSR_TRY(chain_weight_grads(st, k, P, g, acc));
       } else {
         NSR_TRY(net_backward(st, w, k.pack[net], k, P, g, acc));

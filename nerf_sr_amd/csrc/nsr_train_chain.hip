@@ -145,7 +145,9 @@ __device__ __forceinline__ void stage_factors(Scale& cur, const Scale& prev) {
 // re-split of a finished gradient block (in place in its accumulator registers)
 //   MASK:  x = acc * [z > 0]                         (v_cmp + v_cndmask per element)
 //   CONV:  hi = RNE_f16(x) * phi (v_cvt_pk, v_pk_mul), lo = RNE_f16(x phi - hi) (v_fma_mix), max |x| tracked
-//   then   acc = x * cinv  (true scale), stored to the gradient panel by the caller
+//   the masked accumulator x itself is what the caller stores to the gradient panel: x = the true gradient / cinv with
+//   the POINT's power-of-two cinv of this layer, kept once per point and panel (pscale) and applied by the consumer --
+//   the weight-gradient kernel multiplies every staged value by a scale anyway (16 fewer VALU per block here)
 // 17 half-steps as in the forward kernel: half-step 2P = first part of pair P, 2P + 1 = second part of pair P and the
 // lo of pair P - 1.
 // ---------------------------------------------------------------------------------------------------------
@@ -180,9 +182,7 @@ __device__ __forceinline__ void bsplit_a(Acc& p, unsigned mz, Scale& sc, BwdTmp&
         "v_bfe_i32 %4, %5, %8, 1\n\t"
         "v_bfi_b32 %0, %3, 0, %0\n\t"
         "v_bfi_b32 %1, %4, 0, %1\n\t"
-        "v_max3_f32 %2, |%0|, |%1|, %2\n\t"
-        "v_mul_f32 %0, %0, %6\n\t"
-        "v_mul_f32 %1, %1, %6"
+        "v_max3_f32 %2, |%0|, |%1|, %2"
         : "+v"(p.m[2 * P]), "+v"(p.m[2 * P + 1]), "+v"(sc.mx), "=&v"(t0), "=&v"(t1)
         : "v"(mz), "v"(sc.cinv), "n"(15 - 2 * P), "n"(14 - 2 * P));
 }
@@ -203,19 +203,15 @@ __device__ __forceinline__ void bsplit_b(Acc& p, const Scale& sc, BwdTmp& t, u32
     asm volatile(
         "v_fma_mixlo_f16 %1, %2, %4, -%5 op_sel_hi:[0,0,1]\n\t"
         "v_pk_mul_f16 %0, %0, %6\n\t"
-        "v_fma_mixhi_f16 %1, %3, %4, -%5 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_mul_f32 %2, %2, %7\n\t"
-        "v_mul_f32 %3, %3, %7"
-        : "+v"(cur), "=&v"(lo), "+v"(p.m[2 * Q]), "+v"(p.m[2 * Q + 1])
-        : "v"(sc.phi), "v"(prev), "v"(sc.phi2), "v"(sc.cinv));
+        "v_fma_mixhi_f16 %1, %3, %4, -%5 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "+v"(cur), "=&v"(lo)
+        : "v"(p.m[2 * Q]), "v"(p.m[2 * Q + 1]), "v"(sc.phi), "v"(prev), "v"(sc.phi2));
   } else {
     asm volatile(
         "v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_mul_f32 %1, %1, %5\n\t"
-        "v_mul_f32 %2, %2, %5"
-        : "=&v"(lo), "+v"(p.m[2 * Q]), "+v"(p.m[2 * Q + 1])
-        : "v"(sc.phi), "v"(prev), "v"(sc.cinv));
+        "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(lo)
+        : "v"(p.m[2 * Q]), "v"(p.m[2 * Q + 1]), "v"(sc.phi), "v"(prev));
   }
   if (P < 8) bput<(P < 8 ? P : 0)>(cur, h0, h1);
   if (P > 0) bput<Q>(lo, l0, l1);
@@ -280,7 +276,13 @@ struct BwdCtx {
   unsigned voff;
   int lane;
   unsigned* lmax;     // LDS, 16 words: per gradient panel, float bits of the largest magnitude this workgroup wrote
+  float* pscale;      // (10 panels, padded points): stored value x pscale = true gradient
+  int64_t pidx;       // this lane's point slot (group * 32 + m); lanes of the upper half do not write
+  bool writer;
 };
+__device__ __forceinline__ void store_pscale(const BwdCtx& cx, int panel, float v) {
+  if (cx.writer) cx.pscale[(int64_t)panel * cx.dp.n_groups * 32 + cx.pidx] = v;
+}
 // largest true-scale magnitude written to gradient panel `panel` (the weight-gradient kernel scales by it): a no-return
 // LDS atomic per lane now, one global atomicMax per workgroup and panel at the end of the kernel
 __device__ __forceinline__ void publish_max(const BwdCtx& cx, int panel, float v) {
@@ -312,6 +314,7 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
     if (nb == 1) {                             // the previous layer's last block was measured during block 0
       if (prev_panel >= 0) publish_max(cx, prev_panel, prev.mx * prev.cinv);
       stage_factors(cur, prev);
+      store_pscale(cx, panel, cur.cinv);
     }
     if (PREPEND) {
       const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
@@ -367,7 +370,7 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ sgn, float* __restrict__ dpan,
                  const float* __restrict__ d_rgb, int d_rgb_stride, const float* __restrict__ d_sigma, int d_sigma_stride,
-                 int64_t P, unsigned* __restrict__ gmax) {
+                 int64_t P, unsigned* __restrict__ gmax, float* __restrict__ pscale) {
   constexpr int kAux0 = 3 * kSlotFloats;
   __shared__ __attribute__((aligned(16))) float ring[kAux0 + kBwdAuxFloats + 16];
   unsigned* lmax = reinterpret_cast<unsigned*>(ring + kAux0 + kBwdAuxFloats);
@@ -403,6 +406,10 @@ chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ 
   cx.voff = 4u * (unsigned)(m + 128 * h);
   cx.lane = lane;
   cx.lmax = lmax;
+  cx.pscale = pscale;
+  cx.pidx = cx.dp.group * 32 + m;
+  cx.writer = h == 0;
+  store_pscale(cx, 9, 1.0f);   // the colour head's input gradient (prologue) is written at true scale
 
   // ---- prologue: the colour head's input gradient on the VALU (K = 3), masked by dir_encoding's ReLU
   const float g0 = d_rgb[pc * d_rgb_stride + 0], g1 = d_rgb[pc * d_rgb_stride + 1], g2 = d_rgb[pc * d_rgb_stride + 2];
@@ -538,12 +545,12 @@ extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* pack
 
 extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const unsigned* sgn, float* dpan, const float* d_rgb, int d_rgb_stride,
                                           const float* d_sigma, int d_sigma_stride, int64_t P, unsigned* gmax,
-                                          void* stream) {
+                                          float* pscale, void* stream) {
   if (P <= 0) return NSR_OK;
   if (hipMemsetAsync(gmax, 0, 10 * sizeof(unsigned), nsr_stream(stream)) != hipSuccess) return NSR_ERR_LAUNCH;
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   hipLaunchKernelGGL(chain_bwd_kernel, grid, block, 0, nsr_stream(stream), static_cast<const float*>(packed), sgn, dpan, d_rgb,
-                     d_rgb_stride, d_sigma, d_sigma_stride, P, gmax);
+                     d_rgb_stride, d_sigma, d_sigma_stride, P, gmax, pscale);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }

@@ -72,6 +72,7 @@ wgrad_f16x3_kernel(WgradArgs w, int64_t groups_per_slice) {
 
   // staging: float4 number tid + 512 i of the group's contiguous (rows x 32) run = row (tid >> 3) + 64 i, k = 4 (tid & 7)
   f32x4 sa[NA], sb[NB];
+  f32x4 ps = {1.0f, 1.0f, 1.0f, 1.0f};   // per-point scales of this thread's four points (the same for all its rows)
   float rs[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) rs[i] = 0.0f;
@@ -82,6 +83,7 @@ wgrad_f16x3_kernel(WgradArgs w, int64_t groups_per_slice) {
     for (int i = 0; i < NA; ++i) sa[i] = NSR_WGRAD_LOAD(ap + tid + kNT * i);
 #pragma unroll
     for (int i = 0; i < NB; ++i) sb[i] = NSR_WGRAD_LOAD(bp + tid + kNT * i);
+    if (w.a_pscale) ps = reinterpret_cast<const f32x4*>(w.a_pscale + g * 32)[tid & 7];
   };
   auto split_store = [&](const f32x4& v, _Float16* hi_arr, _Float16* lo_arr, int row) {
     h4 hi, lo;
@@ -98,8 +100,9 @@ wgrad_f16x3_kernel(WgradArgs w, int64_t groups_per_slice) {
   auto store = [&]() {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      rs[i] += (sa[i][0] + sa[i][1]) + (sa[i][2] + sa[i][3]);
-      split_store(sa[i] * S, lds, lds + kArrA, (tid >> 3) + 64 * i);
+      const f32x4 t = sa[i] * ps;           // true gradients
+      rs[i] += (t[0] + t[1]) + (t[2] + t[3]);
+      split_store(t * S, lds, lds + kArrA, (tid >> 3) + 64 * i);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
