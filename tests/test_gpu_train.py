@@ -290,3 +290,39 @@ def test_chain_path_ragged_tiles_and_sample_counts(tr):
         num = sum(float((t.grads[n][k].cpu().double() - ref[k]).norm()) ** 2 for k in STATE_DICT_SPEC)
         den = sum(float(ref[k].norm()) ** 2 for k in STATE_DICT_SPEC)
         assert (num / den) ** 0.5 < (1e-3 if n == 0 else 5e-3), (n, (num / den) ** 0.5)
+
+
+def test_chain_path_matches_gemm_path_at_bench_scale(tr, monkeypatch):
+    """The bench's training batch (2,048 rays, 64 + 128 samples = 393,216 sample points, randomized sampling, density
+    noise): the chain path against the layer-by-layer path (gradients on the fp32 MFMA) on identical draws -- the
+    fixtures above hold 96 rays, this is where the split-K factors, multi-tile panels and per-panel scales are at
+    production size.  Losses to 2e-6; every gradient tensor to 1e-3 of its norm, the whole gradient to 2e-4."""
+    from nerf_sr_amd import ops, cameras
+    R = 2048
+    frame = ops.subpixel_rays(cameras.spiral_pose(0.4), (504, 378), cameras.llff_focal(504), 2, True)
+    sel = torch.randperm(frame.shape[0], generator=torch.Generator().manual_seed(3))[: R // 4].cuda()
+    rays = frame[sel].reshape(-1, 8).contiguous()
+    tgt = torch.rand(R // 4, 3, generator=torch.Generator().manual_seed(4)).cuda()
+    res = {}
+    for path in ("gemm", "chain"):
+        if path == "gemm":
+            monkeypatch.setenv("NSR_TRAIN_PATH", "gemm")
+        else:
+            monkeypatch.delenv("NSR_TRAIN_PATH", raising=False)
+        t = tr.Trainer(make_state_dict(99), make_state_dict(100), randomized=True, noise_std=1.0, ray_chunk=R)
+        t.set_input(rays, tgt)
+        torch.manual_seed(77)                      # identical draws for both paths
+        t.loss_and_grads()
+        torch.cuda.synchronize()
+        res[path] = t
+    a, b = res["gemm"], res["chain"]
+    assert float((a.losses - b.losses).abs().max()) < 2e-6
+    for n in range(2):
+        num = den = 0.0
+        for k in STATE_DICT_SPEC:
+            x, y = a.grads[n][k].double(), b.grads[n][k].double()
+            assert torch.isfinite(y).all(), (n, k)
+            e, nx = float((x - y).norm()), float(x.norm())
+            assert e <= 1e-3 * nx + 1e-12, (n, k, e / nx)
+            num, den = num + e * e, den + nx * nx
+        assert (num / den) ** 0.5 < 2e-4, (n, (num / den) ** 0.5)
