@@ -36,7 +36,10 @@ namespace {
 
 constexpr int kW = 256, kPe = 64, kX5 = 320, kGs = 288, kDirOut = 128, kRgbPad = 32;
 constexpr int kSigmaCol = 256, kDeCol = 260;     // columns of the [g | sigma | 0 0 0 | de27 | 0] buffer
-constexpr int kMaxSplits = 256;
+#ifndef NSR_MAX_SPLITS
+#define NSR_MAX_SPLITS 256   // one workgroup per CU.  Same box, 2,048-ray step: 128 -> 6.15 ms, 256 -> 5.30 ms, 512 -> 5.60 ms
+#endif
+constexpr int kMaxSplits = NSR_MAX_SPLITS;
 constexpr int64_t kPartialFloats = (int64_t)kGs * kX5;   // >= every padded weight-gradient shape
 constexpr int kChainSlots = 14, kChainRowSlots = 12;     // chain path: partial sums of a network's 14 weight-gradient
                                                         // products and of its bias row sums, all alive until ONE finishing launch
