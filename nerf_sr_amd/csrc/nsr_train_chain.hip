@@ -10,7 +10,8 @@
 //
 //   prologue (VALU)  dzc = (Wrgb^T d_rgb_pre) * [zcc > 0]                  128 features, K = 3
 //   layer 0          dg  = Wdir[:, :256]^T dzc                             K = 128 (zero-padded to 16 k-steps)
-//   layer 1          dz8 = (Wfinal^T dg + wsigma d_sigma) * [z8 > 0]       K = 256 + 4 prepended k-steps (sigma)
+//   layer 1          dz8 = (Wfinal^T dg + wsigma d_sigma) * [z8 > 0]       K = 256; the density head's rank-1 term is added
+//                                                                          to the finished block on the VALU
 //   layers 2..8      dz_{l-1} = (W_l^T dz_l) * [z_{l-1} > 0], l = 8..2     (l = 5: the h4 columns of the skip layer)
 //
 // Inputs: the sign panels of the forward pass (one bit per pre-activation, nsr_f16x3_core.h) for the ReLU masks;
@@ -33,17 +34,13 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------
-// stream: 9 layers x 8 chunks (one 32-feature output block each), no bias pieces
+// stream: 9 layers x 8 chunks (one 32-feature output block each) of 32 pieces, no bias pieces
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kBwdLayers = 9;
-__device__ __host__ __forceinline__ int bwd_chunk_pieces(int lam) { return lam == 1 ? 40 : 32; }
-__device__ __host__ __forceinline__ int bwd_piece0(int lam, int nb) {
-  if (lam == 0) return 32 * nb;
-  if (lam == 1) return 256 + 40 * nb;
-  return 576 + 256 * (lam - 2) + 32 * nb;
-}
-constexpr int kBwdPieces = 576 + 256 * 7;      // 2368 pieces of 1 KiB
-constexpr int kBwdAuxFloats = 512;             // rgb.weight as [feature][4] (fp32, true scale)
+constexpr int kBwdChunkPieces = 32;            // every chunk: 16 k-steps x (hi, lo)
+__device__ __host__ __forceinline__ int bwd_piece0(int lam, int nb) { return 256 * lam + 32 * nb; }
+constexpr int kBwdPieces = 256 * kBwdLayers;   // 2304 pieces of 1 KiB
+constexpr int kBwdAuxFloats = 768;             // rgb.weight as [feature][4], then sigma.weight [256] (fp32, true scale)
 
 struct BwdPackPtrs {
   const float* p[NSR_N_STATE_TENSORS];
@@ -59,12 +56,8 @@ __global__ void __launch_bounds__(256) pack_bwd_kernel(BwdPackPtrs w, unsigned* 
   unsigned v = 0u;
   if (idx < stream_words) {
     const int piece = idx >> 8, word = idx & 255;
-    int lam, local;
-    if (piece < 256) { lam = 0; local = piece; }
-    else if (piece < 576) { lam = 1; local = piece - 256; }
-    else { lam = 2 + (piece - 576) / 256; local = (piece - 576) % 256; }
-    const int cp = bwd_chunk_pieces(lam);
-    const int nb = local / cp, rem = local % cp;
+    const int lam = piece >> 8, local = piece & 255;
+    const int nb = local / kBwdChunkPieces, rem = local % kBwdChunkPieces;
     const int s = rem >> 1, part = rem & 1;
     const int lane = word >> 2, jj = word & 3;
     const int n = 32 * nb + (lane & 31), h = lane >> 5;
@@ -76,12 +69,8 @@ __global__ void __launch_bounds__(256) pack_bwd_kernel(BwdPackPtrs w, unsigned* 
       if (lam == 0) {                                   // dir_encoding.weight (128, 283): columns 0..255 = g
         const int k = act_feature(8 * s + j, h);
         if (k < 128) x = w.p[18][k * 283 + n];
-      } else if (lam == 1) {                            // sigma.weight (1, 256) in slot 0 of the prepended k-steps,
-        if (s < 4) {                                    // then xyz_encoding_final.weight (256, 256)
-          if (s == 0 && j == 0 && h == 0) x = w.p[20][n];
-        } else {
-          x = w.p[16][act_feature(8 * (s - 4) + j, h) * 256 + n];
-        }
+      } else if (lam == 1) {                            // xyz_encoding_final.weight (256, 256)
+        x = w.p[16][act_feature(8 * s + j, h) * 256 + n];
       } else {                                          // trunk layer l = 10 - lam (8..2), tensor 2 (l - 1)
         const int l = 10 - lam;
         const int k = act_feature(8 * s + j, h);
@@ -92,13 +81,13 @@ __global__ void __launch_bounds__(256) pack_bwd_kernel(BwdPackPtrs w, unsigned* 
     v = pack_hl(f[0], f[1], part);
   } else {
     const int a = idx - stream_words, feat = a >> 2, c = a & 3;
-    v = __float_as_uint(c < 3 ? w.p[22][c * 128 + feat] : 0.0f);
+    v = __float_as_uint(a >= 512 ? w.p[20][a - 512] : (c < 3 ? w.p[22][c * 128 + feat] : 0.0f));
   }
   out[idx] = v;
 }
 
 __device__ __forceinline__ ChunkRef bwd_ref(int lam, int nb, int wave) {
-  return make_ref(bwd_piece0(lam, nb), bwd_chunk_pieces(lam), wave);
+  return make_ref(bwd_piece0(lam, nb), kBwdChunkPieces, wave);
 }
 // chunk number q = 8 lam + nb of the stream; past the end chunk 0 is re-fetched into the idle slot (as in the forward)
 __device__ __forceinline__ ChunkRef bwd_seq(int q, int wave) {
@@ -292,15 +281,18 @@ __device__ __forceinline__ void publish_max(const BwdCtx& cx, int panel, float v
 // One layer `lam` of the chain: operands (bh, bl) -> eight output blocks.
 //   PREV_MASK / PREV_PANEL: the layer before (whose block 7 is still pending on entry): its mask flag and gradient panel
 //   MASK: this layer's outputs are masked by forward panel `panel` (and written to gradient panel `panel`)
-//   PREPEND: 4 extra k-steps ahead of the 16 (sigma operand in slot 0)
+//   ADD: this layer's finished blocks get the density head's rank-1 term, acc += wsigma[feature] * sig (sig = d_sigma at
+//        the accumulators' scale) -- 16 FMAs per block of layer 1 instead of streaming a (mostly zero) k-step for it
 //   LAST: outputs are not converted (nothing consumes them in this kernel)
 //   NEXT_MASK / next_panel: the layer after this one, whose first block's masks are fetched during this layer's last block
 //   FIRST: no layer before this one (layer 0): block 0 has nothing pending to convert or store
-template <bool PREV_MASK, bool MASK, bool PREPEND, bool LAST, bool NEXT_MASK, bool FIRST = false>
+template <bool PREV_MASK, bool MASK, bool ADD, bool LAST, bool NEXT_MASK, bool FIRST = false>
 __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, int next_panel, u32x4 (&bh)[16], u32x4 (&bl)[16], u32x4 (&oh)[16],
-                                          u32x4 (&ol)[16], const u32x4& sig_h, const u32x4& sig_l, Loader& ld, Acc& pend,
+                                          u32x4 (&ol)[16], const float* wsig_h, float d_sigma, Loader& ld, Acc& pend,
                                           Pre& pre, unsigned (&mz)[2], Scale& prev, const BwdCtx& cx) {
   Scale cur{};
+  // d_sigma at the scale of this layer's accumulators (1 / cinv of this layer, known from the layer before: exact powers of two)
+  const float sig = ADD ? d_sigma / (prev.cinv * (1.0f / 64.0f) / prev.phi) : 0.0f;
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) {
     const int q = 8 * lam + nb;
@@ -315,19 +307,6 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
       if (prev_panel >= 0) publish_max(cx, prev_panel, prev.mx * prev.cinv);
       stage_factors(cur, prev);
       store_pscale(cx, panel, cur.cinv);
-    }
-    if (PREPEND) {
-      const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
-      Pre mid;
-      block_mma<4, -1>(
-          acc, pre, a_addr, ld, c2, [&](int s, int part) -> u32x4 { return s == 0 ? (part ? sig_l : sig_h) : zero4; },
-          [&](int) {}, [&](int k) { prefetch_frag(mid, k, a_addr + 8 * 1024); });
-#pragma unroll
-      for (int k = 0; k < kPF; ++k) {
-        pre.ah[k] = mid.ah[k];
-        pre.al[k] = mid.al[k];
-      }
-      a_addr += 8 * 1024;
     }
     // masks of the block AFTER this one (loaded here), of the PENDING block (loaded two blocks ago, same buffer parity)
     const bool load_next = (nb < 7) ? MASK : NEXT_MASK;
@@ -360,6 +339,10 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
     else if (kYoung == 16) mma(std::integral_constant<int, 16>{});
     else if (kYoung == 1) mma(std::integral_constant<int, 1>{});
     else mma(std::integral_constant<int, 0>{});
+    if (ADD) {   // plain C++ on purpose: the compiler inserts the MFMA -> VALU wait states
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc.m[r] = fmaf(wsig_h[32 * nb + 8 * (r >> 2) + (r & 3)], sig, acc.m[r]);
+    }
     pend = acc;
     pre = nxt;
     loader_advance(ld);
@@ -463,14 +446,7 @@ chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ 
     bh[s] = u32x4{0u, 0u, 0u, 0u};
     bl[s] = u32x4{0u, 0u, 0u, 0u};
   }
-  // d_sigma joins at layer 1 with the scale of layer 0's converted outputs (phi of layer 0 is fixed: S x 64 x 2^-6 = S)
-  u32x4 sig_h = u32x4{0u, 0u, 0u, 0u}, sig_l = u32x4{0u, 0u, 0u, 0u};
-  {
-    unsigned a, b;
-    split2(h == 0 ? gs * S : 0.0f, 0.0f, a, b);
-    sig_h[0] = a;
-    sig_l[0] = b;
-  }
+  const float* wsig_h = ring + kAux0 + 512 + 4 * h;   // sigma.weight, this lane half's features (+ 32 nb + 8 (r >> 2) + (r & 3))
   // "previous stage" of layer 0 = the prologue: operands at scale S with max in [2, 4)
   Scale prev;
   prev.cinv = 1.0f / S;      // so that stage_factors() gives layer 0 the accumulator scale 64 S
@@ -493,18 +469,18 @@ chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ 
 
   // layer 0: dg (no mask) -> gradient panel 8.  Its block-0 hook sees a dummy pending block (zeros, converted into the
   // zero padding of its own input, stored nowhere)
-  bwd_layer<false, false, false, false, true, true>(0, -1, 8, 7, bh, bl, oh, ol, sig_h, sig_l, ld, pend, pre, mz, prev, cx);
-  bwd_layer<false, true, true, false, true>(1, 8, 7, 6, oh, ol, bh, bl, sig_h, sig_l, ld, pend, pre, mz, prev, cx);
+  bwd_layer<false, false, false, false, true, true>(0, -1, 8, 7, bh, bl, oh, ol, wsig_h, gs, ld, pend, pre, mz, prev, cx);
+  bwd_layer<false, true, true, false, true>(1, 8, 7, 6, oh, ol, bh, bl, wsig_h, gs, ld, pend, pre, mz, prev, cx);
   // layers 2..8: trunk layers 8..2; outputs dz7..dz1 -> panels 6..0
 #pragma unroll 1
   for (int pair = 0; pair < 3; ++pair) {
     const int lam = 2 + 2 * pair;
-    bwd_layer<true, true, false, false, true>(lam, 9 - lam, 8 - lam, 7 - lam, bh, bl, oh, ol, sig_h, sig_l, ld, pend, pre, mz, prev,
+    bwd_layer<true, true, false, false, true>(lam, 9 - lam, 8 - lam, 7 - lam, bh, bl, oh, ol, wsig_h, gs, ld, pend, pre, mz, prev,
                                               cx);
-    bwd_layer<true, true, false, false, true>(lam + 1, 8 - lam, 7 - lam, 6 - lam, oh, ol, bh, bl, sig_h, sig_l, ld, pend, pre, mz,
+    bwd_layer<true, true, false, false, true>(lam + 1, 8 - lam, 7 - lam, 6 - lam, oh, ol, bh, bl, wsig_h, gs, ld, pend, pre, mz,
                                               prev, cx);
   }
-  bwd_layer<true, true, false, true, false>(8, 1, 0, -1, bh, bl, oh, ol, sig_h, sig_l, ld, pend, pre, mz, prev, cx);
+  bwd_layer<true, true, false, true, false>(8, 1, 0, -1, bh, bl, oh, ol, wsig_h, gs, ld, pend, pre, mz, prev, cx);
   // the last block of dz1: mask, true scale, store
   {
     Scale last{};
