@@ -7,13 +7,14 @@
 
 One "step" = one full pass of the hot path over one synthetic frame: sub-pixel ray generation -> coarse MLP @64
 samples -> compositing -> inverse-CDF resampling -> fine MLP @128 samples -> compositing -> s^2 mean.
-N = 1 (default): BASELINE config #2, the one the metric is quoted on (504x378 <- 252x189, 2x supersampling, NDC,
-190,512 rays).  N > 1 (default): BASELINE config #4 as written -- ONE 1008x756 <- 252x189 frame (4x supersampling,
-762,048 rays) cut into N contiguous LR-pixel blocks, every rank generates and renders its own block and ONE
-all-gather of the rendered LR pixels closes the step: strong scaling (the per-ray work of configs #2 and #4 is
-identical, so rays/s is comparable across N).  ``--scaling weak`` renders one whole frame per rank instead;
-``--config`` picks the frame geometry explicitly.  Weights are synthetic (nerf_sr_amd.weights, "smooth" field),
-inputs are generated on the device: nothing crosses PCIe inside the timed region.
+The workload is the SAME at every N: BASELINE config #2, the one the metric is quoted on (504x378 <- 252x189, 2x
+supersampling, NDC, 190,512 rays), cut into N contiguous LR-pixel blocks; every rank generates and renders its own block
+and ONE all-gather of the rendered LR pixels closes the step -- strong scaling, one metric string for the whole 1/2/4/8
+curve.  BASELINE config #4 (ONE 1008x756 <- 252x189 frame, 4x supersampling, 762,048 rays: the frame BASELINE shards
+over 8 GPUs) is cut and timed the same way right after, in the same process, and reported as the ``config4``
+sub-object.  ``--scaling weak`` renders one whole frame per rank instead; ``--config`` picks one frame geometry
+explicitly.  Weights are synthetic (nerf_sr_amd.weights, "smooth" field), inputs are generated on the device: nothing
+crosses PCIe inside the timed region.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects: ``roofline`` (fine-MLP
 launch, algorithmic FLOPs / HIP-event duration vs the dense MFMA peak of the dtype) and ``cpu_baseline`` (the
@@ -93,15 +94,28 @@ def cpu_baseline(sd_c, sd_f, rays_cpu: torch.Tensor, white_bkgd: bool = False):
                       f"{cores} threads (fixed policy: min({CPU_THREADS}, host threads)) of a {all_cores}-thread host"}, out, n
 
 
-def committed_pmc(precision: str) -> dict:
-    """Counter-derived figures of the fine-pass MLP launch from the committed PMC passes (profiles/r2_pmc.json,
-    written from separate rocprofv3 --pmc runs of this build): HBM bytes per launch ((2 x FETCH_SIZE + WRITE_SIZE) x
-    1024, the guide's gfx950 correction), matrix-pipe busy fraction, effective clock.  {} if absent."""
+PMC_FILE = os.path.join("profiles", "r3_pmc.json")
+
+
+def committed_pmc(precision: str):
+    """Counter-derived figures of the fine-pass MLP launch from the committed PMC passes (profiles/r3_pmc.json, written by
+    scripts/pmc_collect.py from separate rocprofv3 --pmc runs): HBM bytes per launch ((2 x FETCH_SIZE + WRITE_SIZE) x
+    1024, the guide's gfx950 correction), matrix-pipe busy fraction, effective clock.  They are constants of the build they
+    were measured on, NOT measurements of this run: the file records the sha256 of the kernel sources
+    (nerf_sr_amd.build.source_hash) and the figures are dropped (None) when the sources have changed since.
+    Returns (figures or {}, pmc_source record)."""
+    from nerf_sr_amd import build as nsr_build
+    here = nsr_build.source_hash()
     try:
-        with open(os.path.join(REPO, "profiles", "r2_pmc.json")) as f:
-            return json.load(f).get(precision, {})
+        with open(os.path.join(REPO, PMC_FILE)) as f:
+            allp = json.load(f)
     except Exception:
-        return {}
+        return {}, {"file": None, "csrc_sha256": None, "this_build_sha256": here, "matches_this_build": False}
+    rec = allp.get(precision, {})
+    measured_on = allp.get("csrc_sha256")
+    ok = bool(rec) and measured_on == here
+    return (rec if ok else {}), {"file": PMC_FILE, "csrc_sha256": measured_on, "this_build_sha256": here,
+                                 "matches_this_build": ok}
 
 
 def committed_train_traffic(R):
@@ -274,11 +288,13 @@ def main():
     ap.add_argument("--train-precision", default="f16x3", choices=["f16x3", "fp32"],
                     help="training step: forward products on the split-fp16 MFMA (default, fp32-grade) or everything on the fp32 MFMA")
     ap.add_argument("--config", type=int, default=0, choices=[0] + sorted(RENDER_CONFIGS),
-                    help="BASELINE.json render configuration; default: #2 (the one the metric is quoted on) on one GPU, "
-                         "#4 (one 1008x756 frame sharded over the ranks, as BASELINE states it) on several")
+                    help="BASELINE.json render configuration; default: #2 (the one the metric is quoted on) at every N, with "
+                         "#4 (the 1008x756 frame BASELINE shards over 8 GPUs) timed after it as the `config4` sub-object")
     ap.add_argument("--scaling", default="", choices=["", "strong", "weak"],
-                    help="N > 1: strong (default) = ONE frame cut into N contiguous LR-pixel blocks + one all-gather; "
-                         "weak = one whole frame per rank (an N-frame batch)")
+                    help="strong (default, every N): ONE frame cut into N contiguous LR-pixel blocks + one all-gather; "
+                         "weak (N > 1) = one whole frame per rank (an N-frame batch)")
+    ap.add_argument("--no-config4", action="store_true",
+                    help="skip the `config4` sub-object (config #4's frame sharded over the same ranks, timed after the headline)")
     ap.add_argument("--with-refine", action="store_true",
                     help="config #5 only: after the timed render steps run depth -> warp -> refinement network on the "
                          "rendered frame and report that pass separately (`refine` object; not part of `value`)")
@@ -294,107 +310,160 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    cfg_id = args.config or (2 if world == 1 else 4)
-    cfg = RENDER_CONFIGS[cfg_id]
-    IMG_WH, DOWNSCALE, ndc, white = cfg["img_wh"], cfg["downscale"], cfg["ndc"], cfg["white_bkgd"]
-    S2 = DOWNSCALE ** 2
-    RAYS_PER_FRAME = IMG_WH[0] * IMG_WH[1]
-    N_LR = RAYS_PER_FRAME // S2
-    strong = world > 1 and args.scaling != "weak"
-    # this rank's share: a contiguous LR-pixel block of THE frame (strong) or a whole frame of its own (weak / N = 1)
-    lo, hi = nsr_dist.shard_bounds(N_LR, world)[rank] if strong else (0, N_LR)
-    my_rays = (hi - lo) * S2
-    frame_id = 0 if strong else rank
-
     sd_c, sd_f = make_state_dict(99), make_state_dict(100)
     net_c = ops.VanillaMLP(precision=args.precision, device=dev).load_state_dict(sd_c)
     net_f = ops.VanillaMLP(precision=args.precision, device=dev).load_state_dict(sd_f)
-    if ndc:
-        c2w, focal, nf = cameras.spiral_pose(0.4 + 0.35 * frame_id), cameras.llff_focal(IMG_WH[0]), (0.0, 1.0)
-    else:
-        c2w, focal, nf = cameras.spheric_pose(40.0 * frame_id, -30.0, 4.0), cameras.blender_focal(IMG_WH[0]), (2.0, 6.0)
-    ws = torch.empty(ops._lib.load().nsr_forward_rays_workspace_bytes(my_rays, N_COARSE, N_IMPORTANCE),
-                     dtype=torch.uint8, device=dev)
-    outs = {}
-    n_ev = args.steps + args.warmup
-    events = [ops.HipEvents(4) for _ in range(n_ev)]
-
-    def step(i):
-        rays = ops.subpixel_rays(c2w, IMG_WH, focal, DOWNSCALE, ndc, *nf, device=dev, lr_range=(lo, hi)).view(-1, 8)
-        o = ops.forward_rays(net_c, net_f, rays, N_COARSE, N_IMPORTANCE, white, workspace=ws, outs=outs,
-                             events=events[i].handles)
-        lr = ops.sr_mean(o["fine_comp_rgbs"], hi - lo, S2)
-        if world > 1:      # strong: the blocks of one frame; weak: the frames of the batch -- one collective either way
-            lr = nsr_dist.all_gather_pixels(lr, N_LR if strong else N_LR * world)
-        return rays, o, lr
+    weak = world > 1 and args.scaling == "weak"
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        rays, o, frames = step(args.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def time_config(cfg_id: int, steps: int, warmup: int) -> dict:
+        """`steps` timed passes of the hot path over config `cfg_id`'s frame, this rank rendering its LR-pixel block."""
+        cfg = RENDER_CONFIGS[cfg_id]
+        img_wh, s, ndc, white = cfg["img_wh"], cfg["downscale"], cfg["ndc"], cfg["white_bkgd"]
+        s2 = s * s
+        rays_per_frame = img_wh[0] * img_wh[1]
+        n_lr = rays_per_frame // s2
+        # this rank's share: a contiguous LR-pixel block of THE frame (default) or a whole frame of its own (--scaling weak)
+        lo, hi = (0, n_lr) if weak else nsr_dist.shard_bounds(n_lr, world)[rank]
+        frame_id = rank if weak else 0
+        if ndc:
+            c2w, focal, nf = cameras.spiral_pose(0.4 + 0.35 * frame_id), cameras.llff_focal(img_wh[0]), (0.0, 1.0)
+        else:
+            c2w, focal, nf = cameras.spheric_pose(40.0 * frame_id, -30.0, 4.0), cameras.blender_focal(img_wh[0]), (2.0, 6.0)
+        my_rays = (hi - lo) * s2
+        ws = torch.empty(max(ops._lib.load().nsr_forward_rays_workspace_bytes_for(net_c._prec, my_rays, N_COARSE, N_IMPORTANCE), 256),
+                         dtype=torch.uint8, device=dev)
+        outs = {}
+        events = [ops.HipEvents(4) for _ in range(steps + warmup)]
+        n_gather = n_lr * world if weak else n_lr
+
+        def step(i):
+            rays = ops.subpixel_rays(c2w, img_wh, focal, s, ndc, *nf, device=dev, lr_range=(lo, hi)).view(-1, 8)
+            o = ops.forward_rays(net_c, net_f, rays, N_COARSE, N_IMPORTANCE, white, workspace=ws, outs=outs,
+                                 events=events[i].handles)
+            lr = ops.sr_mean(o["fine_comp_rgbs"], hi - lo, s2)
+            if world > 1:      # the blocks of one frame (or, weak, the frames of the batch): ONE collective per step
+                lr = nsr_dist.all_gather_pixels(lr, n_gather)
+            return rays, o, lr
+
+        for i in range(warmup):
+            step(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            rays, o, frame = step(warmup + i)
+        fence()
+        dt = time.perf_counter() - t0
+        gathered_ok = None
+        if world > 1:
+            on_dev = dist.get_backend() == "nccl"
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if on_dev else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            # outside the timed region: did the collective deliver?  Every rank must hold the same assembled image, and
+            # rank r's own block must sit at its place in it
+            mine = ops.sr_mean(o["fine_comp_rgbs"], hi - lo, s2)
+            off = rank * n_lr if weak else lo
+            ok_here = bool(torch.equal(frame[off:off + (hi - lo)], mine))
+            cs = torch.tensor([float(frame.double().sum()), -float(frame.double().sum()), 0.0 if ok_here else 1.0],
+                              dtype=torch.float64, device=dev if on_dev else "cpu")
+            dist.all_reduce(cs, op=dist.ReduceOp.MAX)          # max(x) == -max(-x)  <=>  all ranks hold the same checksum
+            gathered_ok = bool(cs[0].item() == -cs[1].item() and cs[2].item() == 0.0)
+        rays_per_step = rays_per_frame * world if weak else rays_per_frame
+        fine_ms = [events[warmup + i].elapsed_ms(2, 3) for i in range(steps)]
+        coarse_ms = [events[warmup + i].elapsed_ms(0, 1) for i in range(steps)]
+        cap = nsr_dist.shard_bounds(n_gather, world)[0]
+        return {"cfg_id": cfg_id, "cfg": cfg, "img_wh": img_wh, "s": s, "white": white, "rays_per_frame": rays_per_frame,
+                "n_lr": n_lr, "my_rays": my_rays, "rays_per_step": rays_per_step, "dt": dt, "steps": steps, "warmup": warmup,
+                "value": rays_per_step * steps / dt, "ms_per_step": dt / steps * 1e3,
+                "fine_ms": sum(fine_ms) / len(fine_ms), "coarse_ms": sum(coarse_ms) / len(coarse_ms),
+                "rays": rays, "o": o, "c2w": c2w, "focal": focal,
+                "bytes_per_rank": (cap[1] - cap[0]) * 12 if world > 1 else 0, "gathered_ok": gathered_ok}
+
+    def workload(r) -> str:
+        cfg, wh, s = r["cfg"], r["img_wh"], r["s"]
+        how = ""
+        if world > 1 and not weak:
+            how = (f"; ONE frame cut into {world} contiguous LR-pixel blocks ({r['my_rays']:,} rays on rank 0), every rank "
+                   "generates and renders its own block, one all-gather of LR pixels per step")
+        elif weak:
+            how = f"; {world}-frame batch, one frame per rank, one all-gather of LR pixels per step"
+        return (f"BASELINE config #{r['cfg_id']}: {cfg['name']} {wh[0]}x{wh[1]} <- {wh[0] // s}x{wh[1] // s}, {s}x supersampling, "
+                f"64 coarse + 128 fine samples/ray, {r['rays_per_frame']:,} rays per frame" + how)
+
+    # The headline workload is the SAME at every N: config #2's frame (the one BASELINE's metric is quoted on), cut into N
+    # LR-pixel blocks.  Config #4 (the frame BASELINE shards over 8 GPUs) is timed the same way in the same process and
+    # reported as the `config4` sub-object.
+    cfg_id = args.config or 2
+    main_r = time_config(cfg_id, args.steps, args.warmup)
+    c4 = None
+    if not args.config and not args.no_config4 and not weak:
+        c4 = time_config(4, min(args.steps, 3), 1)
 
     if rank == 0:
-        rays_per_step = RAYS_PER_FRAME if strong else RAYS_PER_FRAME * world
-        value = rays_per_step * args.steps / dt
-        fine_ms = [events[args.warmup + i].elapsed_ms(2, 3) for i in range(args.steps)]
-        coarse_ms = [events[args.warmup + i].elapsed_ms(0, 1) for i in range(args.steps)]
-        fine_avg = sum(fine_ms) / len(fine_ms)
+        r = main_r
+        IMG_WH, DOWNSCALE, S2, white = r["img_wh"], r["s"], r["s"] ** 2, r["white"]
+        RAYS_PER_FRAME, my_rays, o, rays = r["rays_per_frame"], r["my_rays"], r["o"], r["rays"]
+        value, fine_avg = r["value"], r["fine_ms"]
         fine_flop = my_rays * (N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT
         achieved = fine_flop / (fine_avg * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
-        pmc = committed_pmc(args.precision) if (cfg_id == 2 and world == 1) else {}
+        pmc, pmc_source = committed_pmc(args.precision)
+        if not (cfg_id == 2 and world == 1):
+            pmc = {}                      # the counters were collected on config #2's unsharded fine-pass launch
         mfma_per_product = 3 if args.precision == "f16x3" else 1
-        if world == 1:
-            how = ""
-        elif strong:
-            how = (f"; ONE frame cut into {world} contiguous LR-pixel blocks ({my_rays:,} rays on rank 0), every rank "
-                   "generates and renders its own block, one all-gather of LR pixels per step")
-        else:
-            how = f"; {world}-frame batch, one frame per rank, one all-gather of LR pixels per step"
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version()) if world > 1 and dist.get_backend() == "nccl" else None
+        except Exception:
+            rccl = None
         res = {
             "metric": f"rays/sec (64+128 samples, {DOWNSCALE}x SS)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
-            "config": {"workload": f"BASELINE config #{cfg_id}: {cfg['name']} {IMG_WH[0]}x{IMG_WH[1]} <- "
-                                   f"{IMG_WH[0] // DOWNSCALE}x{IMG_WH[1] // DOWNSCALE}, {DOWNSCALE}x supersampling, "
-                                   f"64 coarse + 128 fine samples/ray, {RAYS_PER_FRAME:,} rays per frame" + how,
-                       "rays_per_step": rays_per_step, "n_coarse": N_COARSE, "n_importance": N_IMPORTANCE,
+            "config": {"workload": workload(r),
+                       "rays_per_step": r["rays_per_step"], "n_coarse": N_COARSE, "n_importance": N_IMPORTANCE,
                        "precision": args.precision,
-                       "parallelism": f"LR-pixel blocks of one frame x{world}" if strong else f"frame per rank x{world}"},
+                       "parallelism": f"frame per rank x{world}" if weak else f"LR-pixel blocks of one frame x{world}"},
+            "collective": {"backend": dist.get_backend() if world > 1 else None, "world": world, "rccl_version": rccl,
+                           "op": "all_gather_into_tensor" if world > 1 else None, "calls_per_step": 1 if world > 1 else 0,
+                           "bytes_per_rank": r["bytes_per_rank"], "result_identical_on_all_ranks": r["gathered_ok"]},
             "achieved_tflops_whole_path": value * FLOP_PER_RAY / 1e12,
             "roofline": {"bound": "mfma", "kernel": f"mlp kernel, fine pass ({my_rays:,} rays x 128 samples, rank 0)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": pmc.get("hbm_bytes_per_launch"),
-                         "traffic_unit": "HBM bytes/launch (PMC, profiles/r2_pmc.json); algorithmic = SURVEY 8d: 32 B in + 40 B out "
-                                         "per ray (+ 768 B/ray when both weights arrays are written)",
+                         "traffic_unit": f"HBM bytes/launch (PMC constants of the build named in pmc_source, {PMC_FILE}); algorithmic = "
+                                         "SURVEY 8d: 32 B in + 40 B out per ray (+ 768 B/ray when both weights arrays are written)",
                          "algorithmic_bytes_per_launch": my_rays * (32 + 40),
                          "mfma_issued": achieved * mfma_per_product,
                          "mfma_issued_frac": achieved * mfma_per_product / peak,
                          "mfma_busy": pmc.get("mfma_busy"), "effective_clock_ghz": pmc.get("effective_clock_ghz"),
-                         "launch_ms": fine_avg, "coarse_launch_ms": sum(coarse_ms) / len(coarse_ms),
+                         "pmc_source": pmc_source,
+                         "launch_ms": fine_avg, "coarse_launch_ms": r["coarse_ms"],
                          "flop_per_launch": fine_flop,
-                         "note": ("achieved counts ALGORITHMIC flops (2 x 593,408 MAC per point); f16x3 issues 3 MFMAs "
-                                  "per product, so its matrix pipe is busy for 3x this figure (mfma_issued); mfma_busy / "
-                                  "effective_clock_ghz are the committed rocprofv3 counters of this build (config #2)"
+                         "note": ("achieved counts ALGORITHMIC flops (2 x 593,408 MAC per point) over the HIP-event duration of "
+                                  "this run's launches; f16x3 issues 3 MFMAs per product, so its matrix pipe is busy for 3x this "
+                                  "figure (mfma_issued); traffic / mfma_busy / effective_clock_ghz are rocprofv3 counter "
+                                  "constants (config #2, one GPU), null unless pmc_source.matches_this_build"
                                   if args.precision == "f16x3" else
                                   "algorithmic flops, exact fp32 MFMA" if args.precision == "fp32" else
                                   "algorithmic flops, one 16-bit MFMA per product; fast path outside the 1e-4 "
                                   "RGB contract (see the parity block)")},
+            # sticky numerics status words of both networks after every frame of this run (include/nsr.h; 0 = clean)
+            "numerics_status": [net_c.status(), net_f.status()],
         }
+        if c4 is not None:
+            f4 = c4["my_rays"] * (N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT
+            res["config4"] = {"metric": "rays/sec (64+128 samples, 4x SS)", "value": c4["value"], "unit": "rays/s",
+                              "ms_per_step": c4["ms_per_step"], "steps": c4["steps"], "warmup": c4["warmup"],
+                              "scaling": "strong", "workload": workload(c4), "rays_per_step": c4["rays_per_step"],
+                              "fine_launch_ms": c4["fine_ms"], "coarse_launch_ms": c4["coarse_ms"],
+                              "roofline_frac": f4 / (c4["fine_ms"] * 1e-3) / 1e12 / peak,
+                              "bytes_per_rank": c4["bytes_per_rank"], "result_identical_on_all_ranks": c4["gathered_ok"]}
         if world == 1 and not args.no_cpu_baseline:
             mid = (RAYS_PER_FRAME // 2) - (RAYS_PER_FRAME // 2) % S2
             base, ref, n = cpu_baseline(sd_c, sd_f, rays[mid:mid + 32768].cpu(), white_bkgd=white)
@@ -414,7 +483,7 @@ def main():
         else:
             res["cpu_baseline"] = None
         if args.with_refine:
-            res["refine"] = refine_pass(IMG_WH, DOWNSCALE, c2w, focal, o, dev) if (cfg_id == 5 and world == 1) else None
+            res["refine"] = refine_pass(IMG_WH, DOWNSCALE, r["c2w"], r["focal"], o, dev) if (cfg_id == 5 and world == 1) else None
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

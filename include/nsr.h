@@ -14,6 +14,8 @@
  *     buffers and pre-allocates outputs; the library allocates nothing.
  *   - `stream` is a hipStream_t passed as void*; work is only ENQUEUED on it,
  *     the library never synchronises the device or the host.
+ *     Two documented exceptions, both off the per-frame path: nsr_pack_weights (load time) and
+ *     nsr_weights_status wait for `stream` because they hand a device-side verdict back to the host.
  *   - every function returns NSR_OK (0) or a negative nsr_status; no exceptions,
  *     no global mutable state: re-entrant from any number of host threads
  *     (one per GPU under nn.DataParallel, models/networks.py:67).
@@ -36,14 +38,17 @@
 extern "C" {
 #endif
 
-#define NSR_VERSION 100 /* 0.1.0 */
+#define NSR_VERSION 110 /* 0.1.1: numerics status word, gamma epilogue, checked weight packing */
 
 typedef enum nsr_status {
   NSR_OK = 0,
   NSR_ERR_INVALID_ARG = -1, /* null pointer, negative size, misaligned pointer */
   NSR_ERR_UNSUPPORTED = -2, /* sample count / degree / precision outside the built path */
   NSR_ERR_LAUNCH = -3,      /* hipGetLastError() != hipSuccess after an enqueue */
-  NSR_ERR_WORKSPACE = -4    /* workspace smaller than nsr_forward_rays_workspace_bytes() */
+  NSR_ERR_WORKSPACE = -4,   /* workspace smaller than nsr_forward_rays_workspace_bytes() */
+  NSR_ERR_RANGE = -5        /* a weight is non-finite or outside the operand range of the chosen precision
+                               (nsr_pack_weights); the reference's analogue is the NaN trap of
+                               models/nerf_downX_model.py:273-274 */
 } nsr_status;
 
 /* arithmetic the MLP contraction runs in (everything else is always fp32) */
@@ -73,8 +78,42 @@ const char* nsr_status_string(int status);
  * consumes; it is created in caller-owned device memory and must be re-packed
  * after every optimiser step. */
 size_t nsr_packed_weights_bytes(int precision);
-/* w: HOST array of 24 DEVICE pointers (nn.Linear layout (out,in) row-major). */
+/* w: HOST array of 24 DEVICE pointers (nn.Linear layout (out,in) row-major).
+ * Checked: returns NSR_ERR_RANGE (the blob is written all the same) when a weight or bias is non-finite, or when
+ * a weight leaves the operand range of `precision` -- NSR_F16X3 carries 2^6 w as an fp16 (hi, lo) pair and NSR_F16
+ * carries w as fp16, so |w| must stay below 1023.75 / 65520; NSR_FP32 and NSR_BF16 have the fp32 range.  To return
+ * that verdict the call WAITS for `stream` (a load-time call; one of the two synchronising entry points). */
 int nsr_pack_weights(const float* const* w, void* packed_dev, int precision, void* stream);
+/* The same, enqueue only (re-packing inside a training loop): the range verdict lands in the blob's status word as
+ * NSR_FLAG_WEIGHT_RANGE and is read with nsr_weights_status. */
+int nsr_pack_weights_async(const float* const* w, void* packed_dev, int precision, void* stream);
+
+/* ---- numerics status word ------------------------------------------------------
+ * Replaces the reference's `if isnan(out_rgbs).any(): pdb.set_trace()` (models/nerf_downX_model.py:273-274;
+ * SURVEY 8b "Error conventions": a replacement reports an error instead).  Every packed blob ends in a 32-bit STICKY
+ * status word (cleared by nsr_pack_weights*).  Every launch that evaluates the network through that blob ORs flags into
+ * it -- nothing is synchronised, nothing is checked on the host, until the caller asks:
+ *   NSR_FLAG_WEIGHT_RANGE       set while packing, see nsr_pack_weights
+ *   NSR_FLAG_INPUT_RANGE        a ray origin / direction / depth (or an embedded input row) was non-finite, or -- split
+ *                               and single fp16 paths -- a sample position / direction beyond fp16's 65,504
+ *   NSR_FLAG_ACTIVATION_RANGE   NSR_F16X3: a hidden activation left the range in which the (hi, lo) split keeps its 22
+ *                               bits (|h| >= 1023.75: hi saturates there, the value degrades to 11-bit lo precision and
+ *                               is lost beyond 65,504).  Trained checkpoints sit two orders of magnitude below
+ *                               (tests/test_gpu_trained.py); a diverged network trips it.  Re-run with NSR_FP32.
+ *   NSR_FLAG_OUTPUT_NONFINITE   a network output (r, g, b, sigma) was inf / NaN
+ * nsr_weights_status copies the word to *flags_out (HOST), clears it on the device if `clear`, and WAITS for `stream`
+ * (the second synchronising entry point).  The blob is therefore read-mostly, not read-only: `packed_dev` arguments
+ * are const for the weight stream, the status word behind it is written by the kernels. */
+#define NSR_FLAG_WEIGHT_RANGE 1u
+#define NSR_FLAG_INPUT_RANGE 2u
+#define NSR_FLAG_ACTIVATION_RANGE 4u
+#define NSR_FLAG_OUTPUT_NONFINITE 8u
+int nsr_weights_status(const void* packed_dev, int precision, int clear, unsigned* flags_out, void* stream);
+
+/* --gamma_correct (models/nerf_downX_model.py:271-276): render_rays returns pow(rgb, 1 / 2.2) per sample.  An option of
+ * the packed network (stream-ordered write into the blob's tail, read by every later launch; cleared by re-packing):
+ * enable != 0 makes the colour head of every entry point that evaluates this blob apply it. */
+int nsr_weights_set_gamma(void* packed_dev, int precision, int enable, void* stream);
 
 /* ---- R1-R4: sub-pixel ray generation ---------------------------------------
  * Replaces get_ray_directions + get_rays (+ get_ndc_rays) + the einops regroup
@@ -154,7 +193,12 @@ int nsr_resample_along_rays(const float* rays, int ray_stride, const float* z, c
  *   0 coarse_comp_rgbs (R,3)  1 coarse_depth (R)  2 coarse_opacity (R)  3 coarse_weights (R,Nc)
  *   4 fine_comp_rgbs  (R,3)   5 fine_depth (R)    6 fine_opacity (R)    7 fine_weights (R,Nc+Ni)
  * n_importance == 0 skips the fine pass (outs[4..7] untouched, packed_fine may be NULL).
- * workspace: device scratch of nsr_forward_rays_workspace_bytes() bytes. */
+ * workspace: device scratch of nsr_forward_rays_workspace_bytes_for(precision, ...) bytes: the depths and the coarse
+ * weights, 12 * Nc + 4 * Nf bytes per ray, on the fused route (NSR_FP32 / NSR_F16X3 with 64 or 128 samples per pass: the
+ * launch composites its own rays and the (R, N, 4) network output never exists); 16 * (Nc + Nf) bytes per ray more when
+ * a pass has to go through nsr_render_rays + nsr_composite.  nsr_forward_rays_workspace_bytes is the precision-agnostic
+ * upper bound (always sufficient). */
+size_t nsr_forward_rays_workspace_bytes_for(int precision, int64_t R, int n_coarse, int n_importance);
 size_t nsr_forward_rays_workspace_bytes(int64_t R, int n_coarse, int n_importance);
 int nsr_forward_rays(const void* packed_coarse, const void* packed_fine, int precision, const float* rays,
                      int ray_stride, int64_t R, int n_coarse, int n_importance, int white_bkgd, int lindisp,

@@ -9,12 +9,15 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p, POINTER
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSR_LIB_PATH", os.path.join(_HERE, "libnsr.so"))   # override: ablation builds (development)
 
 NSR_FP32, NSR_BF16, NSR_F16X3, NSR_F16 = 0, 1, 2, 3
+NSR_ERR_RANGE = -5
+# numerics status word of a packed network (include/nsr.h)
+FLAGS = {1: "WEIGHT_RANGE", 2: "INPUT_RANGE", 4: "ACTIVATION_RANGE", 8: "OUTPUT_NONFINITE"}
 PRECISIONS = {"fp32": NSR_FP32, "bf16": NSR_BF16, "f16x3": NSR_F16X3, "f16": NSR_F16}
 
 # symbol -> (restype, argtypes); must list every function of include/*.h
@@ -23,6 +26,9 @@ SIGNATURES = {
     "nsr_status_string": (c_char_p, [c_int]),
     "nsr_packed_weights_bytes": (c_size_t, [c_int]),
     "nsr_pack_weights": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p]),
+    "nsr_pack_weights_async": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p]),
+    "nsr_weights_status": (c_int, [c_void_p, c_int, c_int, POINTER(c_uint), c_void_p]),
+    "nsr_weights_set_gamma": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "nsr_gen_rays": (c_int, [POINTER(c_float), c_int, c_int, c_double, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
     "nsr_gen_rays_range": (c_int, [POINTER(c_float), c_int, c_int, c_double, c_int, c_int, c_float, c_float, c_int64, c_int64,
                                    c_void_p, c_void_p]),
@@ -37,6 +43,7 @@ SIGNATURES = {
     "nsr_resample_along_rays": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_void_p]),
     "nsr_forward_rays_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "nsr_forward_rays_workspace_bytes_for": (c_size_t, [c_int, c_int64, c_int, c_int]),
     "nsr_forward_rays": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int,
                                  POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
     "nsr_forward_rays_profiled": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int,
@@ -85,6 +92,20 @@ _lib = None
 
 class NsrError(RuntimeError):
     """A libnsr entry point returned a non-zero nsr_status."""
+
+
+class NsrNumericsError(NsrError, FloatingPointError):
+    """The numerics status word of a packed network is non-zero: non-finite inputs / outputs, or values outside the
+    operand range of the precision -- what the reference traps with ``isnan(out_rgbs).any()`` ->
+    ``pdb.set_trace()`` (models/nerf_downX_model.py:273-274)."""
+
+    def __init__(self, msg: str, flags: int = 0):
+        super().__init__(msg)
+        self.flags = flags
+
+
+def flag_names(flags: int):
+    return [name for bit, name in FLAGS.items() if flags & bit]
 
 
 def load() -> ctypes.CDLL:

@@ -34,10 +34,7 @@ UNITS = [
     ("nsr_image.hip", ["-ffp-contract=off"]),
     ("nsr_api.hip", []),
 ]
-# experiment kernels: compiled (and dispatched, see the #ifdef in nsr_mlp.hip) only in a variant build that defines the flag
-VARIANT_UNITS = {
-    "-DNSR_F16X3_PAIR": ("experiments/nsr_mlp_f16p.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
-}
+VARIANT_UNITS = {}   # -D flag -> (extra source, flags): experiment kernels of an ablation build (none at present)
 
 
 def _hipcc() -> str:
@@ -53,6 +50,20 @@ def _newest_source_mtime() -> float:
         for fn in os.listdir(root):
             m = max(m, os.path.getmtime(os.path.join(root, fn)))
     return m
+
+
+def source_hash() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/*.h; names and contents, sorted): ties a measured
+    figure (profiles/*_pmc.json) to the build it was measured on.  Needs the source tree, not the toolchain."""
+    import hashlib
+    h = hashlib.sha256()
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for fn in sorted(os.listdir(root)):
+            if fn.endswith((".hip", ".h")):
+                h.update(fn.encode())
+                with open(os.path.join(root, fn), "rb") as f:
+                    h.update(f.read())
+    return h.hexdigest()
 
 
 def build(force: bool = False, verbose: bool = True, variant: str = "", defines=()) -> str:

@@ -14,19 +14,34 @@ extern "C" const char* nsr_status_string(int status) {
     case NSR_ERR_UNSUPPORTED: return "configuration outside the built path (sample count, degree or precision)";
     case NSR_ERR_LAUNCH: return "HIP kernel launch failed";
     case NSR_ERR_WORKSPACE: return "workspace too small";
+    case NSR_ERR_RANGE: return "a weight is non-finite or outside the operand range of the precision (use NSR_FP32)";
     default: return "unknown nsr status";
   }
 }
 
 static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
-// workspace carve: z_coarse (R,Nc) | raw_coarse (R,Nc,4) | z_fine (R,Nf) | raw_fine (R,Nf,4) | w_coarse (R,Nc)
-extern "C" size_t nsr_forward_rays_workspace_bytes(int64_t R, int n_coarse, int n_importance) {
+// the fused route (D2 + V1 in one launch, nsr_render_rays_composited) exists for these shapes; everything else takes the
+// network launch followed by the stand-alone compositor and needs the (R, N, 4) raw tensors
+static inline bool fused_route(int precision, int n_samples) {
+  return (precision == NSR_FP32 || precision == NSR_F16X3) && (n_samples == 64 || n_samples == 128);
+}
+
+// workspace carve: z_coarse (R,Nc) | w_coarse (R,Nc) | z_fine (R,Nf) | [unfused route only: raw_coarse (R,Nc,4) | raw_fine (R,Nf,4)]
+extern "C" size_t nsr_forward_rays_workspace_bytes_for(int precision, int64_t R, int n_coarse, int n_importance) {
   if (R < 0 || n_coarse <= 0 || n_importance < 0) return 0;
   const size_t r = (size_t)R, nc = (size_t)n_coarse, nf = (size_t)(n_coarse + n_importance);
-  size_t total = align256(r * nc * 4) + align256(r * nc * 16) + align256(r * nc * 4);
-  if (n_importance > 0) total += align256(r * nf * 4) + align256(r * nf * 16);
+  size_t total = align256(r * nc * 4) + align256(r * nc * 4);
+  if (!fused_route(precision, n_coarse)) total += align256(r * nc * 16);
+  if (n_importance > 0) {
+    total += align256(r * nf * 4);
+    if (!fused_route(precision, n_coarse + n_importance)) total += align256(r * nf * 16);
+  }
   return total;
+}
+// precision-agnostic upper bound (the unfused route of any precision)
+extern "C" size_t nsr_forward_rays_workspace_bytes(int64_t R, int n_coarse, int n_importance) {
+  return nsr_forward_rays_workspace_bytes_for(-1, R, n_coarse, n_importance);
 }
 
 extern "C" int nsr_event_create(void** event_out) {
@@ -64,19 +79,20 @@ extern "C" int nsr_forward_rays_profiled(const void* packed_coarse, const void* 
   };
   if (!packed_coarse || !outs || R < 0 || n_coarse <= 0 || n_importance < 0) return NSR_ERR_INVALID_ARG;
   if (n_importance > 0 && !packed_fine) return NSR_ERR_INVALID_ARG;
-  if (workspace_bytes < nsr_forward_rays_workspace_bytes(R, n_coarse, n_importance)) return NSR_ERR_WORKSPACE;
+  if (workspace_bytes < nsr_forward_rays_workspace_bytes_for(precision, R, n_coarse, n_importance)) return NSR_ERR_WORKSPACE;
   if (R == 0) return NSR_OK;
   if (!rays || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return NSR_ERR_INVALID_ARG;
   const size_t r = (size_t)R, nc = (size_t)n_coarse, nf = (size_t)(n_coarse + n_importance);
   char* ws = static_cast<char*>(workspace);
   float* z_c = reinterpret_cast<float*>(ws);   ws += align256(r * nc * 4);
-  float* raw_c = reinterpret_cast<float*>(ws); ws += align256(r * nc * 16);
   float* w_c_ws = reinterpret_cast<float*>(ws); ws += align256(r * nc * 4);
+  float* raw_c = nullptr;
   float* z_f = nullptr;
   float* raw_f = nullptr;
+  if (!fused_route(precision, n_coarse)) { raw_c = reinterpret_cast<float*>(ws); ws += align256(r * nc * 16); }
   if (n_importance > 0) {
     z_f = reinterpret_cast<float*>(ws);   ws += align256(r * nf * 4);
-    raw_f = reinterpret_cast<float*>(ws); ws += align256(r * nf * 16);
+    if (!fused_route(precision, n_coarse + n_importance)) { raw_f = reinterpret_cast<float*>(ws); ws += align256(r * nf * 16); }
   }
   int rc;
   // S1: coarse depths

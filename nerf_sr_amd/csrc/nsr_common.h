@@ -15,6 +15,33 @@
 
 static inline hipStream_t nsr_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- tail of every packed weight blob (include/nsr.h "numerics status word"): 16 bytes behind the 16-byte-aligned
+// payload of the precision's own layout: word 0 = sticky NSR_FLAG_* status, word 1 = colour-head options
+// (bit 0: --gamma_correct, models/nerf_downX_model.py:271-276), words 2, 3 reserved.
+constexpr size_t kBlobTailBytes = 16;
+constexpr unsigned kOptGamma = 1u;
+static inline size_t nsr_blob_tail_offset(size_t payload_bytes) { return (payload_bytes + 15) & ~(size_t)15; }
+NSR_INTERNAL size_t nsr_payload_bytes(int precision);   // nsr_mlp.hip
+static inline unsigned* nsr_blob_tail(const void* packed_dev, int precision) {
+  return reinterpret_cast<unsigned*>(const_cast<char*>(static_cast<const char*>(packed_dev)) +
+                                     nsr_blob_tail_offset(nsr_payload_bytes(precision)));
+}
+// what the MLP kernels get: the tail (null: the training step's private blob has none).  Flags are raised with one
+// atomic per offending lane (never on a healthy network); the option word is read by the kernel itself, so setting
+// an option is an ordinary stream-ordered write.
+struct NsrTail {
+  unsigned* w;   // null or the 4-word tail
+};
+__device__ __forceinline__ void nsr_raise(const NsrTail& t, unsigned flags) {
+  if (flags != 0u && t.w) atomicOr(t.w, flags);
+}
+__device__ __forceinline__ bool nsr_opt_gamma(const NsrTail& t) {
+  return t.w && (__builtin_nontemporal_load(t.w + 1) & kOptGamma) != 0u;
+}
+__device__ __forceinline__ bool nsr_finite(float x) { return fabsf(x) <= 3.402823466e38f; }   // false for inf and NaN
+// --gamma_correct: out_rgbs = pow(out_rgbs, 1 / 2.2) on the per-sample colours (nerf_downX_model.py:271-276)
+__device__ __forceinline__ float nsr_gamma(float c) { return powf(c, 1.0f / 2.2f); }
+
 // ---- torch.linspace(0, 1, n) element i, fp32 (ATen CPU kernel: symmetric form,
 // start + step*i below the midpoint, end - step*(n-1-i) above it).
 __device__ __forceinline__ float nsr_linspace01(int i, int n) {

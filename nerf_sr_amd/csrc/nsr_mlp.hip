@@ -67,60 +67,121 @@ __global__ void __launch_bounds__(256) pack_fp32_kernel(PackPtrs w, float* __res
   out[idx] = v;
 }
 
-// split-fp16 path (nsr_mlp_f16.hip)
-// split-fp16 kernels: nsr_mlp_f16.hip (the product) -- or, in a -DNSR_F16X3_PAIR ablation build, the block-pair
-// schedule of experiments/nsr_mlp_f16p.hip (measured slower, profiles/r2_f16x3_pair_experiment.md)
-#ifdef NSR_F16X3_PAIR
-#define nsr_f16x3_packed_bytes nsr_f16x3p_packed_bytes
-#define nsr_f16x3_pack nsr_f16x3p_pack
-#define nsr_f16x3_mlp_forward nsr_f16x3p_mlp_forward
-#define nsr_f16x3_render_rays nsr_f16x3p_render_rays
-#endif
+// split-fp16 kernels (nsr_mlp_f16.hip)
 extern "C" NSR_INTERNAL size_t nsr_f16x3_packed_bytes(void);
 extern "C" NSR_INTERNAL int nsr_f16x3_pack(const float* const* w, void* packed_dev, void* stream);
 extern "C" NSR_INTERNAL int nsr_f16x3_mlp_forward(const void* packed, const float* x, int64_t P, int sigma_only, float* out,
-                                     void* stream);
+                                     unsigned* tail, void* stream);
 extern "C" NSR_INTERNAL int nsr_f16x3_render_rays(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
-                                     int N, float* out, void* stream);
+                                     int N, float* out, unsigned* tail, void* stream);
 
 // single 16-bit operand paths (nsr_mlp_h1.hip); bf = 1: bf16, 0: fp16
 extern "C" NSR_INTERNAL size_t nsr_h1_packed_bytes(void);
 extern "C" NSR_INTERNAL int nsr_h1_pack(int bf, const float* const* w, void* packed_dev, void* stream);
 extern "C" NSR_INTERNAL int nsr_h1_mlp_forward(int bf, const void* packed, const float* x, int64_t P, int sigma_only,
-                                               float* out, void* stream);
+                                               float* out, unsigned* tail, void* stream);
 extern "C" NSR_INTERNAL int nsr_h1_render_rays(int bf, const void* packed, const float* rays, int ray_stride,
-                                               const float* z, int64_t R, int N, float* out, void* stream);
+                                               const float* z, int64_t R, int N, float* out, unsigned* tail, void* stream);
 static inline bool precision_built(int precision) {
   return precision == NSR_FP32 || precision == NSR_F16X3 || precision == NSR_BF16 || precision == NSR_F16;
 }
 static inline bool precision_h1(int precision) { return precision == NSR_BF16 || precision == NSR_F16; }
 
-extern "C" size_t nsr_packed_weights_bytes(int precision) {
+NSR_INTERNAL size_t nsr_payload_bytes(int precision) {
   if (precision == NSR_FP32) return sizeof(float) * (size_t)(kStreamFloats + kAuxFloats);
   if (precision == NSR_F16X3) return nsr_f16x3_packed_bytes();
   if (precision_h1(precision)) return nsr_h1_packed_bytes();
   return 0;
 }
 
-extern "C" int nsr_pack_weights(const float* const* w, void* packed_dev, int precision, void* stream) {
+extern "C" size_t nsr_packed_weights_bytes(int precision) {
+  const size_t payload = nsr_payload_bytes(precision);
+  return payload ? nsr_blob_tail_offset(payload) + kBlobTailBytes : 0;
+}
+
+// Range check of the 24 tensors the blob is made from (include/nsr.h, nsr_pack_weights); the tail is cleared by a
+// memset enqueued in front of this kernel.  limit = largest |w| the precision's operand format carries (weights only;
+// biases stay fp32 everywhere and only have to be finite).
+struct CheckPtrs {
+  const float* p[NSR_N_STATE_TENSORS];
+  int n[NSR_N_STATE_TENSORS];
+};
+__global__ void __launch_bounds__(256) check_weights_kernel(CheckPtrs w, float limit, unsigned* tail) {
+  bool bad = false;
+  for (int t = blockIdx.y; t < NSR_N_STATE_TENSORS; t += gridDim.y) {
+    const float lim = (t & 1) ? 3.402823466e38f : limit;      // odd entries of the state_dict are the biases
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w.n[t]; i += gridDim.x * blockDim.x)
+      bad |= !(fabsf(w.p[t][i]) <= lim);                       // also true for NaN
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(tail, NSR_FLAG_WEIGHT_RANGE);
+}
+
+static const int kStateTensorSizes[NSR_N_STATE_TENSORS] = {
+    kWidth * kPosCh, kWidth, kWidth * kWidth, kWidth, kWidth * kWidth, kWidth, kWidth * kWidth, kWidth,
+    kWidth * (kWidth + kPosCh), kWidth, kWidth * kWidth, kWidth, kWidth * kWidth, kWidth, kWidth * kWidth, kWidth,
+    kWidth * kWidth, kWidth, (kWidth / 2) * (kWidth + kDirCh), kWidth / 2, kWidth, 1, 3 * (kWidth / 2), 3};
+
+// largest weight magnitude whose operand encoding is still finite: fp16 rounds to inf from 65,520 on
+static float precision_weight_limit(int precision) {
+  if (precision == NSR_F16X3) return 65519.996f / 64.0f;   // the stream carries 2^6 w (nsr_f16x3_core.h, kWScale)
+  if (precision == NSR_F16) return 65519.996f;
+  return 3.402823466e38f;
+}
+
+extern "C" int nsr_pack_weights_async(const float* const* w, void* packed_dev, int precision, void* stream) {
   if (!w || !packed_dev) return NSR_ERR_INVALID_ARG;
   if ((reinterpret_cast<uintptr_t>(packed_dev) & 15) != 0) return NSR_ERR_INVALID_ARG;
-  if (precision == NSR_F16X3) {
-    for (int i = 0; i < NSR_N_STATE_TENSORS; ++i)
-      if (!w[i]) return NSR_ERR_INVALID_ARG;
-    return nsr_f16x3_pack(w, packed_dev, stream);
-  }
-  if (precision_h1(precision)) return nsr_h1_pack(precision == NSR_BF16, w, packed_dev, stream);
-  if (precision != NSR_FP32) return NSR_ERR_UNSUPPORTED;
-  PackPtrs pp;
+  if (!precision_built(precision)) return NSR_ERR_UNSUPPORTED;
+  CheckPtrs cp;
   for (int i = 0; i < NSR_N_STATE_TENSORS; ++i) {
     if (!w[i]) return NSR_ERR_INVALID_ARG;
-    pp.p[i] = w[i];
+    cp.p[i] = w[i];
+    cp.n[i] = kStateTensorSizes[i];
   }
+  unsigned* tail = nsr_blob_tail(packed_dev, precision);
+  if (hipMemsetAsync(tail, 0, kBlobTailBytes, nsr_stream(stream)) != hipSuccess) return NSR_ERR_LAUNCH;
+  hipLaunchKernelGGL(check_weights_kernel, dim3(16, NSR_N_STATE_TENSORS), dim3(256), 0, nsr_stream(stream), cp,
+                     precision_weight_limit(precision), tail);
+  NSR_CHECK_LAUNCH();
+  if (precision == NSR_F16X3) return nsr_f16x3_pack(w, packed_dev, stream);
+  if (precision_h1(precision)) return nsr_h1_pack(precision == NSR_BF16, w, packed_dev, stream);
+  PackPtrs pp;
+  for (int i = 0; i < NSR_N_STATE_TENSORS; ++i) pp.p[i] = w[i];
   const int total = kStreamFloats + kAuxFloats;
   hipLaunchKernelGGL(pack_fp32_kernel, dim3((total + 255) / 256), dim3(256), 0, nsr_stream(stream), pp,
                      static_cast<float*>(packed_dev));
   NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
+extern "C" int nsr_weights_status(const void* packed_dev, int precision, int clear, unsigned* flags_out, void* stream) {
+  if (!packed_dev || !flags_out) return NSR_ERR_INVALID_ARG;
+  if (!precision_built(precision)) return NSR_ERR_UNSUPPORTED;
+  unsigned* tail = nsr_blob_tail(packed_dev, precision);
+  hipStream_t st = nsr_stream(stream);
+  unsigned host = 0;
+  if (hipMemcpyAsync(&host, tail, sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess) return NSR_ERR_LAUNCH;
+  if (clear && hipMemsetAsync(tail, 0, sizeof(unsigned), st) != hipSuccess) return NSR_ERR_LAUNCH;
+  if (hipStreamSynchronize(st) != hipSuccess) return NSR_ERR_LAUNCH;
+  *flags_out = host;
+  return NSR_OK;
+}
+
+extern "C" int nsr_pack_weights(const float* const* w, void* packed_dev, int precision, void* stream) {
+  const int rc = nsr_pack_weights_async(w, packed_dev, precision, stream);
+  if (rc != NSR_OK) return rc;
+  unsigned flags = 0;
+  const int rs = nsr_weights_status(packed_dev, precision, 0, &flags, stream);
+  if (rs != NSR_OK) return rs;
+  return (flags & NSR_FLAG_WEIGHT_RANGE) ? NSR_ERR_RANGE : NSR_OK;
+}
+
+extern "C" int nsr_weights_set_gamma(void* packed_dev, int precision, int enable, void* stream) {
+  if (!packed_dev) return NSR_ERR_INVALID_ARG;
+  if (!precision_built(precision)) return NSR_ERR_UNSUPPORTED;
+  unsigned* tail = nsr_blob_tail(packed_dev, precision);
+  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(tail + 1), enable ? (int)kOptGamma : 0, 1, nsr_stream(stream)) != hipSuccess)
+    return NSR_ERR_LAUNCH;
   return NSR_OK;
 }
 
@@ -237,13 +298,16 @@ __device__ __forceinline__ float half_dot(const float (&v)[16 * NB], const float
   return s;
 }
 
+// torch.relu keeps NaN (fmaxf would turn it into 0 and hide a diverged trunk from the output check below)
+__device__ __forceinline__ float relu_nan(float x) { return (x < 0.0f) ? 0.0f : x; }
+
 // MODE 0: x is (P, 90) embedded rows.  MODE 1: x is rays (R, 8), z (R, N) given.
 // NSC > 0 (64 or 128 = samples per ray, MODE 1): the tile's points are whole rays and the kernel composites them itself
 // (nsr_composite.h); `out` may then be null.
 template <int MODE, bool SIGMA_ONLY, int NSC = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ zv,
-                int64_t P, int N, int stride, float* __restrict__ out, NsrCompOut co = NsrCompOut{}) {
+                int64_t P, int N, int stride, float* __restrict__ out, NsrTail tail, NsrCompOut co = NsrCompOut{}) {
   __shared__ __attribute__((aligned(16))) float ring[2 * kChunkBytes / 4];   // 64 KiB
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -260,18 +324,23 @@ mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, c
   const int64_t pc = p < P ? p : P - 1;
 
   float pe[32], de[16];
+  unsigned flags = 0u;   // NSR_FLAG_* of this lane's point, raised once at the end
   if (MODE == 0) {
     const float* row = x + pc * kInCh;
+    bool ok = true;
 #pragma unroll
     for (int t = 0; t < 32; ++t) {
       const int col = pecol(t, h);
       pe[t] = (col == kPad) ? 0.0f : row[col];
+      ok &= nsr_finite(pe[t]);
     }
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int col = dircol(t, h);
       de[t] = (col == kPad) ? 0.0f : row[kPosCh + col];
+      ok &= nsr_finite(de[t]);
     }
+    if (!ok) flags |= NSR_FLAG_INPUT_RANGE;
   } else {
     const int64_t ray = pc / N;
     const NsrRay rq = nsr_load_ray(x, ray, stride);
@@ -280,6 +349,8 @@ mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, c
     // cast_rays (models/utils.py:14): o + z*d, separate multiply and add as ATen does
     const float v[3] = {__fadd_rn(rq.o[0], __fmul_rn(zk, rq.d[0])), __fadd_rn(rq.o[1], __fmul_rn(zk, rq.d[1])),
                         __fadd_rn(rq.o[2], __fmul_rn(zk, rq.d[2]))};
+    if (!(nsr_finite(v[0]) && nsr_finite(v[1]) && nsr_finite(v[2]) && nsr_finite(d[0]) && nsr_finite(d[1]) && nsr_finite(d[2])))
+      flags |= NSR_FLAG_INPUT_RANGE;
     pe[0] = h ? v[2] : v[0];
     pe[1] = h ? 0.0f : v[1];
 #pragma unroll
@@ -316,7 +387,7 @@ mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, c
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) act[16 * nb + r] = fmaxf(acc[nb][r], 0.0f);
+    for (int r = 0; r < 16; ++r) act[16 * nb + r] = relu_nan(acc[nb][r]);
 
   // ---- L2..L8 (+ xyz_encoding_final as "layer 8", no activation)
   constexpr int kLast = SIGMA_ONLY ? 7 : 8;
@@ -329,7 +400,7 @@ mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, c
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) act[16 * nb + r] = fmaxf(acc[nb][r], 0.0f);
+        for (int r = 0; r < 16; ++r) act[16 * nb + r] = relu_nan(acc[nb][r]);
     } else {
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb)
@@ -345,6 +416,8 @@ mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, c
 
   if (SIGMA_ONLY) {
     if (h == 0 && p < P) out[p] = sigma;
+    if (!nsr_finite(sigma)) flags |= NSR_FLAG_OUTPUT_NONFINITE;
+    if (p < P) nsr_raise(tail, flags);
     return;
   }
 
@@ -357,7 +430,7 @@ mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, c
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cfe[16 * nb + r] = fmaxf(acc4[nb][r], 0.0f);
+    for (int r = 0; r < 16; ++r) cfe[16 * nb + r] = relu_nan(acc4[nb][r]);
 
   // ---- rgb head: 128 -> 3, sigmoid
   float rgb[3];
@@ -368,6 +441,12 @@ mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, c
     s += aux[kAuxRgbB + k];
     rgb[k] = 1.0f / (1.0f + expf(-s));
   }
+  if (nsr_opt_gamma(tail)) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rgb[k] = nsr_gamma(rgb[k]);
+  }
+  if (!(nsr_finite(rgb[0]) && nsr_finite(rgb[1]) && nsr_finite(rgb[2]) && nsr_finite(sigma))) flags |= NSR_FLAG_OUTPUT_NONFINITE;
+  if (p < P) nsr_raise(tail, flags);
   if (out && h == 0 && p < P) reinterpret_cast<float4*>(out)[p] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
   if (NSC > 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no weight DMA may still be landing in the ring that is re-used below
@@ -382,14 +461,15 @@ extern "C" int nsr_mlp_forward(const void* packed_dev, int precision, const floa
   if (P == 0) return NSR_OK;   // empty batch: nothing to read or write (pointers may be null)
   if (!x || !out) return NSR_ERR_INVALID_ARG;
   if (!sigma_only && (reinterpret_cast<uintptr_t>(out) & 15) != 0) return NSR_ERR_INVALID_ARG;
-  if (precision == NSR_F16X3) return nsr_f16x3_mlp_forward(packed_dev, x, P, sigma_only, out, stream);
-  if (precision_h1(precision)) return nsr_h1_mlp_forward(precision == NSR_BF16, packed_dev, x, P, sigma_only, out, stream);
+  unsigned* tail = nsr_blob_tail(packed_dev, precision);
+  if (precision == NSR_F16X3) return nsr_f16x3_mlp_forward(packed_dev, x, P, sigma_only, out, tail, stream);
+  if (precision_h1(precision)) return nsr_h1_mlp_forward(precision == NSR_BF16, packed_dev, x, P, sigma_only, out, tail, stream);
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   const float* pk = static_cast<const float*>(packed_dev);
   if (sigma_only)
-    hipLaunchKernelGGL((mlp_fp32_kernel<0, true>), grid, block, 0, nsr_stream(stream), pk, x, nullptr, P, 1, 8, out);
+    hipLaunchKernelGGL((mlp_fp32_kernel<0, true>), grid, block, 0, nsr_stream(stream), pk, x, nullptr, P, 1, 8, out, NsrTail{nsr_blob_tail(packed_dev, precision)});
   else
-    hipLaunchKernelGGL((mlp_fp32_kernel<0, false>), grid, block, 0, nsr_stream(stream), pk, x, nullptr, P, 1, 8, out);
+    hipLaunchKernelGGL((mlp_fp32_kernel<0, false>), grid, block, 0, nsr_stream(stream), pk, x, nullptr, P, 1, 8, out, NsrTail{nsr_blob_tail(packed_dev, precision)});
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
@@ -402,20 +482,21 @@ extern "C" int nsr_render_rays(const void* packed_dev, int precision, const floa
   if (!rays || !z || !out) return NSR_ERR_INVALID_ARG;
   if ((reinterpret_cast<uintptr_t>(out) & 15) != 0 || (ray_stride == 8 && (reinterpret_cast<uintptr_t>(rays) & 15) != 0))
     return NSR_ERR_INVALID_ARG;
-  if (precision == NSR_F16X3) return nsr_f16x3_render_rays(packed_dev, rays, ray_stride, z, R, n_samples, out, stream);
+  unsigned* tail = nsr_blob_tail(packed_dev, precision);
+  if (precision == NSR_F16X3) return nsr_f16x3_render_rays(packed_dev, rays, ray_stride, z, R, n_samples, out, tail, stream);
   if (precision_h1(precision))
-    return nsr_h1_render_rays(precision == NSR_BF16, packed_dev, rays, ray_stride, z, R, n_samples, out, stream);
+    return nsr_h1_render_rays(precision == NSR_BF16, packed_dev, rays, ray_stride, z, R, n_samples, out, tail, stream);
   const int64_t P = R * n_samples;
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   hipLaunchKernelGGL((mlp_fp32_kernel<1, false>), grid, block, 0, nsr_stream(stream),
-                     static_cast<const float*>(packed_dev), rays, z, P, n_samples, ray_stride, out);
+                     static_cast<const float*>(packed_dev), rays, z, P, n_samples, ray_stride, out, NsrTail{tail});
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
 
 /* D2 + V1 in one launch, see include/nsr.h */
 extern "C" NSR_INTERNAL int nsr_f16x3_render_composite(const void* packed, const float* rays, int ray_stride, const float* z,
-                                                       int64_t R, int N, float* raw, const NsrCompOut* co, void* stream);
+                                                       int64_t R, int N, float* raw, const NsrCompOut* co, unsigned* tail, void* stream);
 
 extern "C" int nsr_render_rays_composited(const void* packed_dev, int precision, const float* rays, int ray_stride, const float* z,
                                           int64_t R, int n_samples, int white_bkgd, float* raw, float* comp_rgb, float* depth,
@@ -428,14 +509,15 @@ extern "C" int nsr_render_rays_composited(const void* packed_dev, int precision,
   if ((raw && (reinterpret_cast<uintptr_t>(raw) & 15) != 0) || (ray_stride == 8 && (reinterpret_cast<uintptr_t>(rays) & 15) != 0))
     return NSR_ERR_INVALID_ARG;
   const NsrCompOut co{comp_rgb, depth, opacity, weights, white_bkgd};
-  if (precision == NSR_F16X3) return nsr_f16x3_render_composite(packed_dev, rays, ray_stride, z, R, n_samples, raw, &co, stream);
+  unsigned* tail = nsr_blob_tail(packed_dev, precision);
+  if (precision == NSR_F16X3) return nsr_f16x3_render_composite(packed_dev, rays, ray_stride, z, R, n_samples, raw, &co, tail, stream);
   const int64_t P = R * n_samples;
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   const float* pk = static_cast<const float*>(packed_dev);
   if (n_samples == 64)
-    hipLaunchKernelGGL((mlp_fp32_kernel<1, false, 64>), grid, block, 0, nsr_stream(stream), pk, rays, z, P, n_samples, ray_stride, raw, co);
+    hipLaunchKernelGGL((mlp_fp32_kernel<1, false, 64>), grid, block, 0, nsr_stream(stream), pk, rays, z, P, n_samples, ray_stride, raw, NsrTail{tail}, co);
   else
-    hipLaunchKernelGGL((mlp_fp32_kernel<1, false, 128>), grid, block, 0, nsr_stream(stream), pk, rays, z, P, n_samples, ray_stride, raw, co);
+    hipLaunchKernelGGL((mlp_fp32_kernel<1, false, 128>), grid, block, 0, nsr_stream(stream), pk, rays, z, P, n_samples, ray_stride, raw, NsrTail{tail}, co);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }

@@ -139,8 +139,17 @@ template <int P>
 __device__ __forceinline__ void put(unsigned v, u32x4& d0, u32x4& d1) {
   if (P < 4) d0[P & 3] = v; else d1[P & 3] = v;
 }
+#ifdef NSR_ABL_NO_AMAX   // ablation (scripts/ablate.sh): what the activation-range tracking costs
+#define NSR_AMAX_RELU
+#define NSR_AMAX_NOACT
+#else
+#define NSR_AMAX_RELU "\n\tv_max3_f32 %3, %0, %1, %3"
+#define NSR_AMAX_NOACT "\n\tv_max3_f32 %3, |%0|, |%1|, %3"
+#endif
+// amax: running maximum of |64 x activation| over everything this lane re-splits (one v_max3 per pair): at 65,520 the
+// hi part rounds to inf -> saturates at 1024 after the exponent subtract (NSR_FLAG_ACTIVATION_RANGE, include/nsr.h)
 template <int P, bool RELU>
-__device__ __forceinline__ void resplit_a(const Acc& p, float lower, Resplit& r) {
+__device__ __forceinline__ void resplit_a(const Acc& p, float lower, Resplit& r, float& amax) {
   PairTmp& t = r.t[P & 1];
 #ifdef NSR_ABL_NO_CONVERT
   asm volatile("v_max_f32 %0, %2, %4\n\tv_max_f32 %1, %3, %4" : "=&v"(t.x0), "=&v"(t.x1) : "v"(p.m[2 * P]), "v"(p.m[2 * P + 1]), "v"(lower));
@@ -148,17 +157,19 @@ __device__ __forceinline__ void resplit_a(const Acc& p, float lower, Resplit& r)
 #else
   if (RELU)
     asm volatile(
-        "v_max_f32 %0, %3, 0\n\t"
-        "v_max_f32 %1, %4, 0\n\t"
+        "v_max_f32 %0, %4, 0\n\t"
+        "v_max_f32 %1, %5, 0\n\t"
         "v_cvt_pk_f16_f32 %2, %0, %1"
-        : "=&v"(t.x0), "=&v"(t.x1), "=&v"(t.hi)
+        NSR_AMAX_RELU
+        : "=&v"(t.x0), "=&v"(t.x1), "=&v"(t.hi), "+v"(amax)
         : "v"(p.m[2 * P]), "v"(p.m[2 * P + 1]));
   else
     asm volatile(
-        "v_max_f32 %0, %3, %5\n\t"
-        "v_max_f32 %1, %4, %5\n\t"
-        "v_fma_mixlo_f16 %2, %0, %6, 0 op_sel_hi:[0,0,0]"
-        : "=&v"(t.x0), "=&v"(t.x1), "=&v"(t.hi)
+        "v_max_f32 %0, %4, %6\n\t"
+        "v_max_f32 %1, %5, %6\n\t"
+        "v_fma_mixlo_f16 %2, %0, %7, 0 op_sel_hi:[0,0,0]"
+        NSR_AMAX_NOACT
+        : "=&v"(t.x0), "=&v"(t.x1), "=&v"(t.hi), "+v"(amax)
         : "v"(p.m[2 * P]), "v"(p.m[2 * P + 1]), "v"(lower), "v"(kWInvScale));
 #endif
 }
@@ -204,10 +215,10 @@ __device__ __forceinline__ void resplit_b(Resplit& r, u32x4& h0, u32x4& l0, u32x
 // half-step hs (0..16) of the pending block
 template <bool RELU>
 __device__ __forceinline__ void pending_half_t(int hs, const Acc& p, float lower, Resplit& r, u32x4& h0, u32x4& l0, u32x4& h1,
-                                               u32x4& l1) {
+                                               u32x4& l1, float& amax) {
   switch (hs) {
 #define NSR_HS(P)                                                  \
-    case 2 * P: resplit_a<P, RELU>(p, lower, r); break;            \
+    case 2 * P: resplit_a<P, RELU>(p, lower, r, amax); break;      \
     case 2 * P + 1: resplit_b<P, RELU>(r, h0, l0, h1, l1); break;
     NSR_HS(0) NSR_HS(1) NSR_HS(2) NSR_HS(3) NSR_HS(4) NSR_HS(5) NSR_HS(6) NSR_HS(7)
 #undef NSR_HS
@@ -216,18 +227,20 @@ __device__ __forceinline__ void pending_half_t(int hs, const Acc& p, float lower
   }
 }
 template <bool RELU>
-__device__ __forceinline__ void pending_half(int hs, const Acc& p, Resplit& r, u32x4& h0, u32x4& l0, u32x4& h1, u32x4& l1) {
-  pending_half_t<RELU>(hs, p, RELU ? 0.0f : -__builtin_inff(), r, h0, l0, h1, l1);
+__device__ __forceinline__ void pending_half(int hs, const Acc& p, Resplit& r, u32x4& h0, u32x4& l0, u32x4& h1, u32x4& l1,
+                                             float& amax) {
+  pending_half_t<RELU>(hs, p, RELU ? 0.0f : -__builtin_inff(), r, h0, l0, h1, l1, amax);
 }
 // Schedule over the k-steps of a 16-step chunk: 17 half-steps in k-steps 0..13 (k-steps 0, 1, 2 take two), so that
 // even the operands of k-steps 14, 15 (block 7 of the previous layer) are complete before they are used.
 template <bool RELU>
-__device__ __forceinline__ void pending_step(int s, const Acc& p, Resplit& r, u32x4& h0, u32x4& l0, u32x4& h1, u32x4& l1) {
+__device__ __forceinline__ void pending_step(int s, const Acc& p, Resplit& r, u32x4& h0, u32x4& l0, u32x4& h1, u32x4& l1,
+                                             float& amax) {
   if (s < 3) {
-    pending_half<RELU>(2 * s, p, r, h0, l0, h1, l1);
-    pending_half<RELU>(2 * s + 1, p, r, h0, l0, h1, l1);
+    pending_half<RELU>(2 * s, p, r, h0, l0, h1, l1, amax);
+    pending_half<RELU>(2 * s + 1, p, r, h0, l0, h1, l1, amax);
   } else if (s < 14) {
-    pending_half<RELU>(s + 3, p, r, h0, l0, h1, l1);
+    pending_half<RELU>(s + 3, p, r, h0, l0, h1, l1, amax);
   }
 }
 // colour head: pair P of a finished dir_encoding block (relu) dotted with the three rgb rows
@@ -277,7 +290,7 @@ __device__ __forceinline__ void prefetch_next_chunk(Pre& nxt, int k, const Loade
 template <bool RELU_OUT, bool TRAIN = false>   // relu on L2..L8 (true), none on xyz_encoding_final (L == 8: false)
 __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[16], u32x4 (&oh)[16], u32x4 (&ol)[16],
                                             const u32x4* stash, Loader& ld, int h, Acc& pend, Pre& pre,
-                                            const ChunkRef& after0, const ChunkRef& after1,
+                                            const ChunkRef& after0, const ChunkRef& after1, float& amax,
                                             const PanelRef& tr = PanelRef{}, unsigned voff = 0) {
   const ChunkRef ref0 = layer_ref(L, 0, ld.wave);           // this layer's chunks: piece0 advances by `pieces`
 #pragma unroll
@@ -319,9 +332,9 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
           if (nb == 0)
             // block 7 of the previous layer (always relu'd: the previous layer is L1..L7) -> k-steps 14, 15
             // of THIS layer's input, needed only at the end of this chunk
-            pending_step<true>(s, pend, ptmp, bh[14], bl[14], bh[15], bl[15]);
+            pending_step<true>(s, pend, ptmp, bh[14], bl[14], bh[15], bl[15], amax);
           else
-            pending_step<RELU_OUT>(s, pend, ptmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1]);
+            pending_step<RELU_OUT>(s, pend, ptmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1], amax);
           if (TRAIN && s >= 8) {
             const float* blk = (nb == 0) ? panel_block(tr, L - 1, 7) : panel_block(tr, L, nb - 1);
             if (s >= 14) {
@@ -351,8 +364,8 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
 template <int MODE, bool SIGMA_ONLY, int NS, bool COMP = false, bool TRAIN = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ zv,
-                 int64_t P, int N, int stride, float* __restrict__ out, NsrCompOut co = NsrCompOut{}, float* pan = nullptr,
-                 unsigned* sgn = nullptr) {
+                 int64_t P, int N, int stride, float* __restrict__ out, NsrTail tail, NsrCompOut co = NsrCompOut{},
+                 float* pan = nullptr, unsigned* sgn = nullptr) {
   // 3 x 41 KiB weight ring + per-wave stash of the encoded position (8 fragments x 64 lanes x 16 B = 8 KiB
   // per wave) + the colour-head block (rgb weights and bias, 448 floats): 160,512 B of the CU's 160 KiB
   constexpr int kStash0 = 3 * kSlotFloats, kAux0 = kStash0 + 4 * 8 * 256;
@@ -390,18 +403,24 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   const unsigned voff = 4u * (unsigned)(m + 128 * h);   // panel stores: point m of the group, lane half h = 4 rows on
 
   float pe[32], de[16];
+  unsigned flags = 0u;     // NSR_FLAG_* of this lane's point, raised once at the end
+  float amax = 0.0f;       // see resplit_a
   if (MODE == 0) {
     const float* row = x + pc * kInCh;
+    bool ok = true;
 #pragma unroll
     for (int t = 0; t < 32; ++t) {
       const int col = pecol(t, h);
       pe[t] = (col == kPad) ? 0.0f : row[col];
+      ok &= fabsf(pe[t]) <= 65504.0f;
     }
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int col = dircol(t, h);
       de[t] = (col == kPad) ? 0.0f : row[kPosCh + col];
+      ok &= fabsf(de[t]) <= 65504.0f;
     }
+    if (!ok) flags |= NSR_FLAG_INPUT_RANGE;
   } else {
     const int64_t ray = pc / ((NS > 0) ? NS : N);
     const NsrRay rq = nsr_load_ray(x, ray, stride);
@@ -409,6 +428,11 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     const float d[3] = {rq.v[0], rq.v[1], rq.v[2]};           // the direction that is ENCODED
     const float v[3] = {__fadd_rn(rq.o[0], __fmul_rn(zk, rq.d[0])), __fadd_rn(rq.o[1], __fmul_rn(zk, rq.d[1])),
                         __fadd_rn(rq.o[2], __fmul_rn(zk, rq.d[2]))};
+    // the raw coordinates are operands too (columns 0..2 of both encodings): fp16's range, and false for NaN
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ok = ok && fabsf(v[c]) <= 65504.0f && fabsf(d[c]) <= 65504.0f;
+    if (!ok) flags |= NSR_FLAG_INPUT_RANGE;
     pe[0] = h ? v[2] : v[0];
     pe[1] = h ? 0.0f : v[1];
 #pragma unroll
@@ -505,7 +529,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
               for (int q4 = 0; q4 < 5; ++q4)
                 if (q4 < 4 || s == 0)
                   pending_half<true>((s == 0 ? 0 : 4 * s + 1) + q4, pend, ptmp, bh[2 * nb - 2], bl[2 * nb - 2], bh[2 * nb - 1],
-                                     bl[2 * nb - 1]);
+                                     bl[2 * nb - 1], amax);
               if (TRAIN) {
                 const float* blk = panel_block(tr, 0, nb - 1);
 #pragma unroll
@@ -531,15 +555,15 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
 #pragma unroll 1
   for (int pair = 0; pair < 3; ++pair) {
     const int L = 1 + 2 * pair;
-    trunk_layer<true, TRAIN>(L, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(L + 1, 0, wave), layer_ref(L + 1, 1, wave), tr, voff);
-    trunk_layer<true, TRAIN>(L + 1, oh, ol, bh, bl, stash, ld, h, pend, pre, layer_ref(L + 2, 0, wave), layer_ref(L + 2, 1, wave), tr,
-                             voff);
+    trunk_layer<true, TRAIN>(L, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(L + 1, 0, wave), layer_ref(L + 1, 1, wave), amax, tr, voff);
+    trunk_layer<true, TRAIN>(L + 1, oh, ol, bh, bl, stash, ld, h, pend, pre, layer_ref(L + 2, 0, wave), layer_ref(L + 2, 1, wave), amax,
+                             tr, voff);
   }
   if (SIGMA_ONLY) {   // xyz_encoding_final is not evaluated: L8 is followed by the density head, then nothing
-    trunk_layer<true>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, sigma_ref(wave), end_ref(wave));
+    trunk_layer<true>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, sigma_ref(wave), end_ref(wave), amax);
   } else {
-    trunk_layer<true, TRAIN>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave), tr, voff);
-    trunk_layer<false, TRAIN>(8, oh, ol, bh, bl, stash, ld, h, pend, pre, sigma_ref(wave), dir_ref(0, wave), tr, voff);
+    trunk_layer<true, TRAIN>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave), amax, tr, voff);
+    trunk_layer<false, TRAIN>(8, oh, ol, bh, bl, stash, ld, h, pend, pre, sigma_ref(wave), dir_ref(0, wave), amax, tr, voff);
   }
 
   // ---- density head: sigma.weight as row 0 of one more 32-row block over h8 (= oh/ol: the input of
@@ -557,9 +581,9 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
         [&](int s, int part) -> u32x4 { return part ? ol[s] : oh[s]; },
         [&](int s) {
           if (SIGMA_ONLY)
-            pending_step<true>(s, pend, ptmp, oh[14], ol[14], oh[15], ol[15]);
+            pending_step<true>(s, pend, ptmp, oh[14], ol[14], oh[15], ol[15], amax);
           else
-            pending_step<false>(s, pend, ptmp, bh[14], bl[14], bh[15], bl[15]);
+            pending_step<false>(s, pend, ptmp, bh[14], bl[14], bh[15], bl[15], amax);
           if (TRAIN && s >= 14) {   // xyz_encoding_final's last block (no sign bits: nothing is masked by it)
             const float* blk = panel_block(tr, 8, 7);
 #pragma unroll
@@ -575,6 +599,9 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   }
   if (SIGMA_ONLY) {
     if (h == 0 && p < P) out[p] = sigma;
+    if (amax >= 65520.0f) flags |= NSR_FLAG_ACTIVATION_RANGE;
+    if (!nsr_finite(sigma)) flags |= NSR_FLAG_OUTPUT_NONFINITE;
+    if (p < P) nsr_raise(tail, flags);
     dma_drain();   // no LDS-DMA may be in flight when the workgroup's LDS is released
     return;
   }
@@ -636,6 +663,13 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     s += aux[hx::kAuxRgbB + k];
     rgb[k] = 1.0f / (1.0f + expf(-s));
   }
+  if (!TRAIN && nsr_opt_gamma(tail)) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rgb[k] = nsr_gamma(rgb[k]);
+  }
+  if (amax >= 65520.0f) flags |= NSR_FLAG_ACTIVATION_RANGE;
+  if (!(nsr_finite(rgb[0]) && nsr_finite(rgb[1]) && nsr_finite(rgb[2]) && nsr_finite(sigma))) flags |= NSR_FLAG_OUTPUT_NONFINITE;
+  if (p < P) nsr_raise(tail, flags);
   if (out && h == 0 && p < P) reinterpret_cast<float4*>(out)[p] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
   dma_drain();     // no LDS-DMA may be in flight when the workgroup's LDS is released (or re-used just below)
   if (COMP) composite_tile<(COMP ? NS : 64)>(ring, h == 0, wave, m, lane, make_float4(rgb[0], rgb[1], rgb[2], sigma), zv[pc],
@@ -644,35 +678,38 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
 
 template <int MODE, bool SIGMA_ONLY>
 static int launch_f16x3(const void* packed, const float* x, const float* z, int64_t P, int N, int stride, float* out,
-                        hipStream_t st) {
+                        unsigned* tail_w, hipStream_t st) {
+  const NsrTail tail{tail_w};
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   const float* pk = static_cast<const float*>(packed);
   if (MODE == 1 && N == 64)
-    hipLaunchKernelGGL((mlp_f16x3_kernel<MODE, SIGMA_ONLY, 64>), grid, block, 0, st, pk, x, z, P, N, stride, out);
+    hipLaunchKernelGGL((mlp_f16x3_kernel<MODE, SIGMA_ONLY, 64>), grid, block, 0, st, pk, x, z, P, N, stride, out, tail);
   else if (MODE == 1 && N == 128)
-    hipLaunchKernelGGL((mlp_f16x3_kernel<MODE, SIGMA_ONLY, 128>), grid, block, 0, st, pk, x, z, P, N, stride, out);
+    hipLaunchKernelGGL((mlp_f16x3_kernel<MODE, SIGMA_ONLY, 128>), grid, block, 0, st, pk, x, z, P, N, stride, out, tail);
   else
-    hipLaunchKernelGGL((mlp_f16x3_kernel<MODE, SIGMA_ONLY, 0>), grid, block, 0, st, pk, x, z, P, N, stride, out);
+    hipLaunchKernelGGL((mlp_f16x3_kernel<MODE, SIGMA_ONLY, 0>), grid, block, 0, st, pk, x, z, P, N, stride, out, tail);
   if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
   return NSR_OK;
 }
 
 extern "C" NSR_INTERNAL int nsr_f16x3_mlp_forward(const void* packed, const float* x, int64_t P, int sigma_only, float* out,
-                                     void* stream) {
-  return sigma_only ? launch_f16x3<0, true>(packed, x, nullptr, P, 1, 8, out, nsr_stream(stream))
-                    : launch_f16x3<0, false>(packed, x, nullptr, P, 1, 8, out, nsr_stream(stream));
+                                     unsigned* tail, void* stream) {
+  return sigma_only ? launch_f16x3<0, true>(packed, x, nullptr, P, 1, 8, out, tail, nsr_stream(stream))
+                    : launch_f16x3<0, false>(packed, x, nullptr, P, 1, 8, out, tail, nsr_stream(stream));
 }
 
 // render_rays + VolumetricRenderer.forward in one launch (n_samples 64 or 128); raw (R * N, 4) optional
 extern "C" NSR_INTERNAL int nsr_f16x3_render_composite(const void* packed, const float* rays, int ray_stride, const float* z,
-                                                       int64_t R, int N, float* raw, const NsrCompOut* co, void* stream) {
+                                                       int64_t R, int N, float* raw, const NsrCompOut* co, unsigned* tail_w,
+                                                       void* stream) {
+  const NsrTail tail{tail_w};
   const int64_t P = R * N;
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   const float* pk = static_cast<const float*>(packed);
   if (N == 64)
-    hipLaunchKernelGGL((mlp_f16x3_kernel<1, false, 64, true>), grid, block, 0, nsr_stream(stream), pk, rays, z, P, N, ray_stride, raw, *co);
+    hipLaunchKernelGGL((mlp_f16x3_kernel<1, false, 64, true>), grid, block, 0, nsr_stream(stream), pk, rays, z, P, N, ray_stride, raw, tail, *co);
   else if (N == 128)
-    hipLaunchKernelGGL((mlp_f16x3_kernel<1, false, 128, true>), grid, block, 0, nsr_stream(stream), pk, rays, z, P, N, ray_stride, raw, *co);
+    hipLaunchKernelGGL((mlp_f16x3_kernel<1, false, 128, true>), grid, block, 0, nsr_stream(stream), pk, rays, z, P, N, ray_stride, raw, tail, *co);
   else
     return NSR_ERR_UNSUPPORTED;
   if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
@@ -691,12 +728,12 @@ extern "C" NSR_INTERNAL int nsr_f16x3_train_forward(const void* packed, const fl
   const int64_t P = R * N;
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   hipLaunchKernelGGL((mlp_f16x3_kernel<1, false, 0, false, true>), grid, block, 0, nsr_stream(stream),
-                     static_cast<const float*>(packed), rays, z, P, N, ray_stride, raw, NsrCompOut{}, pan, sgn);
+                     static_cast<const float*>(packed), rays, z, P, N, ray_stride, raw, NsrTail{nullptr}, NsrCompOut{}, pan, sgn);
   if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
   return NSR_OK;
 }
 
 extern "C" NSR_INTERNAL int nsr_f16x3_render_rays(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
-                                     int N, float* out, void* stream) {
-  return launch_f16x3<1, false>(packed, rays, z, R * N, N, ray_stride, out, nsr_stream(stream));
+                                     int N, float* out, unsigned* tail, void* stream) {
+  return launch_f16x3<1, false>(packed, rays, z, R * N, N, ray_stride, out, tail, nsr_stream(stream));
 }

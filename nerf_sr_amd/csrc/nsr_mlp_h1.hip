@@ -359,7 +359,7 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bin)[16], u32x4 (&bou
 template <int MODE, bool SIGMA_ONLY, bool BF>
 __global__ void __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kWaves / 4, kWaves / 4)))
 mlp_h1_kernel(const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ zv, int64_t P,
-              int N, int stride, float* __restrict__ out) {
+              int N, int stride, float* __restrict__ out, NsrTail tail) {
   // 3 x 41 KiB weight ring + per-wave stash of the encoded position (4 fragments x 64 lanes x 16 B) + colour head
   // (8 waves: 125,952 + 32,768 + 1,792 = 160,512 B of the 163,840)
   constexpr int kStash0 = 3 * kSlotFloats, kAux0 = kStash0 + kWaves * 4 * 256;
@@ -388,6 +388,19 @@ mlp_h1_kernel(const float* __restrict__ packed, const float* __restrict__ x, con
   const int64_t pc = p < P ? p : P - 1;
   float pe[32], de[16];
   encode_point<MODE>(x, zv, pc, N, stride, h, pe, de);
+  // status word (include/nsr.h): the fast paths check what enters and what leaves -- inputs inside the operand format's
+  // range (an fp16 operand beyond 65,504 is inf; bf16 has fp32's range) and finite outputs; hidden activations are not
+  // tracked here (NSR_F16 / NSR_BF16 are not parity paths)
+  unsigned flags = 0u;
+  {
+    const float lim = BF ? 3.0e38f : 65504.0f;
+    bool ok = true;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) ok &= fabsf(pe[t]) <= lim;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) ok &= fabsf(de[t]) <= lim;
+    if (!ok) flags |= NSR_FLAG_INPUT_RANGE;
+  }
   u32x4 pe4[4], de2[2];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
@@ -477,6 +490,8 @@ mlp_h1_kernel(const float* __restrict__ packed, const float* __restrict__ x, con
   }
   if (SIGMA_ONLY) {
     if (h == 0 && p < P) out[p] = sigma;
+    if (!nsr_finite(sigma)) flags |= NSR_FLAG_OUTPUT_NONFINITE;
+    if (p < P) nsr_raise(tail, flags);
     dma_drain();   // no LDS-DMA may be in flight when the workgroup's LDS is released
     return;
   }
@@ -510,17 +525,24 @@ mlp_h1_kernel(const float* __restrict__ packed, const float* __restrict__ x, con
     s += aux[kAuxRgbB + k];
     rgb[k] = 1.0f / (1.0f + expf(-s));
   }
+  if (nsr_opt_gamma(tail)) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rgb[k] = nsr_gamma(rgb[k]);
+  }
+  if (!(nsr_finite(rgb[0]) && nsr_finite(rgb[1]) && nsr_finite(rgb[2]) && nsr_finite(sigma))) flags |= NSR_FLAG_OUTPUT_NONFINITE;
+  if (p < P) nsr_raise(tail, flags);
   if (h == 0 && p < P) reinterpret_cast<float4*>(out)[p] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
   dma_drain();     // no LDS-DMA may be in flight when the workgroup's LDS is released
 }
 
 template <int MODE, bool SIGMA_ONLY>
 static int launch(bool bf, const void* packed, const float* x, const float* z, int64_t P, int N, int stride, float* out,
-                  hipStream_t st) {
+                  unsigned* tail_w, hipStream_t st) {
+  const NsrTail tail{tail_w};
   const dim3 grid((unsigned)((P + kTile - 1) / kTile)), block(64 * kWaves);
   const float* pk = static_cast<const float*>(packed);
-  if (bf) hipLaunchKernelGGL((mlp_h1_kernel<MODE, SIGMA_ONLY, true>), grid, block, 0, st, pk, x, z, P, N, stride, out);
-  else hipLaunchKernelGGL((mlp_h1_kernel<MODE, SIGMA_ONLY, false>), grid, block, 0, st, pk, x, z, P, N, stride, out);
+  if (bf) hipLaunchKernelGGL((mlp_h1_kernel<MODE, SIGMA_ONLY, true>), grid, block, 0, st, pk, x, z, P, N, stride, out, tail);
+  else hipLaunchKernelGGL((mlp_h1_kernel<MODE, SIGMA_ONLY, false>), grid, block, 0, st, pk, x, z, P, N, stride, out, tail);
   if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
   return NSR_OK;
 }
@@ -547,12 +569,12 @@ extern "C" NSR_INTERNAL int nsr_h1_pack(int bf, const float* const* w, void* pac
 }
 
 extern "C" NSR_INTERNAL int nsr_h1_mlp_forward(int bf, const void* packed, const float* x, int64_t P, int sigma_only,
-                                               float* out, void* stream) {
-  return sigma_only ? h1::launch<0, true>(bf != 0, packed, x, nullptr, P, 1, 8, out, nsr_stream(stream))
-                    : h1::launch<0, false>(bf != 0, packed, x, nullptr, P, 1, 8, out, nsr_stream(stream));
+                                               float* out, unsigned* tail, void* stream) {
+  return sigma_only ? h1::launch<0, true>(bf != 0, packed, x, nullptr, P, 1, 8, out, tail, nsr_stream(stream))
+                    : h1::launch<0, false>(bf != 0, packed, x, nullptr, P, 1, 8, out, tail, nsr_stream(stream));
 }
 
 extern "C" NSR_INTERNAL int nsr_h1_render_rays(int bf, const void* packed, const float* rays, int ray_stride,
-                                               const float* z, int64_t R, int N, float* out, void* stream) {
-  return h1::launch<1, false>(bf != 0, packed, rays, z, R * N, N, ray_stride, out, nsr_stream(stream));
+                                               const float* z, int64_t R, int N, float* out, unsigned* tail, void* stream) {
+  return h1::launch<1, false>(bf != 0, packed, rays, z, R * N, N, ray_stride, out, tail, nsr_stream(stream));
 }

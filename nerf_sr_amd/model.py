@@ -24,6 +24,7 @@ def default_options(**kw) -> SimpleNamespace:
         deg_pos=10, deg_dir=4, dim_pos=3, dim_dir=3, dim_rgb=3, downscale=2, img_wh=(504, 378),
         sigma_activation="relu", color_activation="sigmoid", gamma_correct=False,
         ray_chunk=4096, point_chunk=262144, precision="fp32",
+        check_numerics=True,    # forward() raises on NaN / out-of-range values (the reference: pdb, nerf_downX_model.py:273-274)
     )
     for k, v in kw.items():
         setattr(opt, k, v)
@@ -37,8 +38,6 @@ class NeRFDownXModel:
     def __init__(self, opt: Optional[SimpleNamespace] = None, device="cuda"):
         self.opt = opt or default_options()
         self.device = torch.device(device)
-        if self.opt.gamma_correct:
-            raise NotImplementedError("--gamma_correct is off in every reference script; not built")
         self.netCoarse = VanillaMLP(self.opt, precision=self.opt.precision, device=self.device)
         self.netFine = VanillaMLP(self.opt, precision=self.opt.precision, device=self.device)
         self.models = {"coarse": self.netCoarse, "fine": self.netFine}
@@ -54,6 +53,9 @@ class NeRFDownXModel:
         ``{epoch}_net_Coarse.pth`` / ``{epoch}_net_Fine.pth`` (models/base_model.py:181-219)."""
         self.netCoarse.load_state_dict(sd_coarse)
         self.netFine.load_state_dict(sd_fine)
+        if getattr(self.opt, "gamma_correct", False):    # render_rays returns rgb ** (1 / 2.2) (:271-276)
+            self.netCoarse.set_gamma_correct(True)
+            self.netFine.set_gamma_correct(True)
         return self
 
     # -- mode toggles (nerf_downX_model.py:250-258) ------------------------------
@@ -86,7 +88,8 @@ class NeRFDownXModel:
         opt = self.opt
         if not self.randomized:
             self._outs = ops.forward_rays(self.netCoarse, self.netFine if opt.N_importance > 0 else None, rays,
-                                          opt.N_coarse, opt.N_importance, opt.white_bkgd, opt.lindisp)
+                                          opt.N_coarse, opt.N_importance, opt.white_bkgd, opt.lindisp,
+                                          check=bool(getattr(opt, "check_numerics", True)))
             return self._outs
         # randomized (training-mode) forward: same kernels, stage by stage, jitter drawn with torch.rand
         o, d, near, far = rays[:, 0:3], rays[:, 3:6], rays[:, 6:7], rays[:, 7:8]
@@ -102,6 +105,10 @@ class NeRFDownXModel:
             if opt.noise_std > 0:
                 sig2 = sig2 + torch.randn_like(sig2) * opt.noise_std
             out.update(zip(ops.OUT_KEYS[4:], self.renderer(rgb2, sig2, z2, opt.white_bkgd)))
+        if getattr(opt, "check_numerics", True):
+            self.netCoarse.check("coarse network")
+            if opt.N_importance > 0:
+                self.netFine.check("fine network")
         return out
 
     def forward(self):

@@ -194,8 +194,42 @@ class VanillaMLP:
             v = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v.detach()
             dev[k] = v.to(device=self.device, dtype=torch.float32).contiguous()
         ptrs = (c_void_p * len(dev))(*[c_void_p(t.data_ptr()) for t in dev.values()])
-        _lib.check(_lib.load().nsr_pack_weights(ptrs, _p(self.packed), self._prec, _stream()), "nsr_pack_weights")
+        rc = _lib.load().nsr_pack_weights(ptrs, _p(self.packed), self._prec, _stream())
+        if rc == _lib.NSR_ERR_RANGE:
+            raise _lib.NsrNumericsError(
+                f"state_dict cannot be carried at precision {self.precision!r}: a weight or bias is non-finite"
+                + (" or |w| >= 1023.75 (the split-fp16 stream holds 2^6 w in fp16)" if self.precision == "f16x3" else
+                   " or |w| >= 65520 (fp16 operands)" if self.precision == "f16" else "")
+                + "; load it with precision='fp32'", 1)
+        _lib.check(rc, "nsr_pack_weights")
         self._sd = dev     # keep the fp32 originals alive (state_dict() round trip)
+        self._gamma = False
+        return self
+
+    def set_gamma_correct(self, enable: bool = True):
+        """``--gamma_correct`` (models/nerf_downX_model.py:271-276): the colour head returns ``rgb ** (1 / 2.2)``."""
+        _lib.check(_lib.load().nsr_weights_set_gamma(_p(self.packed), self._prec, int(bool(enable)), _stream()),
+                   "nsr_weights_set_gamma")
+        self._gamma = bool(enable)
+        return self
+
+    def status(self, clear: bool = False) -> int:
+        """The network's sticky numerics status word (``NSR_FLAG_*`` bits, include/nsr.h): 0 = every launch through this
+        network so far saw finite inputs, in-range activations and finite outputs.  Waits for the current stream."""
+        flags = ctypes.c_uint(0)
+        _lib.check(_lib.load().nsr_weights_status(_p(self.packed), self._prec, int(bool(clear)), ctypes.byref(flags), _stream()),
+                   "nsr_weights_status")
+        return int(flags.value)
+
+    def check(self, what: str = "network"):
+        """Raise ``NsrNumericsError`` if the status word is set (and clear it): the reference drops into pdb on NaN
+        colours (models/nerf_downX_model.py:273-274); this is the error a replacement reports instead."""
+        flags = self.status(clear=True)
+        if flags:
+            names = _lib.flag_names(flags)
+            hint = " -- values left the split-fp16 operand range: re-run with precision='fp32'" \
+                if (flags & 4 or (flags & 2 and self.precision in ("f16x3", "f16"))) else ""
+            raise _lib.NsrNumericsError(f"{what} ({self.precision}): numerics status {flags:#x} = {' | '.join(names)}{hint}", flags)
         return self
 
     def state_dict(self):
@@ -283,12 +317,16 @@ OUT_KEYS = ("coarse_comp_rgbs", "coarse_depth", "coarse_opacity", "coarse_weight
 def forward_rays(coarse: VanillaMLP, fine: Optional[VanillaMLP], rays: torch.Tensor, N_coarse: int = 64,
                  N_importance: int = 64, white_bkgd: bool = False, lindisp: bool = False,
                  workspace: Optional[torch.Tensor] = None, outs: Optional[Dict[str, torch.Tensor]] = None,
-                 want_weights: bool = True, events=None) -> Dict[str, torch.Tensor]:
+                 want_weights: bool = True, events=None, check: bool = False) -> Dict[str, torch.Tensor]:
     """Eval-mode forward_rays for the WHOLE batch in one enqueue sequence
     (models/nerf_downX_model.py:280-324; with 11-wide rays: the vanilla model's models/nerf_model.py:207-242):
     returns the reference's 8-entry dict.
     ``workspace`` / ``outs`` let a caller reuse buffers across frames; ``events`` (4 raw
-    hipEvent_t handles from ``HipEvents``) brackets the coarse / fine MLP launches."""
+    hipEvent_t handles from ``HipEvents``) brackets the coarse / fine MLP launches.
+    ``check=True`` reads both networks' numerics status words after the enqueue (one stream wait) and raises
+    ``NsrNumericsError`` on non-finite inputs / outputs or out-of-range activations -- the reference's NaN trap
+    (models/nerf_downX_model.py:273-274) as an exception; ``False`` leaves the sticky flags for a later
+    ``net.check()`` / ``net.status()`` (nothing is synchronised)."""
     lib = _lib.load()
     rays = _f32(rays, "rays")
     rays = rays.reshape(-1, rays.shape[-1])
@@ -299,7 +337,7 @@ def forward_rays(coarse: VanillaMLP, fine: Optional[VanillaMLP], rays: torch.Ten
     if fine is not None and fine._prec != coarse._prec:
         raise ValueError("coarse and fine networks must use the same precision")
     dev = rays.device
-    need = lib.nsr_forward_rays_workspace_bytes(R, N_coarse, N_importance)
+    need = lib.nsr_forward_rays_workspace_bytes_for(coarse._prec, R, N_coarse, N_importance)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
     Nf = N_coarse + N_importance
@@ -319,6 +357,10 @@ def forward_rays(coarse: VanillaMLP, fine: Optional[VanillaMLP], rays: torch.Ten
                                              coarse._prec, _p(rays), stride, R, N_coarse, N_importance, int(bool(white_bkgd)),
                                              int(bool(lindisp)), ptrs, _p(workspace), workspace.numel(), _stream(), ev),
                "nsr_forward_rays")
+    if check:
+        coarse.check("coarse network")
+        if fine is not None and N_importance > 0:
+            fine.check("fine network")
     return outs
 
 

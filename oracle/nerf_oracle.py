@@ -245,19 +245,24 @@ def mlp_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, sigma_only: bool =
     return torch.cat([rgb, sigma], -1)
 
 
-def render_points(sd, xyz: torch.Tensor, dir_embedded: torch.Tensor, point_chunk: int = 262144):
+def render_points(sd, xyz: torch.Tensor, dir_embedded: torch.Tensor, point_chunk: int = 262144,
+                  gamma_correct: bool = False):
     """(R, N, 3) points + (R, 27) dir embedding -> rgb (R, N, 3), sigma (R, N).
 
     Restates ``models/nerf_downX_model.py:260-278`` (render_rays): PE of the points,
     ``repeat_interleave`` of the per-ray dir embedding, concat to (P, 90), MLP in
-    ``point_chunk`` slices (``utils/utils.py:130-152``).
+    ``point_chunk`` slices (``utils/utils.py:130-152``); ``gamma_correct``: ``out_rgbs = pow(out_rgbs, 1/2.2)``
+    (``:271-276``, ``--gamma_correct``).
     """
     R, N = xyz.shape[:2]
     pts = xyz.reshape(-1, 3)
     x = torch.cat([posenc(pts, 10), dir_embedded.repeat_interleave(N, dim=0)], -1)
     outs = [mlp_forward(sd, x[i:i + point_chunk]) for i in range(0, x.shape[0], point_chunk)]
     out = torch.cat(outs, 0).view(R, N, 4)
-    return out[..., :3], out[..., 3]
+    rgb = out[..., :3]
+    if gamma_correct:
+        rgb = torch.pow(rgb, 1 / 2.2)
+    return rgb, out[..., 3]
 
 
 # ----------------------------------------------------------------------------
@@ -289,7 +294,7 @@ def composite(rgb: torch.Tensor, sigma: torch.Tensor, z: torch.Tensor, white_bkg
 # ----------------------------------------------------------------------------
 
 def forward_rays(sd_coarse, sd_fine, rays: torch.Tensor, n_coarse: int = 64, n_importance: int = 64,
-                 white_bkgd: bool = False, lindisp: bool = False, ray_chunk: int = 4096):
+                 white_bkgd: bool = False, lindisp: bool = False, ray_chunk: int = 4096, gamma_correct: bool = False):
     """Eval-mode ``forward_rays`` over (R, 8) rays -> dict of the 8 reference outputs.
 
     Restates ``models/nerf_downX_model.py:280-313`` chunked as ``:316-324``
@@ -303,13 +308,13 @@ def forward_rays(sd_coarse, sd_fine, rays: torch.Tensor, n_coarse: int = 64, n_i
         o, d, near, far = r[:, 0:3], r[:, 3:6], r[:, 6:7], r[:, 7:8]
         de = posenc(r[:, 8:11] if r.shape[1] == 11 else d, 4)
         z, xyz = sample_coarse(o, d, near, far, n_coarse, lindisp)
-        rgb, sig = render_points(sd_coarse, xyz, de)
+        rgb, sig = render_points(sd_coarse, xyz, de, gamma_correct=gamma_correct)
         c_rgb, c_depth, c_op, c_w = composite(rgb, sig, z, white_bkgd)
         res = {"coarse_comp_rgbs": c_rgb, "coarse_depth": c_depth, "coarse_opacity": c_op,
                "coarse_weights": c_w}
         if n_importance > 0:
             z2, xyz2 = resample_fine(o, d, z, c_w, n_importance)
-            rgb2, sig2 = render_points(sd_fine, xyz2, de)
+            rgb2, sig2 = render_points(sd_fine, xyz2, de, gamma_correct=gamma_correct)
             f_rgb, f_depth, f_op, f_w = composite(rgb2, sig2, z2, white_bkgd)
             res.update({"fine_comp_rgbs": f_rgb, "fine_depth": f_depth, "fine_opacity": f_op,
                         "fine_weights": f_w})

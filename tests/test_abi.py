@@ -37,20 +37,29 @@ def test_header_symbols_exported_and_bound(lib):
 
 
 def test_version_and_status_strings(lib):
-    assert lib.nsr_version() == 100
+    assert lib.nsr_version() == 110
     assert lib.nsr_status_string(0) == b"ok"
-    for code in (-1, -2, -3, -4, -99):
+    for code in (-1, -2, -3, -4, -5, -99):
         assert len(lib.nsr_status_string(code)) > 0
 
 
 def test_sizes(lib):
     nbytes = lib.nsr_packed_weights_bytes(_lib.NSR_FP32)
-    # fragment stream (zero padded K) + aux block: a bit more than the raw parameters
+    # fragment stream (zero padded K) + aux block + the 16-byte tail (status word, options): a bit more than the raw parameters
     assert N_PARAMS * 4 <= nbytes <= int(N_PARAMS * 4 * 1.05)
+    for prec in (_lib.NSR_FP32, _lib.NSR_BF16, _lib.NSR_F16X3, _lib.NSR_F16):
+        assert lib.nsr_packed_weights_bytes(prec) % 16 == 0
+    assert lib.nsr_packed_weights_bytes(9) == 0
     R, nc, ni = 190512, 64, 64
     ws = lib.nsr_forward_rays_workspace_bytes(R, nc, ni)
     assert ws >= R * (nc * 4 + nc * 16 + nc * 4 + (nc + ni) * 4 + (nc + ni) * 16)
     assert lib.nsr_forward_rays_workspace_bytes(-1, nc, ni) == 0
+    # the fused route (fp32 / f16x3 at 64 + 128 samples) never materialises the (R, N, 4) network outputs
+    fused = lib.nsr_forward_rays_workspace_bytes_for(_lib.NSR_F16X3, R, nc, ni)
+    assert R * (2 * nc * 4 + (nc + ni) * 4) <= fused <= R * (2 * nc * 4 + (nc + ni) * 4) + 1024 and fused * 3 < ws
+    assert lib.nsr_forward_rays_workspace_bytes_for(_lib.NSR_FP32, R, nc, ni) == fused
+    assert lib.nsr_forward_rays_workspace_bytes_for(_lib.NSR_F16, R, nc, ni) == ws              # fast paths: network, then compositor
+    assert lib.nsr_forward_rays_workspace_bytes_for(_lib.NSR_F16X3, R, 96, 32) == R * (2 * 96 * 4 + 96 * 16 + 128 * 4)    # 96 coarse: unfused; 128 fine: fused
 
 
 def test_invalid_arguments_are_rejected_before_any_launch(lib):
@@ -71,6 +80,17 @@ def test_invalid_arguments_are_rejected_before_any_launch(lib):
     assert lib.nsr_unflatten(one, 12, 16, 5, 3, one, null) == -1
     outs = (c_void_p * 8)()
     assert lib.nsr_forward_rays(one, one, 0, one, 8, 4, 64, 64, 0, 0, outs, c_void_p(256), 16, null) == -4
+    # status word / options / checked packing: argument validation comes before anything is enqueued or waited for
+    flags = ctypes.c_uint(0)
+    assert lib.nsr_weights_status(null, 2, 0, ctypes.byref(flags), null) == -1
+    assert lib.nsr_weights_status(one, 2, 0, None, null) == -1
+    assert lib.nsr_weights_status(one, 9, 0, ctypes.byref(flags), null) == -2
+    assert lib.nsr_weights_set_gamma(null, 2, 1, null) == -1 and lib.nsr_weights_set_gamma(one, 9, 1, null) == -2
+    p24 = (c_void_p * 24)(*[one] * 24)
+    for pack in (lib.nsr_pack_weights, lib.nsr_pack_weights_async):
+        assert pack(p24, null, 2, null) == -1 and pack(p24, c_void_p(24), 2, null) == -1      # null / misaligned blob
+        assert pack(p24, one, 9, null) == -2
+        assert pack((c_void_p * 24)(), one, 0, null) == -1                                       # null tensor
     # zero-sized work is a no-op success
     assert lib.nsr_posenc(one, 0, 10, one, null) == 0
     assert lib.nsr_composite(one, 3, one, 1, one, 0, 64, 0, null, null, null, null, null) == 0

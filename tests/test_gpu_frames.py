@@ -238,8 +238,9 @@ def test_config5_full_size_end_to_end(ops):
 def test_bench_two_ranks_on_one_gpu_gloo():
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), on THIS box: both
     ranks share the one GPU and exchange over gloo (NSR_DIST_BACKEND; RCCL refuses two ranks per device).  Checks the
-    N > 1 code path end to end: config #4's frame cut in two LR-pixel blocks, one all-gather per step, max-over-ranks
-    timing, one JSON line from rank 0 with the contract's fields."""
+    N > 1 code path end to end: the SAME workload and metric string as N = 1 (config #2's frame cut in two LR-pixel
+    blocks), config #4 cut the same way as the `config4` sub-object, one all-gather per step whose result is verified
+    identical on both ranks, max-over-ranks timing, one JSON line from rank 0 with the contract's fields."""
     import json
     import os
     import socket
@@ -257,9 +258,27 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
     d = json.loads(lines[0])
+    one = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-config4"], cwd=repo, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    # one workload per scaling curve: N = 2 reports the metric N = 1 reports, on the same frame
+    assert d["metric"] == d1["metric"] == "rays/sec (64+128 samples, 2x SS)"
+    assert d["config"]["rays_per_step"] == d1["config"]["rays_per_step"] == 190512
+    assert d1["n_gpus"] == 1 and d1["scaling"] == "strong" and d1["collective"]["world"] == 1 and d1["collective"]["backend"] is None
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 2 and d["warmup"] == 1
     assert d["unit"] == "rays/s" and d["higher_is_better"] is True and d["data"] == "synthetic" and d["vs_baseline"] is None
-    assert "config #4" in d["config"]["workload"] and d["config"]["rays_per_step"] == 762048
-    assert abs(d["value"] - 762048 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert "config #2" in d["config"]["workload"] and "2 contiguous LR-pixel blocks" in d["config"]["workload"]
+    assert abs(d["value"] - 190512 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert 2e5 < d["value"] < 1e7                       # two ranks time-slicing one GPU: about the single-GPU rate
     assert d["roofline"]["bound"] == "mfma" and 0.0 < d["roofline"]["frac"] < 1.0 and d["cpu_baseline"] is None
+    c = d["collective"]
+    assert c["backend"] == "gloo" and c["world"] == 2 and c["calls_per_step"] == 1 and c["bytes_per_rank"] == 23814 * 12
+    assert c["result_identical_on_all_ranks"] is True and c["rccl_version"] is None          # gloo here; RCCL on a multi-GPU node
+    c4 = d["config4"]
+    assert "config #4" in c4["workload"] and c4["rays_per_step"] == 762048 and c4["metric"] == "rays/sec (64+128 samples, 4x SS)"
+    assert c4["result_identical_on_all_ranks"] is True and abs(c4["value"] - 762048 / (c4["ms_per_step"] * 1e-3)) <= 1e-6 * c4["value"]
+    assert d["numerics_status"] == [0, 0]
+    src = d["roofline"]["pmc_source"]
+    assert set(src) == {"file", "csrc_sha256", "this_build_sha256", "matches_this_build"}
+    assert d["roofline"]["traffic"] is None             # the counter constants belong to the unsharded config #2 launch

@@ -130,3 +130,23 @@ def test_edge_cases(golden_dir):
     near, far = 2.0 * torch.ones(R, 1), 6.0 * torch.ones(R, 1)
     _close(oc.sample_coarse(o, d, near, far, 64, u=_t(e["u_coarse"]))[0], e["z_coarse_rand"], 1e-6)
     _close(oc.sample_coarse(o, d, near, far, 64, lindisp=True)[0], e["z_coarse_lindisp"], 1e-6)
+
+
+def test_gamma_correct_forward(golden_dir):
+    """--gamma_correct (models/nerf_downX_model.py:271-276): fixture made by the reference with opt.gamma_correct = True."""
+    g = np.load(os.path.join(golden_dir, "gamma.npz"))
+    for tag, white in (("llff", False), ("blender", True)):
+        p = np.load(os.path.join(golden_dir, f"path_{tag}.npz"))
+        sd_c = oc.to_torch_sd(make_state_dict(int(p["seed_coarse"])))
+        sd_f = oc.to_torch_sd(make_state_dict(int(p["seed_fine"])))
+        rays = _t(p["rays"])[:int(g[f"{tag}_n_rays"])]
+        out = oc.forward_rays(sd_c, sd_f, rays, 64, 64, white, gamma_correct=True)
+        for k, v in out.items():
+            _close(v, g[f"{tag}_{k}"], 1e-5 if "depth" in k else ATOL)
+        plain = oc.forward_rays(sd_c, sd_f, rays, 64, 64, white)
+        assert float((plain["fine_comp_rgbs"] - out["fine_comp_rgbs"]).abs().max()) > 1e-2      # the option does something
+        o, d, near, far = rays[:, 0:3], rays[:, 3:6], rays[:, 6:7], rays[:, 7:8]
+        z, xyz = oc.sample_coarse(o, d, near, far, 64)
+        rgb, sig = oc.render_points(sd_c, xyz, oc.posenc(d, 4), gamma_correct=True)
+        _close(rgb[:16], g[f"{tag}_coarse_point_rgb"])
+        _close(sig[:16], g[f"{tag}_coarse_point_sigma"], 1e-5)

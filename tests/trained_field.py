@@ -1,0 +1,198 @@
+"""TEST INFRASTRUCTURE: a *trained* density field for the frame-scale parity tests (no checkpoint or dataset can be
+downloaded, and the synthetic fields of ``nerf_sr_amd.weights`` are random networks, not scenes).
+
+An analytic hard-surface scene -- opaque spheres in front of a textured wall (forward-facing / NDC family) or against a
+white background (inward-facing / Blender family) -- gives exact pixel colours by ray intersection, for any pose, with no
+image file.  Both networks are trained on it from kaiming initialisation with this repository's own ``Trainer`` (the HIP
+training step) exactly as ``train.py`` drives the reference: random LR pixels of random training poses,
+their s*s sub-pixel rays, the LR target = mean of the s*s analytic sub-pixel colours, randomized sampling, density noise
+for the forward-facing family (``scripts/train_llff_downX.sh``: ``--noise_std 1``), Adam at 5e-4.  The result is what the
+parity tests need: surfaces (fine weights concentrated on a few samples), empty space, and trained-scale activations.
+
+The scene lives in the space the rays live in: NDC for the forward-facing family (``get_ndc_rays`` maps the rays of every
+pose into the NDC frame of the world camera, so a geometry fixed in NDC is consistent across poses), world space for the
+Blender family.  Everything here is torch elementwise on whatever device the rays are on.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from nerf_sr_amd import cameras
+from nerf_sr_amd.weights import make_state_dict
+
+# centre (x, y, z), radius, albedo (r, g, b)
+SPHERES_NDC = [((-0.45, 0.10, -0.35), 0.26, (0.85, 0.25, 0.20)), ((0.30, -0.20, -0.05), 0.30, (0.20, 0.65, 0.30)),
+               ((0.05, 0.35, 0.30), 0.22, (0.25, 0.35, 0.90)), ((-0.25, -0.35, 0.45), 0.20, (0.90, 0.80, 0.20)),
+               ((0.55, 0.30, 0.55), 0.24, (0.70, 0.30, 0.75))]
+WALL_Z_NDC = 0.9
+SPHERES_WORLD = [((0.0, 0.0, 0.0), 0.75, (0.85, 0.25, 0.20)), ((0.95, 0.25, 0.35), 0.40, (0.20, 0.65, 0.30)),
+                 ((-0.80, -0.30, 0.55), 0.45, (0.25, 0.35, 0.90)), ((0.15, 0.85, -0.70), 0.35, (0.90, 0.80, 0.20)),
+                 ((-0.35, -0.75, -0.80), 0.38, (0.70, 0.30, 0.75))]
+LIGHT = (0.35, 0.55, -0.76)
+
+
+def analytic_colours(rays: torch.Tensor, family: str) -> torch.Tensor:
+    """Exact colour of every ray (R, 8) -> (R, 3): nearest sphere hit inside [near, far] (Lambert shading, fixed light);
+    otherwise the checker wall at NDC z = 0.9 (``family='llff'``) or the white background (``'blender'``)."""
+    o, d = rays[:, 0:3].double(), rays[:, 3:6].double()
+    near, far = rays[:, 6].double(), rays[:, 7].double()
+    spheres = SPHERES_NDC if family == "llff" else SPHERES_WORLD
+    light = torch.tensor(LIGHT, dtype=torch.float64, device=rays.device)
+    light = light / light.norm()
+    dd = (d * d).sum(-1)
+    best_t = torch.full_like(near, float("inf"))
+    colour = torch.ones(rays.shape[0], 3, dtype=torch.float64, device=rays.device)
+    if family == "llff":
+        t_wall = (WALL_Z_NDC - o[:, 2]) / d[:, 2]
+        p = o + t_wall[:, None] * d
+        check = ((torch.floor(p[:, 0] * 4.0) + torch.floor(p[:, 1] * 4.0)) % 2 == 0).double()[:, None]
+        tone = 0.5 + 0.5 * torch.stack([torch.sin(3.0 * p[:, 0]), torch.cos(2.0 * p[:, 1]), torch.sin(p[:, 0] + p[:, 1])], -1)
+        colour = check * (0.25 + 0.5 * tone) + (1 - check) * (0.85 - 0.35 * tone)
+        best_t = t_wall
+    for c, r, alb in spheres:
+        c_t = torch.tensor(c, dtype=torch.float64, device=rays.device)
+        oc_ = o - c_t
+        b = (oc_ * d).sum(-1)
+        disc = b * b - dd * ((oc_ * oc_).sum(-1) - r * r)
+        t = (-b - torch.sqrt(disc.clamp_min(0))) / dd
+        hit = (disc > 0) & (t > near) & (t < far) & (t < best_t)
+        n = (o + t[:, None] * d - c_t) / r
+        shade = 0.25 + 0.75 * (n * (-light)).sum(-1).clamp_min(0)
+        col = torch.tensor(alb, dtype=torch.float64, device=rays.device)[None] * shade[:, None]
+        colour = torch.where(hit[:, None], col, colour)
+        best_t = torch.where(hit, t, best_t)
+    return colour.float()
+
+
+FAMILIES = {
+    # img_wh (HR), downscale, ndc, white background, (near, far), density noise of the training script
+    "llff": ((504, 378), 2, True, False, (0.0, 1.0), 1.0),
+    "blender": ((400, 400), 2, False, True, (2.0, 6.0), 0.0),
+}
+
+
+def train_pose(family: str, k: int, n: int) -> Tuple[np.ndarray, float]:
+    wh = FAMILIES[family][0]
+    if family == "llff":
+        return cameras.spiral_pose(2.0 * math.pi * k / n), cameras.llff_focal(wh[0])
+    return cameras.spheric_pose(360.0 * k / n, -30.0 + 20.0 * math.sin(2.0 * math.pi * k / n), 4.0), cameras.blender_focal(wh[0])
+
+
+def eval_pose(family: str) -> Tuple[np.ndarray, float]:
+    """A pose that is NOT a training pose (the frame the parity protocol renders)."""
+    wh = FAMILIES[family][0]
+    if family == "llff":
+        return cameras.spiral_pose(0.4), cameras.llff_focal(wh[0])
+    return cameras.spheric_pose(40.0, -30.0, 4.0), cameras.blender_focal(wh[0])
+
+
+def train_field(family: str, steps: int = 6000, n_poses: int = 12, lr_pixels: int = 512, seed: int = 0, log=None) -> Dict:
+    """Train both networks on the analytic scene; returns ``{"sd_coarse", "sd_fine"}`` (numpy state dicts) + statistics.
+    Runs on the current GPU through ``nerf_sr_amd.train.Trainer`` (precision f16x3, the product training path)."""
+    from nerf_sr_amd import ops
+    from nerf_sr_amd.train import Trainer
+    wh, s, ndc, white, nf, noise = FAMILIES[family]
+    torch.manual_seed(seed)
+    rays, tgts = [], []
+    for k in range(n_poses):
+        c2w, focal = train_pose(family, k, n_poses)
+        r = ops.subpixel_rays(c2w, wh, focal, s, ndc, *nf)                       # (N_lr, s*s, 8)
+        rays.append(r)
+        tgts.append(analytic_colours(r.view(-1, 8), family).view(r.shape[0], s * s, 3).mean(1))
+    # kaiming weights, zero biases: the reference's init (models/networks.py:31-38)
+    sd_c, sd_f = make_state_dict(1000 + seed, "plain", bias_scale=0.0), make_state_dict(2000 + seed, "plain", bias_scale=0.0)
+    tr = Trainer(sd_c, sd_f, white_bkgd=white, downscale=s, randomized=True, noise_std=noise, lr=5e-4, ray_chunk=4096)
+    n_lr = rays[0].shape[0]
+    hist = []
+    pick = np.random.Generator(np.random.PCG64(seed))     # host-side pose choice: no device round trip per step
+    for step in range(steps):
+        k = int(pick.integers(n_poses))
+        idx = torch.randint(n_lr, (lr_pixels,), device=rays[k].device)
+        tr.set_input(rays[k][idx], tgts[k][idx])
+        losses = tr.optimize_parameters()
+        if step % 500 == 0 or step == steps - 1:
+            l = [float(x) for x in losses.tolist()]
+            hist.append((step, l[0], l[1]))
+            if log:
+                log(f"[train {family}] step {step}: mse coarse {l[0]:.5f} fine {l[1]:.5f}  (PSNR fine {-10 * math.log10(max(l[1], 1e-12)):.1f} dB)")
+            if not all(math.isfinite(x) for x in l):
+                raise FloatingPointError(f"training diverged at step {step}: {l}")
+    sds = tr.state_dicts()
+    out = {"sd_coarse": {k: v.cpu().numpy() for k, v in sds[0].items()},
+           "sd_fine": {k: v.cpu().numpy() for k, v in sds[1].items()}, "history": hist, "steps": steps}
+    return out
+
+
+def layer_abs_max(sd: Dict[str, np.ndarray], x: torch.Tensor) -> Dict[str, float]:
+    """max |activation| of every layer of ``VanillaMLP`` (models/networks.py:182-226) on embedded rows x (B, 90), in fp64 on
+    the CPU: what the split-fp16 path's operand range (|h| < 1023.75) has to cover."""
+    lin = torch.nn.functional.linear
+    w = {k: torch.from_numpy(np.asarray(v)).double() for k, v in sd.items()}
+    x = x.double()
+    pe, de = x[:, :63], x[:, 63:]
+    out = {"input": float(x.abs().max())}
+    h = pe
+    for i in range(8):
+        if i == 4:
+            h = torch.cat([pe, h], -1)
+        pre = lin(h, w[f"xyz_encoding_{i + 1}.0.weight"], w[f"xyz_encoding_{i + 1}.0.bias"])
+        h = torch.relu(pre)
+        out[f"xyz_encoding_{i + 1}"] = float(pre.abs().max())
+    out["sigma"] = float(lin(h, w["sigma.weight"], w["sigma.bias"]).abs().max())
+    g = lin(h, w["xyz_encoding_final.weight"], w["xyz_encoding_final.bias"])
+    out["xyz_encoding_final"] = float(g.abs().max())
+    out["dir_encoding"] = float(lin(torch.cat([g, de], -1), w["dir_encoding.0.weight"], w["dir_encoding.0.bias"]).abs().max())
+    out["max_weight"] = max(float(np.abs(v).max()) for k, v in sd.items() if k.endswith("weight"))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ parity protocol
+RGB_TOL = 1e-4
+
+
+def oracle_block(family: str, sd_c, sd_f, n_rays: int, threads: int = 32):
+    """fp32 and fp64 oracle outputs on `n_rays` consecutive rays from the middle of the evaluation frame."""
+    from oracle import nerf_oracle as oc
+    wh, s, ndc, white, nf, _ = FAMILIES[family]
+    c2w, focal = eval_pose(family)
+    rays = oc.subpixel_ray_grid(torch.from_numpy(c2w), wh[1], wh[0], focal, s, ndc, *nf).reshape(-1, 8)
+    lo = (rays.shape[0] // 2) - (rays.shape[0] // 2) % (s * s)
+    blk = rays[lo:lo + n_rays].contiguous()
+    old = torch.get_num_threads()
+    torch.set_num_threads(min(threads, old))
+    with torch.no_grad():
+        ref = oc.forward_rays(oc.to_torch_sd(sd_c), oc.to_torch_sd(sd_f), blk, 64, 64, white)
+        ref64 = oc.forward_rays(oc.to_torch_sd(sd_c, torch.float64), oc.to_torch_sd(sd_f, torch.float64), blk.double(), 64, 64, white)
+    torch.set_num_threads(old)
+    return blk, ref, ref64
+
+
+def parity_stats(hip: Dict[str, torch.Tensor], ref, ref64) -> Dict:
+    """The contract, per ray: |dRGB| of the fine colours <= max(1e-4, 2 x the oracle's own fp32-vs-fp64 gap on
+    that ray) -- two fp32 evaluations of an ill-conditioned ray may each sit `gap` away from the exact result, on opposite
+    sides.  Returns the error distribution, the number of rays whose bound is the conditioning term ("exempt": 2 gap >
+    1e-4), and the violations."""
+    d = (hip["fine_comp_rgbs"].cpu().double() - ref["fine_comp_rgbs"].double()).abs().max(-1)[0]
+    gap = (ref["fine_comp_rgbs"].double() - ref64["fine_comp_rgbs"]).abs().max(-1)[0]
+    d64 = (hip["fine_comp_rgbs"].cpu().double() - ref64["fine_comp_rgbs"]).abs().max(-1)[0]
+    bound = torch.clamp_min(2.0 * gap, RGB_TOL)
+    q = lambda t, p: float(torch.quantile(t, p))
+    dc = (hip["coarse_comp_rgbs"].cpu().double() - ref["coarse_comp_rgbs"].double()).abs().max(-1)[0]
+    return {
+        "rays": int(d.numel()),
+        "hip_vs_oracle32": {"median": float(d.median()), "p99": q(d, 0.99), "p999": q(d, 0.999), "max": float(d.max()),
+                            "over_1e-4": int((d > RGB_TOL).sum())},
+        "oracle64_vs_oracle32": {"median": float(gap.median()), "p99": q(gap, 0.99), "p999": q(gap, 0.999), "max": float(gap.max()),
+                                 "over_1e-4": int((gap > RGB_TOL).sum())},
+        "hip_vs_oracle64": {"median": float(d64.median()), "p99": q(d64, 0.99), "max": float(d64.max()), "over_1e-4": int((d64 > RGB_TOL).sum())},
+        "exempt_rays": int((2.0 * gap > RGB_TOL).sum()),
+        "violations": int((d > bound).sum()),
+        "worst_violation": float((d - bound).max()),
+        "coarse_max": float(dc.max()),
+        "fine_weight_peak_median": float(ref["fine_weights"].max(-1)[0].median()),
+        "fine_opacity_mean": float(ref["fine_opacity"].mean()),
+    }
