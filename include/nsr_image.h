@@ -1,8 +1,10 @@
 /* nsr_image.h — C ABI of the LR-target construction of the downX datasets.
  *
  * Replaces, per training image, `img.resize(img_wh, Image.LANCZOS)`, `img.resize((W/s, H/s), Image.LANCZOS)`,
- * `ToTensor` and the regroup '(h s1) (w s2) c -> (h w) (s1 s2) c' of data/llff_downX_dataset.py:312-329 and
- * data/blender_downX_dataset.py:117-135.  The resampling arithmetic is Pillow's 8-bit path (src/libImaging/Resample.c:
+ * `ToTensor` and the regroup '(h s1) (w s2) c -> (h w) (s1 s2) c' of data/llff_downX_dataset.py:312-329 (RGB) and
+ * data/blender_downX_dataset.py:104-135 (RGBA: Pillow resamples such images premultiplied -- PIL/Image.py `resize`:
+ * convert("RGBa") -> resample -> convert("RGBA"), src/libImaging/Convert.c rgbA2rgba / rgba2rgbA -- and the dataset
+ * then blends onto white, `rgb * a + (1 - a)`; nsr_rgba_premultiply_u8 + nsr_image_to_targets_rgba).  The resampling arithmetic is Pillow's 8-bit path (src/libImaging/Resample.c:
  * precompute_coeffs, normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc / Vertical_8bpc; the reference does not
  * pin a Pillow version, the algorithm has been stable since 3.x): LANCZOS (a = 3) weights normalised in double,
  * rounded to 22-bit fixed point, int32 accumulation, clip to [0, 255]; horizontal pass first.  Results are
@@ -33,6 +35,14 @@ int nsr_resample_pass_u8(const uint8_t* src, int H, int W, int C, int axis, int 
 /* ToTensor + regroup: img (H, W, 3) uint8 -> out (H/s * W/s, s*s, 3) fp32 = img / 255, LR-pixel-major, sub-pixel
  * index dy*s+dx (the layout of the ray tensor, nsr_gen_rays).  s = 1: the plain (H*W, 3) target tensor. */
 int nsr_image_to_targets(const uint8_t* img, int H, int W, int s, float* out, void* stream);
+
+/* RGBA images.  nsr_rgba_premultiply_u8: Pillow's RGBA -> "RGBa" (inverse == 0: colour bytes c -> MULDIV255(c, a)) and
+ * "RGBa" -> RGBA (inverse != 0: c -> clip8(255 c / a), copied when a is 0 or 255) over n_px interleaved 4-byte pixels
+ * (4-byte aligned; src == dst allowed).  An RGBA resize = premultiply, the two nsr_resample_pass_u8 passes with C = 4,
+ * un-premultiply.  nsr_image_to_targets_rgba: img (H, W, 4) uint8 -> out (H/s * W/s, s*s, 3) fp32 =
+ * rgb / 255 * (a / 255) + (1 - a / 255) (data/blender_downX_dataset.py:117-120), same order as nsr_image_to_targets. */
+int nsr_rgba_premultiply_u8(const uint8_t* src, int64_t n_px, int inverse, uint8_t* dst, void* stream);
+int nsr_image_to_targets_rgba(const uint8_t* img, int H, int W, int s, float* out, void* stream);
 
 #ifdef __cplusplus
 }

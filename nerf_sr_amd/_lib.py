@@ -83,6 +83,8 @@ SIGNATURES = {
     "nsr_lanczos_coeffs": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "nsr_resample_pass_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "nsr_image_to_targets": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "nsr_rgba_premultiply_u8": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "nsr_image_to_targets_rgba": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nsr_linear": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64,
                            c_int64, c_int, c_int, c_void_p]),
 }

@@ -86,4 +86,24 @@ struct WgradArgs {
 };
 NSR_INTERNAL int wgrad_f16x3(const WgradArgs& w, hipStream_t st);
 
+// All products of one network pass as ONE launch (nsr_wgrad_f16.hip, wgrad_jobs_kernel).  Fill j[0..n).w (P, splits and
+// of the entries are ignored: every product has jobs.n_groups point groups; slot s of product p is the M x N tile at
+// w.partial + s * w.split_stride, its row sums at w.row_sums + s * M), call wgrad_jobs_plan, hand out the partial /
+// row-sum slots (n_slots of each job), launch with the workgroup count the plan returned.
+struct WgradJob {
+  WgradArgs w;
+  int64_t cost0;      // start of the product in the work list (plan)
+  int cost;           // M + N: panel rows read per point group (plan)
+  int w_first;        // first workgroup that touches the product (plan)
+  int n_slots;        // workgroups that touch it = partial slots it owns (plan)
+};
+constexpr int kMaxWgradJobs = 16;
+struct WgradJobs {
+  WgradJob j[kMaxWgradJobs];
+  int n;
+  int64_t n_groups, total_cost, per_wg;
+};
+NSR_INTERNAL int wgrad_jobs_plan(WgradJobs& jobs, int64_t P, int n_wg);
+NSR_INTERNAL int wgrad_jobs_f16x3(const WgradJobs& jobs, int n_wg, hipStream_t st);
+
 }  // namespace nsr

@@ -58,7 +58,67 @@ __global__ void __launch_bounds__(256) image_to_targets_kernel(const uint8_t* __
   out[idx] = __fdiv_rn((float)img[((int64_t)py * W + px) * 3 + c], 255.0f);
 }
 
+// Pillow's RGBA <-> premultiplied "RGBa" conversions (src/libImaging/Convert.c rgbA2rgba / rgba2rgbA), one thread per pixel
+__global__ void __launch_bounds__(256) premultiply_kernel(const uint8_t* src, uint8_t* dst,   // src == dst allowed
+                                                          int64_t n_px, int inverse) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_px) return;
+  const uchar4 p = reinterpret_cast<const uchar4*>(src)[i];
+  const unsigned a = p.w;
+  unsigned c[3] = {p.x, p.y, p.z};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (!inverse) {
+      const unsigned t = c[k] * a + 128u;                 // MULDIV255
+      c[k] = ((t >> 8) + t) >> 8;
+    } else if (a != 0u && a != 255u) {
+      const unsigned q = (255u * c[k]) / a;
+      c[k] = q > 255u ? 255u : q;
+    }
+  }
+  reinterpret_cast<uchar4*>(dst)[i] = make_uchar4((uint8_t)c[0], (uint8_t)c[1], (uint8_t)c[2], p.w);
+}
+
+// ToTensor + blend onto white + regroup of an RGBA image: rgb / 255 * (a / 255) + (1 - a / 255), separate fp32 operations
+// like the dataset's tensor expression (this unit is compiled with -ffp-contract=off)
+__global__ void __launch_bounds__(256) image_to_targets_rgba_kernel(const uint8_t* __restrict__ img, int H, int W, int s,
+                                                                    float* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over the OUTPUT (N_lr, s*s, 3)
+  const int64_t total = (int64_t)H * W * 3;
+  if (idx >= total) return;
+  const int c = (int)(idx % 3);
+  const int64_t r = idx / 3;
+  const int s2 = s * s, w_lr = W / s;
+  const int64_t lr = r / s2;
+  const int sub = (int)(r % s2);
+  const int py = (int)(lr / w_lr) * s + sub / s, px = (int)(lr % w_lr) * s + sub % s;
+  const uint8_t* p = img + ((int64_t)py * W + px) * 4;
+  const float a = __fdiv_rn((float)p[3], 255.0f);
+  out[idx] = __fadd_rn(__fmul_rn(__fdiv_rn((float)p[c], 255.0f), a), __fsub_rn(1.0f, a));
+}
+
 }  // namespace
+
+extern "C" int nsr_rgba_premultiply_u8(const uint8_t* src, int64_t n_px, int inverse, uint8_t* dst, void* stream) {
+  if (n_px < 0) return NSR_ERR_INVALID_ARG;
+  if (n_px == 0) return NSR_OK;
+  if (!src || !dst || (reinterpret_cast<uintptr_t>(src) & 3) || (reinterpret_cast<uintptr_t>(dst) & 3)) return NSR_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(premultiply_kernel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, nsr_stream(stream), src, dst, n_px,
+                     inverse ? 1 : 0);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
+extern "C" int nsr_image_to_targets_rgba(const uint8_t* img, int H, int W, int s, float* out, void* stream) {
+  if (H < 0 || W < 0 || s <= 0 || (H > 0 && W > 0 && (H % s != 0 || W % s != 0))) return NSR_ERR_INVALID_ARG;
+  const int64_t total = (int64_t)H * W * 3;
+  if (total == 0) return NSR_OK;
+  if (!img || !out) return NSR_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(image_to_targets_rgba_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nsr_stream(stream), img,
+                     H, W, s, out);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
 
 extern "C" int nsr_lanczos_ksize(int in_size, int out_size) {
   if (in_size <= 0 || out_size <= 0) return 0;

@@ -712,11 +712,22 @@ float* panel_of(float* set, int64_t P, int panel) {   // nsr_f16x3_core.h: panel
 }
 
 // weight and bias gradients from the panels: zpan = forward pre-activations x 2^6 (kWScale), dpan = true-scale
-// gradients of the pre-activations; d_rgb_pre in k.drgb (P, 32), d_sigma in column 256 of k.g1 (P, 288)
+// gradients of the pre-activations; d_rgb_pre in k.drgb (P, 32), d_sigma in column 256 of k.g1 (P, 288).
+// The 14 panel x panel products of the network are ONE launch (wgrad_jobs_kernel, nsr_wgrad_f16.hip): ~256 workgroups
+// share the products' point groups by bytes, a 256 x 256 product ends up with ~21 partial tiles instead of the 256 a
+// launch of its own needed to fill the chip -- 12 x fewer partial sums to write, and for finish_jobs_kernel to read
+// back.  NSR_WGRAD_JOBS=0 selects the per-product launches (round 2; kept for A/B runs).
 int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g, int acc) {
   const int sp = n_splits(P);
+  const int64_t sp_max = sp;   // the workspace's slots are sized for the largest pass (work_floats): at least this one's
   constexpr float kInv = 1.0f / 64.0f;
+  const char* env = getenv("NSR_WGRAD_JOBS");
+  const bool one_launch = !(env && env[0] == '0');
   FinishJobs jobs{};
+  WgradJobs wj{};
+  struct Placed { int job, fin; };     // finish job `fin` reduces the partial tiles (fin >= 0) / row sums (~fin) of product `job`
+  Placed placed[2 * kMaxFinishJobs];
+  int n_placed = 0;
   int n_big = 0, n_row = 0;
   auto big_slot = [&]() { return k.slots + (int64_t)(n_big++) * sp * 256 * 256; };     // sp <= the workspace's sp_max
   auto row_slot = [&]() { return k.row_part + (int64_t)(n_row++) * sp * 256; };
@@ -725,26 +736,41 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
     FinishJob& q = jobs.j[jobs.n++];
     q.kind = 0; q.dst = dst; q.dst_ld = dst_ld; q.dc0 = dc0; q.rows = rows; q.cols = cols; q.partial = partial;
     q.stride = (int64_t)256 * 256; q.splits = sp; q.p_ld = p_ld; q.accumulate = acc; q.enc_rows = enc_rows; q.scale = 1.0f;
+    return jobs.n - 1;
   };
   auto sum_rows = [&](float* dst, int rows, const float* partial) {
     FinishJob& q = jobs.j[jobs.n++];
     q.kind = 1; q.dst = dst; q.rows = rows; q.cols = 1; q.partial = partial; q.splits = sp; q.accumulate = acc; q.scale = 1.0f;
+    return jobs.n - 1;
   };
-  // product of gradient panel a with forward panel b -> a fresh slot (+ the bias row sums of a)
-  auto product = [&](int a_panel, int b_panel, int b_relu, float** part, float** rs) {
-    *part = big_slot();
-    float* r = rs ? row_slot() : nullptr;
-    if (rs) *rs = r;
+  // product of gradient panel a with forward panel b (+ the bias row sums of a): a launch of its own into a fresh slot, or
+  // an entry of the job table (slots are handed out after the plan); returns the product's index
+  auto product = [&](int a_panel, int b_panel, int b_relu, float** part, float** rs) -> int {
     WgradArgs w{};
     w.A = panel_of(k.dpan, P, a_panel); w.M = a_panel == 9 ? 128 : 256; w.a_gstride = 32 * w.M;
     w.B = panel_of(k.zpan, P, b_panel); w.N = b_panel >= 10 ? 64 : 256; w.b_gstride = 32 * w.N; w.b_relu = b_relu;
     w.P = P; w.a_max_bits = k.gmax + a_panel;
     w.a_pscale = k.pscale + (int64_t)a_panel * n_groups_of(P) * 32;
     w.out_scale = b_panel >= 10 ? 1.0f : kInv;    // the encodings are stored at true scale, the pre-activations x 2^6
-    w.partial = *part; w.split_stride = (int64_t)256 * 256; w.splits = sp; w.row_sums = r;
-    return wgrad_f16x3(w, st);
+    w.split_stride = (int64_t)256 * 256; w.splits = sp;
+    if (one_launch) {
+      if (wj.n >= kMaxWgradJobs) return -1;
+      w.partial = k.slots;                       // placeholder (validated non-null); real slots after the plan
+      w.row_sums = rs ? k.row_part : nullptr;
+      wj.j[wj.n].w = w;
+      *part = nullptr;
+      if (rs) *rs = nullptr;
+      return wj.n++;
+    }
+    *part = big_slot();
+    float* r = rs ? row_slot() : nullptr;
+    if (rs) *rs = r;
+    w.partial = *part; w.row_sums = r;
+    return wgrad_f16x3(w, st) == NSR_OK ? 0 : -1;
   };
+  auto note = [&](int job, int fin) { placed[n_placed++] = Placed{job, fin}; };
   float *part, *rs;
+  int pj;
   const int64_t per = (P / 32 + sp - 1) / sp;
   // rgb head: d_rgb_pre^T relu(zcc), a stream over the panel
   part = big_slot();
@@ -754,15 +780,15 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
   sum_rows(g[kRgbW], 3 * 128, part);
   NSR_TRY(colsum(st, k.drgb, kRgbPad, P, 0, 3, g[kRgbB], acc, k.partial));
   // dir_encoding: dzc^T [g | de]
-  NSR_TRY(product(9, 8, 0, &part, &rs));
-  place(g[kDirW], 283, 0, 128, 256, part, kW, 0);
-  sum_rows(g[kDirB], kDirOut, rs);
-  NSR_TRY(product(9, 11, 0, &part, nullptr));
-  place(g[kDirW], 283, 256, 128, 27, part, kPe, 2);
+  if ((pj = product(9, 8, 0, &part, &rs)) < 0) return NSR_ERR_LAUNCH;
+  note(pj, place(g[kDirW], 283, 0, 128, 256, part, kW, 0));
+  note(pj, ~sum_rows(g[kDirB], kDirOut, rs));
+  if ((pj = product(9, 11, 0, &part, nullptr)) < 0) return NSR_ERR_LAUNCH;
+  note(pj, place(g[kDirW], 283, 256, 128, 27, part, kPe, 2));
   // xyz_encoding_final: dg^T relu(z8); sigma: d_sigma^T relu(z8)
-  NSR_TRY(product(8, 7, 1, &part, &rs));
-  place(g[kFinalW], 256, 0, 256, 256, part, kW, 0);
-  sum_rows(g[kFinalB], kW, rs);
+  if ((pj = product(8, 7, 1, &part, &rs)) < 0) return NSR_ERR_LAUNCH;
+  note(pj, place(g[kFinalW], 256, 0, 256, 256, part, kW, 0));
+  note(pj, ~sum_rows(g[kFinalB], kW, rs));
   part = big_slot();
   hipLaunchKernelGGL((panel_wsums_kernel<256, 1>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 7), P, k.g1 + kSigmaCol, kGs,
                      0.0f, kInv, per, part);
@@ -773,17 +799,49 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
   for (int L = 8; L >= 1; --L) {
     float* gw = g[2 * (L - 1)];
     rs = nullptr;
+    int pj_rs = -1;
     if (L > 1) {
-      NSR_TRY(product(L - 1, L - 2, 1, &part, &rs));
-      place(gw, L == 5 ? 319 : 256, L == 5 ? 63 : 0, 256, 256, part, kW, 0);
+      if ((pj = product(L - 1, L - 2, 1, &part, &rs)) < 0) return NSR_ERR_LAUNCH;
+      note(pj, place(gw, L == 5 ? 319 : 256, L == 5 ? 63 : 0, 256, 256, part, kW, 0));
+      pj_rs = pj;
     }
     if (L == 1 || L == 5) {   // over the encoded position (panel 10, 64 rows in register order)
-      NSR_TRY(product(L - 1, 10, 0, &part, L == 1 ? &rs : nullptr));
-      place(gw, L == 1 ? 63 : 319, 0, 256, 63, part, kPe, 1);
+      if ((pj = product(L - 1, 10, 0, &part, L == 1 ? &rs : nullptr)) < 0) return NSR_ERR_LAUNCH;
+      note(pj, place(gw, L == 1 ? 63 : 319, 0, 256, 63, part, kPe, 1));
+      if (L == 1) pj_rs = pj;
     }
-    sum_rows(g[2 * (L - 1) + 1], kW, rs);
+    note(pj_rs, ~sum_rows(g[2 * (L - 1) + 1], kW, rs));
   }
   if (n_big > kChainSlots || n_row > kChainRowSlots || jobs.n > kMaxFinishJobs) return NSR_ERR_UNSUPPORTED;   // cannot happen
+  if (one_launch) {
+    // as many workgroups as there are CUs -- fewer for a small pass, so that the partial tiles fit the slots the
+    // workspace holds (sized by sp_max) and a workgroup always has a few point groups to sweep
+    int64_t want = 10 * (sp_max - 1);
+    want = want < 1 ? 1 : (want > 256 ? 256 : want);
+    const int n_wg = wgrad_jobs_plan(wj, P, (int)want);
+    float* next_big = k.slots + (int64_t)n_big * sp * 256 * 256;          // behind the two head slots taken above
+    float* next_row = k.row_part;
+    const float* big_end = k.slots + (int64_t)kChainSlots * sp_max * 256 * 256;
+    const float* row_end = k.row_part + (int64_t)kChainRowSlots * sp_max * 256;
+    for (int p = 0; p < wj.n; ++p) {
+      WgradJob& q = wj.j[p];
+      q.w.partial = next_big;
+      next_big += (int64_t)q.n_slots * 256 * 256;
+      if (q.w.row_sums) {
+        q.w.row_sums = next_row;
+        next_row += (int64_t)q.n_slots * q.w.M;
+      }
+    }
+    if (next_big > big_end || next_row > row_end) return NSR_ERR_WORKSPACE;   // cannot happen (see `want`)
+    for (int i = 0; i < n_placed; ++i) {
+      const WgradJob& q = wj.j[placed[i].job];
+      const bool rows = placed[i].fin < 0;
+      FinishJob& f = jobs.j[rows ? ~placed[i].fin : placed[i].fin];
+      f.partial = rows ? q.w.row_sums : q.w.partial;
+      f.splits = q.n_slots;
+    }
+    NSR_TRY(wgrad_jobs_f16x3(wj, n_wg, st));
+  }
   hipLaunchKernelGGL(finish_jobs_kernel, dim3(256, jobs.n), dim3(256), 0, st, jobs);
   NSR_CHECK_LAUNCH();
   return NSR_OK;

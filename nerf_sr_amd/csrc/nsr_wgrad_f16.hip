@@ -35,25 +35,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define NSR_WGRAD_LOAD(p) __builtin_nontemporal_load(p)
 #endif
 
+#ifndef NSR_SLICE_INLINE
+#define NSR_SLICE_INLINE __forceinline__
+#endif
 constexpr int kTK = 32, kLd = kTK + 8;   // one point group per K tile; LDS row stride in halves (80 B: conflict-free b128 reads)
 constexpr int kNT = 512;                 // 8 waves, each a (32 BM) x (32 BN) tile of the TM x TN product
 
 // TM x TN (BM, BN) = 256 x 256 (4, 2): trunk layers; 128 x 256 (2, 2): dir_encoding over g; 256 x 64 (1, 2): a trunk
 // layer over the encoded position; 128 x 64 (1, 1): dir_encoding over the encoded direction
+// One slice of one product: the point groups [g_begin, g_end) of w's panels -> partial slot `slot` (+ row sums).  `lds`:
+// 2 * TM * kLd + 2 * kTN * kLd halves.  Ends behind a workgroup barrier (the caller may re-use the LDS at once).
 template <int TM, int kTN, int BM, int BN>
-__global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2)))
-wgrad_f16x3_kernel(WgradArgs w, int64_t groups_per_slice) {
+__device__ NSR_SLICE_INLINE void wgrad_slice(const WgradArgs& w, int64_t g_begin, int64_t g_end, int64_t slot, _Float16* lds) {
   constexpr int WM = TM / (32 * BM), WN = kTN / (32 * BN);   // wave grid
   static_assert(WM * WN == 8, "tile does not split over 8 waves");
   constexpr int kArrA = TM * kLd, kArrB = kTN * kLd;
   constexpr int NA = TM * kTK / 4 / kNT, NB = kTN * kTK / 4 / kNT;   // float4 per thread and K tile: 4 (2) and 4
-  __shared__ __attribute__((aligned(16))) _Float16 lds[2 * kArrA + 2 * kArrB];   // A hi | A lo | B hi | B lo
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM, li = lane & 31, h = lane >> 5;
-  const int z = blockIdx.x;
-  const int64_t n_groups = w.P / 32;
-  const int64_t g_begin = (int64_t)z * groups_per_slice;
-  const int64_t g_end = (g_begin + groups_per_slice < n_groups) ? g_begin + groups_per_slice : n_groups;
+  const int64_t z = slot;
 
   // power-of-two pre-scale of A from the panel's maximum magnitude
   const float amax = __uint_as_float(*w.a_max_bits);
@@ -169,13 +169,62 @@ wgrad_f16x3_kernel(WgradArgs w, int64_t groups_per_slice) {
   }
 }
 
+constexpr int kLdsHalves = 2 * 256 * kLd + 2 * 256 * kLd;   // the largest tile (256 x 256)
+
+template <int TM, int kTN, int BM, int BN>
+__global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wgrad_f16x3_kernel(WgradArgs w, int64_t groups_per_slice) {
+  __shared__ __attribute__((aligned(16))) _Float16 lds[2 * TM * kLd + 2 * kTN * kLd];   // A hi | A lo | B hi | B lo
+  const int64_t n_groups = w.P / 32;
+  const int64_t g_begin = (int64_t)blockIdx.x * groups_per_slice;
+  const int64_t g_end = (g_begin + groups_per_slice < n_groups) ? g_begin + groups_per_slice : n_groups;
+  wgrad_slice<TM, kTN, BM, BN>(w, g_begin, g_end, blockIdx.x, lds);
+}
+
+// ALL weight-gradient products of one network pass in ONE launch (WgradJobs, nsr_gemm.h).  The products' point groups
+// form one work list, product after product, a group of product p costing cost_p = M + N panel rows (the kernel is HBM
+// bound: a group's time is the bytes it reads).  Workgroup w owns the cost range [w, w + 1) * per_wg of that list, i.e.
+// for every product it overlaps the groups whose start cost falls inside -- so the ~256 resident workgroups (one per CU)
+// carry the same number of bytes, each sweeps a few hundred point groups before it writes a partial tile instead of the
+// 16-32 a per-product launch with 256 slices each allowed, and a product owns about as many partial slots as its share
+// of the bytes (21 for a 256 x 256 trunk product instead of 256).  Deterministic: the mapping is static, no atomics.
+__global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) wgrad_jobs_kernel(WgradJobs jobs) {
+  __shared__ __attribute__((aligned(16))) _Float16 lds[kLdsHalves];
+  const int64_t lo = (int64_t)blockIdx.x * jobs.per_wg;
+  const int64_t hi = (lo + jobs.per_wg < jobs.total_cost) ? lo + jobs.per_wg : jobs.total_cost;
+  for (int p = 0; p < jobs.n; ++p) {
+    const WgradJob& q = jobs.j[p];
+    const int64_t c0 = q.cost0, c1 = c0 + jobs.n_groups * q.cost;
+    if (hi <= c0 || lo >= c1) continue;     // wave-uniform
+    const int64_t a = (lo > c0 ? lo : c0) - c0, b = (hi < c1 ? hi : c1) - c0;
+    const int64_t g_begin = (a + q.cost - 1) / q.cost;
+    int64_t g_end = (b + q.cost - 1) / q.cost;
+    if (g_end > jobs.n_groups) g_end = jobs.n_groups;
+    const int64_t slot = (int64_t)blockIdx.x - q.w_first;
+    WgradArgs w = q.w;
+    w.P = jobs.n_groups * 32;
+    if (w.M == 256 && w.N == 256) wgrad_slice<256, 256, 4, 2>(w, g_begin, g_end, slot, lds);
+    else if (w.M == 128 && w.N == 256) wgrad_slice<128, 256, 2, 2>(w, g_begin, g_end, slot, lds);
+    else if (w.M == 256 && w.N == 64) wgrad_slice<256, 64, 1, 2>(w, g_begin, g_end, slot, lds);
+    else wgrad_slice<128, 64, 1, 1>(w, g_begin, g_end, slot, lds);
+  }
+}
+
 }  // namespace
 
+static int wgrad_shape(const WgradArgs& w) {
+  return (w.N == 256 ? 0 : (w.N == 64 ? 2 : -8)) + (w.M == 256 ? 0 : (w.M == 128 ? 1 : -8));
+}
+static bool wgrad_args_ok(const WgradArgs& w) {
+  if (!w.A || !w.B || !w.partial || !w.a_max_bits || wgrad_shape(w) < 0) return false;
+  if (w.a_gstride % 4 || w.b_gstride % 4) return false;
+  return !((reinterpret_cast<uintptr_t>(w.A) & 15) || (reinterpret_cast<uintptr_t>(w.B) & 15));
+}
+
 NSR_INTERNAL int wgrad_f16x3(const WgradArgs& w, hipStream_t st) {
-  const int shape = (w.N == 256 ? 0 : (w.N == 64 ? 2 : -8)) + (w.M == 256 ? 0 : (w.M == 128 ? 1 : -8));
-  if (!w.A || !w.B || !w.partial || !w.a_max_bits || w.splits < 1 || shape < 0) return NSR_ERR_INVALID_ARG;
-  if (w.P < 0 || w.P % 32 != 0 || w.a_gstride % 4 || w.b_gstride % 4) return NSR_ERR_INVALID_ARG;
-  if ((reinterpret_cast<uintptr_t>(w.A) & 15) || (reinterpret_cast<uintptr_t>(w.B) & 15)) return NSR_ERR_INVALID_ARG;
+  const int shape = wgrad_shape(w);
+  if (!wgrad_args_ok(w) || w.splits < 1) return NSR_ERR_INVALID_ARG;
+  if (w.P < 0 || w.P % 32 != 0) return NSR_ERR_INVALID_ARG;
   if (w.P == 0) return NSR_OK;
   const int64_t n_groups = w.P / 32;
   const int64_t per = (n_groups + w.splits - 1) / w.splits;
@@ -184,6 +233,39 @@ NSR_INTERNAL int wgrad_f16x3(const WgradArgs& w, hipStream_t st) {
   else if (shape == 1) hipLaunchKernelGGL((wgrad_f16x3_kernel<128, 256, 2, 2>), grid, block, 0, st, w, per);
   else if (shape == 2) hipLaunchKernelGGL((wgrad_f16x3_kernel<256, 64, 1, 2>), grid, block, 0, st, w, per);
   else hipLaunchKernelGGL((wgrad_f16x3_kernel<128, 64, 1, 1>), grid, block, 0, st, w, per);
+  if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
+  return NSR_OK;
+}
+
+// fills cost0 / w_first / n_slots of every job and the work-list totals for `n_wg` workgroups; returns the number of
+// workgroups actually needed (<= n_wg)
+NSR_INTERNAL int wgrad_jobs_plan(WgradJobs& jobs, int64_t P, int n_wg) {
+  jobs.n_groups = P / 32;
+  int64_t c = 0;
+  for (int p = 0; p < jobs.n; ++p) {
+    jobs.j[p].cost = jobs.j[p].w.M + jobs.j[p].w.N;
+    jobs.j[p].cost0 = c;
+    c += jobs.n_groups * jobs.j[p].cost;
+  }
+  jobs.total_cost = c;
+  if (n_wg < 1) n_wg = 1;
+  jobs.per_wg = (c + n_wg - 1) / n_wg;
+  if (jobs.per_wg < 1) jobs.per_wg = 1;
+  for (int p = 0; p < jobs.n; ++p) {
+    WgradJob& q = jobs.j[p];
+    const int64_t c1 = q.cost0 + jobs.n_groups * q.cost;
+    q.w_first = (int)(q.cost0 / jobs.per_wg);
+    q.n_slots = jobs.n_groups > 0 ? (int)((c1 - 1) / jobs.per_wg) - q.w_first + 1 : 0;
+  }
+  return (int)((c + jobs.per_wg - 1) / jobs.per_wg);
+}
+
+NSR_INTERNAL int wgrad_jobs_f16x3(const WgradJobs& jobs, int n_wg, hipStream_t st) {
+  if (jobs.n < 0 || jobs.n > kMaxWgradJobs || jobs.n_groups < 0) return NSR_ERR_INVALID_ARG;
+  for (int p = 0; p < jobs.n; ++p)
+    if (!wgrad_args_ok(jobs.j[p].w)) return NSR_ERR_INVALID_ARG;
+  if (jobs.n == 0 || jobs.n_groups == 0 || n_wg < 1) return NSR_OK;
+  hipLaunchKernelGGL(wgrad_jobs_kernel, dim3((unsigned)n_wg), dim3(kNT), 0, st, jobs);
   if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
   return NSR_OK;
 }

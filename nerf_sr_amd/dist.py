@@ -95,6 +95,18 @@ def all_reduce_sum_(buffers, group=None) -> None:
             dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
 
 
+def all_ranks_agree(ok: bool, device=None, group=None) -> bool:
+    """Logical AND of ``ok`` over the ranks of ``group`` (one tiny MIN all-reduce; plain ``ok`` for world == 1): the
+    collective form of an error check, so that every rank takes the same branch."""
+    rank, world = _world(group)
+    if world == 1:
+        return bool(ok)
+    on_dev = dist.get_backend(group) != "gloo" and device is not None
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if on_dev else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()) == 1)
+
+
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise the default process group from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR / MASTER_PORT).  Returns (rank, local_rank, world).  No-op for world == 1."""

@@ -245,16 +245,25 @@ def lanczos_tables(in_size: int, out_size: int):
 
 def resize_lanczos_u8(img, out_wh):
     """``PIL.Image.resize(out_wh, Image.LANCZOS)`` of an (H, W, C) uint8 image ON THE DEVICE, bit-identical to Pillow
-    (horizontal pass, then vertical pass; include/nsr_image.h).  ``img``: uint8 torch tensor on the GPU."""
+    (horizontal pass, then vertical pass; include/nsr_image.h).  ``img``: uint8 torch tensor on the GPU.
+    C = 4 is an RGBA image: resampled premultiplied, like Pillow does (``convert("RGBa")`` -> resample ->
+    ``convert("RGBA")``); C = 1 / 3: plain channels.  Other channel counts have no Pillow mode behind them."""
     import torch
     from . import _lib
     from .ops import _check_device, _p, _stream
     if img.dtype != torch.uint8 or img.ndim != 3:
         raise TypeError("img must be an (H, W, C) uint8 tensor")
     _check_device(img.device, "img")
+    if img.shape[2] not in (1, 3, 4):
+        raise ValueError(f"img must have 1 (L), 3 (RGB) or 4 (RGBA) channels, got {img.shape[2]}")
     img = img.contiguous()
     lib = _lib.load()
     w, h = int(out_wh[0]), int(out_wh[1])
+    rgba = img.shape[2] == 4 and (w, h) != (img.shape[1], img.shape[0])
+    if rgba:
+        pre = torch.empty_like(img)
+        _lib.check(lib.nsr_rgba_premultiply_u8(_p(img), img.shape[0] * img.shape[1], 0, _p(pre), _stream()), "nsr_rgba_premultiply_u8")
+        img = pre
     for axis, out_size in ((1, w), (0, h)):
         H, W, C = img.shape
         in_size = W if axis == 1 else H
@@ -266,23 +275,31 @@ def resize_lanczos_u8(img, out_wh):
         _lib.check(lib.nsr_resample_pass_u8(_p(img), H, W, C, axis, out_size, _p(b_dev), _p(k_dev), kk.shape[1], _p(dst),
                                             _stream()), "nsr_resample_pass_u8")
         img = dst
+    if rgba:
+        _lib.check(lib.nsr_rgba_premultiply_u8(_p(img), img.shape[0] * img.shape[1], 1, _p(img), _stream()), "nsr_rgba_premultiply_u8")
     return img
 
 
 def lr_targets(img_u8, img_wh, downscale: int):
     """What the downX datasets keep per training image (data/llff_downX_dataset.py:312-329, ``ds_method='lanc'``):
     the scene image -> HR ``img_wh`` -> LR ``img_wh / s`` (LANCZOS, 8 bit), then ``rgbs`` (N_lr, 3) = LR / 255 and
-    ``rgbs_ori`` (N_lr, s*s, 3) = HR / 255 in the ray tensor's LR-pixel-major order.  Everything on the device."""
+    ``rgbs_ori`` (N_lr, s*s, 3) = HR / 255 in the ray tensor's LR-pixel-major order.  Everything on the device.
+    A 4-channel image is the Blender datasets' RGBA case (data/blender_downX_dataset.py:104-120): both resizes run on
+    the RGBA image (premultiplied resampling) and the targets are blended onto white, ``rgb * a + (1 - a)``."""
     import torch
     from . import _lib
     from .ops import _p, _stream
     W, H = int(img_wh[0]), int(img_wh[1])
     s = int(downscale)
+    if img_u8.ndim != 3 or img_u8.shape[2] not in (3, 4):
+        raise ValueError(f"img_u8 must be (H, W, 3) RGB or (H, W, 4) RGBA, got {tuple(img_u8.shape)}")
     hr = resize_lanczos_u8(img_u8, (W, H))
     lr = resize_lanczos_u8(hr, (W // s, H // s))
     lib = _lib.load()
     rgbs = torch.empty((H // s) * (W // s), 3, dtype=torch.float32, device=hr.device)
     ori = torch.empty((H // s) * (W // s), s * s, 3, dtype=torch.float32, device=hr.device)
-    _lib.check(lib.nsr_image_to_targets(_p(lr), H // s, W // s, 1, _p(rgbs), _stream()), "nsr_image_to_targets")
-    _lib.check(lib.nsr_image_to_targets(_p(hr), H, W, s, _p(ori), _stream()), "nsr_image_to_targets")
+    fn, name = (lib.nsr_image_to_targets_rgba, "nsr_image_to_targets_rgba") if hr.shape[2] == 4 else \
+        (lib.nsr_image_to_targets, "nsr_image_to_targets")
+    _lib.check(fn(_p(lr), H // s, W // s, 1, _p(rgbs), _stream()), name)
+    _lib.check(fn(_p(hr), H, W, s, _p(ori), _stream()), name)
     return rgbs, ori

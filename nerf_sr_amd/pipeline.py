@@ -35,13 +35,18 @@ def world_to_camera(c2w) -> np.ndarray:
 @torch.no_grad()
 def render_warp_refine(model: NeRFDownXModel, net: refine.MaxPoolingModel, c2w, ref_c2w, ref_img: torch.Tensor,
                        focal: float, ndc: bool, near: float = 0.0, far: float = 1.0, patch_len: int = 64,
-                       num_ref_patches: int = 8, batch: int = 32, events: Optional[list] = None) -> Dict[str, torch.Tensor]:
+                       num_ref_patches: int = 8, batch: int = 32, events: Optional[list] = None,
+                       depth_kind: Optional[str] = None) -> Dict[str, torch.Tensor]:
     """One synthesised view through the whole of config #5.
 
     ``model``: the render path with its two networks loaded; ``net``: the refinement network; ``c2w``: pose of the
     view to synthesise; ``ref_c2w`` / ``ref_img`` (3, H, W) in [0, 1]: pose and HR image of the reference view (view 0
     of the scene in the reference).  ``events``: optional list of 4 ``torch.cuda.Event`` recorded before the render,
     after it, after the warp and after the refinement pass.
+    ``depth_kind`` says what the rendered depth map holds (``warp.DEPTH_KINDS``): default ``'ndc'`` for NDC scenes and
+    ``'ray'`` (distance along the unit-norm ray: this build's definition for Blender scenes) otherwise; pass ``'metric'``
+    to use the depth as it is, which is what the reference's ``warp.py:120-126`` does for ``spheric_poses`` LLFF scenes
+    (needed to reproduce its ``{i}_locs.npz`` there).
     Returns the HR render (H, W, 3), the HR depth map (H, W), ``locs`` (H, W, 3) float64 and the refined image
     (3, H, W) in [0, 1]."""
     def mark(i):
@@ -51,7 +56,11 @@ def render_warp_refine(model: NeRFDownXModel, net: refine.MaxPoolingModel, c2w, 
     res = model.render_image(c2w, focal, ndc, near, far)
     depth_hw = model.unflatten_reshape(model.out_fine_depth_ori.reshape(-1, 1))[..., 0].contiguous()   # {i}-fine-depth-ori
     mark(1)
-    locs = warp.depth_warp(depth_hw, c2w, world_to_camera(ref_c2w), focal, "ndc" if ndc else "ray")
+    if depth_kind is None:
+        depth_kind = "ndc" if ndc else "ray"
+    if depth_kind not in warp.DEPTH_KINDS:
+        raise ValueError(f"depth_kind must be one of {list(warp.DEPTH_KINDS)}")
+    locs = warp.depth_warp(depth_hw, c2w, world_to_camera(ref_c2w), focal, depth_kind)
     mark(2)
     # the refine dataset normalises images to [-1, 1] (T.Normalize(0.5, 0.5), data/llff_refine_dataset.py:252-255)
     sr = (res["hr_rgb"].permute(2, 0, 1) * 2.0 - 1.0).contiguous()

@@ -76,8 +76,8 @@ class Trainer:
                  lambda_coarse_mse: float = 1.0, lambda_fine_mse: float = 1.0, ray_chunk: int = 4096,
                  precision: str = "f16x3", device="cuda"):
         if precision not in ("fp32", "f16x3"):
-            raise ValueError("precision must be 'fp32' (all products on the fp32 MFMA) or 'f16x3' (forward products on "
-                             "the split-fp16 MFMA, fp32-grade; gradients on the fp32 MFMA)")
+            raise ValueError("precision must be 'fp32' (every product on the fp32 MFMA, layer by layer) or 'f16x3' (every "
+                             "product -- forward, input and weight gradients -- on the split-fp16 MFMA, fp32-grade)")
         self.precision, self._prec = precision, _lib.PRECISIONS[precision]
         self.device = torch.device(device)
         self.params = [_to_dev(sd_coarse, self.device), _to_dev(sd_fine, self.device)]
@@ -89,6 +89,8 @@ class Trainer:
         # global-batch MEAN loss, like DistributedDataParallel's averaging (models/networks.py:84).  None = derive it
         # from the default process group at each step; a number pins it (e.g. a custom group).
         self.grad_scale: Optional[float] = None
+        self.group = None          # process group of the data-parallel replicas (None = the default group); the 1 / world
+        #                            loss scale, the gradient all-reduce and the finite-loss vote all use THIS group
         self.check_finite = False  # debug: raise when the loss is not finite (see optimize_parameters)
         self.N_coarse, self.N_importance = int(N_coarse), int(N_importance)
         self.white_bkgd, self.lindisp = bool(white_bkgd), bool(lindisp)
@@ -128,7 +130,7 @@ class Trainer:
         ``self.losses`` (device float[2], UNscaled: this rank's lambda-weighted MSEs) and ``self.grads`` (already
         scaled by 1 / world for the data-parallel SUM, see ``grad_scale``)."""
         from .dist import _world
-        gs = float(self.grad_scale) if self.grad_scale is not None else 1.0 / _world()[1]
+        gs = float(self.grad_scale) if self.grad_scale is not None else 1.0 / _world(self.group)[1]
         rays = self.data_rays
         R, stride = rays.shape[0], _ray_stride(rays)
         if draws is None:
@@ -171,7 +173,7 @@ class Trainer:
         all-reduce (SUM) per network of the flat 2.4 MB gradient buffer (RCCL over xGMI; gloo in the CPU tests of
         ``dist.py``) leaves the global-mean gradient on every rank; the Adam step then runs replicated."""
         from .dist import all_reduce_sum_
-        all_reduce_sum_(self.flat_grads, group)
+        all_reduce_sum_(self.flat_grads, self.group if group is None else group)
 
     def optimizer_step(self):
         """torch.optim.Adam.step over both networks (:201-204, :408)."""
@@ -190,11 +192,15 @@ class Trainer:
         weights silently; ``self.check_finite = True`` adds a host check of the loss (one sync per step) that raises
         and points at ``precision='fp32'`` (the reference itself drops into pdb on NaN, nerf_downX_model.py:273)."""
         self.loss_and_grads(draws)
-        if self.check_finite and not bool(torch.isfinite(self.losses).all()):
-            raise FloatingPointError(
-                f"non-finite training loss {self.losses.tolist()} at step {self.step + 1}: the run diverged"
-                + (" or left the fp16 range of the split-fp16 forward; retry with precision='fp32'"
-                   if self.precision == "f16x3" else ""))
+        if self.check_finite:
+            # every rank votes and every rank raises: a rank that raised alone would leave the others waiting in the
+            # gradient all-reduce
+            from .dist import all_ranks_agree
+            if not all_ranks_agree(bool(torch.isfinite(self.losses).all()), self.device, self.group):
+                raise FloatingPointError(
+                    f"non-finite training loss at step {self.step + 1} (this rank: {self.losses.tolist()}): the run diverged"
+                    + (" or left the fp16 range of the split-fp16 forward; retry with precision='fp32'"
+                       if self.precision == "f16x3" else ""))
         self.all_reduce_grads()
         self.optimizer_step()
         return self.losses

@@ -17,8 +17,12 @@ reference tree: ``pillow`` (unpinned in requirements.txt; the resampler has been
   * a pass computes ``clip8((2^21 + sum_k pixel_k w_k) >> 22)`` in int32; the horizontal pass runs first (into an
     8-bit intermediate image), the vertical pass second.
 
-Pinned by ``tests/golden/lanczos.npz`` (made by running Pillow itself in the development container,
-``make_golden_image.py``): bit-exact.
+RGBA images (the Blender scenes; data/blender_downX_dataset.py:104-118) are resampled premultiplied: Pillow's ``resize``
+converts RGBA -> "RGBa" (``rgbA2rgba``: ``MULDIV255``), resamples the four channels as above, and converts back
+(``rgba2rgbA``: ``clip8(255 c / a)``); the dataset then blends onto white in fp32.
+
+Pinned by ``tests/golden/lanczos.npz`` and ``lanczos_rgba.npz`` (made by running Pillow itself in the development
+container, ``make_golden_image.py`` / ``make_golden_image_rgba.py``): bit-exact.
 """
 from __future__ import annotations
 
@@ -87,6 +91,52 @@ def resize_lanczos_u8(img: np.ndarray, out_wh) -> np.ndarray:
     if h != H:
         out = _pass(out, *lanczos_coeffs(H, h), axis=0)
     return out
+
+
+def premultiply_rgba(img: np.ndarray) -> np.ndarray:
+    """Pillow's RGBA -> "RGBa" conversion (src/libImaging/Convert.c ``rgbA2rgba``): colour bytes become
+    ``MULDIV255(c, a) = (t = c a + 128, ((t >> 8) + t) >> 8)``, alpha is kept."""
+    c = img[..., :3].astype(np.uint32)
+    a = img[..., 3:4].astype(np.uint32)
+    t = c * a + 128
+    out = img.copy()
+    out[..., :3] = (((t >> 8) + t) >> 8).astype(np.uint8)
+    return out
+
+
+def unpremultiply_rgba(img: np.ndarray) -> np.ndarray:
+    """Pillow's "RGBa" -> RGBA conversion (``rgba2rgbA``): ``clip8(255 c / a)`` (integer division) unless alpha is 0 or
+    255, where the colour bytes are copied."""
+    c = img[..., :3].astype(np.uint32)
+    a = img[..., 3:4].astype(np.uint32)
+    q = np.minimum((255 * c) // np.maximum(a, 1), 255).astype(np.uint8)
+    out = img.copy()
+    out[..., :3] = np.where((a == 0) | (a == 255), img[..., :3], q)
+    return out
+
+
+def resize_lanczos_rgba_u8(img: np.ndarray, out_wh) -> np.ndarray:
+    """``Image.fromarray(img, "RGBA").resize(out_wh, Image.LANCZOS)``: Pillow resamples RGBA images premultiplied
+    (PIL/Image.py ``resize``: ``convert("RGBa")`` -> resize -> ``convert("RGBA")``)."""
+    return unpremultiply_rgba(resize_lanczos_u8(premultiply_rgba(img), out_wh))
+
+
+def lr_targets_rgba(img_u8: np.ndarray, img_wh, downscale: int):
+    """The Blender datasets' variant (data/blender_downX_dataset.py:104-118): RGBA scene image -> HR -> LR (both resized
+    as RGBA), ``ToTensor``, then ``rgb * a + (1 - a)`` (blend onto white, fp32) -> ``rgbs`` (N_lr, 3), ``rgbs_ori``
+    (N_lr, s*s, 3)."""
+    W, H = int(img_wh[0]), int(img_wh[1])
+    s = int(downscale)
+    hr = resize_lanczos_rgba_u8(img_u8, (W, H))
+    lr = resize_lanczos_rgba_u8(hr, (W // s, H // s))
+
+    def blend(x):
+        f = x.astype(np.float32) / np.float32(255.0)
+        return f[..., :3] * f[..., 3:4] + (np.float32(1.0) - f[..., 3:4])
+    hr_f, lr_f = blend(hr), blend(lr)
+    h, w = H // s, W // s
+    ori = hr_f.reshape(h, s, w, s, 3).transpose(0, 2, 1, 3, 4).reshape(h * w, s * s, 3)
+    return lr_f.reshape(-1, 3), ori
 
 
 def lr_targets(img_u8: np.ndarray, img_wh, downscale: int):

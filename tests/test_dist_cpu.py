@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from nerf_sr_amd.dist import all_gather_pixels, all_reduce_sum_, render_sharded, shard_bounds
+from nerf_sr_amd.dist import all_gather_pixels, all_ranks_agree, all_reduce_sum_, render_sharded, shard_bounds
 
 
 def test_shard_bounds_cover_and_balance():
@@ -60,18 +60,33 @@ def _worker(rank, world, port, n_lr, q):
         for j in range(2):
             mean = sum(per_rank[r][j] / world for r in range(world))
             ok = ok and torch.allclose(mine[j], mean, rtol=0, atol=1e-6)
+        # the collective form of an error check (Trainer.check_finite): one dissenting rank is seen by all, so nobody is
+        # left waiting in the next collective
+        ok = ok and all_ranks_agree(True) and not all_ranks_agree(rank != world - 1)
+        # ... and the same collectives on a SUBGROUP (ranks 0 and 1 of a larger job): scale and exchange follow the group
+        if world >= 3:
+            sub = dist.new_group(ranks=[0, 1])
+            if rank < 2:
+                from nerf_sr_amd.dist import _world
+                ok = ok and _world(sub) == (rank, 2)
+                g2 = [torch.full((5,), float(rank + 1)) / 2]
+                all_reduce_sum_(g2, sub)
+                ok = ok and torch.equal(g2[0], torch.full((5,), 1.5))
+                ok = ok and all_ranks_agree(True, None, sub) and not all_ranks_agree(rank == 0, None, sub)
         q.put((rank, bool(ok)))
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_lr", [47628, 47629, 3])
-def test_world2_gloo_sharded_render_matches_single_process(n_lr):
+@pytest.mark.parametrize("world,n_lr", [(2, 47628), (2, 47629), (2, 3), (4, 47628), (4, 5), (3, 2)])
+def test_gloo_sharded_render_matches_single_process(world, n_lr):
+    """world 2 / 3 / 4, even and uneven blocks, and worlds with EMPTY tail shards (5 pixels on 4 ranks: blocks of 2, 2, 1, 0;
+    2 pixels on 3 ranks: 1, 1, 0)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_lr, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_lr, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -80,6 +95,6 @@ def test_world2_gloo_sharded_render_matches_single_process(n_lr):
             p.kill()
             pytest.fail("gloo worker hung")
         assert p.exitcode == 0
-    res = sorted(q.get(timeout=5) for _ in range(2))
-    assert [r for r, _ in res] == [0, 1]
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert [r for r, _ in res] == list(range(world))
     assert all(ok for _, ok in res)

@@ -213,6 +213,12 @@ def test_config5_composed_small_vs_oracles(ops):
     want = (rt.stitch(pred, starts, 64, W, H) + 1.0) * 0.5
     assert float(np.abs(out["refined"].cpu().numpy() - want).max()) <= 2e-5
     assert refs.min() >= -1 and (refs >= 0).any()                               # warped reference patches were used
+    # the caller-facing switch: 'metric' = the depth as it is (the reference's spheric_poses branch, warp.py:120-126)
+    out_m = pipeline.render_warp_refine(model, net, c2w, ref_c2w, ref_img.cuda(), focal, False, 2.0, 6.0, depth_kind="metric")
+    assert np.array_equal(out_m["locs"].cpu().numpy(), wo.depth_warp(out_m["depth"].cpu().numpy(), c2w, w2c, focal, "metric"))
+    assert not np.array_equal(out_m["locs"].cpu().numpy(), locs_want)
+    with pytest.raises(ValueError):
+        pipeline.render_warp_refine(model, net, c2w, ref_c2w, ref_img.cuda(), focal, False, 2.0, 6.0, depth_kind="z")
 
 
 def test_config5_full_size_end_to_end(ops):

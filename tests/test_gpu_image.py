@@ -50,3 +50,27 @@ def test_fern_sized_image_vs_oracle(nio):
     gray = img[:400, :300, :1].copy()
     assert np.array_equal(nio.resize_lanczos_u8(torch.from_numpy(gray).cuda(), (450, 123)).cpu().numpy(),
                           io_oracle.resize_lanczos_u8(gray, (450, 123)))
+
+
+def test_rgba_resize_and_targets_vs_pillow_fixture(nio, golden_dir):
+    """Blender scenes are RGBA (data/blender_downX_dataset.py:104-120): premultiplied resampling, blend onto white."""
+    g = np.load(os.path.join(golden_dir, "lanczos_rgba.npz"))
+    for name in ("obj", "noise"):
+        src = torch.from_numpy(g[name]).cuda()
+        for w, h in ((64, 64), (32, 32), (40, 30), (120, 70)):
+            assert np.array_equal(nio.resize_lanczos_u8(src, (w, h)).cpu().numpy(), g[f"{name}_{w}x{h}"]), (name, w, h)
+        assert torch.equal(nio.resize_lanczos_u8(src, (src.shape[1], src.shape[0])), src)     # identity size: untouched
+    for s in (2, 4):
+        rgbs, ori = nio.lr_targets(torch.from_numpy(g["obj"]).cuda(), (64, 64), s)
+        assert np.array_equal(rgbs.cpu().numpy(), g[f"rgbs_s{s}"]) and np.array_equal(ori.cpu().numpy(), g[f"rgbs_ori_s{s}"])
+    # an 800 x 800 RGBA render (the Blender scenes' native size) -> HR 400 x 400 -> LR 200 x 200 (BASELINE config #3)
+    rng = np.random.default_rng(9)
+    yy, xx = np.mgrid[0:800, 0:800]
+    a = np.clip((300.0 - np.hypot(xx - 400.0, yy - 380.0)) * 25.0, 0, 255)
+    img = np.stack([127 + 100 * np.sin(xx / 23.0), (xx + yy) % 256, 255 - (xx // 16 + yy // 12) % 256, a], -1)
+    img = np.clip(img + rng.integers(-10, 11, img.shape) * (img[..., 3:4] > 0), 0, 255).astype(np.uint8)
+    rgbs, ori = nio.lr_targets(torch.from_numpy(img).cuda(), (400, 400), 2)
+    want_rgbs, want_ori = io_oracle.lr_targets_rgba(img, (400, 400), 2)
+    assert np.array_equal(rgbs.cpu().numpy(), want_rgbs) and np.array_equal(ori.cpu().numpy(), want_ori)
+    with pytest.raises(ValueError):
+        nio.lr_targets(torch.zeros(8, 8, 2, dtype=torch.uint8, device="cuda"), (4, 4), 2)

@@ -40,3 +40,16 @@ def test_libnsr_host_tables_equal_the_oracle():
         b, kk = nsr_io.lanczos_tables(n_in, n_out)
         wb, wk = io.lanczos_coeffs(n_in, n_out)
         assert np.array_equal(b, wb) and np.array_equal(kk, wk), (n_in, n_out)
+
+
+def test_rgba_resize_and_targets_match_pillow(golden_dir):
+    """Blender scenes are RGBA: premultiplied resampling and the blend onto white (data/blender_downX_dataset.py:104-118)."""
+    g = np.load(os.path.join(golden_dir, "lanczos_rgba.npz"))
+    for name in ("obj", "noise"):
+        assert np.array_equal(io.premultiply_rgba(g[name]), g[f"{name}_RGBa"])
+        assert np.array_equal(io.unpremultiply_rgba(g[f"{name}_RGBa"]), g[f"{name}_RGBa_back"])
+        for w, h in ((64, 64), (32, 32), (40, 30), (120, 70)):
+            assert np.array_equal(io.resize_lanczos_rgba_u8(g[name], (w, h)), g[f"{name}_{w}x{h}"]), (name, w, h)
+    for s in (2, 4):
+        rgbs, ori = io.lr_targets_rgba(g["obj"], (64, 64), s)
+        assert np.array_equal(rgbs, g[f"rgbs_s{s}"]) and np.array_equal(ori, g[f"rgbs_ori_s{s}"])
