@@ -50,16 +50,16 @@ def _camera(cid):
 _ORACLE_CACHE = {}
 
 
-def _oracle_block(cid):
+def _oracle_block(cid, field="smooth"):
     """fp32 and fp64 oracle outputs of the test block of config `cid` (cached: both precisions use it)."""
-    if cid in _ORACLE_CACHE:
-        return _ORACLE_CACHE[cid]
+    if (cid, field) in _ORACLE_CACHE:
+        return _ORACLE_CACHE[(cid, field)]
     wh, s, ndc, white = CONFIGS[cid]
     c2w, f, nf = _camera(cid)
     rays = oc.subpixel_ray_grid(torch.from_numpy(c2w), wh[1], wh[0], f, s, ndc, *nf).reshape(-1, 8)
     lo = (rays.shape[0] // 2) - (rays.shape[0] // 2) % (s * s)
     blk = rays[lo:lo + N_RAYS].contiguous()
-    sd_c, sd_f = make_state_dict(99), make_state_dict(100)
+    sd_c, sd_f = make_state_dict(99, field=field), make_state_dict(100, field=field)
     threads = torch.get_num_threads()
     torch.set_num_threads(min(32, threads))
     t0 = time.time()
@@ -68,9 +68,9 @@ def _oracle_block(cid):
         ref64 = oc.forward_rays(oc.to_torch_sd(sd_c, torch.float64), oc.to_torch_sd(sd_f, torch.float64), blk.double(),
                                 64, 64, white)
     torch.set_num_threads(threads)
-    print(f"[config #{cid}] oracle fp32 + fp64 on {N_RAYS} rays: {time.time() - t0:.1f} s")
-    _ORACLE_CACHE[cid] = (lo, blk, ref, ref64)
-    return _ORACLE_CACHE[cid]
+    print(f"[config #{cid} {field}] oracle fp32 + fp64 on {N_RAYS} rays: {time.time() - t0:.1f} s")
+    _ORACLE_CACHE[(cid, field)] = (lo, blk, ref, ref64)
+    return _ORACLE_CACHE[(cid, field)]
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "fp32"])
@@ -113,6 +113,43 @@ def test_frame_scale_parity(ops, cid, prec):
     far = nf[1]
     assert float((o["fine_depth"] - ref["fine_depth"]).abs()[~exempt].max()) <= 2e-4 * far
     assert float((o["fine_opacity"] - ref["fine_opacity"]).abs()[~exempt].max()) <= 2e-4
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "fp32"])
+@pytest.mark.parametrize("cid", [2, 3])
+def test_sharp_field_envelope_parity(ops, cid, prec):
+    """The "sharp" stress field (white PE spectrum, x30 density head, weights.make_state_dict) at frame scale, both
+    contract-grade precisions: the reference algorithm itself is chaotic there -- its own fp32 and fp64 evaluations differ by
+    > 1e-4 on 7-10 % of the rays and by up to 0.15 -- so a per-ray bound is meaningless and parity is an ENVELOPE: no
+    statistic of the HIP-vs-oracle32 error distribution (median, p99, p99.9, rays over 1e-4, max) may be worse than 2 x the
+    same statistic of the oracle's fp64-vs-fp32 distribution.  (The trained fields of test_gpu_trained.py are where the
+    per-ray contract is asserted on realistic densities.)  Coarse colours, which have no resampling in front of them,
+    stay tight on every ray."""
+    wh, s, ndc, white = CONFIGS[cid]
+    lo, blk, ref, ref64 = _oracle_block(cid, "sharp")
+    sd_c, sd_f = make_state_dict(99, field="sharp"), make_state_dict(100, field="sharp")
+    net_c = ops.VanillaMLP(precision=prec).load_state_dict(sd_c)
+    net_f = ops.VanillaMLP(precision=prec).load_state_dict(sd_f)
+    o = {k: v.cpu() for k, v in ops.forward_rays(net_c, net_f, blk.cuda(), 64, 64, white, check=True).items()}
+    # coarse colours: no resampling in front of them, but the x30 density head multiplies the fp32 rounding of the trunk, so
+    # the yardstick is again the oracle's own fp32-vs-fp64 distance (1.7e-5 / 2e-4 measured on #2 / #3), not 1e-5
+    c_gap = float((ref64["coarse_comp_rgbs"] - ref["coarse_comp_rgbs"].double()).abs().max())
+    c_err = float((o["coarse_comp_rgbs"] - ref["coarse_comp_rgbs"]).abs().max())
+    print(f"[config #{cid} sharp {prec}] coarse max|dRGB| {c_err:.2e} (oracle fp32 vs fp64: {c_gap:.2e})")
+    assert c_err <= max(1e-5, 3.0 * c_gap)
+    e_hip = (o["fine_comp_rgbs"].double() - ref["fine_comp_rgbs"].double()).abs().max(-1)[0]
+    e_ref = (ref64["fine_comp_rgbs"] - ref["fine_comp_rgbs"].double()).abs().max(-1)[0]
+    q = lambda t, p: float(torch.quantile(t, p))
+    print(f"[config #{cid} sharp {prec}] HIP vs oracle32: median {float(e_hip.median()):.1e} p99 {q(e_hip, 0.99):.1e} p99.9 "
+          f"{q(e_hip, 0.999):.1e} max {float(e_hip.max()):.1e} over 1e-4: {int((e_hip > RGB_TOL).sum())} | oracle64 vs oracle32: "
+          f"median {float(e_ref.median()):.1e} p99 {q(e_ref, 0.99):.1e} p99.9 {q(e_ref, 0.999):.1e} max {float(e_ref.max()):.1e} "
+          f"over 1e-4: {int((e_ref > RGB_TOL).sum())}")
+    assert int((e_ref > RGB_TOL).sum()) > N_RAYS // 50                       # the field is what it claims to be
+    assert float(e_hip.median()) <= 2 * float(e_ref.median()) and q(e_hip, 0.99) <= 2 * q(e_ref, 0.99)
+    assert q(e_hip, 0.999) <= 2 * q(e_ref, 0.999) and float(e_hip.max()) <= 2 * float(e_ref.max())
+    assert int((e_hip > RGB_TOL).sum()) <= 2 * int((e_ref > RGB_TOL).sum())
+    # the image the reference evaluates on: PSNR(build, oracle32) no worse than PSNR(oracle64, oracle32) by more than 3 dB
+    assert oc.psnr(o["fine_comp_rgbs"], ref["fine_comp_rgbs"]) >= oc.psnr(ref64["fine_comp_rgbs"].float(), ref["fine_comp_rgbs"]) - 3.0
 
 
 @pytest.mark.parametrize("cid", [2, 3])

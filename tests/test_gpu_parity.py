@@ -287,22 +287,25 @@ def test_randomized_forward_runs_and_is_bounded(ops, fam):
     assert m.out_fine_weights.shape == (256, 128)
 
 
-def test_sharp_field_statistical_parity(ops, fam):
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
+def test_sharp_field_statistical_parity(ops, fam, prec):
     """Stress field (white spectrum, x30 density head): the reference algorithm itself is
     chaotic there — its own fp32 and fp64 evaluations differ by >1e-2 RGB on ~5 % of the rays
     (weights.make_state_dict docstring) — so parity is statistical: the HIP path must be as
-    close to the fp32 oracle as the fp64 oracle is."""
+    close to the fp32 oracle as the fp64 oracle is.  (256 rays here; the frame-scale version with the full
+    envelope rule is tests/test_gpu_frames.py::test_sharp_field_envelope_parity.)"""
     g = fam[0]
     white = bool(g["white_bkgd"])
     sd_c, sd_f = make_state_dict(99, field="sharp"), make_state_dict(100, field="sharp")
-    net_c = ops.VanillaMLP().load_state_dict(sd_c)
-    net_f = ops.VanillaMLP().load_state_dict(sd_f)
+    net_c = ops.VanillaMLP(precision=prec).load_state_dict(sd_c)
+    net_f = ops.VanillaMLP(precision=prec).load_state_dict(sd_f)
     rays = torch.from_numpy(g["rays"])
     o32 = oc.forward_rays(oc.to_torch_sd(sd_c), oc.to_torch_sd(sd_f), rays, 64, 64, white)
     o64 = oc.forward_rays(oc.to_torch_sd(sd_c, torch.float64), oc.to_torch_sd(sd_f, torch.float64), rays.double(), 64, 64, white)
     hip = ops.forward_rays(net_c, net_f, rays.cuda(), 64, 64, white)
     # coarse pass has no resampling in front of it: tight everywhere
-    _close(hip["coarse_comp_rgbs"], o32["coarse_comp_rgbs"], RGB_TOL)
+    _close(hip["coarse_comp_rgbs"], o32["coarse_comp_rgbs"],
+           max(RGB_TOL, 3.0 * float((o64["coarse_comp_rgbs"] - o32["coarse_comp_rgbs"].double()).abs().max())))
     e_hip = (hip["fine_comp_rgbs"].cpu().double() - o32["fine_comp_rgbs"].double()).abs().max(-1)[0]
     e_ref = (o64["fine_comp_rgbs"] - o32["fine_comp_rgbs"].double()).abs().max(-1)[0]
     assert float(e_hip.median()) < 2e-5
