@@ -1,12 +1,14 @@
 """Frame-scale tests of the HIP path on the BASELINE frame geometries (run on the GPU box with ``pytest -m gpu``).
 
 1. PARITY AT FRAME SCALE, configs #2-#5, both contract-grade precisions: 16,384 consecutive rays from the middle of
-   one frame of each geometry against the CPU oracle.  Asserted on EVERY ray: max |dRGB| <= 1e-4 of the fine
-   colours -- with one explicit, counted exemption: a ray on which the oracle's OWN fp32 evaluation is more than
-   1e-4 away from its fp64 evaluation (the reference's inverse-CDF resampling amplifies the fp32 rounding noise of
-   the coarse weights: no second fp32 implementation, the reference on another BLAS included, can be held to 1e-4
-   there).  The exemption is bounded (at most 4 rays of 16,384 per geometry) and the number of exempted rays is
-   printed.  Also asserted: |dPSNR| <= 1e-3 dB against a common target, coarse colours <= 1e-5, s^2 means <= 1e-4.
+   one frame of each geometry against the CPU oracle.  Asserted on EVERY ray: |dRGB| of the fine colours <= max(1e-4,
+   2 x the oracle's OWN fp32-vs-fp64 gap on that ray) -- the reference's inverse-CDF resampling amplifies the fp32
+   rounding noise of the coarse weights, so two fp32 evaluations of an ill-conditioned ray may each sit `gap` away from
+   the exact result, on opposite sides: no second fp32 implementation, the reference on another BLAS included, can be
+   held closer.  The rays whose bound is the second term are counted, printed and bounded (at most 8 of 16,384 per
+   geometry on the smooth field).  Also asserted: |dPSNR| <= 1e-3 dB against a common target, coarse colours <= 1e-5,
+   s^2 means <= 1e-4.  The same protocol on a sharp stress field (envelope rule) follows; on TRAINED fields it is
+   tests/test_gpu_trained.py.
 2. SHARDING: config #4's frame (1008 x 756 <- 252 x 189) rendered in 2 and in 3 contiguous LR-pixel blocks on one
    device is bit-identical to the unsplit render (what ``render_image_sharded`` does on N GPUs, minus the gather).
 3. CONFIG #5 COMPOSED: render -> depth -> warp (ray-distance variant) -> refinement network, stage by stage against
@@ -26,7 +28,7 @@ pytestmark = pytest.mark.gpu
 
 RGB_TOL, PSNR_TOL = 1e-4, 1e-3
 N_RAYS = 16384
-MAX_EXEMPT = 4
+MAX_EXEMPT = 8
 # BASELINE.json configs: HR size (W, H), supersampling, NDC?, white background?
 CONFIGS = {2: ((504, 378), 2, True, False), 3: ((400, 400), 2, False, True), 4: ((1008, 756), 4, True, False),
            5: ((800, 800), 4, False, True)}
@@ -94,13 +96,17 @@ def test_frame_scale_parity(ops, cid, prec):
     assert float((o["coarse_comp_rgbs"] - ref["coarse_comp_rgbs"]).abs().max()) <= 1e-5
     d = (o["fine_comp_rgbs"].double() - ref["fine_comp_rgbs"].double()).abs().max(-1)[0]
     gap = (ref["fine_comp_rgbs"].double() - ref64["fine_comp_rgbs"]).abs().max(-1)[0]      # the oracle's own fp32 vs fp64
-    exempt = gap > RGB_TOL
+    # the contract, per ray: |dRGB| <= max(1e-4, 2 x the oracle's own fp32-vs-fp64 gap on that ray) -- two fp32 evaluations of
+    # an ill-conditioned ray may each sit `gap` away from the exact result, on opposite sides
+    bound = torch.clamp_min(2.0 * gap, RGB_TOL)
+    exempt = 2.0 * gap > RGB_TOL                 # rays whose bound is the conditioning term
     over = d > RGB_TOL
     print(f"[config #{cid} {prec}] fine max|dRGB| {float(d.max()):.2e} (non-exempt {float(d[~exempt].max()):.2e}), "
           f"p99.9 {float(torch.quantile(d, 0.999)):.2e}, median {float(d.median()):.1e}; rays over 1e-4: {int(over.sum())}, "
-          f"exempt (oracle fp32-vs-fp64 gap > 1e-4): {int(exempt.sum())}; oracle gap max {float(gap.max()):.2e}")
+          f"rays whose bound is 2 x oracle gap (> 1e-4): {int(exempt.sum())}; oracle gap max {float(gap.max()):.2e}; "
+          f"violations: {int((d > bound).sum())}")
     assert int(exempt.sum()) <= MAX_EXEMPT
-    assert int((over & ~exempt).sum()) == 0, f"{int((over & ~exempt).sum())} non-exempt rays exceed 1e-4 (max {float(d[~exempt].max()):.2e})"
+    assert int((d > bound).sum()) == 0, f"{int((d > bound).sum())} rays exceed max(1e-4, 2 x oracle gap) (worst by {float((d - bound).max()):.2e})"
     # the s^2 means: the image the reference trains and evaluates on
     lr = ops.sr_mean(o["fine_comp_rgbs"].cuda(), N_RAYS // s2, s2).cpu()
     lr_ref = oc.sr_mean(ref["fine_comp_rgbs"], N_RAYS // s2, s2)

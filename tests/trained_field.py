@@ -191,8 +191,13 @@ def parity_stats(hip: Dict[str, torch.Tensor], ref, ref64) -> Dict:
         "hip_vs_oracle64": {"median": float(d64.median()), "p99": q(d64, 0.99), "max": float(d64.max()), "over_1e-4": int((d64 > RGB_TOL).sum())},
         "exempt_rays": int((2.0 * gap > RGB_TOL).sum()),
         "violations": int((d > bound).sum()),
+        # violations on rays that are NOT ill-conditioned by the oracle's own measure (gap < 2.5e-5), or beyond 4 x gap:
+        # no amount of resampling noise explains those
+        "hard_violations": int(((d > bound) & ((gap < 0.25 * RGB_TOL) | (d > 4.0 * gap))).sum()),
         "worst_violation": float((d - bound).max()),
+        "worst_rays": [{"d": float(d[i]), "oracle_gap": float(gap[i])} for i in torch.argsort(d - bound, descending=True)[:4].tolist()],
         "coarse_max": float(dc.max()),
+        "coarse_oracle_gap_max": float((ref64["coarse_comp_rgbs"] - ref["coarse_comp_rgbs"].double()).abs().max()),
         "fine_weight_peak_median": float(ref["fine_weights"].max(-1)[0].median()),
         "fine_opacity_mean": float(ref["fine_opacity"].mean()),
     }
