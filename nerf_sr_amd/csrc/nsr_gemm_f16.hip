@@ -8,6 +8,7 @@
 // one 8-wave workgroup per CU, so the MFMAs of one wave hide the staging and barriers of the other).  A is fp32 in memory and is split into (hi, lo) on its way from
 // registers to LDS; B arrives pre-split.  Optional implicit im2col: the A rows are gathered from an NHWC activation
 // (a K tile of 32 channels never straddles a tap because cin % 32 == 0), so a 3 x 3 convolution needs no col matrix.
+#include <stdlib.h>
 #include "nsr_gemm.h"
 #include "nsr_gemm_epilogue.h"
 
@@ -473,7 +474,12 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   // fill the chip (small M: the 8 x 8 decoder layers of the refinement network), twice as many 4-wave 128 x 128
   // tiles are the better trade -- the panel re-read then comes out of L2
   const int64_t row_tiles = (g.M + kTM - 1) / kTM;
-  const bool wide = g.N >= 256 && row_tiles * ((g.N + 255) / 256) >= 512;
+  bool wide = g.N >= 256 && row_tiles * ((g.N + 255) / 256) >= 512;
+  // development switches (A/B runs on one box): NSR_GEMM_TILE=narrow|wide overrides the choice, NSR_GEMM_TK=32 keeps K tiles of 32
+  const char* e_tile = getenv("NSR_GEMM_TILE");
+  const char* e_tk = getenv("NSR_GEMM_TK");
+  if (e_tile && e_tile[0] == 'n') wide = false;
+  if (e_tile && e_tile[0] == 'w') wide = g.N >= 256;
   const int tn = wide ? 256 : 128;
   const int n_col_tiles = (g.N + tn - 1) / tn;
   const int64_t n_blocks = row_tiles * n_col_tiles;
@@ -483,7 +489,8 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
     if (wide) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<4>), dim3((unsigned)n_blocks), dim3(512), 0, st, a, n_col_tiles);
     else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<2>), dim3((unsigned)n_blocks), dim3(256), 0, st, a, n_col_tiles);
 #else
-    const bool k64 = (g.K % 64) == 0 && (a.conv.cin <= 0 || (a.conv.cin % 64) == 0) && !NSR_GEMM_K32_ONLY;
+    const bool k64 = (g.K % 64) == 0 && (a.conv.cin <= 0 || (a.conv.cin % 64) == 0) && !NSR_GEMM_K32_ONLY &&
+                     !(e_tk && e_tk[0] == '3');
     if (wide && k64) hipLaunchKernelGGL((gemm_f16x3_kernel<4, true, 64>), grid, dim3(512), 0, st, a, n_col_tiles, n_blocks);
     else if (wide) hipLaunchKernelGGL((gemm_f16x3_kernel<4, true>), grid, dim3(512), 0, st, a, n_col_tiles, n_blocks);
     else if (k64) hipLaunchKernelGGL((gemm_f16x3_kernel<2, true, 64>), grid, dim3(256), 0, st, a, n_col_tiles, n_blocks);
