@@ -44,16 +44,16 @@ struct RowSrc {   // where the four A rows this thread stages come from (implici
 // (hi, lo) fp16 planes out: bias -> activation -> split -> two 4-byte stores per lane and row pair.  Lane (column li)
 // of an accumulator block holds one column of 16 rows; neighbouring lanes swap one value per row pair so that every
 // lane owns TWO adjacent columns of ONE row and the 2-byte elements leave as packed 4-byte words.
-template <int TN>
-__device__ __forceinline__ void epilogue_planes(const GemmF16Args& a, f32x16 (&acc)[2][2], const bool (&col_on)[2], int64_t m0,
+template <int BN>
+__device__ __forceinline__ void epilogue_planes(const GemmF16Args& a, f32x16 (&acc)[2][BN], const bool (&col_on)[BN], int64_t m0,
                                                 int n0, int wm, int wn, int li, int h) {
   const GemmArgs& g = a.g;
   const bool scaled = g.acc_scale != 0.0f && g.acc_scale != 1.0f;
   const bool odd = li & 1;
 #pragma unroll
-  for (int bj = 0; bj < 2; ++bj) {
+  for (int bj = 0; bj < BN; ++bj) {
     if (!col_on[bj]) continue;                       // wave-uniform
-    const int n = n0 + 64 * wn + 32 * bj + li;
+    const int n = n0 + 32 * BN * wn + 32 * bj + li;
     const float bias = (g.bias && n < g.N) ? g.bias[n] : 0.0f;
     const int col = n & ~1;
 #pragma unroll
@@ -103,13 +103,17 @@ __device__ __forceinline__ int64_t xcd_tile(int64_t launch_idx, int64_t n_blocks
 
 // APL: A comes as (hi, lo) fp16 planes.  TK: K tile, 32 or (plane A only) 64 halves -- twice the MFMAs between two
 // barriers for the same staging overhead, 110 KB of LDS on the 8-wave tile
-template <int WN, bool APL, int TK = 32>
+// BN: accumulator blocks per wave along N.  2 (default): a wave owns 64 x 64.  4: a wave owns 64 x 128 -- the 128 x 256 tile
+// is then ONE workgroup of four waves (one per SIMD), two such workgroups share a CU and run out of phase, and a k-step
+// reads 12 fragments for 24 MFMAs instead of 8 for 12 (the 8-wave tile keeps the LDS port ~90 % as busy as the matrix pipe)
+template <int WN, bool APL, int TK = 32, int BN = 2>
 __global__ void __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))   // <= 256 registers
 gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
   static_assert(TK == 32 || (APL && TK == 64), "K tiles of 64 are built for pre-split A only");
+  static_assert(BN == 2 || (APL && TK == 32), "64 x 128 wave tiles: pre-split A, K tiles of 32 (register budget)");
   constexpr int kLd = TK + 8, kArrA = kTM * kLd;            // shadow the 32-wide constants of the file
   constexpr int kCh = TK / 8;                               // 16-byte chunks (8 halves) per row and plane
-  constexpr int NT = 128 * WN, kTN = 64 * WN, kArrB = kTN * kLd;
+  constexpr int NT = 128 * WN, kTN = 32 * BN * WN, kArrB = kTN * kLd;
   __shared__ __attribute__((aligned(16))) _Float16 lds[2 * kArrA + 2 * kArrB];   // A hi | A lo | B hi | B lo
   const GemmArgs& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -125,16 +129,16 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
   const int n_tiles = (int)(g.K / TK);
   const bool conv = a.conv.cin > 0;
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][BN];
 #pragma unroll
   for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-    for (int bj = 0; bj < 2; ++bj)
+    for (int bj = 0; bj < BN; ++bj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.0f;
-  bool col_on[2];
+  bool col_on[BN];
 #pragma unroll
-  for (int bj = 0; bj < 2; ++bj) col_on[bj] = (n0 + 64 * wn + 32 * bj) < g.N;
+  for (int bj = 0; bj < BN; ++bj) col_on[bj] = (n0 + 32 * BN * wn + 32 * bj) < g.N;
 
   // ---- staging assignment.  fp32 A: NA x (row = (tid >> 3) + (NT / 8) i, float4 column c4 = tid & 7), split on the way
   // to LDS; plane A: NP x (row = (tid >> 2) + (NT / 4) i, 8-half chunk c8 = tid & 3) of each plane, copied as it is.
@@ -162,15 +166,19 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
       arow[i] = m * g.lda;
     }
   }
-  const unsigned short* bh_row[NBP];
-  const unsigned short* bl_row[NBP];
+  // BN == 2: one pointer pair per staged B row (rows past N clamp to the last one).  BN == 4 (full column tiles only,
+  // N % 256 == 0): ONE base pointer, the rows kBRows apart and the lo plane at a wave-uniform distance -- 14 registers less
+  constexpr int NPTR = BN == 2 ? NBP : 1;
+  const unsigned short* bh_row[NPTR];
+  const unsigned short* bl_row[NPTR];
 #pragma unroll
-  for (int i = 0; i < NBP; ++i) {
+  for (int i = 0; i < NPTR; ++i) {
     int n = n0 + br0 + kBRows * i;
     n = n < g.N ? n : g.N - 1;
     bh_row[i] = a.Bh + (int64_t)n * a.ldbh;
     bl_row[i] = a.Bl + (int64_t)n * a.ldbh;
   }
+  const int64_t b_step = (int64_t)kBRows * a.ldbh, b_lo = a.Bl - a.Bh;
   f32x4 sa[APL ? 1 : NA];
   u32x4 sah[APL ? NA : 1], sal[APL ? NA : 1];
   u32x4 sbh[NBP], sbl[NBP];
@@ -209,8 +217,14 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
     }
 #pragma unroll
     for (int i = 0; i < NBP; ++i) {
-      sbh[i] = *reinterpret_cast<const u32x4*>(bh_row[i] + k0 + 8 * c8);
-      sbl[i] = *reinterpret_cast<const u32x4*>(bl_row[i] + k0 + 8 * c8);
+      if constexpr (BN == 2) {
+        sbh[i] = *reinterpret_cast<const u32x4*>(bh_row[i] + k0 + 8 * c8);
+        sbl[i] = *reinterpret_cast<const u32x4*>(bl_row[i] + k0 + 8 * c8);
+      } else {
+        const unsigned short* q = bh_row[0] + i * b_step + k0 + 8 * c8;
+        sbh[i] = *reinterpret_cast<const u32x4*>(q);
+        sbl[i] = *reinterpret_cast<const u32x4*>(q + b_lo);
+      }
     }
   };
   auto store = [&]() {
@@ -246,23 +260,23 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
     __syncthreads();
     if (t + 1 < n_tiles) load(t + 1);
     const _Float16* ap = lds + (64 * wm + li) * kLd + 8 * h;
-    const _Float16* bp = lds + 2 * kArrA + (64 * wn + li) * kLd + 8 * h;
+    const _Float16* bp = lds + 2 * kArrA + (32 * BN * wn + li) * kLd + 8 * h;
 #pragma unroll
     for (int s = 0; s < TK / 16; ++s) {
-      h8 ah[2], al[2], bh[2], bl[2];
+      h8 ah[2], al[2], bh[BN], bl[BN];
 #pragma unroll
       for (int bi = 0; bi < 2; ++bi) {
         ah[bi] = *reinterpret_cast<const h8*>(ap + 32 * bi * kLd + 16 * s);
         al[bi] = *reinterpret_cast<const h8*>(ap + kArrA + 32 * bi * kLd + 16 * s);
       }
 #pragma unroll
-      for (int bj = 0; bj < 2; ++bj) {
+      for (int bj = 0; bj < BN; ++bj) {
         bh[bj] = *reinterpret_cast<const h8*>(bp + 32 * bj * kLd + 16 * s);
         bl[bj] = *reinterpret_cast<const h8*>(bp + kArrB + 32 * bj * kLd + 16 * s);
       }
 #pragma unroll
-      for (int bj = 0; bj < 2; ++bj)
-        if (col_on[bj]) {
+      for (int bj = 0; bj < BN; ++bj)
+        if (BN == 4 || col_on[bj]) {     // BN == 4: full column tiles only
 #pragma unroll
           for (int bi = 0; bi < 2; ++bi) {
             acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[bi], bh[bj], acc[bi][bj], 0, 0, 0);   // small terms first
@@ -273,8 +287,12 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
     }
     __syncthreads();
   }
-  if (a.Ch) epilogue_planes<kTN>(a, acc, col_on, m0, n0, wm, wn, li, h);
-  else gemm_epilogue<kTN>(g, acc, col_on, m0, n0, wm, wn, li, h, tid, 0, bid / n_col_tiles, reinterpret_cast<float*>(lds));
+  if constexpr (BN == 2) {
+    if (a.Ch) epilogue_planes<2>(a, acc, col_on, m0, n0, wm, wn, li, h);
+    else gemm_epilogue<kTN>(g, acc, col_on, m0, n0, wm, wn, li, h, tid, 0, bid / n_col_tiles, reinterpret_cast<float*>(lds));
+  } else {
+    epilogue_planes<BN>(a, acc, col_on, m0, n0, wm, wn, li, h);       // launched for plane output only (gemm_f16x3)
+  }
 }
 
 
@@ -434,7 +452,7 @@ gemm_f16x3_dma_kernel(GemmF16Args a, int n_col_tiles) {
     }
   }
   if (a.Ch) {
-    epilogue_planes<kTN>(a, acc, col_on, m0, n0, wm, wn, li, h);
+    epilogue_planes<2>(a, acc, col_on, m0, n0, wm, wn, li, h);
   } else {
     __syncthreads();   // the shared epilogue may use the LDS image for its column sums
     gemm_epilogue<kTN>(g, acc, col_on, m0, n0, wm, wn, li, h, tid, 0, bid / n_col_tiles, reinterpret_cast<float*>(lds));
@@ -473,13 +491,22 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   // 8-wave 128 x 256 tiles read an A row panel once (activations: HBM traffic); when there are too few of them to
   // fill the chip (small M: the 8 x 8 decoder layers of the refinement network), twice as many 4-wave 128 x 128
   // tiles are the better trade -- the panel re-read then comes out of L2
+  // Tile choice (one MI355X box, 800 x 800 refinement pass, profiles/r3_refine_tiles.txt): two 4-wave workgroups per CU
+  // beat one 8-wave workgroup whatever they compute -- they run out of phase, so one stages and waits at its barriers
+  // while the other feeds the matrix pipe (8-wave 128 x 256: 41.4 ms; 4-wave 128 x 128 everywhere: 40.0).  Of the 4-wave
+  // shapes, the 128 x 256 tile with 64 x 128 per wave ("quad", BN = 4: the A panel is read once and a k-step costs 12
+  // fragment reads per 24 MFMAs) wins where there are enough row tiles to fill the chip with it; 128 x 128 otherwise.
   const int64_t row_tiles = (g.M + kTM - 1) / kTM;
-  bool wide = g.N >= 256 && row_tiles * ((g.N + 255) / 256) >= 512;
-  // development switches (A/B runs on one box): NSR_GEMM_TILE=narrow|wide overrides the choice, NSR_GEMM_TK=32 keeps K tiles of 32
+  const bool quad_ok = g.N >= 256 && (g.N % 256) == 0 && a.Ah && a.Ch;
+  bool wide = false;                                   // the 8-wave tile: NSR_GEMM_TILE=wide only
+  bool four_wave_wide = quad_ok && row_tiles * (g.N / 256) >= 1024;
+  // development switches (A/B runs on one box): NSR_GEMM_TILE=narrow|wide|quad overrides the choice, NSR_GEMM_TK=32 keeps K tiles of 32
   const char* e_tile = getenv("NSR_GEMM_TILE");
   const char* e_tk = getenv("NSR_GEMM_TK");
-  if (e_tile && e_tile[0] == 'n') wide = false;
-  if (e_tile && e_tile[0] == 'w') wide = g.N >= 256;
+  if (e_tile && e_tile[0] == 'n') four_wave_wide = false;
+  if (e_tile && e_tile[0] == 'w') { wide = g.N >= 256; four_wave_wide = false; }
+  if (e_tile && e_tile[0] == 'q') four_wave_wide = quad_ok;
+  if (four_wave_wide) wide = true;   // 128 x 256 tile on four waves (64 x 128 each)
   const int tn = wide ? 256 : 128;
   const int n_col_tiles = (g.N + tn - 1) / tn;
   const int64_t n_blocks = row_tiles * n_col_tiles;
@@ -491,7 +518,8 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
 #else
     const bool k64 = (g.K % 64) == 0 && (a.conv.cin <= 0 || (a.conv.cin % 64) == 0) && !NSR_GEMM_K32_ONLY &&
                      !(e_tk && e_tk[0] == '3');
-    if (wide && k64) hipLaunchKernelGGL((gemm_f16x3_kernel<4, true, 64>), grid, dim3(512), 0, st, a, n_col_tiles, n_blocks);
+    if (four_wave_wide) hipLaunchKernelGGL((gemm_f16x3_kernel<2, true, 32, 4>), grid, dim3(256), 0, st, a, n_col_tiles, n_blocks);
+    else if (wide && k64) hipLaunchKernelGGL((gemm_f16x3_kernel<4, true, 64>), grid, dim3(512), 0, st, a, n_col_tiles, n_blocks);
     else if (wide) hipLaunchKernelGGL((gemm_f16x3_kernel<4, true>), grid, dim3(512), 0, st, a, n_col_tiles, n_blocks);
     else if (k64) hipLaunchKernelGGL((gemm_f16x3_kernel<2, true, 64>), grid, dim3(256), 0, st, a, n_col_tiles, n_blocks);
     else hipLaunchKernelGGL((gemm_f16x3_kernel<2, true>), grid, dim3(256), 0, st, a, n_col_tiles, n_blocks);
