@@ -44,8 +44,8 @@ struct RowSrc {   // where the four A rows this thread stages come from (implici
 // (hi, lo) fp16 planes out: bias -> activation -> split -> two 4-byte stores per lane and row pair.  Lane (column li)
 // of an accumulator block holds one column of 16 rows; neighbouring lanes swap one value per row pair so that every
 // lane owns TWO adjacent columns of ONE row and the 2-byte elements leave as packed 4-byte words.
-template <int BN>
-__device__ __forceinline__ void epilogue_planes(const GemmF16Args& a, f32x16 (&acc)[2][BN], const bool (&col_on)[BN], int64_t m0,
+template <int BN, int BM = 2>
+__device__ __forceinline__ void epilogue_planes(const GemmF16Args& a, f32x16 (&acc)[BM][BN], const bool (&col_on)[BN], int64_t m0,
                                                 int n0, int wm, int wn, int li, int h) {
   const GemmArgs& g = a.g;
   const bool scaled = g.acc_scale != 0.0f && g.acc_scale != 1.0f;
@@ -57,8 +57,8 @@ __device__ __forceinline__ void epilogue_planes(const GemmF16Args& a, f32x16 (&a
     const float bias = (g.bias && n < g.N) ? g.bias[n] : 0.0f;
     const int col = n & ~1;
 #pragma unroll
-    for (int bi = 0; bi < 2; ++bi) {
-      const int64_t mb = m0 + 64 * wm + 32 * bi + 4 * h;
+    for (int bi = 0; bi < BM; ++bi) {
+      const int64_t mb = m0 + 32 * BM * wm + 32 * bi + 4 * h;
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         float x[4];
@@ -496,6 +496,11 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   // while the other feeds the matrix pipe (8-wave 128 x 256: 41.4 ms; 4-wave 128 x 128 everywhere: 40.0).  Of the 4-wave
   // shapes, the 128 x 256 tile with 64 x 128 per wave ("quad", BN = 4: the A panel is read once and a k-step costs 12
   // fragment reads per 24 MFMAs) wins where there are enough row tiles to fill the chip with it; 128 x 128 otherwise.
+  // Going further the same way -- ONE wave per SIMD with 128 x 128 (or 128 x 64) per wave, 16 fragment reads per 48 MFMAs --
+  // was built and measured SLOWER (48.0 ms; every layer, e.g. 5.54 vs 5.08 ms): with a single wave nothing hides the
+  // staging loads, the ds_writes and the two barriers of a K tile but the wave's own instruction order, and the
+  // compiler's order does not (the inference kernel gets there with a hand-pinned schedule and an LDS-DMA ring).
+  // Numbers and the kernel's description: profiles/r3_refine_tiles.txt.
   const int64_t row_tiles = (g.M + kTM - 1) / kTM;
   const bool quad_ok = g.N >= 256 && (g.N % 256) == 0 && a.Ah && a.Ch;
   bool wide = false;                                   // the 8-wave tile: NSR_GEMM_TILE=wide only
