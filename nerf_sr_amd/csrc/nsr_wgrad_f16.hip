@@ -201,8 +201,7 @@ __global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))
     int64_t g_end = (b + q.cost - 1) / q.cost;
     if (g_end > jobs.n_groups) g_end = jobs.n_groups;
     const int64_t slot = (int64_t)blockIdx.x - q.w_first;
-    WgradArgs w = q.w;
-    w.P = jobs.n_groups * 32;
+    const WgradArgs& w = q.w;               // the slices never read w.P / w.splits
     if (w.M == 256 && w.N == 256) wgrad_slice<256, 256, 4, 2>(w, g_begin, g_end, slot, lds);
     else if (w.M == 128 && w.N == 256) wgrad_slice<128, 256, 2, 2>(w, g_begin, g_end, slot, lds);
     else if (w.M == 256 && w.N == 64) wgrad_slice<256, 64, 1, 2>(w, g_begin, g_end, slot, lds);
