@@ -64,6 +64,14 @@ struct GemmF16Args {
   int64_t a_plane;
   unsigned short* Ch;
   int64_t c_plane;
+  // GROUPED ROWS (conv gather + plane output only; group == 8 or 0): the GEMM's row index m runs member-fastest over groups
+  // of 8 images, m = (b * px + pixel) * 8 + r with px = Ho * Wo, i.e. the 8 rows 8 q .. 8 q + 7 are one output pixel of the
+  // 8 images b * 8 + r.  Gather and per-image output use image b * 8 + r as usual (output row (b * 8 + r) * px + pixel);
+  // additionally the epilogue writes the maximum over the 8 members to row q of the planes Mh (hi) / Mh + m_plane (lo),
+  // row stride ldm halves -- torch.max over the reference patches (networks.py:980-983) without a pass of its own.
+  int group;
+  unsigned short* Mh;
+  int64_t m_plane, ldm;
 };
 NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st);
 // v = kSplitScale * w[i];  hi[i] = fp16(v), lo[i] = fp16(v - hi[i])   (round to nearest)

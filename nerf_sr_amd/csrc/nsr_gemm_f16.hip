@@ -44,12 +44,26 @@ struct RowSrc {   // where the four A rows this thread stages come from (implici
 // (hi, lo) fp16 planes out: bias -> activation -> split -> two 4-byte stores per lane and row pair.  Lane (column li)
 // of an accumulator block holds one column of 16 rows; neighbouring lanes swap one value per row pair so that every
 // lane owns TWO adjacent columns of ONE row and the 2-byte elements leave as packed 4-byte words.
-template <int BN, int BM = 2>
-__device__ __forceinline__ void epilogue_planes(const GemmF16Args& a, f32x16 (&acc)[BM][BN], const bool (&col_on)[BN], int64_t m0,
-                                                int n0, int wm, int wn, int li, int h) {
+template <int BN, int BM, bool GROUPED>
+__device__ __forceinline__ void epilogue_planes_t(const GemmF16Args& a, f32x16 (&acc)[BM][BN], const bool (&col_on)[BN], int64_t m0,
+                                                  int n0, int wm, int wn, int li, int h) {
   const GemmArgs& g = a.g;
   const bool scaled = g.acc_scale != 0.0f && g.acc_scale != 1.0f;
   const bool odd = li & 1;
+  // GROUPED (nsr_gemm.h): rows 8 q .. 8 q + 7 = one pixel of 8 images; output row of member r: row0 + r * px
+  const unsigned per = GROUPED ? (unsigned)(a.conv.Ho * a.conv.Wo) : 1u;
+  const unsigned n_q = (unsigned)(g.M / 8);
+  int64_t row0[BM][4];
+  if (GROUPED) {
+#pragma unroll
+    for (int bi = 0; bi < BM; ++bi)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const unsigned q = (unsigned)((m0 + 32 * BM * wm + 32 * bi) / 8) + rq;      // < 2^31: M / 8 pixels
+        const unsigned b = q / per;
+        row0[bi][rq] = (int64_t)b * 8 * per + (q - b * per);
+      }
+  }
 #pragma unroll
   for (int bj = 0; bj < BN; ++bj) {
     if (!col_on[bj]) continue;                       // wave-uniform
@@ -79,16 +93,39 @@ __device__ __forceinline__ void epilogue_planes(const GemmF16Args& a, f32x16 (&a
           const _Float16 h0 = (_Float16)c0, h1 = (_Float16)c1;
           const _Float16 l0 = (_Float16)(c0 - (float)h0), l1 = (_Float16)(c1 - (float)h1);
           if (m < g.M && col < g.n_valid) {
-            const int64_t off = m * g.ldc + col;
+            const int64_t out_row = GROUPED ? row0[bi][rq] + (int64_t)(4 * h + 2 * pr + (odd ? 1 : 0)) * per : m;
+            const int64_t off = out_row * g.ldc + col;
             *reinterpret_cast<unsigned*>(a.Ch + off) =
                 (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
             *reinterpret_cast<unsigned*>(a.Ch + a.c_plane + off) =
                 (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
           }
         }
+        if (GROUPED) {   // max over the 8 members: four in this lane, four in the lane of the other half; then pair the columns
+          float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          const float nb = __shfl_xor(mx, 1, 64);
+          const unsigned q = (unsigned)((m0 + 32 * BM * wm + 32 * bi) / 8) + rq;
+          if (h == 0 && !odd && q < n_q && col < g.n_valid) {
+            const _Float16 h0 = (_Float16)mx, h1 = (_Float16)nb;      // split(max) == lexicographic max of the splits (RNE is monotone)
+            const _Float16 l0 = (_Float16)(mx - (float)h0), l1 = (_Float16)(nb - (float)h1);
+            const int64_t off = (int64_t)q * a.ldm + col;
+            *reinterpret_cast<unsigned*>(a.Mh + off) =
+                (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            *reinterpret_cast<unsigned*>(a.Mh + a.m_plane + off) =
+                (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+          }
+        }
       }
     }
   }
+}
+// the plain instantiation carries none of the grouped-row arithmetic (the K = 32 first layers are epilogue-bound)
+template <int BN, int BM = 2>
+__device__ __forceinline__ void epilogue_planes(const GemmF16Args& a, f32x16 (&acc)[BM][BN], const bool (&col_on)[BN], int64_t m0,
+                                                int n0, int wm, int wn, int li, int h) {
+  if (a.group == 8) epilogue_planes_t<BN, BM, true>(a, acc, col_on, m0, n0, wm, wn, li, h);
+  else epilogue_planes_t<BN, BM, false>(a, acc, col_on, m0, n0, wm, wn, li, h);
 }
 
 // launch index -> tile index, see the kernel
@@ -158,9 +195,15 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
     m = m < g.M ? m : g.M - 1;
     if (conv) {
       const int64_t per = (int64_t)a.conv.Ho * a.conv.Wo;
-      rs[i].img = (int)(m / per);
-      rs[i].oy = (int)((m % per) / a.conv.Wo);
-      rs[i].ox = (int)(m % a.conv.Wo);
+      int64_t img = m / per, pix = m % per;
+      if (a.group == 8) {                      // grouped rows: m = (b * px + pixel) * 8 + r (nsr_gemm.h)
+        const int64_t q = m >> 3;
+        img = (q / per) * 8 + (m & 7);
+        pix = q % per;
+      }
+      rs[i].img = (int)img;
+      rs[i].oy = (int)(pix / a.conv.Wo);
+      rs[i].ox = (int)(pix % a.conv.Wo);
       arow[i] = 0;
     } else {
       arow[i] = m * g.lda;
@@ -296,169 +339,10 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
 }
 
 
-#ifdef NSR_GEMM_DMA
-// ---------------------------------------------------------------------------------------------------------------
-// EXPERIMENT (built only with -DNSR_GEMM_DMA; correct -- the refinement tests pass on it -- but SLOWER than the
-// register-staged kernel above: 48.5 vs 44.5 ms per 800 x 800 refinement pass.  An LDS-DMA costs the issuing wave
-// 60-180 cycles against a handful for a plain global_load_dwordx4, and this kernel has the registers to stage through.)
-// The same product for PRE-SPLIT operands on both sides (A planes, B pre-split weights), fed by LDS-DMA.
-//
-// With both operands already fp16 there is nothing to convert on the way in, so the tiles go global -> LDS directly
-// (global_load_lds_dwordx4: 64 lanes x 16 B per wave-instruction, no staging registers, no ds_write) into a
-// DOUBLE-buffered LDS image: tile t + 1 streams in while tile t is on the matrix pipe, one barrier per K tile.
-// An LDS-DMA lands lane-linear (lane L at base + 16 L), so the image is made of 1 KiB blocks that ARE MFMA fragments:
-// block (32 rows, k-step s, plane) holds at 16 (32 h + li) the 8 halves k = 16 s + 8 h .. + 7 of row li -- what lane
-// (li, h) feeds to v_mfma_f32_32x32x16_f16 -- so every fragment read is a conflict-free ds_read_b128 and every lane's
-// DMA source is one contiguous 16-byte run of a row (the implicit-im2col gather costs nothing extra: each lane computes
-// the address of ITS row under the current tap; rows in the zero padding read a 16-byte zero constant).
-// K tile = 32 (two k-steps, 24 MFMAs per wave); per buffer 16 KiB of A + 16 / 32 KiB of B.
-__device__ __attribute__((aligned(16))) const unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
-
-__device__ __forceinline__ void glds16_gather(const void* src, unsigned lds_dst_uniform) {
-  asm volatile(
-      "s_mov_b32 m0, %1\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %0, off"
-      :
-      : "v"(src), "s"(lds_dst_uniform)
-      : "memory");
-}
-
-template <int WN>
-__global__ void __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))
-gemm_f16x3_dma_kernel(GemmF16Args a, int n_col_tiles) {
-  constexpr int NW = 2 * WN;                       // waves per workgroup
-  constexpr int kTN = 64 * WN;
-  constexpr int kABlocks = 16, kBBlocks = (kTN / 32) * 4;          // 1 KiB blocks per K tile: (row block, k-step, plane)
-  constexpr int kBufBytes = (kABlocks + kBBlocks) * 1024;
-  constexpr int kPerWave = (kABlocks + kBBlocks) / NW;             // DMA instructions per wave and K tile (6 / 8)
-  constexpr int kAPerWave = kABlocks / NW;                         // ... of which A blocks (2 / 4)
-  __shared__ __attribute__((aligned(16))) char lds[2 * kBufBytes];
-  const GemmArgs& g = a.g;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 1, wn = wave >> 1, li = lane & 31, h = lane >> 5;
-  const int64_t bid = blockIdx.x;
-  const int64_t m0 = (bid / n_col_tiles) * kTM;
-  const int n0 = (int)(bid % n_col_tiles) * kTN;
-  const int n_tiles = (int)(g.K / kTK);
-  const bool conv = a.conv.cin > 0;
-  const unsigned lds0 = (unsigned)(size_t)((const __attribute__((address_space(3))) char*)lds);
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-    for (int bj = 0; bj < 2; ++bj)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.0f;
-  bool col_on[2];
-#pragma unroll
-  for (int bj = 0; bj < 2; ++bj) col_on[bj] = (n0 + 64 * wn + 32 * bj) < g.N;
-
-  // ---- this wave's DMA blocks: d = wave + NW i.  d < 16: A block (row block d >> 2, k-step (d >> 1) & 1, plane d & 1);
-  // else B block e = d - 16 (column block e >> 2, k-step, plane).  A lane serves row `li` of the block, halves 8 h ..
-  int64_t a_row[kAPerWave];           // element offset of the lane's A row (conv: under the current tap), -1 = zero row
-  RowSrc rs[kAPerWave];
-  const unsigned short* b_src[kPerWave - kAPerWave];
-#pragma unroll
-  for (int i = 0; i < kAPerWave; ++i) {
-    const int d = wave + NW * i;
-    int64_t m = m0 + 32 * (d >> 2) + li;
-    m = m < g.M ? m : g.M - 1;
-    if (conv) {
-      const int64_t per = (int64_t)a.conv.Ho * a.conv.Wo;
-      rs[i].img = (int)(m / per);
-      rs[i].oy = (int)((m % per) / a.conv.Wo);
-      rs[i].ox = (int)(m % a.conv.Wo);
-      a_row[i] = 0;
-    } else {
-      a_row[i] = m * g.lda;
-    }
-  }
-#pragma unroll
-  for (int i = kAPerWave; i < kPerWave; ++i) {
-    const int e = wave + NW * i - kABlocks;
-    int n = n0 + 32 * (e >> 2) + li;
-    n = n < g.N ? n : g.N - 1;
-    b_src[i - kAPerWave] = ((e & 1) ? a.Bl : a.Bh) + (int64_t)n * a.ldbh + 16 * ((e >> 1) & 1) + 8 * h;
-  }
-
-  auto issue = [&](int t, int buf) {
-    const int64_t k0 = (int64_t)t * kTK;
-    int64_t koff = k0;
-    if (conv) {
-      const int cbase = (int)(k0 % a.conv.cin);
-      koff = cbase;
-      if (cbase == 0) {   // the K tile enters the next tap: new source pixel for every row
-        const int tap = (int)(k0 / a.conv.cin), ky = tap / 3, kx = tap % 3;
-        const int Hin = a.conv.up ? 2 * a.conv.Hs : a.conv.Hs, Win = a.conv.up ? 2 * a.conv.Ws : a.conv.Ws;
-#pragma unroll
-        for (int i = 0; i < kAPerWave; ++i) {
-          const int iy = rs[i].oy * a.conv.stride + ky - 1, ix = rs[i].ox * a.conv.stride + kx - 1;
-          a_row[i] = -1;
-          if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
-            const int sy = a.conv.up ? iy >> 1 : iy, sx = a.conv.up ? ix >> 1 : ix;
-            a_row[i] = (((int64_t)rs[i].img * a.conv.Hs + sy) * a.conv.Ws + sx) * g.lda;
-          }
-        }
-      }
-    }
-    const unsigned base = lds0 + (unsigned)buf * kBufBytes;
-#pragma unroll
-    for (int i = 0; i < kAPerWave; ++i) {
-      const int d = wave + NW * i;
-      const unsigned short* src = a.Ah + ((d & 1) ? a.a_plane : 0) + a_row[i] + koff + 16 * ((d >> 1) & 1) + 8 * h;
-      glds16_gather(a_row[i] >= 0 ? static_cast<const void*>(src) : static_cast<const void*>(g_zero16), base + (unsigned)d * 1024u);
-    }
-#pragma unroll
-    for (int i = kAPerWave; i < kPerWave; ++i) {
-      const int d = wave + NW * i;
-      glds16_gather(b_src[i - kAPerWave] + k0, base + (unsigned)d * 1024u);
-    }
-  };
-
-  if (n_tiles > 0) issue(0, 0);
-  for (int t = 0; t < n_tiles; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t have landed ...
-    __syncthreads();                                    // ... everyone's have, and everyone is done with tile t - 1
-    if (t + 1 < n_tiles) issue(t + 1, (t + 1) & 1);
-    const char* buf = lds + (t & 1) * kBufBytes + lane * 16;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      h8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-      for (int bi = 0; bi < 2; ++bi) {
-        const int blk = ((2 * wm + bi) * 2 + s) * 2;
-        ah[bi] = *reinterpret_cast<const h8*>(buf + blk * 1024);
-        al[bi] = *reinterpret_cast<const h8*>(buf + (blk + 1) * 1024);
-      }
-#pragma unroll
-      for (int bj = 0; bj < 2; ++bj) {
-        const int blk = kABlocks + ((2 * wn + bj) * 2 + s) * 2;
-        bh[bj] = *reinterpret_cast<const h8*>(buf + blk * 1024);
-        bl[bj] = *reinterpret_cast<const h8*>(buf + (blk + 1) * 1024);
-      }
-#pragma unroll
-      for (int bj = 0; bj < 2; ++bj)
-        if (col_on[bj]) {
-#pragma unroll
-          for (int bi = 0; bi < 2; ++bi) {
-            acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[bi], bh[bj], acc[bi][bj], 0, 0, 0);   // small terms first
-            acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[bi], bl[bj], acc[bi][bj], 0, 0, 0);
-            acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[bi], bh[bj], acc[bi][bj], 0, 0, 0);
-          }
-        }
-    }
-  }
-  if (a.Ch) {
-    epilogue_planes<2>(a, acc, col_on, m0, n0, wm, wn, li, h);
-  } else {
-    __syncthreads();   // the shared epilogue may use the LDS image for its column sums
-    gemm_epilogue<kTN>(g, acc, col_on, m0, n0, wm, wn, li, h, tid, 0, bid / n_col_tiles, reinterpret_cast<float*>(lds));
-  }
-}
-#endif   // NSR_GEMM_DMA
+// (Round 2's LDS-DMA fed variant of this kernel -- pre-split operands streamed global -> LDS into a double-buffered,
+// fragment-ordered image -- was correct and 9 % slower on the refinement pass (48.5 vs 44.5 ms: an LDS-DMA costs the
+// issuing wave 60-180 cycles against a handful for a plain global_load_dwordx4, and this kernel has the registers to
+// stage through); it was removed in round 3, the measurement is in DESIGN section 9.)
 
 }  // namespace
 
@@ -487,10 +371,12 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
     return NSR_ERR_INVALID_ARG;
   }
   if (a.conv.cin > 0 && ((a.conv.cin % kTK) != 0 || g.K != 9 * a.conv.cin)) return NSR_ERR_INVALID_ARG;
+  if (a.group != 0) {   // grouped rows: conv gather, plane output, whole groups, packed column pairs of the max planes
+    if (a.group != 8 || a.conv.cin <= 0 || !a.Ch || !a.Mh || (g.M % 8) || (a.ldm % 2) || (a.m_plane % 2) ||
+        (reinterpret_cast<uintptr_t>(a.Mh) & 3))
+      return NSR_ERR_INVALID_ARG;
+  }
   if (g.M == 0) return NSR_OK;
-  // 8-wave 128 x 256 tiles read an A row panel once (activations: HBM traffic); when there are too few of them to
-  // fill the chip (small M: the 8 x 8 decoder layers of the refinement network), twice as many 4-wave 128 x 128
-  // tiles are the better trade -- the panel re-read then comes out of L2
   // Tile choice (one MI355X box, 800 x 800 refinement pass, profiles/r3_refine_tiles.txt): two 4-wave workgroups per CU
   // beat one 8-wave workgroup whatever they compute -- they run out of phase, so one stages and waits at its barriers
   // while the other feeds the matrix pipe (8-wave 128 x 256: 41.4 ms; 4-wave 128 x 128 everywhere: 40.0).  Of the 4-wave
@@ -517,10 +403,6 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   const int64_t n_blocks = row_tiles * n_col_tiles;
   const dim3 grid((unsigned)(((n_blocks + 7) / 8) * 8));
   if (a.Ah) {
-#ifdef NSR_GEMM_DMA   // experiment (measured 9 % slower on the refinement pass, see the kernel's header)
-    if (wide) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<4>), dim3((unsigned)n_blocks), dim3(512), 0, st, a, n_col_tiles);
-    else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<2>), dim3((unsigned)n_blocks), dim3(256), 0, st, a, n_col_tiles);
-#else
     const bool k64 = (g.K % 64) == 0 && (a.conv.cin <= 0 || (a.conv.cin % 64) == 0) && !NSR_GEMM_K32_ONLY &&
                      !(e_tk && e_tk[0] == '3');
     if (four_wave_wide) hipLaunchKernelGGL((gemm_f16x3_kernel<2, true, 32, 4>), grid, dim3(256), 0, st, a, n_col_tiles, n_blocks);
@@ -528,7 +410,6 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
     else if (wide) hipLaunchKernelGGL((gemm_f16x3_kernel<4, true>), grid, dim3(512), 0, st, a, n_col_tiles, n_blocks);
     else if (k64) hipLaunchKernelGGL((gemm_f16x3_kernel<2, true, 64>), grid, dim3(256), 0, st, a, n_col_tiles, n_blocks);
     else hipLaunchKernelGGL((gemm_f16x3_kernel<2, true>), grid, dim3(256), 0, st, a, n_col_tiles, n_blocks);
-#endif
   } else {
     if (wide) hipLaunchKernelGGL((gemm_f16x3_kernel<4, false>), grid, dim3(512), 0, st, a, n_col_tiles, n_blocks);
     else hipLaunchKernelGGL((gemm_f16x3_kernel<2, false>), grid, dim3(256), 0, st, a, n_col_tiles, n_blocks);

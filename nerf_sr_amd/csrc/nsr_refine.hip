@@ -14,6 +14,7 @@
 // same 4 bytes per element as fp32), written by the producing GEMM's epilogue and staged by the consuming GEMM as
 // they are -- a 3 x 3 convolution reads every activation nine times, splitting it once instead of nine times is what
 // the kernel's issue slots were spent on (nsr_gemm.h: GemmF16Args::Ah / Ch).
+#include <stdlib.h>
 #include "nsr_common.h"
 #include "nsr_gemm.h"
 #include "../../include/nsr_refine.h"
@@ -247,8 +248,10 @@ inline int64_t plane_of(const Act& t) { return t.rows * t.ld; }
 
 // one convolution layer: src (NHWC activation; NCHW fp32 input tensor for layer 0) -> dst (NHWC slice; the last layer
 // writes fp32 in both modes)
+// `mx` (NSR_F16X3, implicit gather, n_img a multiple of 8): also write the maximum over each group of 8 consecutive images
+// into this slice -- the GEMM then orders its rows member-fastest and reduces in its epilogue (nsr_gemm.h, GemmF16Args::group)
 int conv(hipStream_t st, const float* packed, int precision, int v, int l, const Act& src, const float* src_nchw, int n_img,
-         int Hs, int Ws, float* col, const Act& dst) {
+         int Hs, int Ws, float* col, const Act& dst, const Act* mx = nullptr) {
   const Layer& L = kLayersV[v][l];
   const bool nchw = src_nchw != nullptr, f16 = precision == NSR_F16X3, last = l == NSR_REFINE_N_LAYERS - 1;
   const int Hin = L.up ? 2 * Hs : Hs, Win = L.up ? 2 * Ws : Ws;
@@ -286,21 +289,29 @@ int conv(hipStream_t st, const float* packed, int precision, int v, int l, const
     a.Ch = hi_of(dst);
     a.c_plane = plane_of(dst);
   }
+  if (mx) {
+    if (!implicit || last || (n_img % 8) != 0) return NSR_ERR_INVALID_ARG;
+    a.group = 8;
+    a.Mh = hi_of(*mx);
+    a.m_plane = plane_of(*mx);
+    a.ldm = mx->ld;
+  }
   return gemm_f16x3(a, st);
 }
 
 // Model_VNPCAT_Encoder.forward (networks.py:760-774): features x2, x4, x6, x7 into the four destination slots
+// mx[4] (optional): where the maxima over groups of 8 images of the four features go (the reference patches' F_max_i)
 int encoder(hipStream_t st, const float* packed, int prec, int v, const Work& k, const float* x_nchw, int n_img, int H, int W,
-            const Act& d0, const Act& d1, const Act& d2, const Act& d3) {
+            const Act& d0, const Act& d1, const Act& d2, const Act& d3, const Act* mx = nullptr) {
   const int64_t px0 = (int64_t)H * W;
   const Act a128{k.a, n_img * px0, 128, 0}, a256{k.a, n_img * px0 / 4, 256, 0}, a512{k.a, n_img * px0 / 16, 512, 0};
   NSR_TRY(conv(st, packed, prec, v, 0, Act{}, x_nchw, n_img, H, W, k.col, a128));
-  NSR_TRY(conv(st, packed, prec, v, 1, a128, nullptr, n_img, H, W, k.col, d0));
+  NSR_TRY(conv(st, packed, prec, v, 1, a128, nullptr, n_img, H, W, k.col, d0, mx ? mx + 0 : nullptr));
   NSR_TRY(conv(st, packed, prec, v, 2, d0, nullptr, n_img, H, W, k.col, a256));
-  NSR_TRY(conv(st, packed, prec, v, 3, a256, nullptr, n_img, H / 2, W / 2, k.col, d1));
+  NSR_TRY(conv(st, packed, prec, v, 3, a256, nullptr, n_img, H / 2, W / 2, k.col, d1, mx ? mx + 1 : nullptr));
   NSR_TRY(conv(st, packed, prec, v, 4, d1, nullptr, n_img, H / 2, W / 2, k.col, a512));
-  NSR_TRY(conv(st, packed, prec, v, 5, a512, nullptr, n_img, H / 4, W / 4, k.col, d2));
-  NSR_TRY(conv(st, packed, prec, v, 6, d2, nullptr, n_img, H / 4, W / 4, k.col, d3));
+  NSR_TRY(conv(st, packed, prec, v, 5, a512, nullptr, n_img, H / 4, W / 4, k.col, d2, mx ? mx + 2 : nullptr));
+  NSR_TRY(conv(st, packed, prec, v, 6, d2, nullptr, n_img, H / 4, W / 4, k.col, d3, mx ? mx + 3 : nullptr));
   return NSR_OK;
 }
 
@@ -372,11 +383,19 @@ int forward(const void* packed_v, int prec, int v, const float* x_synth, const f
   if (v == 0) {
     // encoder on the B * R reference patches, then the max over the R references (F_max_i)
     const Act fc0{k.fc0, nref * px0, 128, 0}, fc1{k.fc1, nref * px1, 256, 0}, fc2{k.fc2, nref * px2, 512, 0}, fc3{k.fc3, nref * px3, 512, 0};
-    NSR_TRY(encoder(st, packed, prec, v, k, x_candi, B * R, H, W, fc0, fc1, fc2, fc3));
-    NSR_TRY(max_refs(st, prec, fc0, 128, B, R, px0, slice(cat7, 256)));
-    NSR_TRY(max_refs(st, prec, fc1, 256, B, R, px1, slice(cat5, 512)));
-    NSR_TRY(max_refs(st, prec, fc2, 512, B, R, px2, slice(cat3, 1024)));
-    NSR_TRY(max_refs(st, prec, fc3, 512, B, R, px3, slice(cat1, 512)));
+    const bool fused_max = prec == NSR_F16X3 && R == 8 && !getenv("NSR_REFINE_SEPARATE_MAX");   // env: A/B runs
+    if (fused_max) {
+      // the reference's 8 patches per tile (llff_refine_dataset.py: num_ref_patches): the producing GEMMs reduce over them
+      // in their epilogues -- the four max kernels (1.1 ms per 800 x 800 frame, 5.1 GB read at 4.5 TB/s) are gone
+      const Act mx[4] = {slice(cat7, 256), slice(cat5, 512), slice(cat3, 1024), slice(cat1, 512)};
+      NSR_TRY(encoder(st, packed, prec, v, k, x_candi, B * R, H, W, fc0, fc1, fc2, fc3, mx));
+    } else {
+      NSR_TRY(encoder(st, packed, prec, v, k, x_candi, B * R, H, W, fc0, fc1, fc2, fc3));
+      NSR_TRY(max_refs(st, prec, fc0, 128, B, R, px0, slice(cat7, 256)));
+      NSR_TRY(max_refs(st, prec, fc1, 256, B, R, px1, slice(cat5, 512)));
+      NSR_TRY(max_refs(st, prec, fc2, 512, B, R, px2, slice(cat3, 1024)));
+      NSR_TRY(max_refs(st, prec, fc3, 512, B, R, px3, slice(cat1, 512)));
+    }
   }
   // Model_VNPCAT_Decoder(_NoPooling).forward (networks.py:827-857, 906-935); a / b ping-pong, the *_up layers write into
   // the next concatenated buffer
