@@ -119,10 +119,16 @@ def committed_pmc(precision: str):
 
 
 def committed_train_traffic(R):
-    """HBM bytes per training step from the committed PMC run (profiles/r2_train_traffic.json, measured at 2,048 rays)."""
+    """HBM bytes per training step from the committed PMC run (profiles/r3_train_traffic.json, measured at 2,048 rays by
+    scripts/pmc_train_traffic.sh): a constant of the build it names (sha256 of the kernel sources), not a measurement of
+    this run; None when the sources have changed since."""
+    from nerf_sr_amd import build as nsr_build
     try:
-        with open(os.path.join(REPO, "profiles", "r2_train_traffic.json")) as f:
-            return int(json.load(f)["hbm_bytes_per_step"] * (R / 2048.0))
+        with open(os.path.join(REPO, "profiles", "r3_train_traffic.json")) as f:
+            d = json.load(f)
+        if d.get("csrc_sha256") != nsr_build.source_hash():
+            return None
+        return int(d["hbm_bytes_per_step"] * (R / 2048.0))
     except Exception:
         return None
 
@@ -206,7 +212,7 @@ def main_train(args):
                                "mfma_tflops_issued": 3 * achieved,
                                "note": "algorithmic bytes = 44,800 B of panel traffic per sample point x 192 points per ray "
                                        "(split-K partial sums, weight streams and per-ray arrays excluded; traffic = PMC-measured HBM bytes of all kernels "
-                                       "of a step, profiles/r2_train_traffic.json); "
+                                       "of a step, profiles/r3_train_traffic.json, null if the kernel sources changed since); "
                                        "mfma_tflops_issued = 3 fp16 MFMAs per product x 3 x the forward MACs"}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import train_oracle as to     # checker/baseline only; never on the product path
