@@ -28,6 +28,11 @@ extern "C" {
  * split-K partials; for NSR_F16X3 the pre-activation / gradient panels, ~35 KB per sample point in all).  0 on invalid
  * arguments. */
 size_t nsr_train_workspace_bytes(int64_t ray_chunk, int n_coarse, int n_importance);
+/* The same for the path `precision` selects (what nsr_train_loss_and_grads checks): NSR_F16X3 -> the chain path's panels,
+ * sign words and weight streams without the per-layer activation / gradient matrices of the GEMM path (~22 KB per sample
+ * point instead of ~33); NSR_FP32 (or NSR_F16X3 under NSR_TRAIN_PATH=gemm) -> the GEMM path's buffers without the panels
+ * (~13 KB).  nsr_train_workspace_bytes is the union: sufficient whatever runs. */
+size_t nsr_train_workspace_bytes_for(int precision, int64_t ray_chunk, int n_coarse, int n_importance);
 
 /* Losses and d(loss_tot)/d(weights) of one batch.
  *   loss_tot = lambda_coarse * mse(mean_s2(coarse rgb), target) + lambda_fine * mse(mean_s2(fine rgb), target)

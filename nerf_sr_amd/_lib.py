@@ -55,6 +55,7 @@ SIGNATURES = {
     "nsr_unflatten": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     # ---- include/nsr_train.h
     "nsr_train_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "nsr_train_workspace_bytes_for": (c_size_t, [c_int, c_int64, c_int, c_int]),
     "nsr_train_loss_and_grads": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                          c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_int, c_int64,

@@ -480,22 +480,27 @@ struct Work {   // per-pass buffers, sized for P_max = chunk * (Nc + Ni) sample 
   unsigned* gmax;   // float bits of the largest magnitude in each gradient panel (written by the backward chain)
 };
 
-int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base) {
+// mode 0: every buffer of both paths (nsr_train_workspace_bytes: sufficient whatever runs); 1: the layer-by-layer GEMM path
+// only; 2: the chain path only (no per-layer activation / gradient matrices: 11 KB per sample point less)
+int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base, int mode = 0) {
   const int64_t nf = nc + ni, P = chunk * nf;
   int64_t off = 0;
-  auto take = [&](int64_t n) {
+  auto take_if = [&](bool on, int64_t n) {
+    if (!on) return static_cast<float*>(nullptr);
     float* p = base ? base + off : nullptr;
     off += align64(n);
     return p;
   };
+  auto take = [&](int64_t n) { return take_if(true, n); };
+  const bool gemm_path = mode != 2, chain_path = mode != 1;
   Work tmp;
   Work& k = w ? *w : tmp;
-  k.x5 = take(P * kX5);
-  for (int L = 1; L <= 8; ++L) k.h[L] = (L == 4) ? nullptr : take(P * kW);   // h4 lives in x5[:, 64:]
-  k.gs = take(P * kGs);
-  k.cc = take(P * kDirOut);
+  k.x5 = take_if(gemm_path, P * kX5);
+  for (int L = 1; L <= 8; ++L) k.h[L] = (L == 4) ? nullptr : take_if(gemm_path, P * kW);   // h4 lives in x5[:, 64:]
+  k.gs = take_if(gemm_path, P * kGs);
+  k.cc = take_if(gemm_path, P * kDirOut);
   k.rgb = take(P * 4);   k.sig = take(P);
-  k.g0 = take(P * kGs);   k.g1 = take(P * kGs);
+  k.g0 = take_if(gemm_path, P * kGs);   k.g1 = take(P * kGs);     // the chain path keeps d_sigma in column 256 of g1
   k.drgb = take(P * kRgbPad);
   k.col_tiles = take((P / 128 + 1) * kW + 2 * 64 * kW + 64);   // per-tile column sums + 64 slices of doubles
   k.z_c = take(chunk * nc);   k.z_f = take(chunk * nf);   k.w_c = take(chunk * nc);
@@ -504,7 +509,7 @@ int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base) {
   k.partial = take(kMaxSplits * kPartialFloats);           // also scratch of the small bias sums
   // chain path: every second pass of a network waits for one launch; sized by the split-K factor of the larger pass
   const int64_t sp_max = (P + 511) / 512 < 1 ? 1 : ((P + 511) / 512 > kMaxSplits ? kMaxSplits : (P + 511) / 512);
-  k.slots = take(kChainSlots * sp_max * 256 * 256);
+  k.slots = take_if(chain_path, kChainSlots * sp_max * 256 * 256);
   k.block_sums = reinterpret_cast<double*>(take(2 * (chunk / 256 + 2)));
   k.carry = reinterpret_cast<double*>(take(8));
   for (int n = 0; n < 2; ++n) {
@@ -514,14 +519,14 @@ int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base) {
     q.split = reinterpret_cast<unsigned short*>(take((kSplitHalves + 1) / 2));
   }
   const int64_t pan = nsr_f16x3_train_panel_floats(P);
-  k.zpan = take(pan);   k.dpan = take(pan);
-  k.row_part = take(kChainRowSlots * sp_max * 256);
-  k.gmax = reinterpret_cast<unsigned*>(take(64));
-  k.pscale = take(10 * ((P + 127) / 128) * 128);
-  k.sgn = reinterpret_cast<unsigned*>(take(nsr_f16x3_train_sign_words(P)));
+  k.zpan = take_if(chain_path, pan);   k.dpan = take_if(chain_path, pan);
+  k.row_part = take_if(chain_path, kChainRowSlots * sp_max * 256);
+  k.gmax = reinterpret_cast<unsigned*>(take_if(chain_path, 64));
+  k.pscale = take_if(chain_path, 10 * ((P + 127) / 128) * 128);
+  k.sgn = reinterpret_cast<unsigned*>(take_if(chain_path, nsr_f16x3_train_sign_words(P)));
   for (int n = 0; n < 2; ++n) {
-    k.stream_f[n] = take((int64_t)(nsr_f16x3_packed_bytes() / 4));
-    k.stream_b[n] = take((int64_t)(nsr_chain_bwd_packed_bytes() / 4));
+    k.stream_f[n] = take_if(chain_path, (int64_t)(nsr_f16x3_packed_bytes() / 4));
+    k.stream_b[n] = take_if(chain_path, (int64_t)(nsr_chain_bwd_packed_bytes() / 4));
   }
   return off;
 }
@@ -872,6 +877,12 @@ int composite_bwd(hipStream_t st, const Work& k, const float* z, int64_t R, int 
 
 }  // namespace
 
+extern "C" size_t nsr_train_workspace_bytes_for(int precision, int64_t ray_chunk, int n_coarse, int n_importance) {
+  if (ray_chunk <= 0 || n_coarse < 2 || n_importance < 1 || n_coarse + n_importance > 256) return 0;
+  if (precision != NSR_FP32 && precision != NSR_F16X3) return 0;
+  return (size_t)work_floats(ray_chunk, n_coarse, n_importance, nullptr, nullptr, chain_selected(precision) ? 2 : 1) * sizeof(float);
+}
+
 extern "C" size_t nsr_train_workspace_bytes(int64_t ray_chunk, int n_coarse, int n_importance) {
   if (ray_chunk <= 0 || n_coarse < 2 || n_importance < 1 || n_coarse + n_importance > 256) return 0;
   return (size_t)work_floats(ray_chunk, n_coarse, n_importance, nullptr, nullptr) * sizeof(float);
@@ -905,11 +916,11 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
   if (!rays || !target_lr || !outs[0] || !outs[4] || !lr_coarse || !lr_fine || !losses || !workspace)
     return NSR_ERR_INVALID_ARG;
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return NSR_ERR_INVALID_ARG;
-  if (workspace_bytes < nsr_train_workspace_bytes(ray_chunk, n_coarse, n_importance)) return NSR_ERR_WORKSPACE;
+  if (workspace_bytes < nsr_train_workspace_bytes_for(precision, ray_chunk, n_coarse, n_importance)) return NSR_ERR_WORKSPACE;
   const bool noisy = noise_std > 0.0f;
   hipStream_t st = nsr_stream(stream);
   Work k;
-  work_floats(ray_chunk, n_coarse, n_importance, &k, static_cast<float*>(workspace));
+  work_floats(ray_chunk, n_coarse, n_importance, &k, static_cast<float*>(workspace), chain_selected(precision) ? 2 : 1);
   const int nc = n_coarse, nf = n_coarse + n_importance;
   const int64_t n_lr_total = R / s2;
   const double mse_scale = 1.0 / (3.0 * (double)n_lr_total);

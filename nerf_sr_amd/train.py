@@ -140,7 +140,7 @@ class Trainer:
         nc, nf = self.N_coarse, self.N_coarse + self.N_importance
         chunk = min(self.ray_chunk, R) if self.ray_chunk > 0 else R
         lib = _lib.load()
-        need = lib.nsr_train_workspace_bytes(chunk, nc, self.N_importance)
+        need = lib.nsr_train_workspace_bytes_for(self._prec, chunk, nc, self.N_importance)   # the buffers of the path this precision takes
         if need == 0:
             raise _lib.NsrError("sample counts outside the built path")
         if self._ws is None or self._ws.numel() < need:

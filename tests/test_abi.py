@@ -111,6 +111,10 @@ def test_next_row_entry_points_validate_before_any_launch(lib):
     ws = lib.nsr_train_workspace_bytes(2048, 64, 64)
     assert ws > 2048 * 128 * 3000 * 4                       # > 12 KB of activations per sample point
     assert lib.nsr_train_workspace_bytes(0, 64, 64) == 0 and lib.nsr_train_workspace_bytes(64, 64, 300) == 0
+    # per path: neither path needs the other's buffers (the union is what the precision-agnostic function reports)
+    ws_chain, ws_gemm = lib.nsr_train_workspace_bytes_for(2, 2048, 64, 64), lib.nsr_train_workspace_bytes_for(0, 2048, 64, 64)
+    assert 0 < ws_gemm < ws_chain < ws and ws_chain + ws_gemm > ws and ws - ws_chain > 2048 * 128 * 2500 * 4
+    assert lib.nsr_train_workspace_bytes_for(1, 2048, 64, 64) == 0
     p24 = (c_void_p * 24)(*[one] * 24)
     outs = (c_void_p * 8)(*[one] * 8)
     args = lambda R, s2, nc, ni, chunk, wsb: (p24, p24, p24, p24, one, 8, R, s2, one, nc, ni, 0, 0, null, null, null, null,
