@@ -116,6 +116,14 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch FIRST: libnsr.so needs libamdhip64.so.7 and so does torch, which ships its own copy; the dynamic linker keeps
+    # whichever instance of that SONAME is loaded first for the whole process.  With libnsr first the process ends up on the
+    # system runtime underneath torch's other bundled ROCm libraries and the first kernel launch fails (seen on the GPU box
+    # when build() -- which binds the library without touching torch -- ran in front of smoke() in one process).
+    try:
+        import torch  # noqa: F401
+    except ImportError:      # a torch-less host can still bind the C ABI (host-only entry points, symbol checks)
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m nerf_sr_amd.build` "
