@@ -207,7 +207,10 @@ class VanillaMLP:
         return self
 
     def set_gamma_correct(self, enable: bool = True):
-        """``--gamma_correct`` (models/nerf_downX_model.py:271-276): the colour head returns ``rgb ** (1 / 2.2)``."""
+        """``--gamma_correct`` (models/nerf_downX_model.py:271-276): the colour head returns ``rgb ** (1 / 2.2)``.
+        An option of the PACKED network: call it after ``load_state_dict`` (re-packing clears it)."""
+        if self._sd is None:
+            raise RuntimeError("VanillaMLP.set_gamma_correct called before load_state_dict")
         _lib.check(_lib.load().nsr_weights_set_gamma(_p(self.packed), self._prec, int(bool(enable)), _stream()),
                    "nsr_weights_set_gamma")
         self._gamma = bool(enable)
@@ -216,6 +219,8 @@ class VanillaMLP:
     def status(self, clear: bool = False) -> int:
         """The network's sticky numerics status word (``NSR_FLAG_*`` bits, include/nsr.h): 0 = every launch through this
         network so far saw finite inputs, in-range activations and finite outputs.  Waits for the current stream."""
+        if self._sd is None:
+            raise RuntimeError("VanillaMLP.status called before load_state_dict (the blob, and its status word, are not initialised)")
         flags = ctypes.c_uint(0)
         _lib.check(_lib.load().nsr_weights_status(_p(self.packed), self._prec, int(bool(clear)), ctypes.byref(flags), _stream()),
                    "nsr_weights_status")
