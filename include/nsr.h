@@ -98,8 +98,8 @@ int nsr_pack_weights_async(const float* const* w, void* packed_dev, int precisio
  *                               and single fp16 paths -- a sample position / direction beyond fp16's 65,504
  *   NSR_FLAG_ACTIVATION_RANGE   NSR_F16X3: a hidden activation left the range in which the (hi, lo) split keeps its 22
  *                               bits (|h| >= 1023.75: hi saturates there, the value degrades to 11-bit lo precision and
- *                               is lost beyond 65,504).  Trained checkpoints sit two orders of magnitude below
- *                               (tests/test_gpu_trained.py); a diverged network trips it.  Re-run with NSR_FP32.
+ *                               is lost beyond 66,528).  The networks trained in tests/test_gpu_trained.py reach 165
+ *                               (6 x below the limit); a diverged network trips it.  Re-run with NSR_FP32.
  *   NSR_FLAG_OUTPUT_NONFINITE   a network output (r, g, b, sigma) was inf / NaN
  * nsr_weights_status copies the word to *flags_out (HOST), clears it on the device if `clear`, and WAITS for `stream`
  * (the second synchronising entry point).  The blob is therefore read-mostly, not read-only: `packed_dev` arguments
