@@ -62,14 +62,9 @@ def _oracle_block(cid, field="smooth"):
     lo = (rays.shape[0] // 2) - (rays.shape[0] // 2) % (s * s)
     blk = rays[lo:lo + N_RAYS].contiguous()
     sd_c, sd_f = make_state_dict(99, field=field), make_state_dict(100, field=field)
-    threads = torch.get_num_threads()
-    torch.set_num_threads(min(32, threads))
+    from tests.util import oracle_fp32_and_fp64
     t0 = time.time()
-    with torch.no_grad():
-        ref = oc.forward_rays(oc.to_torch_sd(sd_c), oc.to_torch_sd(sd_f), blk, 64, 64, white)
-        ref64 = oc.forward_rays(oc.to_torch_sd(sd_c, torch.float64), oc.to_torch_sd(sd_f, torch.float64), blk.double(),
-                                64, 64, white)
-    torch.set_num_threads(threads)
+    ref, ref64 = oracle_fp32_and_fp64(sd_c, sd_f, blk, white)        # both evaluations side by side, 32 threads each
     print(f"[config #{cid} {field}] oracle fp32 + fp64 on {N_RAYS} rays: {time.time() - t0:.1f} s")
     _ORACLE_CACHE[(cid, field)] = (lo, blk, ref, ref64)
     return _ORACLE_CACHE[(cid, field)]

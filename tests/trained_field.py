@@ -162,12 +162,8 @@ def oracle_block(family: str, sd_c, sd_f, n_rays: int, threads: int = 32):
     rays = oc.subpixel_ray_grid(torch.from_numpy(c2w), wh[1], wh[0], focal, s, ndc, *nf).reshape(-1, 8)
     lo = (rays.shape[0] // 2) - (rays.shape[0] // 2) % (s * s)
     blk = rays[lo:lo + n_rays].contiguous()
-    old = torch.get_num_threads()
-    torch.set_num_threads(min(threads, old))
-    with torch.no_grad():
-        ref = oc.forward_rays(oc.to_torch_sd(sd_c), oc.to_torch_sd(sd_f), blk, 64, 64, white)
-        ref64 = oc.forward_rays(oc.to_torch_sd(sd_c, torch.float64), oc.to_torch_sd(sd_f, torch.float64), blk.double(), 64, 64, white)
-    torch.set_num_threads(old)
+    from tests.util import oracle_fp32_and_fp64
+    ref, ref64 = oracle_fp32_and_fp64(sd_c, sd_f, blk, white, threads=threads)    # side by side, `threads` ATen threads each
     return blk, ref, ref64
 
 
