@@ -157,3 +157,15 @@ def test_next_row_entry_points_validate_before_any_launch(lib):
     assert lib.nsr_refine_forward(one, 1, one, one, 1, 8, 64, 64, one, one, 1 << 40, null) == -2     # bf16: not a mode
     assert lib.nsr_refine_forward(one, 2, one, one, 1, 8, 64, 64, one, one, 16, null) == -4
     assert lib.nsr_refine_forward(one, 0, one, one, 0, 8, 64, 64, one, one, 0, null) == 0
+
+
+def test_integration_md_only_names_exported_entry_points(lib):
+    """INTEGRATION.md is the binding a reference maintainer would copy: every `nsr_*` entry point it names must exist in the
+    headers, in the library and in the ctypes table (documentation drift guard)."""
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    named = sorted(set(re.findall(r"\b(nsr_[a-z_0-9]+)\s*\(", text)) | set(re.findall(r"lib\.(nsr_[a-z_0-9]+)", text)))
+    named = [n for n in named if n not in ("nsr_binding", "nsr_status")]          # the stub's module name / the enum
+    assert len(named) >= 20
+    declared = set(_declared_symbols())
+    for n in named:
+        assert n in declared and hasattr(lib, n) and n in _lib.SIGNATURES, f"INTEGRATION.md names {n}, which libnsr does not export"
