@@ -200,3 +200,38 @@ def test_gamma_correct_matches_the_reference(ops, golden_dir, prec, tag, white):
     m.netCoarse.set_gamma_correct(False)
     rgb0, _ = ops.render_rays(m.netCoarse, r, z)
     assert float((rgb0[:16].cpu() - torch.from_numpy(p["coarse_point_rgb"])).abs().max()) <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------- HIP graph capture
+@pytest.mark.parametrize("prec", ["f16x3", "fp32"])
+def test_forward_rays_is_hip_graph_capturable(ops, rays, prec):
+    """The library only ENQUEUES on the caller's stream (include/nsr.h): no allocation, no synchronisation, no host-side
+    state -- so one forward_rays call can be captured into a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed on new
+    ray data.  This is what a caller with the reference's small 4,096-ray chunks needs (launch-bound there); the replay must
+    be bit-identical to the eager call, and the numerics flags raised by a replay land in the same status words."""
+    net_c = ops.VanillaMLP(precision=prec).load_state_dict(make_state_dict(99))
+    net_f = ops.VanillaMLP(precision=prec).load_state_dict(make_state_dict(100))
+    R = rays.shape[0]
+    static_rays = rays.clone()
+    ws = torch.empty(max(_lib.load().nsr_forward_rays_workspace_bytes_for(net_c._prec, R, 64, 64), 256), dtype=torch.uint8, device="cuda")
+    outs = {}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                                   # warm-up outside the capture (allocates the outputs)
+        ops.forward_rays(net_c, net_f, static_rays, 64, 64, False, workspace=ws, outs=outs)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.forward_rays(net_c, net_f, static_rays, 64, 64, False, workspace=ws, outs=outs)
+    other = rays.flip(0).contiguous()
+    static_rays.copy_(other)
+    graph.replay()
+    torch.cuda.synchronize()
+    got = {k: v.clone() for k, v in outs.items()}
+    want = ops.forward_rays(net_c, net_f, other, 64, 64, False)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    assert net_c.status() == 0 and net_f.status() == 0
+    static_rays[5, 3] = float("nan")
+    graph.replay()
+    assert net_c.status(clear=True) & INPUT
