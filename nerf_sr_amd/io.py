@@ -19,11 +19,11 @@ import os
 import struct
 from collections import OrderedDict
 from dataclasses import dataclass
-from typing import Dict, List, Tuple
+from typing import Dict, Tuple
 
 import numpy as np
 
-from .weights import STATE_DICT_SPEC, check_state_dict
+from .weights import STATE_DICT_SPEC
 
 # ------------------------------------------------------------------------------------------------ checkpoints
 
