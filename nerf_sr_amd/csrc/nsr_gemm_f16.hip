@@ -3,7 +3,8 @@
 // Workgroup = 2 x WN waves, each wave a 64 x 64 quadrant (2 x 2 accumulator blocks): 4 waves on a 128 x 128 tile, or
 // 8 waves on 128 x 256 when N >= 256 (the A panel -- activations, HBM traffic -- is then read once); K tiles of 32 =
 // two MFMA k-steps.  LDS holds the tile as four fp16 arrays (A hi, A lo, B hi, B lo; row stride 40 halves = 80 B,
-// which makes the 16-byte fragment reads of eight consecutive rows hit eight different 16-byte bank groups);
+// which makes the 16-byte fragment reads of eight consecutive rows hit eight different 16-byte bank groups; the staging
+// stores need their own lane -> row assignment to stay conflict-free at that pitch, see stage_row);
 // single buffered with register prefetch (40 / 60 KB per workgroup; two waves per SIMD: two 4-wave workgroups or
 // one 8-wave workgroup per CU, so the MFMAs of one wave hide the staging and barriers of the other).  A is fp32 in memory and is split into (hi, lo) on its way from
 // registers to LDS; B arrives pre-split.  Optional implicit im2col: the A rows are gathered from an NHWC activation
@@ -24,6 +25,23 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define NSR_GEMM_K32_ONLY 0
 #endif
 constexpr int kTM = 128, kTK = 32;   // row tile; default K tile (the kernels pad LDS rows by 8 halves)
+
+// Staging row of a thread (16-byte chunks, kCh per row and plane).  K tiles of 32: a row is 64 B of data at an 80 B pitch
+// and a ds_write_b128 is served eight consecutive lanes per LDS cycle out of 32 banks (128 B) -- lanes 0-3 on row r and
+// lanes 4-7 on row r + 1 overlap by four banks, a 2-way conflict on EVERY staging store (PMC, profiles/r3_refine_pmc.json:
+// 7.7 conflict cycles per store, 16 array cycles against the instruction's 13).  Rows r and r + 4 are 320 B = 16 banks
+// apart and do not collide, so the eight lanes take rows {r, r + 4}.  K tiles of 64: eight lanes = one 128 B row, no conflict.
+// (-DNSR_GEMM_NO_WROWS: the consecutive-row assignment, for A/B runs.)
+template <int kCh>
+__device__ __forceinline__ int stage_row(int tid) {
+#ifndef NSR_GEMM_NO_WROWS
+  if constexpr (kCh == 4) {
+    const int g8 = tid >> 3;
+    return (g8 >> 2) * 8 + (g8 & 3) + 4 * ((tid >> 2) & 1);
+  }
+#endif
+  return tid / kCh;
+}
 
 __global__ void split_f16_kernel(const float* __restrict__ w, int64_t n, unsigned short* __restrict__ hi,
                                  unsigned short* __restrict__ lo) {
@@ -143,7 +161,11 @@ __device__ __forceinline__ int64_t xcd_tile(int64_t launch_idx, int64_t n_blocks
 // BN: accumulator blocks per wave along N.  2 (default): a wave owns 64 x 64.  4: a wave owns 64 x 128 -- the 128 x 256 tile
 // is then ONE workgroup of four waves (one per SIMD), two such workgroups share a CU and run out of phase, and a k-step
 // reads 12 fragments for 24 MFMAs instead of 8 for 12 (the 8-wave tile keeps the LDS port ~90 % as busy as the matrix pipe)
-template <int WN, bool APL, int TK = 32, int BN = 2>
+// FULLN: every column block of the tile is inside N (N a multiple of the tile width) -- the k-steps are then straight-line
+// code.  With the test `col_on[bj]` in the loop the compiler cannot prove it wave-uniform, wraps every group of six MFMAs
+// in an EXEC-mask branch, and each k-step becomes read 8 fragments -> wait -> 12 MFMAs with nothing in flight across the
+// block boundaries.
+template <int WN, bool APL, int TK = 32, int BN = 2, bool FULLN = false>
 __global__ void __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))   // <= 256 registers
 gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
   static_assert(TK == 32 || (APL && TK == 64), "K tiles of 64 are built for pre-split A only");
@@ -183,8 +205,8 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
   // (with K tiles of 64: eight chunks per row, rows (tid >> 3) + (NT / 8) i)
   constexpr int NA = APL ? kTM * kCh / NT : 1024 / NT, kARows = APL ? NT / kCh : NT / 8, kBRows = NT / kCh;
   constexpr int NBP = kTN * kCh / NT;                       // B chunks per thread and plane
-  const int c4 = tid & 7, c8 = tid % kCh, br0 = tid / kCh;
-  const int ar0 = APL ? (tid / kCh) : (tid >> 3);
+  const int c4 = tid & 7, c8 = tid % kCh, br0 = stage_row<kCh>(tid);
+  const int ar0 = APL ? stage_row<kCh>(tid) : (tid >> 3);
   const int a_col = APL ? 8 * c8 : 4 * c4;                  // column offset inside the K tile, in elements
   // row base of the A operand in ELEMENTS from its base pointer (fp32: g.A floats; planes: a.Ah halves); -1 = zero row
   int64_t arow[NA];
@@ -319,7 +341,7 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
       }
 #pragma unroll
       for (int bj = 0; bj < BN; ++bj)
-        if (BN == 4 || col_on[bj]) {     // BN == 4: full column tiles only
+        if (BN == 4 || FULLN || col_on[bj]) {     // BN == 4: full column tiles only
 #pragma unroll
           for (int bi = 0; bi < 2; ++bi) {
             acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[bi], bh[bj], acc[bi][bj], 0, 0, 0);   // small terms first
@@ -394,6 +416,7 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   // development switches (A/B runs on one box): NSR_GEMM_TILE=narrow|wide|quad overrides the choice, NSR_GEMM_TK=32 keeps K tiles of 32
   const char* e_tile = getenv("NSR_GEMM_TILE");
   const char* e_tk = getenv("NSR_GEMM_TK");
+  const char* e_fulln = getenv("NSR_GEMM_FULLN");      // =0: keep the column test in the k-steps (A/B)
   if (e_tile && e_tile[0] == 'n') four_wave_wide = false;
   if (e_tile && e_tile[0] == 'w') { wide = g.N >= 256; four_wave_wide = false; }
   if (e_tile && e_tile[0] == 'q') four_wave_wide = quad_ok;
@@ -405,10 +428,13 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   if (a.Ah) {
     const bool k64 = (g.K % 64) == 0 && (a.conv.cin <= 0 || (a.conv.cin % 64) == 0) && !NSR_GEMM_K32_ONLY &&
                      !(e_tk && e_tk[0] == '3');
+    const bool fulln = (g.N % 128) == 0 && !(e_fulln && e_fulln[0] == '0');   // four-wave 128 x 128 tiles only
     if (four_wave_wide) hipLaunchKernelGGL((gemm_f16x3_kernel<2, true, 32, 4>), grid, dim3(256), 0, st, a, n_col_tiles, n_blocks);
     else if (wide && k64) hipLaunchKernelGGL((gemm_f16x3_kernel<4, true, 64>), grid, dim3(512), 0, st, a, n_col_tiles, n_blocks);
     else if (wide) hipLaunchKernelGGL((gemm_f16x3_kernel<4, true>), grid, dim3(512), 0, st, a, n_col_tiles, n_blocks);
+    else if (k64 && fulln) hipLaunchKernelGGL((gemm_f16x3_kernel<2, true, 64, 2, true>), grid, dim3(256), 0, st, a, n_col_tiles, n_blocks);
     else if (k64) hipLaunchKernelGGL((gemm_f16x3_kernel<2, true, 64>), grid, dim3(256), 0, st, a, n_col_tiles, n_blocks);
+    else if (fulln) hipLaunchKernelGGL((gemm_f16x3_kernel<2, true, 32, 2, true>), grid, dim3(256), 0, st, a, n_col_tiles, n_blocks);
     else hipLaunchKernelGGL((gemm_f16x3_kernel<2, true>), grid, dim3(256), 0, st, a, n_col_tiles, n_blocks);
   } else {
     if (wide) hipLaunchKernelGGL((gemm_f16x3_kernel<4, false>), grid, dim3(512), 0, st, a, n_col_tiles, n_blocks);
