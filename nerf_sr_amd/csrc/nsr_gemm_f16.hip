@@ -326,6 +326,10 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
     if (t + 1 < n_tiles) load(t + 1);
     const _Float16* ap = lds + (64 * wm + li) * kLd + 8 * h;
     const _Float16* bp = lds + 2 * kArrA + (32 * BN * wn + li) * kLd + 8 * h;
+    // the k-steps run at raised priority: the wave sharing this SIMD is, by then, usually staging its next tile (address
+    // arithmetic, loads, LDS stores), and its VALU / SALU stream otherwise takes issue slots between this wave's MFMAs
+    // (-1 % on the refinement pass, interleaved A/B, profiles/r3_refine_tiles.txt)
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < TK / 16; ++s) {
       h8 ah[2], al[2], bh[BN], bl[BN];
@@ -350,6 +354,7 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
           }
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
   }
   if constexpr (BN == 2) {

@@ -10,7 +10,8 @@ cd $R
 : > $O/summary.txt
 for r in 1 2 3; do
   for v in "$@"; do
-    env $v timeout 200 python scripts/prof_refine.py 256 3 2>&1 | tail -2 | tr '\n' ' ' | sed "s/^/round $r [$v]: /" | tee -a $O/summary.txt; echo | tee -a $O/summary.txt
+    out=$(env $v timeout 200 python scripts/prof_refine.py 256 3 2>&1 | tail -2 | tr '\n' ' ')
+    echo "round $r [$v]: $out" | tee -a $O/summary.txt
   done
 done
 timeout 600 python -m pytest tests/test_gpu_refine.py tests/test_gpu_frames.py::test_config5_composed_small_vs_oracles -q -m gpu -x 2>&1 | tail -2 | tee -a $O/summary.txt
