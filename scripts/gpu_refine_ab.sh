@@ -14,4 +14,4 @@ for r in 1 2 3; do
     echo "round $r [$v]: $out" | tee -a $O/summary.txt
   done
 done
-timeout 600 python -m pytest tests/test_gpu_refine.py tests/test_gpu_frames.py::test_config5_composed_small_vs_oracles -q -m gpu -x 2>&1 | tail -2 | tee -a $O/summary.txt
+[ -n "$AB_SKIP_TESTS" ] || timeout 600 python -m pytest tests/test_gpu_refine.py tests/test_gpu_frames.py::test_config5_composed_small_vs_oracles -q -m gpu -x 2>&1 | tail -2 | tee -a $O/summary.txt
