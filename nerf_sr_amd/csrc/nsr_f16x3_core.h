@@ -120,7 +120,17 @@ struct Loader {
   const char* dma_base;
   unsigned dma_lds;
   int dma_count;
+#ifdef NSR_ABL_TIMELINE
+  unsigned long long* tk = nullptr;   // k-step stamps of ONE designated chunk (null elsewhere; compile-time after inlining)
+#endif
 };
+#ifdef NSR_ABL_TIMELINE
+__device__ __forceinline__ unsigned long long tl_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return t;
+}
+#endif
 
 __device__ __forceinline__ void loader_prepare_dma(Loader& ld, const ChunkRef& c, unsigned slot_lds) {
   ld.dma_count = c.count;
@@ -240,6 +250,9 @@ __device__ __forceinline__ void block_mma(Acc& acc, const Pre& pre, unsigned a_a
   }
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
+#ifdef NSR_ABL_TIMELINE
+    if (ld.tk && NSTEP == 16 && (s == 0 || s == 4 || s == 8 || s == 11 || s == 14)) ld.tk[s == 0 ? 0 : (s == 4 ? 1 : (s == 8 ? 2 : (s == 11 ? 3 : 4)))] = tl_now();
+#endif
     if (s == BAR) loader_publish<YOUNGER>(ld, c2, strict);
     if (s + kPF < NSTEP) {
       ah[s + kPF] = a_pieces[(2 * (s + kPF)) * 64];

@@ -291,7 +291,11 @@ template <bool RELU_OUT, bool TRAIN = false>   // relu on L2..L8 (true), none on
 __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[16], u32x4 (&oh)[16], u32x4 (&ol)[16],
                                             const u32x4* stash, Loader& ld, int h, Acc& pend, Pre& pre,
                                             const ChunkRef& after0, const ChunkRef& after1, float& amax,
-                                            const PanelRef& tr = PanelRef{}, unsigned voff = 0) {
+                                            const PanelRef& tr = PanelRef{}, unsigned voff = 0
+#ifdef NSR_ABL_TIMELINE
+                                            , unsigned long long* ld_tk_buf = nullptr
+#endif
+                                            ) {
   const ChunkRef ref0 = layer_ref(L, 0, ld.wave);           // this layer's chunks: piece0 advances by `pieces`
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) {
@@ -307,6 +311,10 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
     Resplit ptmp;
     unsigned sbits = 0u;
     unsigned a_addr = ld.slot_cur + ld.lane_off;
+#ifdef NSR_ABL_TIMELINE
+    ld.tk = (L == 7 && nb == 3) ? ld_tk_buf : nullptr;
+    if (L == 7 && nb == 4) ld_tk_buf[5] = tl_now();
+#endif
     const unsigned next_bias = (unsigned)(c1.pieces - 1) * 1024u;
     Pre nxt;
     if (L == 4) {
@@ -357,6 +365,23 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
   }
 }
 
+// NSR_ABL_TIMELINE (development build only, scripts/timeline.py): s_memtime stamps at the phase boundaries of every
+// workgroup's wave, fetched with nsr_dbg_timeline(); never defined in the product build.
+#ifdef NSR_ABL_TIMELINE
+constexpr int kTlGroups = 65536, kTlSlots = 10;
+__device__ unsigned long long nsr_tl[kTlGroups * 4 * kTlSlots];
+__device__ unsigned long long nsr_tk[kTlGroups * 4 * 8];
+#define NSR_TL(k) (tl[k] = tl_now())
+extern "C" int nsr_dbg_ksteps(void* host_dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(nsr_tk), bytes < sizeof(nsr_tk) ? bytes : sizeof(nsr_tk), 0, hipMemcpyDeviceToHost);
+}
+extern "C" int nsr_dbg_timeline(void* host_dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(nsr_tl), bytes < sizeof(nsr_tl) ? bytes : sizeof(nsr_tl), 0, hipMemcpyDeviceToHost);
+}
+#else
+#define NSR_TL(k) ((void)0)
+#endif
+
 // COMP: the tile's points are whole rays (MODE 1, NS = 64 or 128) and the kernel composites them itself (V1 fused into
 // D2 + M1: the (R, N, 4) network output never goes to HBM); `out` may then be null.
 // TRAIN: the forward pass of the training step (nsr_train.hip): additionally keeps every layer's pre-activations for the
@@ -374,12 +399,19 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 31, h = lane >> 5;
   const float* aux = ring + kAux0;          // LDS copy, visible after the first barrier
+#ifdef NSR_ABL_TIMELINE
+  unsigned long long tl[8], tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  NSR_TL(0);
   for (int i = threadIdx.x; i < hx::kAuxFloats; i += 256) ring[kAux0 + i] = packed[kPiecesTotal * 256 + i];
 
   Loader ld;
   ld.stream = packed;
   ld.wave = wave;
   ld.lane_off = (unsigned)lane * 16u;
+#ifdef NSR_ABL_TIMELINE
+  ld.tk = nullptr;
+#endif
   ld.slot_cur = lds_addr(ring);
   ld.slot_next = ld.slot_cur + kSlotBytes;
   ld.slot_free = ld.slot_cur + 2 * kSlotBytes;
@@ -499,6 +531,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   Acc pend;
   Pre pre;
 
+  NSR_TL(1);
   // ---- L1: two chunks of four output blocks, 4 k-steps each; block b is re-split during block b+1.
   // Publish point at the chunk start (chunk 0 / 1 were issued above; chunk j+2 is fetched here).
 #pragma unroll
@@ -549,6 +582,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     loader_advance(ld);
   }
 
+  NSR_TL(2);
   // ---- L2..L8 (+ xyz_encoding_final), two layers per trip so the register sets swap roles.  Three trips of relu
   // layers (L2..L7); the last pair (L8 + xyz_encoding_final, which has no relu) is peeled so that the activation is a
   // compile-time property of every re-split.
@@ -562,10 +596,16 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   if (SIGMA_ONLY) {   // xyz_encoding_final is not evaluated: L8 is followed by the density head, then nothing
     trunk_layer<true>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, sigma_ref(wave), end_ref(wave), amax);
   } else {
+#ifdef NSR_ABL_TIMELINE
+    trunk_layer<true, TRAIN>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave), amax, tr, voff, tk);
+    ld.tk = nullptr;
+#else
     trunk_layer<true, TRAIN>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave), amax, tr, voff);
+#endif
     trunk_layer<false, TRAIN>(8, oh, ol, bh, bl, stash, ld, h, pend, pre, sigma_ref(wave), dir_ref(0, wave), amax, tr, voff);
   }
 
+  NSR_TL(3);
   // ---- density head: sigma.weight as row 0 of one more 32-row block over h8 (= oh/ol: the input of
   // xyz_encoding_final, still intact).  The pending block is xyz_encoding_final's last one (-> bh, no
   // activation), or L8's last one in a sigma_only launch (-> oh, relu).
@@ -606,6 +646,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     return;
   }
 
+  NSR_TL(4);
   // ---- dir_encoding (cat([g, de]) -> 128, relu) fused with the rgb head (128 -> 3, sigmoid)
   float rgb[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -644,6 +685,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     pre = nxt;
     loader_advance(ld);
   }
+  NSR_TL(5);
 #pragma unroll
   for (int s = 0; s < 8; ++s) rgb_step<0>(s, pend, aux + hx::kAuxRgbW + 32 * 3, h, rgb);
   if (TRAIN) {
@@ -672,8 +714,21 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   if (p < P) nsr_raise(tail, flags);
   if (out && h == 0 && p < P) reinterpret_cast<float4*>(out)[p] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
   dma_drain();     // no LDS-DMA may be in flight when the workgroup's LDS is released (or re-used just below)
+  NSR_TL(6);
   if (COMP) composite_tile<(COMP ? NS : 64)>(ring, h == 0, wave, m, lane, make_float4(rgb[0], rgb[1], rgb[2], sigma), zv[pc],
                                             P / NS, co);
+#ifdef NSR_ABL_TIMELINE
+  NSR_TL(7);
+  if (lane == 0 && blockIdx.x < kTlGroups) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
+    unsigned long long* dst = nsr_tl + ((size_t)blockIdx.x * 4 + wave) * kTlSlots;
+    for (int k = 0; k < 8; ++k) dst[k] = tl[k];
+    dst[8] = hwid;
+    dst[9] = xcc;
+    for (int k = 0; k < 8; ++k) nsr_tk[((size_t)blockIdx.x * 4 + wave) * 8 + k] = tk[k];
+  }
+#endif
 }
 
 template <int MODE, bool SIGMA_ONLY>
