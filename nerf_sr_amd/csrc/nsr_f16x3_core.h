@@ -62,6 +62,11 @@ __device__ __forceinline__ void glds16_asm(const char* base_uniform, unsigned la
       : "v"(lane_off), "s"(base_uniform), "s"(lds_dst_uniform), "i"(OFF)
       : "memory");
 }
+// a further piece of the 4 KiB group whose first piece set M0 (same base, same M0)
+template <int OFF>
+__device__ __forceinline__ void glds16_keep_asm(const char* base_uniform, unsigned lane_off) {
+  asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(lane_off), "s"(base_uniform), "i"(OFF) : "memory");
+}
 // two consecutive pieces (OFF, OFF + 1024) with ONE M0 write
 template <int OFF>
 __device__ __forceinline__ void glds16x2_asm(const char* base_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
@@ -146,12 +151,23 @@ __device__ __forceinline__ void loader_issue(const Loader& ld, int i) {
   if (i < 8 || i < ld.dma_count) {   // every wave owns at least 8 pieces of every chunk
     const char* base = ld.dma_base + (i >> 2) * 4096;
     const unsigned dst = ld.dma_lds + (unsigned)(i >> 2) * 4096u;
+#ifndef NSR_ABL_M0_EVERY
+    // pieces 4q+1..4q+3 reuse the M0 piece 4q wrote (they are issued in order, and nothing else in these kernels
+    // touches M0 -- checked on the ISA by scripts/isa_census.py --m0)
+    switch (i & 3) {
+      case 0: glds16_asm<0>(base, ld.lane_off, dst); break;
+      case 1: glds16_keep_asm<1024>(base, ld.lane_off); break;
+      case 2: glds16_keep_asm<2048>(base, ld.lane_off); break;
+      default: glds16_keep_asm<3072>(base, ld.lane_off); break;
+    }
+#else
     switch (i & 3) {
       case 0: glds16_asm<0>(base, ld.lane_off, dst); break;
       case 1: glds16_asm<1024>(base, ld.lane_off, dst); break;
       case 2: glds16_asm<2048>(base, ld.lane_off, dst); break;
       default: glds16_asm<3072>(base, ld.lane_off, dst); break;
     }
+#endif
   }
 }
 
@@ -176,16 +192,24 @@ __device__ __forceinline__ void loader_advance(Loader& ld) {
 // the publish point of chunk j+1 (see protocol above), then start fetching chunk j+2
 // YOUNGER: vector-memory operations known to have been issued AFTER the last DMA piece this publish point waits for
 // (they may stay in flight); strict: ... unless this call site cannot vouch for them (runtime, wave-uniform)
-template <int YOUNGER = 0>
+template <int YOUNGER = 0, bool PREPARE = true>
 __device__ __forceinline__ void loader_publish(Loader& ld, const ChunkRef& c2, bool strict = false) {
 #ifndef NSR_ABL_NO_DRAIN
   if (YOUNGER > 0 && strict) dma_drain();
   else dma_drain_but<YOUNGER>();
 #endif
 #ifndef NSR_ABL_NO_BARRIER
+#ifndef NSR_ABL_FENCED_BARRIER
+  // s_barrier alone: what the publish point orders is (a) every wave's DMA pieces of chunk j+1 (each wave has just waited
+  // for its own: vmcnt) and (b) every wave's READS of chunk j-1, which were consumed by MFMAs a whole chunk ago.  The
+  // LDS reads in flight here are fragment prefetches of the CURRENT chunk, which nobody overwrites: __syncthreads()'s
+  // lgkmcnt(0) would only stall the wave on them.
+  asm volatile("s_barrier" ::: "memory");
+#else
   __syncthreads();
 #endif
-  loader_prepare_dma(ld, c2, ld.slot_free);
+#endif
+  if (PREPARE) loader_prepare_dma(ld, c2, ld.slot_free);
 }
 
 __device__ __forceinline__ h8 as_h8(const u32x4& v) { return __builtin_bit_cast(h8, v); }
@@ -277,6 +301,61 @@ __device__ __forceinline__ void block_mma(Acc& acc, const Pre& pre, unsigned a_a
         loader_issue(ld, 2 * (s - BAR) + 1);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Gap-aware form of block_mma (round 4; the inference kernel uses it everywhere).  A wave alone on its SIMD hides at most
+// ~5 single-issue instructions behind one 32-cycle MFMA, and only if they sit in THAT MFMA's gap: the k-step-granular form
+// above lets hipcc put all of a k-step's fillers (2 fragment reads + 7 re-split VALU + 2 DMA pieces and their SALU) behind
+// the k-step's FIRST MFMA, and the measured price was ~5 cycles for every filler beyond the fifth (profiles/
+// r4_timeline_before_128.json: quiet k-steps 103 cycles, the double-half-step k-steps 122, the DMA k-steps 140-155, against
+// 96 of matrix time).  Here every k-step is three fenced (MFMA + fillers) segments:
+//   gap 0: a_lo*b_hi + the fragment reads of k-step s + kPF (or next(k, 0)) + hook(s, 0)
+//   gap 1: a_hi*b_lo + hook(s, 1)
+//   gap 2: a_hi*b_hi + hook(s, 2) + next(k, 2)
+// and the chunk's DMA pieces go one per gap (gaps 1 and 2 of k-steps BAR..BAR+5, each with its own M0 write).
+template <int NSTEP, int BAR, int YOUNGER = 0, class BOf, class Hook, class Next>
+__device__ __forceinline__ void block_mma3(Acc& acc, const Pre& pre, unsigned a_addr, Loader& ld, const ChunkRef& c2,
+                                           BOf&& b_of, Hook&& hook, Next&& next, bool strict = false) {
+  static_assert(NSTEP >= kPF, "sequence shorter than the prefetch depth");
+  const u32x4* a_pieces = lds_vec(a_addr);
+  u32x4 ah[NSTEP], al[NSTEP];
+#pragma unroll
+  for (int s = 0; s < kPF; ++s) {
+    ah[s] = pre.ah[s];
+    al[s] = pre.al[s];
+  }
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+#ifdef NSR_ABL_TIMELINE
+    if (ld.tk && NSTEP == 16 && (s == 0 || s == 4 || s == 8 || s == 11 || s == 14)) ld.tk[s == 0 ? 0 : (s == 4 ? 1 : (s == 8 ? 2 : (s == 11 ? 3 : 4)))] = tl_now();
+#endif
+    // the DMA descriptor of chunk j+2 (six SALU) is formed three k-steps ahead of the publish point, in a quiet gap: the
+    // previous chunk's last piece went out at its k-step BAR+5, and slot_free does not change inside a chunk
+    if (BAR >= 3 && s == BAR - 3) loader_prepare_dma(ld, c2, ld.slot_free);
+    if (s == BAR) loader_publish<YOUNGER, (BAR < 3)>(ld, c2, strict);
+    const u32x4 bh = b_of(s, 0), bl = b_of(s, 1);
+    // ---- gap 0.  a_lo first: it is the younger of the step's two fragment loads, so ONE lgkmcnt wait serves all three
+    acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(al[s]), as_h8(bh), acc.m, 0, 0, 0);
+    if (s + kPF < NSTEP) {
+      ah[s + kPF] = a_pieces[(2 * (s + kPF)) * 64];
+      al[s + kPF] = a_pieces[(2 * (s + kPF) + 1) * 64];
+    } else {
+      next(s + kPF - NSTEP, 0);
+    }
+    hook(s, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- gap 1
+    acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bl), acc.m, 0, 0, 0);
+    hook(s, 1);
+    if (BAR >= 0 && s >= BAR && s < BAR + 6) loader_issue(ld, 2 * (s - BAR));
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- gap 2
+    acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bh), acc.m, 0, 0, 0);
+    hook(s, 2);
+    if (s + kPF >= NSTEP) next(s + kPF - NSTEP, 2);
+    if (BAR >= 0 && s >= BAR && s < BAR + 6) loader_issue(ld, 2 * (s - BAR) + 1);
     __builtin_amdgcn_sched_barrier(0);
   }
 }

@@ -231,49 +231,58 @@ __device__ __forceinline__ void pending_half(int hs, const Acc& p, Resplit& r, u
                                              float& amax) {
   pending_half_t<RELU>(hs, p, RELU ? 0.0f : -__builtin_inff(), r, h0, l0, h1, l1, amax);
 }
-// Schedule over the k-steps of a 16-step chunk: 17 half-steps in k-steps 0..13 (k-steps 0, 1, 2 take two), so that
-// even the operands of k-steps 14, 15 (block 7 of the previous layer) are complete before they are used.
+// Schedule over the gaps of a 16-step chunk (block_mma3): half-step i (0..15) in gap 1 + (i & 1) of k-step i >> 1, the
+// last one (two instructions) in gap 0 of k-step 8, next to that gap's fragment reads.  One half-step (3-4 VALU) per
+// MFMA gap, finished before the publish point and the DMA gaps of k-steps 8..13, and long before the operands of k-steps
+// 14, 15 (block 7 of the previous layer) are used.
 template <bool RELU>
-__device__ __forceinline__ void pending_step(int s, const Acc& p, Resplit& r, u32x4& h0, u32x4& l0, u32x4& h1, u32x4& l1,
-                                             float& amax) {
-  if (s < 3) {
-    pending_half<RELU>(2 * s, p, r, h0, l0, h1, l1, amax);
-    pending_half<RELU>(2 * s + 1, p, r, h0, l0, h1, l1, amax);
-  } else if (s < 14) {
-    pending_half<RELU>(s + 3, p, r, h0, l0, h1, l1, amax);
+__device__ __forceinline__ void pending_gap(int s, int g, const Acc& p, Resplit& r, u32x4& h0, u32x4& l0, u32x4& h1, u32x4& l1,
+                                            float& amax) {
+  if (g == 0) {
+    if (s == 8) pending_half<RELU>(16, p, r, h0, l0, h1, l1, amax);
+    return;
   }
+  const int i = 2 * s + g - 1;
+  if (i < 16) pending_half<RELU>(i, p, r, h0, l0, h1, l1, amax);
 }
-// colour head: pair P of a finished dir_encoding block (relu) dotted with the three rgb rows
+// colour head: pair P of a finished dir_encoding block (relu) dotted with rgb row K; the weights come in through `w2`,
+// read from LDS one k-step earlier (rgb_load) so that their latency is not exposed inside a 32-cycle gap
 template <int P>
-__device__ __forceinline__ void pair_rgb(const Acc& p, const float* w32, int h, float (&rgb)[3]) {
+__device__ __forceinline__ float2 pair_rgb_w(const float* w32, int h, int k) {
+  constexpr int r = 2 * P;                       // registers r, r+1 <-> features 8*(r>>2) + 4h + (r&3), +1
+  return *reinterpret_cast<const float2*>(w32 + 128 * k + 8 * (r >> 2) + 4 * h + (r & 3));
+}
+template <int P>
+__device__ __forceinline__ void pair_rgb_k(const Acc& p, float2 w2, float& acc) {
   const float x0 = fmaxf(p.m[2 * P], 0.0f);
   const float x1 = fmaxf(p.m[2 * P + 1], 0.0f);
-  constexpr int r = 2 * P;                       // registers r, r+1 <-> features 8*(r>>2) + 4h + (r&3), +1
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float2 w2 = *reinterpret_cast<const float2*>(w32 + 128 * k + 8 * (r >> 2) + 4 * h + (r & 3));
-    rgb[k] = fmaf(x1, w2.y, fmaf(x0, w2.x, rgb[k]));
-  }
+  acc = fmaf(x1, w2.y, fmaf(x0, w2.x, acc));
 }
+// k-step s, gap g: channel g of pair s - S0 is accumulated, the weights of pair s - S0 + 1 are fetched
 template <int S0>
-__device__ __forceinline__ void rgb_step(int s, const Acc& p, const float* w32, int h, float (&rgb)[3]) {
-  if (s == S0 + 0) pair_rgb<0>(p, w32, h, rgb);
-  if (s == S0 + 1) pair_rgb<1>(p, w32, h, rgb);
-  if (s == S0 + 2) pair_rgb<2>(p, w32, h, rgb);
-  if (s == S0 + 3) pair_rgb<3>(p, w32, h, rgb);
-  if (s == S0 + 4) pair_rgb<4>(p, w32, h, rgb);
-  if (s == S0 + 5) pair_rgb<5>(p, w32, h, rgb);
-  if (s == S0 + 6) pair_rgb<6>(p, w32, h, rgb);
-  if (s == S0 + 7) pair_rgb<7>(p, w32, h, rgb);
+__device__ __forceinline__ void rgb_gap(int s, int g, const Acc& p, const float* w32, int h, float (&rgb)[3], float2 (&w2)[3]) {
+  const int P = s - S0;
+  switch (P) {
+#define NSR_RG(Q) case Q: pair_rgb_k<Q>(p, w2[g], rgb[g]); break;
+    NSR_RG(0) NSR_RG(1) NSR_RG(2) NSR_RG(3) NSR_RG(4) NSR_RG(5) NSR_RG(6) NSR_RG(7)
+#undef NSR_RG
+    default: break;
+  }
+  switch (P + 1) {
+#define NSR_RW(Q) case Q: w2[g] = pair_rgb_w<Q>(w32, h, g); break;
+    NSR_RW(0) NSR_RW(1) NSR_RW(2) NSR_RW(3) NSR_RW(4) NSR_RW(5) NSR_RW(6) NSR_RW(7)
+#undef NSR_RW
+    default: break;
+  }
 }
 
 
 constexpr int kConvStep0 = 6;   // colour head: pending dir block is consumed in k-steps 6..13 (one pair each)
 
 // prefetch of the NEXT chunk (sequence position j+1) during the last three k-steps of chunk j
-__device__ __forceinline__ void prefetch_next_chunk(Pre& nxt, int k, const Loader& ld, unsigned bias_off, int h) {
-  prefetch_frag(nxt, k, ld.slot_next + ld.lane_off);
-  if (k == 1) prefetch_bias(nxt, ld.slot_next + bias_off, h);
+__device__ __forceinline__ void prefetch_next_chunk(Pre& nxt, int k, int g, const Loader& ld, unsigned bias_off, int h) {
+  if (g == 0) prefetch_frag(nxt, k, ld.slot_next + ld.lane_off);
+  if (g == 2 && k == 1) prefetch_bias(nxt, ld.slot_next + bias_off, h);
 }
 
 // One 256 -> 256 trunk layer L (1..8; 8 = xyz_encoding_final): in (bh, bl) -> out (oh, ol).
@@ -324,9 +333,11 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
 #pragma unroll
       for (int i = 0; i < 8; ++i) pe8[i] = stash[i * 64];
       Pre mid;
-      block_mma<4, -1>(
-          cur, pre, a_addr, ld, c2, [&](int s, int part) -> u32x4 { return pe8[4 * part + s]; }, [&](int) {},
-          [&](int k) { prefetch_frag(mid, k, a_addr + 8 * 1024); });
+      block_mma3<4, -1>(
+          cur, pre, a_addr, ld, c2, [&](int s, int part) -> u32x4 { return pe8[4 * part + s]; }, [&](int, int) {},
+          [&](int k, int g) {
+            if (g == 0) prefetch_frag(mid, k, a_addr + 8 * 1024);
+          });
 #pragma unroll
       for (int k = 0; k < kPF; ++k) {
         pre.ah[k] = mid.ah[k];
@@ -334,16 +345,16 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
       }
       a_addr += 8 * 1024;
     }
-    block_mma<16, kBar, (TRAIN ? 17 : 0)>(
+    block_mma3<16, kBar, (TRAIN ? 17 : 0)>(
         cur, pre, a_addr, ld, c2, [&](int s, int part) -> u32x4 { return part ? bl[s] : bh[s]; },
-        [&](int s) {
+        [&](int s, int g) {
           if (nb == 0)
             // block 7 of the previous layer (always relu'd: the previous layer is L1..L7) -> k-steps 14, 15
             // of THIS layer's input, needed only at the end of this chunk
-            pending_step<true>(s, pend, ptmp, bh[14], bl[14], bh[15], bl[15], amax);
+            pending_gap<true>(s, g, pend, ptmp, bh[14], bl[14], bh[15], bl[15], amax);
           else
-            pending_step<RELU_OUT>(s, pend, ptmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1], amax);
-          if (TRAIN && s >= 8) {
+            pending_gap<RELU_OUT>(s, g, pend, ptmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1], amax);
+          if (TRAIN && s >= 8 && g == 2) {
             const float* blk = (nb == 0) ? panel_block(tr, L - 1, 7) : panel_block(tr, L, nb - 1);
             if (s >= 14) {
 #pragma unroll
@@ -356,7 +367,7 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
                          ld.lane_off >> 2);
           }
         },
-        [&](int k) { prefetch_next_chunk(nxt, k, ld, next_bias, h); },
+        [&](int k, int g) { prefetch_next_chunk(nxt, k, g, ld, next_bias, h); },
         // the block before the first trunk block is L1's last one, whose stores interleave with its DMA
         TRAIN && L == 1 && nb == 0);
     pend = cur;
@@ -532,38 +543,43 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   Pre pre;
 
   NSR_TL(1);
-  // ---- L1: two chunks of four output blocks, 4 k-steps each; block b is re-split during block b+1.
-  // Publish point at the chunk start (chunk 0 / 1 were issued above; chunk j+2 is fetched here).
+  // ---- L1: two chunks of four output blocks, 4 k-steps each; block b is re-split during block b+1 (17 half-steps
+  // over the block's 12 MFMA gaps: 1 / 2 / 1-2 per gap), and the head of block b+1 (first fragments + bias) is read
+  // during block b's last three k-steps.  Publish point at the chunk start (chunk 0 / 1 were issued above; chunk j+2
+  // is fetched here, one piece per k-step).
+  Pre l1pre;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     loader_publish(ld, layer_ref(1, c, wave));    // chunk j+2 = first / second chunk of L2
     const unsigned a_chunk = ld.slot_cur + ld.lane_off;
     const unsigned next_bias = 32u * 1024u;       // L1 chunk 1 and L2's chunks: 32 weight pieces, then the bias
-    Pre nxt;
+    if (c == 0) {
+#pragma unroll
+      for (int k = 0; k < kPF; ++k) prefetch_frag(l1pre, k, a_chunk);
+      prefetch_bias(l1pre, ld.slot_cur + 32 * 1024, h);
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int nb = 4 * c + g;
       const unsigned a_addr = a_chunk + g * 8 * 1024;
-      Pre mine;
-#pragma unroll
-      for (int k = 0; k < kPF; ++k) prefetch_frag(mine, k, a_addr);
-      prefetch_bias(mine, ld.slot_cur + 32 * 1024 + 128 * g, h);
+      Pre nxt;
       Acc cur;
-      cur.m = mine.bias;
+      cur.m = l1pre.bias;
       Resplit ptmp;
       unsigned sbits = 0u;
-      block_mma<4, -1>(
-          cur, mine, a_addr, ld, end_ref(wave), [&](int s, int part) -> u32x4 { return part ? pel[s] : peh[s]; },
-          [&](int s) {
+      block_mma3<4, -1>(
+          cur, l1pre, a_addr, ld, end_ref(wave), [&](int s, int part) -> u32x4 { return part ? pel[s] : peh[s]; },
+          [&](int s, int gp) {
             const int i = 4 * g + s;        // DMA of chunk j+2: one piece per k-step over the chunk's 16 k-steps
-            if (i < 11) loader_issue(ld, i);
-            if (nb > 0) {   // the block has only four k-steps: 5 + 4 + 4 + 4 of the 17 half-steps
+            if (gp == 0 && i < 11) loader_issue(ld, i);
+            if (nb > 0) {
+              // half-steps of the pending block: k-step 0 takes 0 | 1, 2 | 3, 4; k-step s >= 1 takes 4s+1 | 4s+2, 4s+3 | 4s+4
+              const int first = (s == 0) ? (gp == 0 ? 0 : 2 * gp - 1) : 4 * s + (gp == 0 ? 1 : (gp == 1 ? 2 : 4));
+              const int count = (gp == 1 || (s == 0 && gp == 2)) ? 2 : 1;
 #pragma unroll
-              for (int q4 = 0; q4 < 5; ++q4)
-                if (q4 < 4 || s == 0)
-                  pending_half<true>((s == 0 ? 0 : 4 * s + 1) + q4, pend, ptmp, bh[2 * nb - 2], bl[2 * nb - 2], bh[2 * nb - 1],
-                                     bl[2 * nb - 1], amax);
-              if (TRAIN) {
+              for (int q = 0; q < count; ++q)
+                pending_half<true>(first + q, pend, ptmp, bh[2 * nb - 2], bl[2 * nb - 2], bh[2 * nb - 1], bl[2 * nb - 1], amax);
+              if (TRAIN && gp == 2) {
                 const float* blk = panel_block(tr, 0, nb - 1);
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) panel_store(4 * s + q4, pend, blk, voff);
@@ -573,14 +589,21 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
               }
             }
           },
-          [&](int k) {
-            if (c == 1 && g == 3) prefetch_next_chunk(nxt, k, ld, next_bias, h);   // head of the first trunk chunk
+          [&](int k, int gp) {
+            // head of the next block: same chunk | chunk 1 (published together with chunk 0) | the first trunk chunk
+            // (published at this chunk's start)
+            const unsigned frag = (g < 3) ? a_addr + 8 * 1024 : ld.slot_next + ld.lane_off;
+            const unsigned bias = (g < 3) ? ld.slot_cur + 32 * 1024 + 128 * (g + 1)
+                                          : ld.slot_next + (c == 0 ? 32u * 1024u : next_bias);
+            if (gp == 0) prefetch_frag(nxt, k, frag);
+            if (gp == 2 && k == 1) prefetch_bias(nxt, bias, h);
           });
       pend = cur;
+      l1pre = nxt;
     }
-    if (c == 1) pre = nxt;
     loader_advance(ld);
   }
+  pre = l1pre;
 
   NSR_TL(2);
   // ---- L2..L8 (+ xyz_encoding_final), two layers per trip so the register sets swap roles.  Three trips of relu
@@ -616,22 +639,22 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     Resplit ptmp;
     const unsigned next_bias = 36u * 1024u;       // dir_encoding chunks: 36 weight pieces, then the bias
     Pre nxt;
-    block_mma<16, kBar, (TRAIN ? 17 : 0)>(
+    block_mma3<16, kBar, (TRAIN ? 17 : 0)>(
         cur, pre, ld.slot_cur + ld.lane_off, ld, SIGMA_ONLY ? end_ref(wave) : dir_ref(1, wave),
         [&](int s, int part) -> u32x4 { return part ? ol[s] : oh[s]; },
-        [&](int s) {
+        [&](int s, int g) {
           if (SIGMA_ONLY)
-            pending_step<true>(s, pend, ptmp, oh[14], ol[14], oh[15], ol[15], amax);
+            pending_gap<true>(s, g, pend, ptmp, oh[14], ol[14], oh[15], ol[15], amax);
           else
-            pending_step<false>(s, pend, ptmp, bh[14], bl[14], bh[15], bl[15], amax);
-          if (TRAIN && s >= 14) {   // xyz_encoding_final's last block (no sign bits: nothing is masked by it)
+            pending_gap<false>(s, g, pend, ptmp, bh[14], bl[14], bh[15], bl[15], amax);
+          if (TRAIN && s >= 14 && g == 2) {   // xyz_encoding_final's last block (no sign bits: nothing is masked by it)
             const float* blk = panel_block(tr, 8, 7);
 #pragma unroll
             for (int r = 0; r < 8; ++r) panel_store(8 * (s - 14) + r, pend, blk, voff);
           }
         },
-        [&](int k) {
-          if (!SIGMA_ONLY) prefetch_next_chunk(nxt, k, ld, next_bias, h);
+        [&](int k, int g) {
+          if (!SIGMA_ONLY) prefetch_next_chunk(nxt, k, g, ld, next_bias, h);
         });
     sigma = cur.m[0] * kWInvScale;           // row 0 of the block lives in register 0 of the h == 0 lanes
     pre = nxt;
@@ -649,6 +672,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   NSR_TL(4);
   // ---- dir_encoding (cat([g, de]) -> 128, relu) fused with the rgb head (128 -> 3, sigmoid)
   float rgb[3] = {0.0f, 0.0f, 0.0f};
+  float2 w2[3];          // colour-head weights of the pair consumed in the next k-step (rgb_gap)
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
     Acc cur;
@@ -662,9 +686,10 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     auto b_of = [&](int s, int part) -> u32x4 {
       return (s < 16) ? (part ? bl[s & 15] : bh[s & 15]) : (part ? del[s & 1] : deh[s & 1]);
     };
-    auto hook = [&](int s) {
-      if (nb > 0) rgb_step<kConvStep0>(s, pend, aux + hx::kAuxRgbW + 32 * (nb - 1), h, rgb);
-      if (TRAIN && nb > 0 && s >= 8 && s < 16) {
+    auto hook = [&](int s, int g) {
+      // the pending dir block is consumed in k-steps 6..13, one pair per k-step, one colour channel per gap
+      if (nb > 0) rgb_gap<kConvStep0>(s, g, pend, aux + hx::kAuxRgbW + 32 * (nb - 1), h, rgb, w2);
+      if (TRAIN && nb > 0 && s >= 8 && s < 16 && g == 2) {
         const float* blk = panel_block(tr, 9, nb - 1);
         if (s >= 14) {
 #pragma unroll
@@ -675,19 +700,26 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
         if (s == 15) sign_store(sbits, sign_block(tr.sgn, tr.group, 9, nb - 1), ld.lane_off >> 2);
       }
     };
-    auto next = [&](int k) {
-      if (nb < 3) prefetch_next_chunk(nxt, k, ld, next_bias, h);
+    auto next = [&](int k, int g) {
+      if (nb < 3) prefetch_next_chunk(nxt, k, g, ld, next_bias, h);
     };
-    if (!TRAIN || nb == 1) block_mma<18, kBar>(cur, pre, a_seq, ld, c2, b_of, hook, next);
-    else if (nb == 0) block_mma<18, kBar, 16>(cur, pre, a_seq, ld, c2, b_of, hook, next);
-    else block_mma<18, kBar, 17>(cur, pre, a_seq, ld, c2, b_of, hook, next);
+    if (!TRAIN || nb == 1) block_mma3<18, kBar>(cur, pre, a_seq, ld, c2, b_of, hook, next);
+    else if (nb == 0) block_mma3<18, kBar, 16>(cur, pre, a_seq, ld, c2, b_of, hook, next);
+    else block_mma3<18, kBar, 17>(cur, pre, a_seq, ld, c2, b_of, hook, next);
     pend = cur;
     pre = nxt;
     loader_advance(ld);
   }
   NSR_TL(5);
+  {
+    const float* w32 = aux + hx::kAuxRgbW + 32 * 3;
 #pragma unroll
-  for (int s = 0; s < 8; ++s) rgb_step<0>(s, pend, aux + hx::kAuxRgbW + 32 * 3, h, rgb);
+    for (int g = 0; g < 3; ++g) w2[g] = pair_rgb_w<0>(w32, h, g);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) rgb_gap<0>(s, g, pend, w32, h, rgb, w2);
+  }
   if (TRAIN) {
     const float* blk = panel_block(tr, 9, 3);
     unsigned sbits = 0u;

@@ -22,6 +22,7 @@ def default_options(**kw) -> SimpleNamespace:
     opt = SimpleNamespace(
         N_coarse=64, N_importance=64, lindisp=False, white_bkgd=False, randomized=True, noise_std=0.0,
         deg_pos=10, deg_dir=4, dim_pos=3, dim_dir=3, dim_rgb=3, downscale=2, img_wh=(504, 378),
+        D=8, W=256, skips=[4], no_dir=False,        # models/networks.py:124-128; anything else raises (ops.check_mlp_options)
         sigma_activation="relu", color_activation="sigmoid", gamma_correct=False,
         ray_chunk=4096, point_chunk=262144, precision="fp32",
         check_numerics=True,    # forward() raises on NaN / out-of-range values (the reference: pdb, nerf_downX_model.py:273-274)
@@ -37,12 +38,15 @@ class NeRFDownXModel:
 
     def __init__(self, opt: Optional[SimpleNamespace] = None, device="cuda"):
         self.opt = opt or default_options()
+        ops.check_mlp_options(self.opt)
+        if int(self.opt.N_coarse) < 2 or int(self.opt.N_importance) < 0:
+            raise ValueError("N_coarse must be >= 2 and N_importance >= 0")
+        self.renderer = VolumetricRenderer(self.opt)      # validates sigma_activation before any device is touched
         self.device = torch.device(device)
         self.netCoarse = VanillaMLP(self.opt, precision=self.opt.precision, device=self.device)
         self.netFine = VanillaMLP(self.opt, precision=self.opt.precision, device=self.device)
         self.models = {"coarse": self.netCoarse, "fine": self.netFine}
         self.embeddings = {"pos": PositionalEncoding(3, self.opt.deg_pos), "dir": PositionalEncoding(3, self.opt.deg_dir)}
-        self.renderer = VolumetricRenderer(self.opt)
         self.randomized = False
         self._ws = None
         self._outs: Dict[str, torch.Tensor] = {}
@@ -142,16 +146,27 @@ class NeRFDownXModel:
 
     @torch.no_grad()
     def render_image_sharded(self, c2w, focal: float, ndc: bool, near: float = 0.0, far: float = 1.0, group=None,
-                             lr_range=None, workspace=None, outs=None):
+                             lr_range=None, workspace=None, outs=None, gather: str = "lr"):
         """One frame rendered by all ranks of ``group`` together (BASELINE config #4): the LR-pixel range
         is cut into contiguous blocks (``dist.shard_bounds``; an LR pixel's s*s sub-rays stay on one GPU), every rank
-        GENERATES its own ray block on its device (nothing is scattered), runs the eval-mode ``forward_rays`` on it,
-        takes the s*s means, and ONE all-gather of [r, g, b, depth] per LR pixel assembles the image on every rank.
-        Replaces the per-MLP-call scatter / gather of nn.DataParallel (models/networks.py:54-69).  No reduction
-        crosses a block boundary, so the result is bit-identical to ``render_image`` on one GPU.
-        ``lr_range`` overrides this rank's block (single-process tests).  Returns the full LR image and depth plus
-        this rank's own outputs."""
+        GENERATES its own ray block on its device (nothing is scattered), runs the eval-mode ``forward_rays`` on it, and
+        ONE all-gather assembles the frame on every rank.  Replaces the per-MLP-call scatter / gather of
+        nn.DataParallel (models/networks.py:54-69).  No reduction crosses a block boundary, so the result is
+        bit-identical to ``render_image`` on one GPU.
+
+        ``gather``: what the collective carries.
+          * ``"lr"`` (default): the s*s means, [r, g, b, depth] per LR pixel (16 B / LR pixel) -> ``lr_rgb``, ``lr_depth``.
+          * ``"hr"``: the rendered pixels themselves -- ``fine_comp_rgbs``, 12 B per ray (9.1 MB for config
+            #4) -- the reference's test-time deliverable (``unflatten_reshape`` of ``out_fine_comp_rgbs_ori``,
+            models/nerf_downX_model.py:410-416, feeding calculate_vis :430-450 and test :621-669).  Blocks are
+            LR-pixel-major, so the gathered buffer IS the (n_lr * s*s, 3) ray-major tensor ``unflatten_reshape`` takes:
+            every rank returns ``hr_rgb`` (H, W, 3), and ``lr_rgb`` as the s*s means of the gathered rays (the same
+            arithmetic on the same values as the per-block means).  ``lr_depth`` is not part of this exchange.
+        ``lr_range`` overrides this rank's block and skips the collective (single-process tests).  Returns the assembled
+        arrays plus this rank's own outputs (``local``) and ``bytes_per_rank`` (payload of the collective)."""
         from . import dist as nsr_dist
+        if gather not in ("lr", "hr"):
+            raise ValueError("gather must be 'lr' or 'hr'")
         opt = self.opt
         s, s2 = int(opt.downscale), int(opt.downscale) ** 2
         n_lr = (opt.img_wh[1] // s) * (opt.img_wh[0] // s)
@@ -162,9 +177,23 @@ class NeRFDownXModel:
         out = ops.forward_rays(self.netCoarse, self.netFine if fine else None, rays, opt.N_coarse, opt.N_importance,
                                opt.white_bkgd, opt.lindisp, workspace=workspace, outs=outs)
         tag = "fine" if fine else "coarse"
+        cap = nsr_dist.shard_bounds(n_lr, world)[0]
+        if gather == "hr":
+            # one row per LR pixel holding its s*s rendered rays: the block structure all_gather_pixels assumes
+            local = out[f"{tag}_comp_rgbs"].reshape(hi - lo, s2 * 3)
+            full = local if lr_range is not None else nsr_dist.all_gather_pixels(local, n_lr, group)
+            res = {"lr_range": (lo, hi), "local": out, "bytes_per_rank": (cap[1] - cap[0]) * s2 * 12}
+            if lr_range is None:
+                hr_rays = full.reshape(n_lr * s2, 3)
+                res["hr_rgb"] = self.unflatten_reshape(hr_rays)
+                res["lr_rgb"] = ops.sr_mean(hr_rays, n_lr, s2)
+            else:
+                res["hr_rays"] = full.reshape((hi - lo) * s2, 3)
+            return res
         local = torch.empty(hi - lo, 4, dtype=torch.float32, device=self.device)
         if hi > lo:
             local[:, :3] = ops.sr_mean(out[f"{tag}_comp_rgbs"], hi - lo, s2)
             local[:, 3:] = ops.sr_mean(out[f"{tag}_depth"], hi - lo, s2)
         full = local if lr_range is not None else nsr_dist.all_gather_pixels(local, n_lr, group)
-        return {"lr_rgb": full[:, :3], "lr_depth": full[:, 3], "lr_range": (lo, hi), "local": out}
+        return {"lr_rgb": full[:, :3], "lr_depth": full[:, 3], "lr_range": (lo, hi), "local": out,
+                "bytes_per_rank": (cap[1] - cap[0]) * 16}

@@ -19,7 +19,7 @@ from .weights import STATE_DICT_SPEC, check_state_dict, IN_CH
 
 __all__ = [
     "subpixel_rays", "PositionalEncoding", "sample_along_rays", "resample_along_rays", "cast_rays",
-    "VanillaMLP", "VolumetricRenderer", "render_rays", "render_rays_composited", "forward_rays", "sr_mean", "unflatten_reshape",
+    "VanillaMLP", "VolumetricRenderer", "check_mlp_options", "render_rays", "render_rays_composited", "forward_rays", "sr_mean", "unflatten_reshape",
 ]
 
 
@@ -164,6 +164,32 @@ def resample_along_rays(ori, dir, z_vals, weights, num_samples: int, randomized:
 
 
 # ----------------------------------------------------------------------------- M1
+# the one architecture the HIP kernels are built for: the values every script of the reference uses
+_MLP_FIXED = {"D": 8, "W": 256, "skips": [4], "no_dir": False, "color_activation": "sigmoid", "deg_pos": 10, "deg_dir": 4,
+              "dim_pos": 3, "dim_dir": 3, "dim_rgb": 3, "stop_grad": False}
+
+
+def check_mlp_options(opt) -> None:
+    """Reject every VanillaMLP option value the kernels do not implement (models/networks.py:124-128 ``--D --W --skips
+    --no_dir``, :160-173 ``no_dir`` / ``color_activation``; models/embedding.py degrees) instead of silently computing
+    the default architecture: a replacement that ignores ``color_activation='none'`` would return sigmoid colours
+    without a word.  Options that are absent from ``opt`` count as the reference's defaults."""
+    if opt is None:
+        return
+    bad = []
+    for name, want in _MLP_FIXED.items():
+        if not hasattr(opt, name):
+            continue
+        got = getattr(opt, name)
+        got = list(got) if isinstance(got, (list, tuple)) else got
+        if got != want:
+            bad.append(f"{name}={got!r} (built: {want!r})")
+    if bad:
+        raise ValueError("VanillaMLP option(s) outside the built path (the MFMA kernels are laid out for the 8 x 256 network with "
+                         "a skip at layer 5, the view-direction branch and a sigmoid colour head, models/networks.py:131-180): "
+                         + ", ".join(bad))
+
+
 class VanillaMLP:
     """The 8x256 NeRF MLP; mirrors models/networks.py:121-226.
 
@@ -176,6 +202,7 @@ class VanillaMLP:
     def __init__(self, opt=None, precision: str = "fp32", device="cuda"):
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {list(_lib.PRECISIONS)}")
+        check_mlp_options(opt)
         self.precision = precision
         self._prec = _lib.PRECISIONS[precision]
         self.device = torch.device(device)
@@ -263,7 +290,8 @@ class VolumetricRenderer:
     def __init__(self, opt=None):
         act = getattr(opt, "sigma_activation", "relu") if opt is not None else "relu"
         if act != "relu":
-            raise ValueError("the built path implements sigma_activation='relu' only")
+            raise ValueError(f"sigma_activation={act!r}: the built path implements 'relu' only (models/rendering.py:69-73; no "
+                             "script of the reference uses 'softplus')")
 
     def forward(self, rgb, sigma, z_vals, white_bkgd: bool):
         rgb, sigma, z_vals = _f32(rgb, "rgb"), _f32(sigma, "sigma"), _f32(z_vals, "z_vals")
