@@ -87,12 +87,15 @@ struct NsrCompOut {
 
 // Epilogue of a 128-point MLP tile whose points are whole rays (NS = 64: two rays, NS = 128: one ray): stage the tile's
 // (r, g, b, sigma) and z in `lds` (>= 640 floats, free for the workgroup to use; the caller has drained its DMAs), then
-// one wavefront per ray composites.  `mine`: this lane holds the result of point wave * 32 + m.
-template <int NS>
+// one wavefront per ray composites.  `mine`: this lane holds the result of point wave * 32 + m.  `tile`: index of the
+// 128-point tile in the launch (blockIdx.x for one-tile workgroups).  DEDICATED: `lds` is used for nothing else and at
+// least one workgroup barrier lies between two calls (persistent kernels), so the barrier that protects the previous
+// content is not needed.
+template <int NS, bool DEDICATED = false>
 __device__ __forceinline__ void composite_tile(float* lds, bool mine, int wave, int m, int lane, float4 value, float zk,
-                                               int64_t n_rays, const NsrCompOut& co) {
+                                               int64_t n_rays, const NsrCompOut& co, int64_t tile) {
   static_assert(NS == 64 || NS == 128, "tiles of 128 points must hold whole rays");
-  __syncthreads();                                 // every wave is done with whatever the LDS region held before
+  if (!DEDICATED) __syncthreads();                 // every wave is done with whatever the LDS region held before
   float4* st = reinterpret_cast<float4*>(lds);
   float* zst = lds + 4 * 128;
   if (mine) {
@@ -102,7 +105,7 @@ __device__ __forceinline__ void composite_tile(float* lds, bool mine, int wave, 
   __syncthreads();
   constexpr int kRays = 128 / NS;
   if (wave < kRays) {
-    const int64_t ray = (int64_t)blockIdx.x * kRays + wave;
+    const int64_t ray = tile * kRays + wave;
     if (ray < n_rays)
       composite_ray<NS / 64>(lds + 4 * NS * wave, 4, lds + 4 * NS * wave + 3, 4, zst + NS * wave, NS, co.white, lane, ray,
                              co.comp_rgb, co.depth, co.opacity, co.weights);

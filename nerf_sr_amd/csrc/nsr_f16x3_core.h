@@ -52,30 +52,44 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // chunk.  OFF (0..3072) is added to BOTH the global and the LDS address, so one (base, M0) pair serves
 // four consecutive 1 KiB pieces.  M0 is written in the same statement that consumes it (hipcc reserves
 // M0 and uses it nowhere else in this kernel).
+// The base is copied into a scratch SGPR pair INSIDE the statement: when hipcc has spilled the descriptor to VGPR lanes
+// it restores it with v_readlane right in front of the statement, and a VMEM instruction that reads a VALU-written SGPR
+// needs five wait states which hipcc's hazard pass cannot see through inline asm (round 4: a persistent-loop build read
+// a stale pair and faulted).  An SALU read is interlocked, and the copy doubles as the wait state after the M0 write.
+// M0 is a reserved register for hipcc (it never allocates it: naming it in a clobber list is a warning), so the pieces
+// 4q+1 .. 4q+3 of a 4 KiB group reuse the M0 piece 4q wrote (glds16_keep_asm).
 template <int OFF>
 __device__ __forceinline__ void glds16_asm(const char* base_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
+  unsigned long long tmp;
   asm volatile(
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %0, %1 offset:%3"
-      :
+      "s_mov_b32 m0, %3\n\t"
+      "s_mov_b64 %0, %2\n\t"
+      "global_load_lds_dwordx4 %1, %0 offset:%4"
+      : "=&s"(tmp)
       : "v"(lane_off), "s"(base_uniform), "s"(lds_dst_uniform), "i"(OFF)
       : "memory");
 }
 // a further piece of the 4 KiB group whose first piece set M0 (same base, same M0)
 template <int OFF>
 __device__ __forceinline__ void glds16_keep_asm(const char* base_uniform, unsigned lane_off) {
-  asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(lane_off), "s"(base_uniform), "i"(OFF) : "memory");
+  unsigned long long tmp;
+  asm volatile(
+      "s_mov_b64 %0, %2\n\t"
+      "global_load_lds_dwordx4 %1, %0 offset:%3"
+      : "=&s"(tmp)
+      : "v"(lane_off), "s"(base_uniform), "i"(OFF)
+      : "memory");
 }
 // two consecutive pieces (OFF, OFF + 1024) with ONE M0 write
 template <int OFF>
 __device__ __forceinline__ void glds16x2_asm(const char* base_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
+  unsigned long long tmp;
   asm volatile(
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %0, %1 offset:%3\n\t"
-      "global_load_lds_dwordx4 %0, %1 offset:%4"
-      :
+      "s_mov_b32 m0, %3\n\t"
+      "s_mov_b64 %0, %2\n\t"
+      "global_load_lds_dwordx4 %1, %0 offset:%4\n\t"
+      "global_load_lds_dwordx4 %1, %0 offset:%5"
+      : "=&s"(tmp)
       : "v"(lane_off), "s"(base_uniform), "s"(lds_dst_uniform), "i"(OFF), "i"(OFF + 1024)
       : "memory");
 }
@@ -139,7 +153,7 @@ __device__ __forceinline__ unsigned long long tl_now() {
 
 __device__ __forceinline__ void loader_prepare_dma(Loader& ld, const ChunkRef& c, unsigned slot_lds) {
   ld.dma_count = c.count;
-  ld.dma_base = reinterpret_cast<const char*>(ld.stream) + (size_t)(c.piece0 + c.first) * 1024;
+  ld.dma_base = reinterpret_cast<const char*>(ld.stream) + ((unsigned)(c.piece0 + c.first) << 10);   // the stream is < 4 MiB
   ld.dma_lds = slot_lds + (unsigned)c.first * 1024u;
 }
 
@@ -151,23 +165,13 @@ __device__ __forceinline__ void loader_issue(const Loader& ld, int i) {
   if (i < 8 || i < ld.dma_count) {   // every wave owns at least 8 pieces of every chunk
     const char* base = ld.dma_base + (i >> 2) * 4096;
     const unsigned dst = ld.dma_lds + (unsigned)(i >> 2) * 4096u;
-#ifndef NSR_ABL_M0_EVERY
-    // pieces 4q+1..4q+3 reuse the M0 piece 4q wrote (they are issued in order, and nothing else in these kernels
-    // touches M0 -- checked on the ISA by scripts/isa_census.py --m0)
+    // pieces are issued in order, piece 4q first: it writes M0 for its group
     switch (i & 3) {
       case 0: glds16_asm<0>(base, ld.lane_off, dst); break;
       case 1: glds16_keep_asm<1024>(base, ld.lane_off); break;
       case 2: glds16_keep_asm<2048>(base, ld.lane_off); break;
       default: glds16_keep_asm<3072>(base, ld.lane_off); break;
     }
-#else
-    switch (i & 3) {
-      case 0: glds16_asm<0>(base, ld.lane_off, dst); break;
-      case 1: glds16_asm<1024>(base, ld.lane_off, dst); break;
-      case 2: glds16_asm<2048>(base, ld.lane_off, dst); break;
-      default: glds16_asm<3072>(base, ld.lane_off, dst); break;
-    }
-#endif
   }
 }
 
@@ -405,7 +409,9 @@ __device__ __forceinline__ float* panel_block(const PanelRef& t, int panel, int 
 #endif
 template <int R>
 __device__ __forceinline__ void panel_store_r(float v, const float* blk, unsigned voff) {
-  asm volatile("global_store_dword %0, %1, %2 offset:%3" NSR_PANEL_STORE_POLICY : : "v"(voff), "v"(v), "s"(blk), "n"((8 * (R >> 2) + (R & 3)) * 128) : "memory");
+  // base through an in-statement SALU copy: see glds16_asm (VALU-restored SGPR -> VMEM hazard behind inline asm)
+  unsigned long long tmp;
+  asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0 offset:%4" NSR_PANEL_STORE_POLICY : "=&s"(tmp) : "v"(voff), "v"(v), "s"(blk), "n"((8 * (R >> 2) + (R & 3)) * 128) : "memory");
 }
 __device__ __forceinline__ void panel_store(int r, const Acc& p, const float* blk, unsigned voff) {
 #ifdef NSR_ABL_FWD_NO_STORE   // ablation (scripts/): how much of the TRAIN forward kernel is its panel writes
@@ -433,13 +439,15 @@ __device__ __forceinline__ void sign_push(unsigned& bits, float v) {
   asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(bits) : "v"(v));
 }
 __device__ __forceinline__ void sign_store(unsigned bits, const unsigned* blk, unsigned lane4) {
-  asm volatile("global_store_dword %0, %1, %2" : : "v"(lane4), "v"(bits), "s"(blk) : "memory");
+  unsigned long long tmp;
+  asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0" : "=&s"(tmp) : "v"(lane4), "v"(bits), "s"(blk) : "memory");
 }
 
 // value v of this lane into row T (0..31) of a panel block: row pitch 128 B, voff = this lane's byte offset inside the block
 template <int T>
 __device__ __forceinline__ void row_store_t(float v, const float* blk, unsigned voff) {
-  asm volatile("global_store_dword %0, %1, %2 offset:%3" NSR_PANEL_STORE_POLICY : : "v"(voff), "v"(v), "s"(blk), "n"(T * 128) : "memory");
+  unsigned long long tmp;
+  asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0 offset:%4" NSR_PANEL_STORE_POLICY : "=&s"(tmp) : "v"(voff), "v"(v), "s"(blk), "n"(T * 128) : "memory");
 }
 __device__ __forceinline__ void row_store(int t, float v, const float* blk, unsigned voff) {
   switch (t) {

@@ -203,11 +203,14 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // (dma_drain) right before the barrier that publishes the chunk.
 template <int OFF>
 __device__ __forceinline__ void glds16_asm(const char* base_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
+  // base through an in-statement SALU copy (a VALU-restored SGPR feeding VMEM needs wait states hipcc cannot add inside
+  // inline asm): see nsr_f16x3_core.h
+  unsigned long long tmp;
   asm volatile(
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %0, %1 offset:%3"
-      :
+      "s_mov_b32 m0, %3\n\t"
+      "s_mov_b64 %0, %2\n\t"
+      "global_load_lds_dwordx4 %1, %0 offset:%4"
+      : "=&s"(tmp)
       : "v"(lane_off), "s"(base_uniform), "s"(lds_dst_uniform), "i"(OFF)
       : "memory");
 }
@@ -450,7 +453,7 @@ mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, c
   if (out && h == 0 && p < P) reinterpret_cast<float4*>(out)[p] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
   if (NSC > 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no weight DMA may still be landing in the ring that is re-used below
-    composite_tile<(NSC > 0 ? NSC : 64)>(ring, h == 0, wave, m, lane, make_float4(rgb[0], rgb[1], rgb[2], sigma), zv[pc], P / (NSC > 0 ? NSC : 1), co);
+    composite_tile<(NSC > 0 ? NSC : 64)>(ring, h == 0, wave, m, lane, make_float4(rgb[0], rgb[1], rgb[2], sigma), zv[pc], P / (NSC > 0 ? NSC : 1), co, (int64_t)blockIdx.x);
   }
 }
 

@@ -109,6 +109,8 @@ __device__ __forceinline__ ChunkRef dir_ref(int nb, int wave) { return make_ref(
 // past the end of the sequence chunk 0 is re-fetched into the idle slot (32 KiB of dead traffic, twice per
 // tile) so that the first eight DMA issues of every chunk need no bounds test; the kernel drains before exit
 __device__ __forceinline__ ChunkRef end_ref(int wave) { return make_ref(0, 32, wave); }
+// chunks 0 and 1 of the stream (L1): what the last two chunks of a tile fetch for the next tile of the persistent loop
+__device__ __forceinline__ ChunkRef first_ref(int c, int wave) { return make_ref(33 * c, 33, wave); }
 
 
 // Re-split of the pending block: accumulator pair P (registers 2P, 2P+1; P = 0..7) -> activation -> (hi, lo) fp16
@@ -285,6 +287,225 @@ __device__ __forceinline__ void prefetch_next_chunk(Pre& nxt, int k, int g, cons
   if (g == 2 && k == 1) prefetch_bias(nxt, ld.slot_next + bias_off, h);
 }
 
+// ---------------------------------------------------------------------------
+// Encoding of the NEXT tile's sample point in the matrix shadow of the current tile (persistent kernel, MODE 1).
+// cast_rays + both positional encodings + the (hi, lo) split of a point are ~700 VALU instructions; at the top of a
+// tile they run with the matrix pipe idle (5,700 cycles of a 150,000-cycle tile, profiles/r4_timeline_*.json).  Here the
+// same arithmetic -- statement for statement nsr_sincos / split2, so the operands are bit-identical -- is cut into
+// kEncPieces pieces of 3..6 instructions, one per k-step (gap 0, next to the two fragment reads) of
+// xyz_encoding_final's eight chunks, the density block and the first dir_encoding block.  The encoded position goes to
+// the wave's LDS stash (which the current tile stopped reading after L5), the encoded direction waits in 16 registers.
+// Every piece ends in an empty asm volatile on what it produced: LLVM would otherwise sink the arithmetic to its first
+// use (the end of the window).
+// Piece program: 0 = loads (ray record, z; volatile), 1 = cast_rays + range flags, 2 = the raw-coordinate pairs, then seven
+// groups (position frequencies 0..4, direction frequencies 0, 1) of 3 x 6 sincos pieces + 3 split pieces.
+// ---------------------------------------------------------------------------
+constexpr int kEncGroup0 = 3, kEncGroupPieces = 21, kEncPieces = kEncGroup0 + 7 * kEncGroupPieces;   // 150
+// All state is scalars selected by compare chains (pick3 / put3 / put8): the piece index is a constant only AFTER the
+// k-step loops are unrolled, and an array indexed by a not-yet-constant would send the struct to scratch memory -- or,
+// with a 150-way switch per call site, push the loop bodies past the unroller's size limit.
+struct Enc {
+  float o0, o1, o2, d0, d1, d2, w0, w1, w2;   // ray record: origin, direction, the direction that is ENCODED
+  float zk;
+  float v0, v1, v2;                  // the point
+  float x, k, r, r2, s0, t2, hh;     // sincos in flight
+  int q;
+  float a0, a1, a2, a3, a4, a5;      // sin c0..2, cos c0..2 of the current frequency
+  unsigned flags;
+  unsigned dh0, dh1, dh2, dh3, dh4, dh5, dh6, dh7;   // the encoded direction: pairs 0..7, hi and lo
+  unsigned dl0, dl1, dl2, dl3, dl4, dl5, dl6, dl7;
+  unsigned th, tl;                   // a split pair between its two half-pieces
+};
+struct EncIn {
+  const float* rays;
+  const float* zv;
+  int64_t pc;        // the next tile's point of this lane (clamped)
+  int64_t ray;
+  int stride;
+  int h;
+  unsigned* stash;   // this lane's 16 B column of the wave's stash, viewed as words: fragment f, element e at stash[f * 256 + e]
+};
+typedef float vf32x4 __attribute__((ext_vector_type(4)));
+#define NSR_PIN1(a) asm volatile("" : "+v"(a))
+#define NSR_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define NSR_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+__device__ __forceinline__ float pick3(int c, float a, float b, float d) { return c == 0 ? a : (c == 1 ? b : d); }
+__device__ __forceinline__ void put3(int c, float v, float& a, float& b, float& d) {
+  if (c == 0) a = v; else if (c == 1) b = v; else d = v;
+}
+// (x0, x1) -> packed RNE fp16 pair hi and the RNE fp16 pair of the exact residuals (== split2)
+__device__ __forceinline__ void split2_asm(float x0, float x1, unsigned& hi, unsigned& lo) {
+  asm volatile(
+      "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+      "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(hi), "=&v"(lo)
+      : "v"(x0), "v"(x1));
+}
+__device__ __forceinline__ void enc_put_dir(Enc& e, int pair, unsigned hi, unsigned lo) {
+  if (pair == 0) { e.dh0 = hi; e.dl0 = lo; }
+  if (pair == 1) { e.dh1 = hi; e.dl1 = lo; }
+  if (pair == 2) { e.dh2 = hi; e.dl2 = lo; }
+  if (pair == 3) { e.dh3 = hi; e.dl3 = lo; }
+  if (pair == 4) { e.dh4 = hi; e.dl4 = lo; }
+  if (pair == 5) { e.dh5 = hi; e.dl5 = lo; }
+  if (pair == 6) { e.dh6 = hi; e.dl6 = lo; }
+  if (pair == 7) { e.dh7 = hi; e.dl7 = lo; }
+}
+// part: 0 / 1 = first / second half of the piece (2-4 instructions each: with the two fragment reads a gap then holds
+// five fillers, what a lone wave hides behind one MFMA), 2 = the whole piece (first tile)
+__device__ __forceinline__ void enc_piece(int i, int part, Enc& e, const EncIn& in) {
+  if (i < 0 || i >= kEncPieces) return;
+  const bool p0 = part != 1, p1 = part != 0;
+  if (i == 0) {
+    if (!p0) return;
+    // plain loads, held in place by compiler-level memory fences (a volatile load would make hipcc wait for every
+    // one of them on the spot); hipcc's own vmcnt wait lands at the first use, piece 1, most of a tile later
+    asm volatile("" ::: "memory");
+    const NsrRay q = nsr_load_ray(in.rays, in.ray, in.stride);
+    e.zk = in.zv[in.pc];
+    e.o0 = q.o[0]; e.o1 = q.o[1]; e.o2 = q.o[2]; e.d0 = q.d[0]; e.d1 = q.d[1]; e.d2 = q.d[2];
+    e.w0 = q.v[0]; e.w1 = q.v[1]; e.w2 = q.v[2];
+    asm volatile("" ::: "memory");
+    return;
+  }
+  if (i == 1) {   // cast_rays (models/utils.py:14: separate multiply and add) + the operand-range check of the raw coordinates
+    if (p0) {
+      e.v0 = __fadd_rn(e.o0, __fmul_rn(e.zk, e.d0));
+      e.v1 = __fadd_rn(e.o1, __fmul_rn(e.zk, e.d1));
+      e.v2 = __fadd_rn(e.o2, __fmul_rn(e.zk, e.d2));
+      NSR_PIN3(e.v0, e.v1, e.v2);
+    }
+    if (p1) {
+      const bool ok = fabsf(e.v0) <= 65504.0f && fabsf(e.w0) <= 65504.0f && fabsf(e.v1) <= 65504.0f && fabsf(e.w1) <= 65504.0f &&
+                      fabsf(e.v2) <= 65504.0f && fabsf(e.w2) <= 65504.0f;
+      e.flags = ok ? 0u : (unsigned)NSR_FLAG_INPUT_RANGE;
+      NSR_PIN1(e.flags);
+    }
+    return;
+  }
+  if (i == 2) {   // pairs 0 of both encodings: the raw coordinates (x, y | z, 0); pair 7 of the direction: padding
+    unsigned hi, lo;
+    if (p0) {
+      split2_asm(in.h ? e.v2 : e.v0, in.h ? 0.0f : e.v1, hi, lo);
+      in.stash[0] = hi;
+      in.stash[4 * 256] = lo;
+    }
+    if (p1) {
+      split2_asm(in.h ? e.w2 : e.w0, in.h ? 0.0f : e.w1, hi, lo);
+      e.dh0 = hi; e.dl0 = lo;
+      e.dh7 = 0u; e.dl7 = 0u;
+    }
+    return;
+  }
+  const int g = (i - kEncGroup0) / kEncGroupPieces, w = (i - kEncGroup0) % kEncGroupPieces;
+  const bool pos = g < 5;
+  const int f = pos ? g : g - 5;
+  if (w < 18) {
+    const int c = w / 6, sub = w % 6;
+    // nsr_sincos (nsr_common.h), statement for statement
+    if (sub == 0) {
+      if (p0) {
+        e.x = ldexpf(pos ? pick3(c, e.v0, e.v1, e.v2) : pick3(c, e.w0, e.w1, e.w2), (pos ? 5 : 2) * in.h + f);
+        e.k = __fmul_rn(e.x, 0.636619772367581343f);
+        NSR_PIN2(e.x, e.k);
+      }
+      if (p1) {
+        e.k = rintf(e.k);
+        e.r = fmaf(e.k, -1.57079625129699707031f, e.x);
+        NSR_PIN2(e.k, e.r);
+      }
+    } else if (sub == 1) {
+      if (p0) {
+        e.r = fmaf(e.k, -7.54978941586159635335e-08f, e.r);
+        e.r = fmaf(e.k, -5.39030252995776476554e-15f, e.r);
+        NSR_PIN1(e.r);
+      }
+      if (p1) {
+        e.q = (int)e.k;
+        e.r2 = __fmul_rn(e.r, e.r);
+        NSR_PIN2(e.q, e.r2);
+      }
+    } else if (sub == 2) {
+      if (p0) {
+        float sp = fmaf(e.r2, -1.9515295891e-4f, 8.3321608736e-3f);
+        e.s0 = fmaf(sp, e.r2, -1.6666654611e-1f);
+        NSR_PIN1(e.s0);
+      }
+      if (p1) {
+        e.s0 = fmaf(__fmul_rn(e.s0, e.r2), e.r, e.r);
+        NSR_PIN1(e.s0);
+      }
+    } else if (sub == 3) {
+      if (p0) {
+        float cp = fmaf(e.r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+        e.t2 = fmaf(cp, e.r2, 4.166664568298827e-2f);
+        NSR_PIN1(e.t2);
+      }
+      if (p1) {
+        e.t2 = __fmul_rn(e.t2, e.r2);
+        e.hh = fmaf(-0.5f, e.r2, 1.0f);
+        NSR_PIN2(e.t2, e.hh);
+      }
+    } else if (sub == 4) {
+      if (p0) {
+        e.hh = fmaf(e.t2, e.r2, e.hh);          // c0
+        NSR_PIN1(e.hh);
+      }
+      if (p1) {
+        const float ss = (e.q & 1) ? e.hh : e.s0;
+        const float cc = (e.q & 1) ? e.s0 : e.hh;
+        e.s0 = ss;
+        e.t2 = cc;
+        NSR_PIN2(e.s0, e.t2);
+      }
+    } else {
+      if (p0) {
+        float sn = (e.q & 2) ? -e.s0 : e.s0;
+        NSR_PIN1(sn);
+        put3(c, sn, e.a0, e.a1, e.a2);
+      }
+      if (p1) {
+        float cs = ((e.q + 1) & 2) ? -e.t2 : e.t2;
+        NSR_PIN1(cs);
+        put3(c, cs, e.a3, e.a4, e.a5);
+      }
+    }
+    return;
+  }
+  const int j = w - 18;                    // values 2j, 2j + 1 of the frequency -> pair 1 + 3f + j of the encoding
+  const int pair = 1 + 3 * f + j;
+  if (p0) split2_asm(pick3(j, e.a0, e.a2, e.a4), pick3(j, e.a1, e.a3, e.a5), e.th, e.tl);
+  if (p1) {
+    if (pos) {
+      in.stash[(pair >> 2) * 256 + (pair & 3)] = e.th;
+      in.stash[(4 + (pair >> 2)) * 256 + (pair & 3)] = e.tl;
+    } else {
+      enc_put_dir(e, pair, e.th, e.tl);
+    }
+  }
+}
+// Slot schedule: slot t = gap 0 of k-step t of the window [xyz_encoding_final | density | dir_encoding block 0] (128 + 16 +
+// 18 slots) runs piece t - 2 whole.  The loads (piece 0) go out in L8's last chunk; their first use (slot kEncSlot0 =
+// k-step 3 of a chunk) comes five k-steps after the previous chunk's last DMA piece, which has landed: hipcc's vmcnt(0)
+// at that use finds nothing to wait for.  (Measured alternatives, same box: half-pieces spread over L8 .. dir block 1,
+// two per piece: the state then lives through sixteen chunks at 420 registers, hipcc parks it in AGPRs and scratch,
+// +1.6 %; whole pieces here: the reference point.)
+constexpr int kEncSlot0 = 3;
+static_assert(kEncSlot0 + kEncPieces - 2 < 128 + 16 + 18, "the encoding does not fit its window");
+__device__ __forceinline__ void enc_slot(int t, Enc& e, const EncIn& in) {
+  if (t >= kEncSlot0) enc_piece(t - kEncSlot0 + 1, 2, e, in);
+}
+// pieces I0 .. I1 - 1 back to back (the workgroup's first tile): recursion, not a loop -- a 150-trip loop is not unrolled,
+// and a run-time piece index turns the compare chains above into scratch-memory arrays
+template <int I0, int I1>
+__device__ __forceinline__ void enc_all(Enc& e, const EncIn& in) {
+  if constexpr (I0 < I1) {
+    enc_piece(I0, 2, e, in);
+    enc_all<I0 + 1, I1>(e, in);
+  }
+}
+
 // One 256 -> 256 trunk layer L (1..8; 8 = xyz_encoding_final): in (bh, bl) -> out (oh, ol).
 // L == 4 prepends the 4 positional-encoding k-steps (skip connection).  `pend` is the block that
 // finished last (block 7 of the previous layer on entry; block 7 of this layer on exit): it is
@@ -296,11 +517,14 @@ __device__ __forceinline__ void prefetch_next_chunk(Pre& nxt, int k, int g, cons
 // the next publish point -- which must see that DMA landed -- may leave those 17 stores in flight (block_mma's YOUNGER);
 // they have a whole further chunk to reach HBM.  (Spread over k-steps 8..15 and covered by the publish point's
 // vmcnt(0), they stalled the wave on write latency every chunk.)
-template <bool RELU_OUT, bool TRAIN = false>   // relu on L2..L8 (true), none on xyz_encoding_final (L == 8: false)
+// ENC: the layer's gap-0 slots also carry encoding pieces of the next tile's point: 1 (L8) = the loads (piece 0) in the
+// last chunk, 2 (xyz_encoding_final) = slots 16 nb + s of the piece schedule (enc_slot).
+template <bool RELU_OUT, bool TRAIN = false, int ENC = 0>   // relu on L2..L8 (true), none on xyz_encoding_final (L == 8: false)
 __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[16], u32x4 (&oh)[16], u32x4 (&ol)[16],
                                             const u32x4* stash, Loader& ld, int h, Acc& pend, Pre& pre,
                                             const ChunkRef& after0, const ChunkRef& after1, float& amax,
-                                            const PanelRef& tr = PanelRef{}, unsigned voff = 0
+                                            const PanelRef& tr = PanelRef{}, unsigned voff = 0, Enc* enc = nullptr,
+                                            const EncIn* ein = nullptr
 #ifdef NSR_ABL_TIMELINE
                                             , unsigned long long* ld_tk_buf = nullptr
 #endif
@@ -348,6 +572,8 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
     block_mma3<16, kBar, (TRAIN ? 17 : 0)>(
         cur, pre, a_addr, ld, c2, [&](int s, int part) -> u32x4 { return part ? bl[s] : bh[s]; },
         [&](int s, int g) {
+          if (ENC == 1 && g == 0 && nb == 7 && s == 0) enc_piece(0, 2, *enc, *ein);
+          if (ENC == 2 && g == 0) enc_slot(16 * nb + s, *enc, *ein);
           if (nb == 0)
             // block 7 of the previous layer (always relu'd: the previous layer is L1..L7) -> k-steps 14, 15
             // of THIS layer's input, needed only at the end of this chunk
@@ -396,24 +622,48 @@ extern "C" int nsr_dbg_timeline(void* host_dst, size_t bytes) {
 // COMP: the tile's points are whole rays (MODE 1, NS = 64 or 128) and the kernel composites them itself (V1 fused into
 // D2 + M1: the (R, N, 4) network output never goes to HBM); `out` may then be null.
 // TRAIN: the forward pass of the training step (nsr_train.hip): additionally keeps every layer's pre-activations for the
-// backward pass in the training panels `pan` (n_groups = 4 * gridDim.x point groups).
+// backward pass in the training panels `pan` (n_groups = 4 * n_tiles point groups).
+//
+// PERSISTENT TILE LOOP (round 4).  A workgroup takes tiles blockIdx.x, blockIdx.x + gridDim.x, ... of 128 points; the ray
+// kernels (MODE 1, not TRAIN) are launched with one workgroup per CU.  Across a tile boundary
+//   * the weight ring keeps streaming: the last two chunks of a tile fetch chunks 0 and 1 of the stream (the next tile's
+//     L1) instead of idling, and the last block prefetches L1's first fragments: no DMA drain, no cold start;
+//   * the next tile's encoding (cast_rays, 21 sincos, hi/lo split: the old 5,700-cycle prologue) has already run in the
+//     matrix shadow of xyz_encoding_final / density / the first dir_encoding block (enc_piece above);
+//   * the compositing epilogue has its own 2.5 KiB of LDS, so the ring is never drained for it;
+//   * workgroup dispatch, the colour-head block load and the first-chunk DMA wait are paid once per CU, not per tile.
 template <int MODE, bool SIGMA_ONLY, int NS, bool COMP = false, bool TRAIN = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ zv,
                  int64_t P, int N, int stride, float* __restrict__ out, NsrTail tail, NsrCompOut co = NsrCompOut{},
                  float* pan = nullptr, unsigned* sgn = nullptr) {
   // 3 x 41 KiB weight ring + per-wave stash of the encoded position (8 fragments x 64 lanes x 16 B = 8 KiB
-  // per wave) + the colour-head block (rgb weights and bias, 448 floats): 160,512 B of the CU's 160 KiB
-  constexpr int kStash0 = 3 * kSlotFloats, kAux0 = kStash0 + 4 * 8 * 256;
-  __shared__ __attribute__((aligned(16))) float ring[kAux0 + hx::kAuxFloats];
+  // per wave) + the colour-head block (rgb weights and bias, 448 floats) + the compositor's staging area (640 floats):
+  // 163,072 B of the CU's 163,840
+  constexpr int kStash0 = 3 * kSlotFloats, kAux0 = kStash0 + 4 * 8 * 256, kComp0 = kAux0 + hx::kAuxFloats;
+  __shared__ __attribute__((aligned(16))) float ring[kComp0 + 640];
+  // NSR_PERSISTENT (build flag, off in the product): the ray kernels loop over tiles, one workgroup per CU.
+  // NSR_ENC_OVERLAP (with it): the next tile's encoding rides in this tile's matrix shadow.  Both are complete and
+  // bit-identical to the default, and both measured no faster on this power-limited kernel (DESIGN section 3.1,
+  // profiles/r4_persistent_ab.json): same box, fine pass 61.8 ms one tile per workgroup / 61.9 persistent / 62.2 with the
+  // overlapped encoding.
+#ifdef NSR_PERSISTENT
+  constexpr bool PERSIST = (MODE == 1) && !TRAIN && !SIGMA_ONLY;
+#else
+  constexpr bool PERSIST = false;
+#endif
+#ifdef NSR_ENC_OVERLAP
+  constexpr bool OVERLAP = PERSIST;
+#else
+  constexpr bool OVERLAP = false;
+#endif
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 31, h = lane >> 5;
   const float* aux = ring + kAux0;          // LDS copy, visible after the first barrier
 #ifdef NSR_ABL_TIMELINE
   unsigned long long tl[8], tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-  NSR_TL(0);
   for (int i = threadIdx.x; i < hx::kAuxFloats; i += 256) ring[kAux0 + i] = packed[kPiecesTotal * 256 + i];
 
   Loader ld;
@@ -426,28 +676,86 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   ld.slot_cur = lds_addr(ring);
   ld.slot_next = ld.slot_cur + kSlotBytes;
   ld.slot_free = ld.slot_cur + 2 * kSlotBytes;
-  // chunks 0 and 1 stream in behind the encoding prologue
-  loader_prepare_dma(ld, make_ref(0, 33, wave), ld.slot_cur);
+  // chunks 0 and 1 stream in behind the first tile's encoding
+  loader_prepare_dma(ld, first_ref(0, wave), ld.slot_cur);
 #pragma unroll
   for (int i = 0; i < 11; ++i) loader_issue(ld, i);
-  loader_prepare_dma(ld, make_ref(33, 33, wave), ld.slot_next);
+  loader_prepare_dma(ld, first_ref(1, wave), ld.slot_next);
 #pragma unroll
   for (int i = 0; i < 11; ++i) loader_issue(ld, i);
 
-  const int64_t p = (int64_t)blockIdx.x * 128 + wave * 32 + m;
+  const int64_t n_tiles = (P + 127) / 128;
+  const int samples = (NS > 0) ? NS : N;
+  const bool gamma = !TRAIN && nsr_opt_gamma(tail);
+  const unsigned voff = 4u * (unsigned)(m + 128 * h);   // panel stores: point m of the group, lane half h = 4 rows on
+  // the wave's stash of the split position encoding: L5 (skip) re-reads it, which frees 32 registers in the loop
+  u32x4* stash = reinterpret_cast<u32x4*>(ring + kStash0) + wave * 8 * 64 + lane;
+  u32x4 deh[2], del[2];
+  unsigned flags = 0u;     // NSR_FLAG_* of this lane's point, raised once at the end of its tile
+  Enc enc;
+  EncIn ein;
+  ein.rays = x;
+  ein.zv = zv;
+  ein.stride = stride;
+  ein.h = h;
+  ein.stash = reinterpret_cast<unsigned*>(stash);
+  if (OVERLAP) {   // the workgroup's first tile: the one encoding that is exposed
+    const int64_t p0 = (int64_t)blockIdx.x * 128 + wave * 32 + m;
+    ein.pc = p0 < P ? p0 : P - 1;
+    ein.ray = ein.pc / samples;
+    enc_all<0, kEncPieces>(enc, ein);
+    deh[0] = u32x4{enc.dh0, enc.dh1, enc.dh2, enc.dh3};
+    deh[1] = u32x4{enc.dh4, enc.dh5, enc.dh6, enc.dh7};
+    del[0] = u32x4{enc.dl0, enc.dl1, enc.dl2, enc.dl3};
+    del[1] = u32x4{enc.dl4, enc.dl5, enc.dl6, enc.dl7};
+    flags = enc.flags;
+  }
+  Pre l1pre;
+  bool first_tile = true;
+
+  // the kernels that do not overlap the encoding are launched with one tile per workgroup and take the body once: no
+  // loop-carried state, the register budget of the straight-line kernel (their panel stores take SGPR bases in inline asm)
+  int64_t tile = blockIdx.x;
+  if (tile >= n_tiles) {
+    dma_drain();
+    return;
+  }
+#pragma unroll 1
+  do {
+#ifndef NSR_ABL_NO_TILE_LAUNDER
+  // chunk descriptors derive from ld.wave: making it opaque once per tile keeps hipcc from hoisting seventy descriptor
+  // offsets out of the tile loop (and spilling them to VGPR lanes)
+  if (PERSIST) {
+    asm volatile("" : "+s"(wave));
+    ld.wave = wave;
+  }
+#endif
+  NSR_TL(0);
+  const int64_t p = tile * 128 + wave * 32 + m;
   const int64_t pc = p < P ? p : P - 1;
   PanelRef tr{};
   if (TRAIN) {
     tr.base = pan;
-    tr.n_groups = (int64_t)gridDim.x * 4;
-    tr.group = (int64_t)blockIdx.x * 4 + wave;
+    tr.n_groups = n_tiles * 4;
+    tr.group = tile * 4 + wave;
     tr.sgn = sgn;
   }
-  const unsigned voff = 4u * (unsigned)(m + 128 * h);   // panel stores: point m of the group, lane half h = 4 rows on
-
-  float pe[32], de[16];
-  unsigned flags = 0u;     // NSR_FLAG_* of this lane's point, raised once at the end
   float amax = 0.0f;       // see resplit_a
+  u32x4 peh[4], pel[4];
+  if (OVERLAP) {
+    // this tile's encoding was made during the previous tile (or above); the next tile's is made during this one
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      peh[s] = stash[s * 64];
+      pel[s] = stash[(4 + s) * 64];
+    }
+    const int64_t pn = p + (int64_t)gridDim.x * 128;
+    ein.pc = pn < P ? pn : P - 1;          // past the last tile: a harmless re-encoding of the last point
+    ein.ray = ein.pc / samples;
+  } else {
+  // ---- encoding at the top of the tile (VanillaMLP.forward's embedded rows; the training step)
+  flags = 0u;
+  float pe[32], de[16];
   if (MODE == 0) {
     const float* row = x + pc * kInCh;
     bool ok = true;
@@ -501,7 +809,6 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     de[14] = 0.0f;
     de[15] = 0.0f;
   }
-  u32x4 peh[4], pel[4], deh[2], del[2];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     unsigned a[4], b[4];
@@ -530,12 +837,22 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     for (int t = 0; t < 16; ++t) row_store(t, de[t], dblk, voff_de);
   }
 
-  // park the split position encoding in LDS: L5 (skip) re-reads it, which frees 32 registers in the loop
-  u32x4* stash = reinterpret_cast<u32x4*>(ring + kStash0) + wave * 8 * 64 + lane;
+  // park the split position encoding in LDS for L5
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     stash[s * 64] = peh[s];
     stash[(4 + s) * 64] = pel[s];
+  }
+  }   // !OVERLAP
+  if (!PERSIST || first_tile) {
+    // the workgroup's first tile: chunks 0 and 1 (streamed in behind the encoding) + the colour-head block are in LDS
+    // for everybody; the head of L1's first block.  Later tiles get all of this from their predecessor.
+    dma_drain();
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPF; ++k) prefetch_frag(l1pre, k, ld.slot_cur + ld.lane_off);
+    prefetch_bias(l1pre, ld.slot_cur + 32 * 1024, h);
+    first_tile = false;
   }
 
   u32x4 bh[16], bl[16], oh[16], ol[16];
@@ -547,17 +864,13 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   // over the block's 12 MFMA gaps: 1 / 2 / 1-2 per gap), and the head of block b+1 (first fragments + bias) is read
   // during block b's last three k-steps.  Publish point at the chunk start (chunk 0 / 1 were issued above; chunk j+2
   // is fetched here, one piece per k-step).
-  Pre l1pre;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
+    // c == 0: publishes chunk 1 (fetched during the previous tile's last block, or before the loop) and frees the slot
+    // of that block; chunk 0 was published there, and its head is already in `l1pre`
     loader_publish(ld, layer_ref(1, c, wave));    // chunk j+2 = first / second chunk of L2
     const unsigned a_chunk = ld.slot_cur + ld.lane_off;
     const unsigned next_bias = 32u * 1024u;       // L1 chunk 1 and L2's chunks: 32 weight pieces, then the bias
-    if (c == 0) {
-#pragma unroll
-      for (int k = 0; k < kPF; ++k) prefetch_frag(l1pre, k, a_chunk);
-      prefetch_bias(l1pre, ld.slot_cur + 32 * 1024, h);
-    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int nb = 4 * c + g;
@@ -568,7 +881,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
       Resplit ptmp;
       unsigned sbits = 0u;
       block_mma3<4, -1>(
-          cur, l1pre, a_addr, ld, end_ref(wave), [&](int s, int part) -> u32x4 { return part ? pel[s] : peh[s]; },
+          cur, l1pre, a_addr, ld, first_ref(0, wave), [&](int s, int part) -> u32x4 { return part ? pel[s] : peh[s]; },
           [&](int s, int gp) {
             const int i = 4 * g + s;        // DMA of chunk j+2: one piece per k-step over the chunk's 16 k-steps
             if (gp == 0 && i < 11) loader_issue(ld, i);
@@ -617,15 +930,15 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
                              tr, voff);
   }
   if (SIGMA_ONLY) {   // xyz_encoding_final is not evaluated: L8 is followed by the density head, then nothing
-    trunk_layer<true>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, sigma_ref(wave), end_ref(wave), amax);
+    trunk_layer<true>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, sigma_ref(wave), first_ref(0, wave), amax);
   } else {
 #ifdef NSR_ABL_TIMELINE
-    trunk_layer<true, TRAIN>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave), amax, tr, voff, tk);
+    trunk_layer<true, TRAIN, (OVERLAP ? 1 : 0)>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave), amax, tr, voff, &enc, &ein, tk);
     ld.tk = nullptr;
 #else
-    trunk_layer<true, TRAIN>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave), amax, tr, voff);
+    trunk_layer<true, TRAIN, (OVERLAP ? 1 : 0)>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave), amax, tr, voff, &enc, &ein);
 #endif
-    trunk_layer<false, TRAIN>(8, oh, ol, bh, bl, stash, ld, h, pend, pre, sigma_ref(wave), dir_ref(0, wave), amax, tr, voff);
+    trunk_layer<false, TRAIN, (OVERLAP ? 2 : 0)>(8, oh, ol, bh, bl, stash, ld, h, pend, pre, sigma_ref(wave), dir_ref(0, wave), amax, tr, voff, &enc, &ein);
   }
 
   NSR_TL(3);
@@ -640,9 +953,10 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     const unsigned next_bias = 36u * 1024u;       // dir_encoding chunks: 36 weight pieces, then the bias
     Pre nxt;
     block_mma3<16, kBar, (TRAIN ? 17 : 0)>(
-        cur, pre, ld.slot_cur + ld.lane_off, ld, SIGMA_ONLY ? end_ref(wave) : dir_ref(1, wave),
+        cur, pre, ld.slot_cur + ld.lane_off, ld, SIGMA_ONLY ? first_ref(1, wave) : dir_ref(1, wave),
         [&](int s, int part) -> u32x4 { return part ? ol[s] : oh[s]; },
         [&](int s, int g) {
+          if (OVERLAP && g == 0) enc_slot(128 + s, enc, ein);
           if (SIGMA_ONLY)
             pending_gap<true>(s, g, pend, ptmp, oh[14], ol[14], oh[15], ol[15], amax);
           else
@@ -654,7 +968,8 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
           }
         },
         [&](int k, int g) {
-          if (!SIGMA_ONLY) prefetch_next_chunk(nxt, k, g, ld, next_bias, h);
+          // sigma_only: the tile ends here, the next chunk is the next tile's L1 chunk 0 (bias behind 32 weight pieces)
+          prefetch_next_chunk(nxt, k, g, ld, SIGMA_ONLY ? 32u * 1024u : next_bias, h);
         });
     sigma = cur.m[0] * kWInvScale;           // row 0 of the block lives in register 0 of the h == 0 lanes
     pre = nxt;
@@ -665,8 +980,8 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     if (amax >= 65520.0f) flags |= NSR_FLAG_ACTIVATION_RANGE;
     if (!nsr_finite(sigma)) flags |= NSR_FLAG_OUTPUT_NONFINITE;
     if (p < P) nsr_raise(tail, flags);
-    dma_drain();   // no LDS-DMA may be in flight when the workgroup's LDS is released
-    return;
+    l1pre = pre;
+    continue;
   }
 
   NSR_TL(4);
@@ -682,11 +997,12 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     Pre nxt;
     // in flight behind the previous block's DMA: the density block's 16 stores | nothing | a dir block's 16 + sign word
     const unsigned a_seq = ld.slot_cur + ld.lane_off;
-    const ChunkRef c2 = nb < 2 ? dir_ref(nb + 2, wave) : end_ref(wave);
+    const ChunkRef c2 = nb < 2 ? dir_ref(nb + 2, wave) : first_ref(nb - 2, wave);   // ... then the next tile's L1
     auto b_of = [&](int s, int part) -> u32x4 {
       return (s < 16) ? (part ? bl[s & 15] : bh[s & 15]) : (part ? del[s & 1] : deh[s & 1]);
     };
     auto hook = [&](int s, int g) {
+      if (OVERLAP && nb == 0 && g == 0) enc_slot(144 + s, enc, ein);
       // the pending dir block is consumed in k-steps 6..13, one pair per k-step, one colour channel per gap
       if (nb > 0) rgb_gap<kConvStep0>(s, g, pend, aux + hx::kAuxRgbW + 32 * (nb - 1), h, rgb, w2);
       if (TRAIN && nb > 0 && s >= 8 && s < 16 && g == 2) {
@@ -700,8 +1016,8 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
         if (s == 15) sign_store(sbits, sign_block(tr.sgn, tr.group, 9, nb - 1), ld.lane_off >> 2);
       }
     };
-    auto next = [&](int k, int g) {
-      if (nb < 3) prefetch_next_chunk(nxt, k, g, ld, next_bias, h);
+    auto next = [&](int k, int g) {   // the last block hands over to the next tile's L1 (bias behind 32 weight pieces)
+      prefetch_next_chunk(nxt, k, g, ld, nb < 3 ? next_bias : 32u * 1024u, h);
     };
     if (!TRAIN || nb == 1) block_mma3<18, kBar>(cur, pre, a_seq, ld, c2, b_of, hook, next);
     else if (nb == 0) block_mma3<18, kBar, 16>(cur, pre, a_seq, ld, c2, b_of, hook, next);
@@ -737,7 +1053,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     s += aux[hx::kAuxRgbB + k];
     rgb[k] = 1.0f / (1.0f + expf(-s));
   }
-  if (!TRAIN && nsr_opt_gamma(tail)) {
+  if (gamma) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) rgb[k] = nsr_gamma(rgb[k]);
   }
@@ -745,21 +1061,50 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   if (!(nsr_finite(rgb[0]) && nsr_finite(rgb[1]) && nsr_finite(rgb[2]) && nsr_finite(sigma))) flags |= NSR_FLAG_OUTPUT_NONFINITE;
   if (p < P) nsr_raise(tail, flags);
   if (out && h == 0 && p < P) reinterpret_cast<float4*>(out)[p] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
-  dma_drain();     // no LDS-DMA may be in flight when the workgroup's LDS is released (or re-used just below)
   NSR_TL(6);
-  if (COMP) composite_tile<(COMP ? NS : 64)>(ring, h == 0, wave, m, lane, make_float4(rgb[0], rgb[1], rgb[2], sigma), zv[pc],
-                                            P / NS, co);
+  // the compositor's staging area is its own: at least L1's two publish barriers lie between two uses, and the weight
+  // ring keeps streaming underneath
+  if (COMP) composite_tile<(COMP ? NS : 64), true>(ring + kComp0, h == 0, wave, m, lane, make_float4(rgb[0], rgb[1], rgb[2], sigma),
+                                                  zv[pc], P / NS, co, tile);
 #ifdef NSR_ABL_TIMELINE
   NSR_TL(7);
-  if (lane == 0 && blockIdx.x < kTlGroups) {
+  if (lane == 0 && tile < kTlGroups) {
     unsigned hwid, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
-    unsigned long long* dst = nsr_tl + ((size_t)blockIdx.x * 4 + wave) * kTlSlots;
+    unsigned long long* dst = nsr_tl + ((size_t)tile * 4 + wave) * kTlSlots;
     for (int k = 0; k < 8; ++k) dst[k] = tl[k];
     dst[8] = hwid;
     dst[9] = xcc;
-    for (int k = 0; k < 8; ++k) nsr_tk[((size_t)blockIdx.x * 4 + wave) * 8 + k] = tk[k];
+    for (int k = 0; k < 8; ++k) nsr_tk[((size_t)tile * 4 + wave) * 8 + k] = tk[k];
   }
+#endif
+  // hand-over to the next tile: the head of its first L1 block, and the encoding made in this tile's shadow
+  l1pre = pre;
+  if (OVERLAP) {
+    deh[0] = u32x4{enc.dh0, enc.dh1, enc.dh2, enc.dh3};
+    deh[1] = u32x4{enc.dh4, enc.dh5, enc.dh6, enc.dh7};
+    del[0] = u32x4{enc.dl0, enc.dl1, enc.dl2, enc.dl3};
+    del[1] = u32x4{enc.dl4, enc.dl5, enc.dl6, enc.dl7};
+    flags = enc.flags;
+  }
+  } while (PERSIST && (tile += gridDim.x) < n_tiles);
+  dma_drain();     // no LDS-DMA may be in flight when the workgroup's LDS is released (the last tile fetched chunks 0, 1 again)
+}
+
+// one workgroup per CU for the persistent ray kernels (they are LDS- and register-bound to that anyway)
+static int nsr_cu_count() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+    n = 256;
+  return n;
+}
+static dim3 persistent_grid(int64_t P) {
+  const int64_t n_tiles = (P + 127) / 128;
+#ifdef NSR_PERSISTENT
+  const int64_t cus = nsr_cu_count();
+  return dim3((unsigned)(n_tiles < cus ? n_tiles : cus));
+#else
+  return dim3((unsigned)n_tiles);
 #endif
 }
 
@@ -767,7 +1112,8 @@ template <int MODE, bool SIGMA_ONLY>
 static int launch_f16x3(const void* packed, const float* x, const float* z, int64_t P, int N, int stride, float* out,
                         unsigned* tail_w, hipStream_t st) {
   const NsrTail tail{tail_w};
-  const dim3 grid((unsigned)((P + 127) / 128)), block(256);
+  // the ray kernels loop over tiles, one workgroup per CU; the embedded-row kernels keep one tile per workgroup
+  const dim3 grid = (MODE == 1 && !SIGMA_ONLY) ? persistent_grid(P) : dim3((unsigned)((P + 127) / 128)), block(256);
   const float* pk = static_cast<const float*>(packed);
   if (MODE == 1 && N == 64)
     hipLaunchKernelGGL((mlp_f16x3_kernel<MODE, SIGMA_ONLY, 64>), grid, block, 0, st, pk, x, z, P, N, stride, out, tail);
@@ -791,7 +1137,7 @@ extern "C" NSR_INTERNAL int nsr_f16x3_render_composite(const void* packed, const
                                                        void* stream) {
   const NsrTail tail{tail_w};
   const int64_t P = R * N;
-  const dim3 grid((unsigned)((P + 127) / 128)), block(256);
+  const dim3 grid = persistent_grid(P), block(256);
   const float* pk = static_cast<const float*>(packed);
   if (N == 64)
     hipLaunchKernelGGL((mlp_f16x3_kernel<1, false, 64, true>), grid, block, 0, nsr_stream(stream), pk, rays, z, P, N, ray_stride, raw, tail, *co);

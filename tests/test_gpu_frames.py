@@ -206,6 +206,20 @@ def test_sharded_render_is_bit_identical_config4(ops):
     # world = 1 through the collective-free path of all_gather_pixels
     one = model.render_image_sharded(c2w, f, ndc, *nf)
     assert torch.equal(one["lr_rgb"], lr_rgb) and one["lr_range"] == (0, n_lr)
+    # gather="hr": what the collective carries is the rendered pixels themselves (12 B per ray); the blocks, laid end to
+    # end, ARE the ray-major tensor unflatten_reshape takes, so the assembled frame equals render_image's HR image
+    hr_img = whole["hr_rgb"]
+    assert hr_img.shape == (756, 1008, 3)
+    for world in (2, 8):
+        bounds = nsr_dist.shard_bounds(n_lr, world)
+        parts = [model.render_image_sharded(c2w, f, ndc, *nf, lr_range=b, gather="hr") for b in bounds]
+        hr_rays = torch.cat([p["hr_rays"] for p in parts], 0)
+        assert torch.equal(hr_rays, hr_rgb)
+        assert torch.equal(model.unflatten_reshape(hr_rays), hr_img)
+        assert parts[0]["bytes_per_rank"] == (bounds[0][1] - bounds[0][0]) * 16 * 12
+        assert abs(parts[0]["bytes_per_rank"] - 762048 * 12 / world) <= 16 * 12
+    one = model.render_image_sharded(c2w, f, ndc, *nf, gather="hr")
+    assert torch.equal(one["hr_rgb"], hr_img) and torch.equal(one["lr_rgb"], lr_rgb)
 
 
 # ------------------------------------------------------------------------------------------------- config #5
