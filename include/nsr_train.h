@@ -65,6 +65,17 @@ int nsr_train_loss_and_grads(const float* const* w_coarse, const float* const* w
                              int precision, int64_t ray_chunk, float* const* outs, float* lr_coarse, float* lr_fine, float* losses,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* Numerics status of the training step (the reference drops into pdb on NaN colours, nerf_downX_model.py:273-274; a
+ * replacement reports instead).  The FIRST 64 BYTES of the workspace are a sticky status block: with NSR_F16X3 every
+ * nsr_train_loss_and_grads ORs NSR_FLAG_WEIGHT_RANGE (a weight of the iteration's re-pack is non-finite or |w| >= 1023.75:
+ * the split-fp16 stream cannot carry it), NSR_FLAG_INPUT_RANGE / NSR_FLAG_ACTIVATION_RANGE (a raw coordinate or a hidden
+ * activation left the fp16 operand range: products degrade to 11 bits) and NSR_FLAG_OUTPUT_NONFINITE into its first word,
+ * exactly as the inference entry points do into a packed network's tail (nsr.h).  Nothing is synchronised by the step.
+ * nsr_train_status_reset zeroes the block (call it once when the workspace is allocated: the step never clears it);
+ * nsr_train_status copies the word to the host (waits for the stream) and optionally clears it.  NSR_FP32 raises nothing. */
+int nsr_train_status_reset(void* workspace, void* stream);
+int nsr_train_status(void* workspace, int clear, unsigned* flags_out, void* stream);
+
 /* torch.optim.Adam (no weight decay, no amsgrad) on the 24 tensors of one network, in place:
  *   m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g^2;
  *   w -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)        (step counts from 1). */

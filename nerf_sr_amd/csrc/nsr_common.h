@@ -15,6 +15,16 @@
 
 static inline hipStream_t nsr_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Development switches (A/B runs on one box: NSR_GEMM_TILE / NSR_GEMM_TK / NSR_GEMM_FULLN / NSR_REFINE_SEPARATE_MAX /
+// NSR_WGRAD_JOBS) are environment reads, and getenv is not safe against a concurrent setenv: the release library does
+// not contain them (include/nsr.h promises no ambient process state); build with -DNSR_DEV_SWITCHES to get them back.
+// The one documented run-time switch, NSR_TRAIN_PATH (include/nsr_train.h), stays.
+#ifdef NSR_DEV_SWITCHES
+static inline const char* nsr_dev_env(const char* name) { return getenv(name); }
+#else
+static inline const char* nsr_dev_env(const char*) { return nullptr; }
+#endif
+
 // ---- tail of every packed weight blob (include/nsr.h "numerics status word"): 16 bytes behind the 16-byte-aligned
 // payload of the precision's own layout: word 0 = sticky NSR_FLAG_* status, word 1 = colour-head options
 // (bit 0: --gamma_correct, models/nerf_downX_model.py:271-276), words 2, 3 reserved.
@@ -38,6 +48,8 @@ __device__ __forceinline__ void nsr_raise(const NsrTail& t, unsigned flags) {
 __device__ __forceinline__ bool nsr_opt_gamma(const NsrTail& t) {
   return t.w && (__builtin_nontemporal_load(t.w + 1) & kOptGamma) != 0u;
 }
+// torch.max over the reference patches propagates NaN (models/networks.py:980-983); fmaxf drops it
+__device__ __forceinline__ float nsr_max_nan(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
 __device__ __forceinline__ bool nsr_finite(float x) { return fabsf(x) <= 3.402823466e38f; }   // false for inf and NaN
 // --gamma_correct: out_rgbs = pow(out_rgbs, 1 / 2.2) on the per-sample colours (nerf_downX_model.py:271-276)
 __device__ __forceinline__ float nsr_gamma(float c) { return powf(c, 1.0f / 2.2f); }

@@ -120,8 +120,8 @@ __device__ __forceinline__ void epilogue_planes_t(const GemmF16Args& a, f32x16 (
           }
         }
         if (GROUPED) {   // max over the 8 members: four in this lane, four in the lane of the other half; then pair the columns
-          float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
-          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          float mx = nsr_max_nan(nsr_max_nan(x[0], x[1]), nsr_max_nan(x[2], x[3]));      // NaN-propagating, like torch.max
+          mx = nsr_max_nan(mx, __shfl_xor(mx, 32, 64));
           const float nb = __shfl_xor(mx, 1, 64);
           const unsigned q = (unsigned)((m0 + 32 * BM * wm + 32 * bi) / 8) + rq;
           if (h == 0 && !odd && q < n_q && col < g.n_valid) {
@@ -419,9 +419,9 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   bool wide = false;                                   // the 8-wave tile: NSR_GEMM_TILE=wide only
   bool four_wave_wide = quad_ok && row_tiles * (g.N / 256) >= 1024;
   // development switches (A/B runs on one box): NSR_GEMM_TILE=narrow|wide|quad overrides the choice, NSR_GEMM_TK=32 keeps K tiles of 32
-  const char* e_tile = getenv("NSR_GEMM_TILE");
-  const char* e_tk = getenv("NSR_GEMM_TK");
-  const char* e_fulln = getenv("NSR_GEMM_FULLN");      // =0: keep the column test in the k-steps (A/B)
+  const char* e_tile = nsr_dev_env("NSR_GEMM_TILE");
+  const char* e_tk = nsr_dev_env("NSR_GEMM_TK");
+  const char* e_fulln = nsr_dev_env("NSR_GEMM_FULLN");      // =0: keep the column test in the k-steps (A/B)
   if (e_tile && e_tile[0] == 'n') four_wave_wide = false;
   if (e_tile && e_tile[0] == 'w') { wide = g.N >= 256; four_wave_wide = false; }
   if (e_tile && e_tile[0] == 'q') four_wave_wide = quad_ok;

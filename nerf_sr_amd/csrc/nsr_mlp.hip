@@ -128,6 +128,20 @@ static float precision_weight_limit(int precision) {
   return 3.402823466e38f;
 }
 
+// the weight-range check on its own (the training step runs it on the weights it re-packs every iteration)
+extern "C" NSR_INTERNAL int nsr_check_weights_range(const float* const* w, int precision, unsigned* word, void* stream) {
+  CheckPtrs cp;
+  for (int i = 0; i < NSR_N_STATE_TENSORS; ++i) {
+    if (!w[i]) return NSR_ERR_INVALID_ARG;
+    cp.p[i] = w[i];
+    cp.n[i] = kStateTensorSizes[i];
+  }
+  hipLaunchKernelGGL(check_weights_kernel, dim3(16, NSR_N_STATE_TENSORS), dim3(256), 0, nsr_stream(stream), cp,
+                     precision_weight_limit(precision), word);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
 extern "C" int nsr_pack_weights_async(const float* const* w, void* packed_dev, int precision, void* stream) {
   if (!w || !packed_dev) return NSR_ERR_INVALID_ARG;
   if ((reinterpret_cast<uintptr_t>(packed_dev) & 15) != 0) return NSR_ERR_INVALID_ARG;

@@ -1157,11 +1157,11 @@ extern "C" NSR_INTERNAL int64_t nsr_f16x3_train_panel_floats(int64_t P) {
 }
 extern "C" NSR_INTERNAL int64_t nsr_f16x3_train_sign_words(int64_t P) { return sign_panel_words(((P + 127) / 128) * 4); }
 extern "C" NSR_INTERNAL int nsr_f16x3_train_forward(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
-                                                    int N, float* raw, float* pan, unsigned* sgn, void* stream) {
+                                                    int N, float* raw, float* pan, unsigned* sgn, unsigned* status, void* stream) {
   const int64_t P = R * N;
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   hipLaunchKernelGGL((mlp_f16x3_kernel<1, false, 0, false, true>), grid, block, 0, nsr_stream(stream),
-                     static_cast<const float*>(packed), rays, z, P, N, ray_stride, raw, NsrTail{nullptr}, NsrCompOut{}, pan, sgn);
+                     static_cast<const float*>(packed), rays, z, P, N, ray_stride, raw, NsrTail{status}, NsrCompOut{}, pan, sgn);
   if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
   return NSR_OK;
 }

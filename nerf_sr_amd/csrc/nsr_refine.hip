@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) max_refs_kernel(const float* __restrict__
   float4 m = *reinterpret_cast<const float4*>(src + ((b * R) * px_per_img + px) * C + 4 * c4);
   for (int r = 1; r < R; ++r) {
     const float4 t = *reinterpret_cast<const float4*>(src + ((b * R + r) * px_per_img + px) * C + 4 * c4);
-    m.x = fmaxf(m.x, t.x); m.y = fmaxf(m.y, t.y); m.z = fmaxf(m.z, t.z); m.w = fmaxf(m.w, t.w);
+    m.x = nsr_max_nan(m.x, t.x); m.y = nsr_max_nan(m.y, t.y); m.z = nsr_max_nan(m.z, t.z); m.w = nsr_max_nan(m.w, t.w);
   }
   *reinterpret_cast<float4*>(dst + bp * ld + 4 * c4) = m;
 }
@@ -171,7 +171,8 @@ __global__ void __launch_bounds__(256) max_refs_planes_kernel(const unsigned sho
     const h2 th = *reinterpret_cast<const h2*>(src + o), tl = *reinterpret_cast<const h2*>(src + src_plane + o);
 #pragma unroll
     for (int e = 0; e < 2; ++e)
-      if (th[e] > mh[e] || (th[e] == mh[e] && tl[e] > ml[e])) {
+      // NaN-propagating like torch.max (and like the fused epilogue): the first NaN met stays
+      if (!(mh[e] != mh[e]) && (th[e] != th[e] || th[e] > mh[e] || (th[e] == mh[e] && tl[e] > ml[e]))) {
         mh[e] = th[e];
         ml[e] = tl[e];
       }
@@ -383,7 +384,7 @@ int forward(const void* packed_v, int prec, int v, const float* x_synth, const f
   if (v == 0) {
     // encoder on the B * R reference patches, then the max over the R references (F_max_i)
     const Act fc0{k.fc0, nref * px0, 128, 0}, fc1{k.fc1, nref * px1, 256, 0}, fc2{k.fc2, nref * px2, 512, 0}, fc3{k.fc3, nref * px3, 512, 0};
-    const bool fused_max = prec == NSR_F16X3 && R == 8 && !getenv("NSR_REFINE_SEPARATE_MAX");   // env: A/B runs
+    const bool fused_max = prec == NSR_F16X3 && R == 8 && !nsr_dev_env("NSR_REFINE_SEPARATE_MAX");   // env: A/B runs
     if (fused_max) {
       // the reference's 8 patches per tile (llff_refine_dataset.py: num_ref_patches): the producing GEMMs reduce over them
       // in their epilogues -- the four max kernels (1.1 ms per 800 x 800 frame, 5.1 GB read at 4.5 TB/s) are gone

@@ -478,6 +478,7 @@ struct Work {   // per-pass buffers, sized for P_max = chunk * (Nc + Ni) sample 
   unsigned* sgn;    // sign panels of the forward pass (nsr_f16x3_core.h)
   float* pscale;    // per gradient panel and point: stored value x pscale = true gradient (written by the backward chain)
   unsigned* gmax;   // float bits of the largest magnitude in each gradient panel (written by the backward chain)
+  unsigned* status; // sticky NSR_FLAG_* word of the training step (include/nsr_train.h): ALWAYS the first bytes of the workspace
 };
 
 // mode 0: every buffer of both paths (nsr_train_workspace_bytes: sufficient whatever runs); 1: the layer-by-layer GEMM path
@@ -495,6 +496,7 @@ int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base, int mod
   const bool gemm_path = mode != 2, chain_path = mode != 1;
   Work tmp;
   Work& k = w ? *w : tmp;
+  k.status = reinterpret_cast<unsigned*>(take(16));        // offset 0 whatever the path: nsr_train_status reads it blind
   k.x5 = take_if(gemm_path, P * kX5);
   for (int L = 1; L <= 8; ++L) k.h[L] = (L == 4) ? nullptr : take_if(gemm_path, P * kW);   // h4 lives in x5[:, 64:]
   k.gs = take_if(gemm_path, P * kGs);
@@ -726,7 +728,7 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
   const int sp = n_splits(P);
   const int64_t sp_max = sp;   // the workspace's slots are sized for the largest pass (work_floats): at least this one's
   constexpr float kInv = 1.0f / 64.0f;
-  const char* env = getenv("NSR_WGRAD_JOBS");
+  const char* env = nsr_dev_env("NSR_WGRAD_JOBS");
   const bool one_launch = !(env && env[0] == '0');
   FinishJobs jobs{};
   WgradJobs wj{};
@@ -928,6 +930,9 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
   const bool chain = chain_selected(precision);
   if (chain) {
     for (int net = 0; net < 2; ++net) {
+      // the weights are re-packed every iteration: a run whose weights drift beyond what the split-fp16 stream carries
+      // (|w| >= 1023.75, or NaN) raises NSR_FLAG_WEIGHT_RANGE in the step's status word, like nsr_pack_weights does
+      NSR_TRY(nsr_check_weights_range(net ? w_fine : w_coarse, precision, k.status, stream));
       NSR_TRY(nsr_f16x3_pack(net ? w_fine : w_coarse, k.stream_f[net], stream));
       NSR_TRY(nsr_chain_bwd_pack(net ? w_fine : w_coarse, k.stream_b[net], stream));
     }
@@ -961,7 +966,7 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
                            P, N, k.x5, k.gs);
         NSR_CHECK_LAUNCH();
       }
-      if (chain) NSR_TRY(nsr_f16x3_train_forward(k.stream_f[net], rays_c, ray_stride, z, rc, N, k.rgb, k.zpan, k.sgn, stream));
+      if (chain) NSR_TRY(nsr_f16x3_train_forward(k.stream_f[net], rays_c, ray_stride, z, rc, N, k.rgb, k.zpan, k.sgn, k.status, stream));
       else NSR_TRY(net_forward(st, w, k.pack[net], k, P, precision));
       const float* noise = net ? noise_fine : noise_coarse;
       hipLaunchKernelGGL(sigma_noise_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st,
@@ -991,6 +996,23 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
       }
     }
   }
+  return NSR_OK;
+}
+
+extern "C" int nsr_train_status_reset(void* workspace, void* stream) {
+  if (!workspace) return NSR_ERR_INVALID_ARG;
+  if (hipMemsetAsync(workspace, 0, 64, nsr_stream(stream)) != hipSuccess) return NSR_ERR_LAUNCH;
+  return NSR_OK;
+}
+
+extern "C" int nsr_train_status(void* workspace, int clear, unsigned* flags_out, void* stream) {
+  if (!workspace || !flags_out) return NSR_ERR_INVALID_ARG;
+  hipStream_t st = nsr_stream(stream);
+  unsigned host = 0;
+  if (hipMemcpyAsync(&host, workspace, sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess) return NSR_ERR_LAUNCH;
+  if (clear && hipMemsetAsync(workspace, 0, sizeof(unsigned), st) != hipSuccess) return NSR_ERR_LAUNCH;
+  if (hipStreamSynchronize(st) != hipSuccess) return NSR_ERR_LAUNCH;
+  *flags_out = host;
   return NSR_OK;
 }
 

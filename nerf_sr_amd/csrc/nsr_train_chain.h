@@ -4,9 +4,12 @@
 
 // floats of one panel set (10 panels, see nsr_f16x3_core.h) for P sample points
 extern "C" NSR_INTERNAL int64_t nsr_f16x3_train_panel_floats(int64_t P);
-// forward pass: raw (R N, 4) = (rgb, sigma) + the pre-activation panels; `packed` = nsr_f16x3_pack of the weights
+// forward pass: raw (R N, 4) = (rgb, sigma) + the pre-activation panels; `packed` = nsr_f16x3_pack of the weights;
+// status: the step's sticky NSR_FLAG_* word (input / activation range, non-finite outputs) or null
 extern "C" NSR_INTERNAL int nsr_f16x3_train_forward(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
-                                                    int N, float* raw, float* pan, unsigned* sgn, void* stream);
+                                                    int N, float* raw, float* pan, unsigned* sgn, unsigned* status, void* stream);
+// NSR_FLAG_WEIGHT_RANGE into *word if a weight cannot be carried at `precision` (nsr_mlp.hip)
+extern "C" NSR_INTERNAL int nsr_check_weights_range(const float* const* w, int precision, unsigned* word, void* stream);
 // dwords of the sign panels (one bit per pre-activation) for P sample points
 extern "C" NSR_INTERNAL int64_t nsr_f16x3_train_sign_words(int64_t P);
 extern "C" NSR_INTERNAL size_t nsr_f16x3_packed_bytes(void);

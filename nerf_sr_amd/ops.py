@@ -212,6 +212,8 @@ class VanillaMLP:
             raise _lib.NsrError(f"precision {precision!r} is not built into libnsr.so")
         self.packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self._sd = None
+        self._gamma = False
+        self._want_gamma = bool(getattr(opt, "gamma_correct", False)) if opt is not None else False
 
     def load_state_dict(self, sd: Dict[str, "np.ndarray | torch.Tensor"]):
         check_state_dict(sd)
@@ -223,6 +225,10 @@ class VanillaMLP:
         ptrs = (c_void_p * len(dev))(*[c_void_p(t.data_ptr()) for t in dev.values()])
         rc = _lib.load().nsr_pack_weights(ptrs, _p(self.packed), self._prec, _stream())
         if rc == _lib.NSR_ERR_RANGE:
+            # the blob HAS been overwritten with the out-of-range network (include/nsr.h): this object no longer holds a
+            # usable one -- forward() / state_dict() must not go on serving the previous tensors against the new blob
+            self._sd = None
+            self._gamma = False
             raise _lib.NsrNumericsError(
                 f"state_dict cannot be carried at precision {self.precision!r}: a weight or bias is non-finite"
                 + (" or |w| >= 1023.75 (the split-fp16 stream holds 2^6 w in fp16)" if self.precision == "f16x3" else
@@ -231,6 +237,8 @@ class VanillaMLP:
         _lib.check(rc, "nsr_pack_weights")
         self._sd = dev     # keep the fp32 originals alive (state_dict() round trip)
         self._gamma = False
+        if self._want_gamma:       # packing clears the blob's option word: the requested colour-head option is re-applied
+            self.set_gamma_correct(True)
         return self
 
     def set_gamma_correct(self, enable: bool = True):
@@ -240,7 +248,7 @@ class VanillaMLP:
             raise RuntimeError("VanillaMLP.set_gamma_correct called before load_state_dict")
         _lib.check(_lib.load().nsr_weights_set_gamma(_p(self.packed), self._prec, int(bool(enable)), _stream()),
                    "nsr_weights_set_gamma")
-        self._gamma = bool(enable)
+        self._gamma = self._want_gamma = bool(enable)       # remembered: every later load_state_dict re-applies it
         return self
 
     def status(self, clear: bool = False) -> int:

@@ -74,7 +74,12 @@ class Trainer:
                  lindisp: bool = False, downscale: int = 2, randomized: bool = True, noise_std: float = 0.0,
                  lr: float = 5e-4, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
                  lambda_coarse_mse: float = 1.0, lambda_fine_mse: float = 1.0, ray_chunk: int = 4096,
-                 precision: str = "f16x3", device="cuda"):
+                 precision: str = "f16x3", device="cuda", gamma_correct: bool = False):
+        if gamma_correct:
+            # render_rays applies rgb ** (1 / 2.2) per sample under --gamma_correct (models/nerf_downX_model.py:271-276) in
+            # training too; the training kernels have no such branch, and ignoring the option would train another model
+            raise ValueError("training with gamma_correct=True is not built (the HIP training step has no gamma branch); "
+                             "the render path supports it (VanillaMLP.set_gamma_correct)")
         if precision not in ("fp32", "f16x3"):
             raise ValueError("precision must be 'fp32' (every product on the fp32 MFMA, layer by layer) or 'f16x3' (every "
                              "product -- forward, input and weight gradients -- on the split-fp16 MFMA, fp32-grade)")
@@ -145,6 +150,7 @@ class Trainer:
             raise _lib.NsrError("sample counts outside the built path")
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            _lib.check(_lib.load().nsr_train_status_reset(_p(self._ws), _stream()), "nsr_train_status_reset")
         dev = self.device
         o = {"coarse_comp_rgbs": torch.empty(R, 3, device=dev), "coarse_depth": torch.empty(R, device=dev),
              "coarse_opacity": torch.empty(R, device=dev), "coarse_weights": torch.empty(R, nc, device=dev),
@@ -184,6 +190,16 @@ class Trainer:
                 _ptr_array(list(self.exp_avg[n].values())), _ptr_array(list(self.exp_avg_sq[n].values())),
                 self.step, self.lr, self.beta1, self.beta2, self.eps, _stream()), "nsr_adam_step")
 
+    def status(self, clear: bool = False) -> int:
+        """Sticky numerics status word of the training step (``NSR_FLAG_*``, include/nsr_train.h): 0 = every iteration so
+        far packed in-range weights and saw in-range inputs / activations and finite outputs.  Waits for the stream."""
+        if self._ws is None:
+            return 0
+        import ctypes
+        flags = ctypes.c_uint(0)
+        _lib.check(_lib.load().nsr_train_status(_p(self._ws), int(bool(clear)), ctypes.byref(flags), _stream()), "nsr_train_status")
+        return int(flags.value)
+
     def optimize_parameters(self, draws=None):
         """One training iteration (:398-408); returns the device tensor [coarse_mse, fine_mse] (lambda-weighted).
 
@@ -196,6 +212,11 @@ class Trainer:
             # every rank votes and every rank raises: a rank that raised alone would leave the others waiting in the
             # gradient all-reduce
             from .dist import all_ranks_agree
+            flags = self.status(clear=True)
+            if not all_ranks_agree(flags == 0, self.device, self.group):
+                raise _lib.NsrNumericsError(
+                    f"training step {self.step + 1}: numerics status {flags:#x} = {' | '.join(_lib.flag_names(flags)) or 'raised on another rank'}"
+                    " -- weights or activations left the split-fp16 operand range; retry with precision='fp32'", flags)
             if not all_ranks_agree(bool(torch.isfinite(self.losses).all()), self.device, self.group):
                 raise FloatingPointError(
                     f"non-finite training loss at step {self.step + 1} (this rank: {self.losses.tolist()}): the run diverged"

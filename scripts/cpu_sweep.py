@@ -31,7 +31,8 @@ def main():
     sdc, sdf = oc.to_torch_sd(make_state_dict(99)), oc.to_torch_sd(make_state_dict(100))
     frame = oc.subpixel_ray_grid(torch.from_numpy(cameras.spiral_pose(0.4)), 378, 504, cameras.llff_focal(504), 2, True, 0.0, 1.0).reshape(-1, 8)
     mid = frame.shape[0] // 2
-    grid = [(1, 8), (1, 16), (1, 32), (1, 64), (1, host), (2, 32), (2, 64), (4, 16), (4, 32), (8, 16), (16, 8)]
+    grid = [(1, 8), (1, 16), (1, 32), (1, 64), (1, host), (2, 32), (4, 16), (4, 32), (8, 16), (16, 8), (16, 16), (32, 4), (32, 8),
+            (64, 4), (64, 2)]
     grid = [(w, t) for w, t in dict.fromkeys(grid) if w * t <= host]
     res = []
     for w, t in grid:

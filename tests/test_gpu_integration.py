@@ -112,7 +112,12 @@ def test_forward_rays_from_two_host_threads(shared):
         assert _forward(lib, nets[t][0].packed, nets[t][1].packed, rays[t], outs, ws, torch.cuda.current_stream()) == 0
         torch.cuda.synchronize()
         want.append([o.clone() for o in outs])
-    flags_serial = [(nets[t][0].status(clear=True), nets[t][1].status(clear=True)) for t in range(2)]
+    def read_flags():
+        # shared networks have ONE status word each: read (and clear) it once and report it for both threads
+        first = (nets[0][0].status(clear=True), nets[0][1].status(clear=True))
+        return [first, first if shared else (nets[1][0].status(clear=True), nets[1][1].status(clear=True))]
+
+    flags_serial = read_flags()
     assert flags_serial[1][0] & 2 and (shared or flags_serial[0] == (0, 0))
     # ---- two threads, two streams, several rounds
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
@@ -140,7 +145,7 @@ def test_forward_rays_from_two_host_threads(shared):
         for i in range(4):
             for a, b in zip(got[t][i], want[t]):
                 assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), (t, i)
-    flags = [(nets[t][0].status(clear=True), nets[t][1].status(clear=True)) for t in range(2)]
+    flags = read_flags()
     if shared:
         assert flags[0] == flags_serial[1]      # one status word: the poisoned thread's flags, exactly as in the serial run
     else:

@@ -326,3 +326,38 @@ def test_chain_path_matches_gemm_path_at_bench_scale(tr, monkeypatch):
             assert e <= 1e-3 * nx + 1e-12, (n, k, e / nx)
             num, den = num + e * e, den + nx * nx
         assert (num / den) ** 0.5 < 2e-4, (n, (num / den) ** 0.5)
+
+
+def test_training_step_status_word(tr):
+    """The training step has a numerics status word of its own (include/nsr_train.h): weights that leave what the
+    split-fp16 stream carries are flagged by the per-iteration re-pack, a poisoned ray by the forward kernel, and
+    ``check_finite`` turns the word into the error the reference's pdb trap stands for.  fp32 raises nothing."""
+    from nerf_sr_amd import _lib
+    from nerf_sr_amd import ops, cameras
+    gen = torch.Generator().manual_seed(2)
+    rays = ops.subpixel_rays(cameras.spiral_pose(0.4), (504, 378), cameras.llff_focal(504), 2, True)[2000:2016].reshape(-1, 8).contiguous()
+    tgt = torch.rand(16, 3, generator=gen).cuda()
+    t = tr.Trainer(make_state_dict(5), make_state_dict(6), randomized=False, downscale=2, precision="f16x3")
+    t.set_input(rays, tgt)
+    t.optimize_parameters()
+    assert t.status() == 0
+    # a weight beyond the stream's range (|w| >= 1023.75 once scaled by 2^6 leaves fp16): flagged on the next re-pack
+    t.params[1]["xyz_encoding_3.0.weight"][5, 7] = 2000.0
+    t.loss_and_grads()
+    assert t.status() & 1                       # NSR_FLAG_WEIGHT_RANGE
+    assert t.status(clear=True) & 1 and t.status() == 0
+    t.params[1]["xyz_encoding_3.0.weight"][5, 7] = 0.01
+    # a poisoned ray: INPUT_RANGE (and whatever follows from it), surfaced by check_finite as an error
+    bad = rays.clone()
+    bad[9, 1] = float("nan")
+    t.set_input(bad, tgt)
+    t.check_finite = True
+    with pytest.raises(_lib.NsrNumericsError):
+        t.optimize_parameters()
+    assert t.status() == 0                      # the check cleared it
+    # the fp32 path has no operand range to leave
+    t32 = tr.Trainer(make_state_dict(5), make_state_dict(6), randomized=False, downscale=2, precision="fp32")
+    t32.params[1]["xyz_encoding_3.0.weight"][5, 7] = 2000.0
+    t32.set_input(rays, tgt)
+    t32.loss_and_grads()
+    assert t32.status() == 0

@@ -39,3 +39,12 @@ def test_softplus_density_raises():
 def test_model_rejects_softplus_before_touching_a_device():
     with pytest.raises(ValueError):
         NeRFDownXModel(default_options(sigma_activation="softplus"), device="cuda")
+
+
+def test_training_rejects_gamma_correct():
+    """render_rays applies rgb ** (1 / 2.2) in training too (models/nerf_downX_model.py:271-276); the HIP training step has
+    no such branch, so the option must raise instead of training another model."""
+    from nerf_sr_amd import train
+    from nerf_sr_amd.weights import make_state_dict
+    with pytest.raises(ValueError, match="gamma_correct"):
+        train.Trainer(make_state_dict(1), make_state_dict(2), gamma_correct=True, device="cuda")
