@@ -319,7 +319,9 @@ __device__ __forceinline__ void block_mma(Acc& acc, const Pre& pre, unsigned a_a
 //   gap 1: a_hi*b_lo + hook(s, 1)
 //   gap 2: a_hi*b_hi + hook(s, 2) + next(k, 2)
 // and the chunk's DMA pieces go one per gap (gaps 1 and 2 of k-steps BAR..BAR+5, each with its own M0 write).
-template <int NSTEP, int BAR, int YOUNGER = 0, class BOf, class Hook, class Next>
+// DMA = false: the publish point stays, but no chunk is fetched behind it (the last two chunks of a one-tile workgroup:
+// there is no next tile to fetch L1 for).
+template <int NSTEP, int BAR, int YOUNGER = 0, bool DMA = true, class BOf, class Hook, class Next>
 __device__ __forceinline__ void block_mma3(Acc& acc, const Pre& pre, unsigned a_addr, Loader& ld, const ChunkRef& c2,
                                            BOf&& b_of, Hook&& hook, Next&& next, bool strict = false) {
   static_assert(NSTEP >= kPF, "sequence shorter than the prefetch depth");
@@ -337,8 +339,8 @@ __device__ __forceinline__ void block_mma3(Acc& acc, const Pre& pre, unsigned a_
 #endif
     // the DMA descriptor of chunk j+2 (six SALU) is formed three k-steps ahead of the publish point, in a quiet gap: the
     // previous chunk's last piece went out at its k-step BAR+5, and slot_free does not change inside a chunk
-    if (BAR >= 3 && s == BAR - 3) loader_prepare_dma(ld, c2, ld.slot_free);
-    if (s == BAR) loader_publish<YOUNGER, (BAR < 3)>(ld, c2, strict);
+    if (DMA && BAR >= 3 && s == BAR - 3) loader_prepare_dma(ld, c2, ld.slot_free);
+    if (s == BAR) loader_publish<YOUNGER, (DMA && BAR < 3)>(ld, c2, strict);
     const u32x4 bh = b_of(s, 0), bl = b_of(s, 1);
     // ---- gap 0.  a_lo first: it is the younger of the step's two fragment loads, so ONE lgkmcnt wait serves all three
     acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(al[s]), as_h8(bh), acc.m, 0, 0, 0);
@@ -353,13 +355,13 @@ __device__ __forceinline__ void block_mma3(Acc& acc, const Pre& pre, unsigned a_
     // ---- gap 1
     acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bl), acc.m, 0, 0, 0);
     hook(s, 1);
-    if (BAR >= 0 && s >= BAR && s < BAR + 6) loader_issue(ld, 2 * (s - BAR));
+    if (DMA && BAR >= 0 && s >= BAR && s < BAR + 6) loader_issue(ld, 2 * (s - BAR));
     __builtin_amdgcn_sched_barrier(0);
     // ---- gap 2
     acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bh), acc.m, 0, 0, 0);
     hook(s, 2);
     if (s + kPF >= NSTEP) next(s + kPF - NSTEP, 2);
-    if (BAR >= 0 && s >= BAR && s < BAR + 6) loader_issue(ld, 2 * (s - BAR) + 1);
+    if (DMA && BAR >= 0 && s >= BAR && s < BAR + 6) loader_issue(ld, 2 * (s - BAR) + 1);
     __builtin_amdgcn_sched_barrier(0);
   }
 }

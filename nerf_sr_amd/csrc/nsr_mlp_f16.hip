@@ -1017,9 +1017,14 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
       }
     };
     auto next = [&](int k, int g) {   // the last block hands over to the next tile's L1 (bias behind 32 weight pieces)
-      prefetch_next_chunk(nxt, k, g, ld, nb < 3 ? next_bias : 32u * 1024u, h);
+      if (nb < 3 || PERSIST) prefetch_next_chunk(nxt, k, g, ld, nb < 3 ? next_bias : 32u * 1024u, h);
     };
-    if (!TRAIN || nb == 1) block_mma3<18, kBar>(cur, pre, a_seq, ld, c2, b_of, hook, next);
+    // one-tile workgroups fetch nothing behind the last two blocks (the persistent build fetches the next tile's L1 there)
+    constexpr bool kFetch = PERSIST;
+    if (nb >= 2 && !kFetch) {
+      if (!TRAIN) block_mma3<18, kBar, 0, false>(cur, pre, a_seq, ld, c2, b_of, hook, next);
+      else block_mma3<18, kBar, 17, false>(cur, pre, a_seq, ld, c2, b_of, hook, next);
+    } else if (!TRAIN || nb == 1) block_mma3<18, kBar>(cur, pre, a_seq, ld, c2, b_of, hook, next);
     else if (nb == 0) block_mma3<18, kBar, 16>(cur, pre, a_seq, ld, c2, b_of, hook, next);
     else block_mma3<18, kBar, 17>(cur, pre, a_seq, ld, c2, b_of, hook, next);
     pend = cur;

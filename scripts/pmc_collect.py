@@ -1,6 +1,6 @@
-"""Collect the counter constants bench.py quotes (profiles/r3_pmc.json) -- run on the GPU box through gpurun:
+"""Collect the counter constants bench.py quotes (profiles/r4_pmc.json) -- run on the GPU box through gpurun:
 
-    python scripts/pmc_collect.py gpurun_out/r3_pmc.json [precision ...]
+    python scripts/pmc_collect.py gpurun_out/r4_pmc.json [precision ...]
 
 Four separate rocprofv3 --pmc passes (never combined with other trace domains) over scripts/prof_mlp.py <precision> 2, i.e.
 the fine-pass launch forward_rays makes (network + compositing of the tile's own rays; config #2: 190,512 rays x 128
@@ -46,7 +46,7 @@ def run_pass(prec, counters, workdir):
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r3_pmc.json"
+    out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r4_pmc.json"
     precs = sys.argv[2:] or ["f16x3"]
     rep = {"csrc_sha256": nsr_build.source_hash(),
            "how": "scripts/pmc_collect.py: four separate rocprofv3 --pmc passes of scripts/prof_mlp.py (fine-pass launch: 190,512 rays "
