@@ -177,7 +177,7 @@ class NeRFDownXModel:
         out = ops.forward_rays(self.netCoarse, self.netFine if fine else None, rays, opt.N_coarse, opt.N_importance,
                                opt.white_bkgd, opt.lindisp, workspace=workspace, outs=outs)
         tag = "fine" if fine else "coarse"
-        cap = nsr_dist.shard_bounds(n_lr, world)[0]
+        cap = (lo, hi) if lr_range is not None else nsr_dist.shard_bounds(n_lr, world)[0]   # the block the payload is sized by
         if gather == "hr":
             # one row per LR pixel holding its s*s rendered rays: the block structure all_gather_pixels assumes
             local = out[f"{tag}_comp_rgbs"].reshape(hi - lo, s2 * 3)
