@@ -10,6 +10,7 @@
 // registers to LDS; B arrives pre-split.  Optional implicit im2col: the A rows are gathered from an NHWC activation
 // (a K tile of 32 channels never straddles a tap because cin % 32 == 0), so a 3 x 3 convolution needs no col matrix.
 #include <stdlib.h>
+#include <type_traits>
 #include "nsr_gemm.h"
 #include "nsr_gemm_epilogue.h"
 
@@ -138,10 +139,106 @@ __device__ __forceinline__ void epilogue_planes_t(const GemmF16Args& a, f32x16 (
     }
   }
 }
+// The same epilogue for conv_halo_kernel's one-wave-per-SIMD tiles, where nothing else runs while a wave is in it:
+// ReLU and the accumulator scale fixed (every layer that kernel takes: nsr_refine.hip), whole tiles and every column
+// valid (the launch checks), addresses = one scalar base per eight rows + a 32-bit lane offset.
+// Same arithmetic on every element as epilogue_planes_t -- the outputs are bit-identical -- at about a tenth of the code
+// (the general one carries expf / tanhf per element behind run-time branches and 64-bit address arithmetic per store).
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_split_pair(char* ph, char* pl, unsigned off, float c0, float c1) {
+  const f2v c = {c0, c1};
+  const h2v hi = __builtin_convertvector(c, h2v);
+  const f2v r = {c0 - (float)hi[0], c1 - (float)hi[1]};
+  const h2v lo = __builtin_convertvector(r, h2v);
+  *reinterpret_cast<unsigned*>(ph + off) = __builtin_bit_cast(unsigned, hi);
+  *reinterpret_cast<unsigned*>(pl + off) = __builtin_bit_cast(unsigned, lo);
+}
+__device__ __forceinline__ float lane_xor1(float v) {       // the neighbouring lane's value: DPP quad_perm [1, 0, 3, 2], no LDS trip
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+// rows(bi, rq, r0, q): first output row of the eight rows (bi, rq) of this wave (GROUPED: member 0's row) and, GROUPED, the
+// row of the max planes; false = past the end of M.
+// acc(bi, bj): the accumulator block.
+template <int BN, int BM, bool GROUPED, class Acc, class Rows>
+__device__ __forceinline__ void epilogue_planes_relu(const GemmF16Args& a, Acc acc, Rows rows, int n0, int li, int h) {
+  const GemmArgs& g = a.g;
+  const bool odd = li & 1;
+  const unsigned per = GROUPED ? (unsigned)(a.conv.Ho * a.conv.Wo) : 1u;
+  const unsigned rstride = per * (unsigned)g.ldc;                                  // halves from a row / member to the next
+  const unsigned lane_off = ((unsigned)(4 * h + (odd ? 1 : 0)) * rstride + (unsigned)(li & ~1)) * 2u;    // bytes
+  const unsigned pr_off = 4u * rstride;                                            // two rows on, bytes
+  const float scale = g.acc_scale;
+  float bias[BN];
+#pragma unroll
+  for (int bj = 0; bj < BN; ++bj) bias[bj] = g.bias ? g.bias[n0 + 32 * bj + li] : 0.0f;
+#pragma unroll
+  for (int bi = 0; bi < BM; ++bi)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      int64_t r0, q;                                                               // wave-uniform
+      if (!rows(bi, rq, r0, q)) continue;
+      char* const ph = reinterpret_cast<char*>(a.Ch + r0 * g.ldc + n0);
+      char* const pl = ph + a.c_plane * 2;
+      char* const mh = GROUPED ? reinterpret_cast<char*>(a.Mh + q * a.ldm + n0) : nullptr;
+#pragma unroll
+      for (int bj = 0; bj < BN; ++bj) {
+        float x[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = fmaxf(fmaf(acc(bi, bj)[4 * rq + e], scale, bias[bj]), 0.0f);
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const float xa = x[2 * pr], xb = x[2 * pr + 1];
+          const float got = lane_xor1(odd ? xa : xb);
+          store_split_pair(ph, pl, lane_off + (unsigned)pr * pr_off + 64u * bj, odd ? got : xa, odd ? xb : got);
+        }
+        if (GROUPED) {
+          float mx = nsr_max_nan(nsr_max_nan(x[0], x[1]), nsr_max_nan(x[2], x[3]));
+          {
+            // v_permlane32_swap: lanes 32-63 of the first register <-> lanes 0-31 of the second: r0 = the lower half's value in
+            // every lane, r1 = the upper half's; lanes < 32 (which store) combine (own, partner) in epilogue_planes_t's order.
+            // Inline asm: the builtin called with one value for both operands has its two results folded into one (measured:
+            // the max with the partner disappears from the ISA); the nops cover the VALU -> permlane-swap wait states.
+            float r0 = mx, r1 = mx;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(r0), "+v"(r1));
+            mx = nsr_max_nan(r0, r1);
+          }
+          const float nb = lane_xor1(mx);
+          if (h == 0 && !odd) store_split_pair(mh, mh + a.m_plane * 2, (unsigned)li * 2u + 64u * bj, mx, nb);
+        }
+      }
+    }
+}
+
 // the plain instantiation carries none of the grouped-row arithmetic (the K = 32 first layers are epilogue-bound)
 template <int BN, int BM = 2>
 __device__ __forceinline__ void epilogue_planes(const GemmF16Args& a, f32x16 (&acc)[BM][BN], const bool (&col_on)[BN], int64_t m0,
                                                 int n0, int wm, int wn, int li, int h) {
+  const GemmArgs& g = a.g;
+  bool all_on = true;
+#pragma unroll
+  for (int bj = 0; bj < BN; ++bj) all_on = all_on && col_on[bj];
+  const int nw = n0 + 32 * BN * wn;
+  // every refinement layer but the last: ReLU, scaled accumulator, whole column blocks, rows in eights -> the lean epilogue
+  // (wave-uniform choice; the general one stays for the rest and is a tenth as fast per element)
+  if (g.act == kActRelu && g.acc_scale != 0.0f && g.acc_scale != 1.0f && all_on && nw + 32 * BN <= g.n_valid && (g.M % 8) == 0) {
+    const int64_t mrow0 = m0 + 32 * BM * wm;
+    const unsigned per = (unsigned)(a.conv.Ho * a.conv.Wo);
+    auto accf = [&](int bi, int bj) -> const f32x16& { return acc[bi][bj]; };
+    auto rows = [&](int bi, int rq, int64_t& r0, int64_t& q) {
+      r0 = mrow0 + 32 * bi + 8 * rq;
+      if (r0 >= g.M) return false;
+      q = r0 >> 3;
+      if (a.group == 8) {                         // rows 8 q .. 8 q + 7 = one pixel of 8 images (nsr_gemm.h)
+        const unsigned b = (unsigned)q / per;
+        r0 = (int64_t)b * 8 * per + ((unsigned)q - b * per);
+      }
+      return true;
+    };
+    if (a.group == 8) epilogue_planes_relu<BN, BM, true>(a, accf, rows, nw, li, h);
+    else epilogue_planes_relu<BN, BM, false>(a, accf, rows, nw, li, h);
+    return;
+  }
   if (a.group == 8) epilogue_planes_t<BN, BM, true>(a, acc, col_on, m0, n0, wm, wn, li, h);
   else epilogue_planes_t<BN, BM, false>(a, acc, col_on, m0, n0, wm, wn, li, h);
 }
@@ -366,6 +463,262 @@ gemm_f16x3_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA helpers of conv_halo_kernel below (the data movement of the inference MLP kernel, nsr_mlp_f16.hip): one piece =
+// 64 lanes x 16 B, global -> LDS at M0 + 16 lane, counted by vmcnt like any load.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stream_dma_piece(const char* base_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
+  unsigned long long tmp;     // in-statement copy of the base: see nsr_f16x3_core.h (VALU-restored SGPR -> VMEM hazard)
+  asm volatile(
+      "s_mov_b32 m0, %3\n\t"
+      "s_mov_b64 %0, %2\n\t"
+      "global_load_lds_dwordx4 %1, %0"
+      : "=&s"(tmp)
+      : "v"(lane_off), "s"(base_uniform), "s"(lds_dst_uniform)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void stream_vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+__device__ __forceinline__ const u32x4* stream_lds(unsigned byte_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (const u32x4*)(const __attribute__((address_space(3))) u32x4*)(size_t)byte_addr;
+#else
+  (void)byte_addr;
+  return nullptr;
+#endif
+}
+__device__ __forceinline__ h8 stream_h8(const u32x4& v) { return __builtin_bit_cast(h8, v); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stride-1 3 x 3 convolutions with the input patch resident in LDS.
+//
+// The kernels above fetch an activation once per tap: nine times.  At one wave per SIMD and the whole register file as
+// the accumulator (256 x 256 or 512 x 128 outputs per workgroup) that is 21-32 B per CU and clock from L2 with the
+// matrix pipe busy -- more than the chip's L2 delivers (round 4 built that kernel -- B by LDS-DMA ring, A fragments loaded
+// straight from global, bit-identical to the kernel above: with its MFMAs removed it ran only 25 % faster than with
+// them, and it lost to the kernel above on the whole pass, 39.7 vs 38.7 ms; profiles/README.md).  Here a workgroup's outputs are a SPATIAL block (16 x 16 / 16 x 32 pixels of one image; 8 x 4 / 8 x 8
+// pixels of the eight images of a group), the K loop runs channel-chunk-major (16 channels, then the nine taps over
+// them), and the chunk's input patch -- the block plus its one-pixel halo -- sits in LDS, fetched once (1.3-1.9 x the
+// block instead of 9 x) by LDS-DMA one chunk ahead.  A k-step's fragments are then ds_read_b128s of the patch at the tap's
+// offset; B (the weights, shared by the four waves) streams through a 4-slot LDS ring by LDS-DMA, one k-step per slot.
+//
+// Patch layout: an entry = one pixel = 64 B = four 16-B pieces (hi channels 0-7, hi 8-15, lo 0-7, lo 8-15); piece p of
+// entry e sits in slot p ^ ((e >> 2) & 3), so the 16 lanes a ds_read_b128 serves together (16 consecutive entries, or 8
+// images x 2 pixels at an image pitch = 1 mod 4) fall on 16 distinct 16-B bank groups.  Padding pixels are fetched
+// clamped and zeroed in the fragments (every DMA is issued whatever the lane: the publish points count them).
+//
+// Per k-step (tap t of chunk cc), per wave: [patch pieces of chunk cc + 1: taps 0..7] | publish = vmcnt + s_barrier at the
+// middle block | fragments of the next k-step | B pieces of k-step + 3.  In flight at a publish may stay what was issued
+// after the B pieces of k-step + 1 (issued two k-steps back): the previous k-step's patch + B pieces and this one's patch
+// pieces; tap 8 also needs tap 7's patch pieces (older than tap 7's B pieces) for the next chunk's first fragments.
+// ---------------------------------------------------------------------------------------------------------------
+template <int BN, int BM, bool GROUPED>
+struct HaloGeo {
+  static constexpr int NI = GROUPED ? 8 : 1;
+  static constexpr int TW = GROUPED ? 8 : 16, TH = 128 * BM / NI / TW;      // plain: 16 x 16 / 16 x 32; grouped: 8 x 4 / 8 x 8
+  static constexpr int PW = TW + 2, PH = TH + 2;
+  static constexpr int IMG = GROUPED ? PW * PH + (5 - (PW * PH) % 4) % 4 : PW * PH;     // entries per image (grouped: = 1 mod 4)
+  static constexpr int ENTRIES = NI * IMG;
+  static constexpr int PIECES = (ENTRIES * 64 + 1023) / 1024;
+  static constexpr int PP = (PIECES + 3) / 4;        // patch pieces per wave and chunk
+  static constexpr int PPK = (PP + 7) / 8;           // ... per k-step (taps 0..7)
+  static constexpr int PATCH = 4 * PP * 1024;
+  static constexpr int SLOT = BN * 2048;             // B of one k-step: BN column blocks x (hi, lo) x 1 KiB
+  static constexpr int PB = BN / 2;                  // B pieces per wave and k-step
+  static constexpr int ppk(int tap) {                // patch pieces a wave issues in k-step `tap`
+    return (tap < 0 || tap > 7) ? 0 : ((tap + 1) * PPK <= PP ? PPK : (tap * PPK < PP ? PP - tap * PPK : 0));
+  }
+  static constexpr int publish_wait(int tap) { return tap == 8 ? PB : PB + ppk(tap - 1) + ppk(tap); }
+};
+
+template <int BN, int BM, bool GROUPED>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+conv_halo_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
+  using Geo = HaloGeo<BN, BM, GROUPED>;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * Geo::PATCH + 4 * Geo::SLOT];
+  const GemmArgs& g = a.g;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 31, h = lane >> 5;
+  const int64_t bid = xcd_tile(blockIdx.x, n_blocks);
+  if (bid >= n_blocks) return;
+  const int n0 = (int)(bid % n_col_tiles) * (32 * BN);
+  const int64_t st = bid / n_col_tiles;
+  const int Ho = a.conv.Ho, Wo = a.conv.Wo, tiles_x = Wo / Geo::TW, tpi = tiles_x * (Ho / Geo::TH);
+  const int b = (int)(st / tpi), ti = (int)(st % tpi);            // image (group of 8 images) and block within it
+  const int oy0 = (ti / tiles_x) * Geo::TH, ox0 = (ti % tiles_x) * Geo::TW;
+  const int cin = a.conv.cin, ncc = cin / 16, nks = 9 * ncc;
+  const unsigned lds0 = (unsigned)(size_t)((const __attribute__((address_space(3))) unsigned char*)lds);
+  const unsigned ring0 = lds0 + 2u * Geo::PATCH;
+  const unsigned lane16 = (unsigned)lane * 16u;
+
+  // ---- this lane's rows: patch entry under tap (0, 0), and which taps fall inside the image
+  unsigned e0[BM], okm[BM];
+#pragma unroll
+  for (int bi = 0; bi < BM; ++bi) {
+    const int t = 32 * BM * wave + 32 * bi + li;
+    const int dy = GROUPED ? t >> 6 : t >> 4, dx = GROUPED ? (t >> 3) & 7 : t & 15, r = GROUPED ? t & 7 : 0;
+    e0[bi] = (unsigned)(r * Geo::IMG + dy * Geo::PW + dx);
+    unsigned m = 0;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int iy = oy0 + dy + tap / 3 - 1, ix = ox0 + dx + tap % 3 - 1;
+      m |= (iy >= 0 && iy < Ho && ix >= 0 && ix < Wo) ? 1u << tap : 0u;
+    }
+    okm[bi] = m;
+  }
+  // taps under which some row of this wave lies in the padding (most tiles: none): the others skip the zeroing
+  unsigned zt = 0;
+  {
+    unsigned miss = 0;
+#pragma unroll
+    for (int bi = 0; bi < BM; ++bi) miss |= ~okm[bi] & 0x1FFu;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) zt |= __builtin_amdgcn_ballot_w64((miss >> tap) & 1u) != 0 ? 1u << tap : 0u;
+  }
+
+  // ---- patch pieces of this wave: 4 i + wave; byte offset of each lane's 16 B from a.Ah (channel chunk 0)
+  unsigned psrc[Geo::PP];
+#pragma unroll
+  for (int i = 0; i < Geo::PP; ++i) {
+    const int L = (4 * i + wave) * 64 + lane;
+    int e = L >> 2;
+    const int p = (L & 3) ^ ((e >> 2) & 3);
+    e = e < Geo::ENTRIES ? e : Geo::ENTRIES - 1;
+    const int r = e / Geo::IMG;
+    int rem = e - r * Geo::IMG;
+    rem = rem < Geo::PW * Geo::PH ? rem : Geo::PW * Geo::PH - 1;
+    const int py = rem / Geo::PW, px = rem - py * Geo::PW;
+    int iy = oy0 + py - 1, ix = ox0 + px - 1;
+    iy = iy < 0 ? 0 : (iy >= Ho ? Ho - 1 : iy);
+    ix = ix < 0 ? 0 : (ix >= Wo ? Wo - 1 : ix);
+    const int sy = a.conv.up ? iy >> 1 : iy, sx = a.conv.up ? ix >> 1 : ix;
+    const int img = GROUPED ? 8 * b + r : b;
+    const int64_t off = (((int64_t)img * a.conv.Hs + sy) * a.conv.Ws + sx) * g.lda + ((p >> 1) ? a.a_plane : 0) + 8 * (p & 1);
+    psrc[i] = (unsigned)(off * 2);                  // < 2^32: the launch checks
+  }
+  const char* const a_base = reinterpret_cast<const char*>(a.Ah);
+  auto patch_piece = [&](int cc, int i) {           // piece i of this wave for chunk cc (wrapped past the end)
+    const int c = cc >= ncc ? cc - ncc : cc;
+    stream_dma_piece(a_base, psrc[i] + (unsigned)c * 32u, lds0 + (unsigned)(cc & 1) * Geo::PATCH + (unsigned)(4 * i + wave) * 1024u);
+  };
+
+  // ---- B: piece P = PB wave + i of a k-step = column block P / 2, plane P & 1
+  const unsigned b_voff = (unsigned)((li * (int)a.ldbh + 8 * h) * 2);
+  const char* const b_base = reinterpret_cast<const char*>(a.Bh) + (int64_t)n0 * a.ldbh * 2;
+  const int64_t b_lo = (a.Bl - a.Bh) * 2, b_blk = 32 * a.ldbh * 2;
+  auto b_piece = [&](int cc, int tap, int i) {      // k-step (cc, tap), cc possibly one past the end (wraps)
+    const int c = cc >= ncc ? cc - ncc : cc;
+    const int P = Geo::PB * wave + i;
+    const char* src = b_base + (int64_t)(P >> 1) * b_blk + ((P & 1) ? b_lo : 0) + (int64_t)(tap * cin + c * 16) * 2;
+    stream_dma_piece(src, b_voff, ring0 + (unsigned)((cc * 9 + tap) & 3) * Geo::SLOT + (unsigned)P * 1024u);
+  };
+
+  f32x16 acc[BM][1][BN];
+#pragma unroll
+  for (int bi = 0; bi < BM; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < BN; ++bj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[bi][0][bj][r] = 0.0f;
+
+  u32x4 ah[BM], al[BM], bh, bl;
+  auto a_frags = [&](int cc, int tap, u32x4 (&fh)[BM], u32x4 (&fl)[BM]) {
+    const unsigned pbuf = lds0 + (unsigned)(cc & 1) * Geo::PATCH;
+#pragma unroll
+    for (int bi = 0; bi < BM; ++bi) {
+      const unsigned e = e0[bi] + (unsigned)((tap / 3) * Geo::PW + tap % 3);
+      const unsigned ad = pbuf + e * 64u + ((((unsigned)h) ^ ((e >> 2) & 3u)) << 4);
+      fh[bi] = stream_lds(ad)[0];
+      fl[bi] = stream_lds(ad ^ 32u)[0];
+    }
+  };
+
+  // ---- prologue: chunk 0's patch, B of k-steps 0..2, the first publish
+#pragma unroll
+  for (int i = 0; i < Geo::PP; ++i) patch_piece(0, i);
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < Geo::PB; ++i) b_piece(0, k, i);
+  stream_vm_wait<0>();
+  __syncthreads();
+  a_frags(0, 0, ah, al);
+  bh = stream_lds(ring0 + lane16)[0];
+  bl = stream_lds(ring0 + 1024u + lane16)[0];
+
+  auto kstep = [&](auto TAP_c, int cc) {
+    constexpr int tap = decltype(TAP_c)::value;
+    const int ks = cc * 9 + tap;
+    const unsigned slot = ring0 + (unsigned)(ks & 3) * Geo::SLOT, slot_next = ring0 + (unsigned)((ks + 1) & 3) * Geo::SLOT;
+    u32x4 nah[BM], nal[BM];
+    if ((zt >> tap) & 1u) {      // wave-uniform
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int bi = 0; bi < BM; ++bi) {
+        const bool ok = (okm[bi] >> tap) & 1u;
+        ah[bi] = ok ? ah[bi] : zero;
+        al[bi] = ok ? al[bi] : zero;
+      }
+    }
+#pragma unroll
+    for (int bj = 0; bj < BN; ++bj) {
+      if (bj == BN / 2 - 1) {
+#pragma unroll
+        for (int i = 0; i < Geo::ppk(tap); ++i) patch_piece(cc + 1, tap * Geo::PPK + i);
+      }
+      if (bj == BN / 2) {
+        stream_vm_wait<Geo::publish_wait(tap)>();
+        asm volatile("s_barrier" ::: "memory");
+      }
+      const unsigned nxt = (bj < BN - 1 ? slot + (unsigned)(2 * (bj + 1)) * 1024u : slot_next) + lane16;
+      const u32x4 nbh = stream_lds(nxt)[0], nbl = stream_lds(nxt + 1024u)[0];
+      if (bj == BN / 2) {
+        if (tap < 8) a_frags(cc, tap + 1, nah, nal);
+        else a_frags(cc + 1, 0, nah, nal);
+      }
+#pragma unroll
+      for (int bi = 0; bi < BM; ++bi) {
+        acc[bi][0][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(stream_h8(al[bi]), stream_h8(bh), acc[bi][0][bj], 0, 0, 0);   // small terms first
+        acc[bi][0][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(stream_h8(ah[bi]), stream_h8(bl), acc[bi][0][bj], 0, 0, 0);
+        acc[bi][0][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(stream_h8(ah[bi]), stream_h8(bh), acc[bi][0][bj], 0, 0, 0);
+        if (bi == 0 && bj >= BN / 2) b_piece(cc + (tap + 3) / 9, (tap + 3) % 9, bj - BN / 2);
+      }
+      bh = nbh;
+      bl = nbl;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int bi = 0; bi < BM; ++bi) {
+      ah[bi] = nah[bi];
+      al[bi] = nal[bi];
+    }
+  };
+  for (int cc = 0; cc < ncc; ++cc) {
+    kstep(std::integral_constant<int, 0>{}, cc);
+    kstep(std::integral_constant<int, 1>{}, cc);
+    kstep(std::integral_constant<int, 2>{}, cc);
+    kstep(std::integral_constant<int, 3>{}, cc);
+    kstep(std::integral_constant<int, 4>{}, cc);
+    kstep(std::integral_constant<int, 5>{}, cc);
+    kstep(std::integral_constant<int, 6>{}, cc);
+    kstep(std::integral_constant<int, 7>{}, cc);
+    kstep(std::integral_constant<int, 8>{}, cc);
+  }
+  (void)nks;
+  stream_vm_wait<0>();     // the wrapped fetches of the last k-steps
+
+  const unsigned per = (unsigned)(Ho * Wo);
+  epilogue_planes_relu<BN, BM, GROUPED>(a, [&](int bi, int bj) -> const f32x16& { return acc[bi][0][bj]; },
+                                        [&](int bi, int rq, int64_t& r0, int64_t& q) {
+    const int t = 32 * BM * wave + 32 * bi + 8 * rq;           // eight rows: plain 8 pixels along x; grouped one pixel's 8 images
+    const int dy = GROUPED ? t >> 6 : t >> 4, dx = GROUPED ? (t >> 3) & 7 : t & 15;
+    const int64_t pix = (int64_t)(oy0 + dy) * Wo + ox0 + dx;
+    q = (int64_t)b * per + pix;
+    r0 = GROUPED ? (int64_t)b * 8 * per + pix : q;
+    return true;
+  }, n0, li, h);
+}
+
 // (Round 2's LDS-DMA fed variant of this kernel -- pre-split operands streamed global -> LDS into a double-buffered,
 // fragment-ordered image -- was correct and 9 % slower on the refinement pass (48.5 vs 44.5 ms: an LDS-DMA costs the
 // issuing wave 60-180 cycles against a handful for a plain global_load_dwordx4, and this kernel has the registers to
@@ -414,6 +767,54 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   // staging loads, the ds_writes and the two barriers of a K tile but the wave's own instruction order, and the
   // compiler's order does not (the inference kernel gets there with a hand-pinned schedule and an LDS-DMA ring).
   // Numbers and the kernel's description: profiles/r3_refine_tiles.txt.
+  // conv_halo_kernel first: stride-1 3 x 3 gathers from pre-split planes into plane outputs with ReLU, whole 128 / 256
+  // column tiles, whole spatial blocks, 32-bit byte offsets into A (the 8 x 8 decoder layers, the stride-2 layers and the
+  // 3-channel first layers stay on the staged tiles below)
+#ifndef NSR_GEMM_NO_HALO
+  if (a.Ah && a.Ch && a.conv.cin > 0 && a.conv.stride == 1 && (a.conv.cin % 16) == 0 && (g.N % 128) == 0 && g.n_valid == g.N && !g.mask &&
+      !g.col_sums && g.act == kActRelu && g.acc_scale != 0.0f && g.acc_scale != 1.0f && (a.group == 8 || a.group <= 1) &&
+      a.ldbh * 64 < (1 << 30)) {
+    const bool grouped = a.group == 8;
+    const int64_t per_img = (int64_t)a.conv.Ho * a.conv.Wo;
+    const int64_t in_rows = (g.M / per_img) * a.conv.Hs * a.conv.Ws;      // images x source pixels
+    const bool common = (g.M % (per_img * (grouped ? 8 : 1))) == 0 &&
+                        (a.conv.up ? (a.conv.Ho == 2 * a.conv.Hs && a.conv.Wo == 2 * a.conv.Ws) : (a.conv.Ho == a.conv.Hs && a.conv.Wo == a.conv.Ws)) &&
+                        (a.a_plane + in_rows * g.lda) * 2 < ((int64_t)1 << 32);
+    // Shapes (rows x columns of a workgroup): 256 x 256 where N allows it, else 512 x 128 -- the whole register file as the
+    // accumulator; 256 x 128 (half of it) where that wastes fewer CU-rounds: a 16 x 16 decoder layer is 338 of the big tiles,
+    // two rounds of 256 CUs with the second a third full, against three rounds of half-size tiles.
+    const int tw = grouped ? 8 : 16;
+    auto fits = [&](int rows) { const int th = rows / (grouped ? 8 : 1) / tw; return (a.conv.Ho % th) == 0 && (a.conv.Wo % tw) == 0 && (g.M % rows) == 0; };
+    const int n_cu = 256;
+    auto rounds = [&](int64_t blocks) { return (double)((blocks + n_cu - 1) / n_cu); };
+    const bool wide = (g.N % 256) == 0;
+    const int big_rows = wide ? 256 : 512;
+    const bool big_ok = common && fits(big_rows), half_ok = common && fits(256);
+    const int64_t big_blk = (g.M / big_rows) * (g.N / (wide ? 256 : 128)), half_blk = (g.M / 256) * (g.N / 128);
+    // halo or staged is a matter of SHAPE only, never of M: the two sum K in different orders (channel-chunk-major here,
+    // tap-major there), and a batch of one patch must give the bits it gives inside a batch of 256 (tests/test_gpu_refine.py);
+    // the halo shapes among themselves are bit-identical (same k-steps, same order per output element)
+    const bool use_half = half_ok && (!big_ok || 0.5 * 1.05 * rounds(half_blk) < rounds(big_blk));
+    const bool use_big = !use_half && big_ok;
+    if (use_half || use_big) {
+      const int64_t n_blk = use_half ? half_blk : big_blk;
+      const int n_ct = use_half ? g.N / 128 : g.N / (wide ? 256 : 128);
+      const dim3 hgrid((unsigned)(((n_blk + 7) / 8) * 8));
+      if (use_half) {
+        if (grouped) hipLaunchKernelGGL((conv_halo_kernel<4, 2, true>), hgrid, dim3(256), 0, st, a, n_ct, n_blk);
+        else hipLaunchKernelGGL((conv_halo_kernel<4, 2, false>), hgrid, dim3(256), 0, st, a, n_ct, n_blk);
+      } else if (wide) {
+        if (grouped) hipLaunchKernelGGL((conv_halo_kernel<8, 2, true>), hgrid, dim3(256), 0, st, a, n_ct, n_blk);
+        else hipLaunchKernelGGL((conv_halo_kernel<8, 2, false>), hgrid, dim3(256), 0, st, a, n_ct, n_blk);
+      } else {
+        if (grouped) hipLaunchKernelGGL((conv_halo_kernel<4, 4, true>), hgrid, dim3(256), 0, st, a, n_ct, n_blk);
+        else hipLaunchKernelGGL((conv_halo_kernel<4, 4, false>), hgrid, dim3(256), 0, st, a, n_ct, n_blk);
+      }
+      if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
+      return NSR_OK;
+    }
+  }
+#endif
   const int64_t row_tiles = (g.M + kTM - 1) / kTM;
   const bool quad_ok = g.N >= 256 && (g.N % 256) == 0 && a.Ah && a.Ch;
   bool wide = false;                                   // the 8-wave tile: NSR_GEMM_TILE=wide only
