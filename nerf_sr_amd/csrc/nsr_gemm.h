@@ -72,6 +72,11 @@ struct GemmF16Args {
   int group;
   unsigned short* Mh;
   int64_t m_plane, ldm;
+  // STREAM-ORDERED copy of B for conv_halo_kernel (nsr_gemm_f16.hip), or null (then that kernel is not used): 1-KiB units
+  // [column block of 32][k-step = channel chunk cc of 16 x tap: cc * 9 + tap][hi, lo][lane li + 32 h][8 halves], the
+  // halves of a lane = B[32 nb + li][tap * cin + 16 cc + 8 h .. + 8) -- one LDS-DMA piece = one contiguous KiB instead of
+  // 32 rows x 32 B.  Only for conv.cin % 16 == 0 and N % 32 == 0 (no padding columns inside K).
+  const unsigned short* Bs;
 };
 NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st);
 // v = kSplitScale * w[i];  hi[i] = fp16(v), lo[i] = fp16(v - hi[i])   (round to nearest)

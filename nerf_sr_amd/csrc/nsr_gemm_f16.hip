@@ -507,35 +507,63 @@ __device__ __forceinline__ h8 stream_h8(const u32x4& v) { return __builtin_bit_c
 // images x 2 pixels at an image pitch = 1 mod 4) fall on 16 distinct 16-B bank groups.  Padding pixels are fetched
 // clamped and zeroed in the fragments (every DMA is issued whatever the lane: the publish points count them).
 //
-// Per k-step (tap t of chunk cc), per wave: [patch pieces of chunk cc + 1: taps 0..7] | publish = vmcnt + s_barrier at the
-// middle block | fragments of the next k-step | B pieces of k-step + 3.  In flight at a publish may stay what was issued
+// Per k-step (tap t of chunk cc), per wave: [patch pieces of chunk cc + 1: taps 0..7, first half of the blocks] | publish =
+// vmcnt + s_barrier at the middle block | fragments of the next k-step | B pieces of k-step + 3, second half of the blocks.  In flight at a publish may stay what was issued
 // after the B pieces of k-step + 1 (issued two k-steps back): the previous k-step's patch + B pieces and this one's patch
 // pieces; tap 8 also needs tap 7's patch pieces (older than tap 7's B pieces) for the next chunk's first fragments.
 // ---------------------------------------------------------------------------------------------------------------
-template <int BN, int BM, bool GROUPED>
+//
+// Stride 2 (S = 2; the encoder's three down-sampling layers): the block's 3 x 3 footprint is (2 TH + 1) x (2 TW + 1) input
+// pixels, too many to hold twice.  Its rows split by parity -- taps ky = 1 read the TH even rows (region 0), taps ky = 0, 2
+// the TH + 1 odd rows (region 1) -- so a chunk runs the three ky = 1 k-steps first, then the six others, and each region is
+// refilled while the other one is read: the same alternation as the two buffers of stride 1, with phases of 3 and 6
+// k-steps.  Inside a region row the columns are stored even ones first, then the odd ones, so the 16 pixels of a
+// fragment read are again consecutive entries.
+template <int BN, int BM, bool GROUPED, int S>
 struct HaloGeo {
   static constexpr int NI = GROUPED ? 8 : 1;
   static constexpr int TW = GROUPED ? 8 : 16, TH = 128 * BM / NI / TW;      // plain: 16 x 16 / 16 x 32; grouped: 8 x 4 / 8 x 8
-  static constexpr int PW = TW + 2, PH = TH + 2;
-  static constexpr int IMG = GROUPED ? PW * PH + (5 - (PW * PH) % 4) % 4 : PW * PH;     // entries per image (grouped: = 1 mod 4)
-  static constexpr int ENTRIES = NI * IMG;
-  static constexpr int PIECES = (ENTRIES * 64 + 1023) / 1024;
-  static constexpr int PP = (PIECES + 3) / 4;        // patch pieces per wave and chunk
-  static constexpr int PPK = (PP + 7) / 8;           // ... per k-step (taps 0..7)
-  static constexpr int PATCH = 4 * PP * 1024;
+  static constexpr int RW = S == 1 ? TW + 2 : 2 * TW + 1;                  // region width, heights (entries)
+  static constexpr int RH0 = S == 1 ? TH + 2 : TH, RH1 = S == 1 ? TH + 2 : TH + 1;
+  static constexpr int pad1(int x) { return GROUPED ? x + (5 - x % 4) % 4 : x; }      // grouped: image pitch = 1 mod 4
+  static constexpr int IMG0 = pad1(RW * RH0), IMG1 = pad1(RW * RH1);
+  static constexpr int ENT0 = NI * IMG0, ENT1 = NI * IMG1;
+  static constexpr int PP0 = ((ENT0 * 64 + 1023) / 1024 + 3) / 4, PP1 = ((ENT1 * 64 + 1023) / 1024 + 3) / 4;   // pieces per wave
+  static constexpr int PATCH0 = 4 * PP0 * 1024, PATCH1 = 4 * PP1 * 1024;
   static constexpr int SLOT = BN * 2048;             // B of one k-step: BN column blocks x (hi, lo) x 1 KiB
   static constexpr int PB = BN / 2;                  // B pieces per wave and k-step
-  static constexpr int ppk(int tap) {                // patch pieces a wave issues in k-step `tap`
-    return (tap < 0 || tap > 7) ? 0 : ((tap + 1) * PPK <= PP ? PPK : (tap * PPK < PP ? PP - tap * PPK : 0));
+  // k-step j of a chunk: the tap whose weights it uses, the region it reads, the entry offset of its pixel
+  static constexpr int wtap(int j) { return S == 1 ? j : (j < 3 ? 3 + j : (j < 6 ? j - 3 : j)); }
+  static constexpr int region(int j) { return S == 1 ? -1 : (j < 3 ? 0 : 1); }       // -1: the chunk's parity
+  static constexpr int eoff(int j) {
+    const int t = wtap(j), ky = t / 3, kx = t % 3;
+    return S == 1 ? ky * RW + kx : (ky == 2 ? RW : 0) + (kx == 1 ? TW + 1 : (kx == 2 ? 1 : 0));
   }
-  static constexpr int publish_wait(int tap) { return tap == 8 ? PB : PB + ppk(tap - 1) + ppk(tap); }
+  // phases: k-steps [ps, ps + pl) read one region while the other is refilled -- in all k-steps of the phase but the last
+  static constexpr int ps(int j) { return S == 1 ? 0 : (j < 3 ? 0 : 3); }
+  static constexpr int pl(int j) { return S == 1 ? 9 : (j < 3 ? 3 : 6); }
+  static constexpr int fill_pp(int j) { return S == 1 ? PP0 : (j < 3 ? PP1 : PP0); }      // pieces of the region being refilled
+  // ... spread over the first k-steps of the phase only: the region's last piece must have landed by the middle of the
+  // phase's last k-step, and an input that comes from HBM takes 2-3 thousand cycles (1.5-2 k-steps)
+#ifndef NSR_HALO_SPREAD
+#define NSR_HALO_SPREAD 8
+#endif
+  static constexpr int spread(int j) { return S == 1 ? NSR_HALO_SPREAD : (j < 3 ? 1 : 2); }
+  static constexpr int quota(int j) { return (fill_pp(j) + spread(j) - 1) / spread(j); }
+  static constexpr int first(int j) { return (j - ps(j)) * quota(j); }
+  static constexpr int ppk(int j) {                  // patch pieces a wave issues in k-step j
+    if (j < 0 || j > 8 || j == ps(j) + pl(j) - 1) return 0;
+    const int left = fill_pp(j) - first(j);
+    return left <= 0 ? 0 : (left < quota(j) ? left : quota(j));
+  }
+  static constexpr int publish_wait(int j) { return j == ps(j) + pl(j) - 1 ? PB : PB + ppk(j == 0 ? 8 : j - 1) + ppk(j); }
 };
 
-template <int BN, int BM, bool GROUPED>
+template <int BN, int BM, bool GROUPED, int S>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 conv_halo_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
-  using Geo = HaloGeo<BN, BM, GROUPED>;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * Geo::PATCH + 4 * Geo::SLOT];
+  using Geo = HaloGeo<BN, BM, GROUPED, S>;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[Geo::PATCH0 + Geo::PATCH1 + 4 * Geo::SLOT];
   const GemmArgs& g = a.g;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 31, h = lane >> 5;
@@ -544,25 +572,27 @@ conv_halo_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
   const int n0 = (int)(bid % n_col_tiles) * (32 * BN);
   const int64_t st = bid / n_col_tiles;
   const int Ho = a.conv.Ho, Wo = a.conv.Wo, tiles_x = Wo / Geo::TW, tpi = tiles_x * (Ho / Geo::TH);
+  const int Hin = S * Ho, Win = S * Wo;            // input extent in the coordinates the taps address (after the optional x2 upsample)
   const int b = (int)(st / tpi), ti = (int)(st % tpi);            // image (group of 8 images) and block within it
   const int oy0 = (ti / tiles_x) * Geo::TH, ox0 = (ti % tiles_x) * Geo::TW;
-  const int cin = a.conv.cin, ncc = cin / 16, nks = 9 * ncc;
+  const int cin = a.conv.cin, ncc = cin / 16;
   const unsigned lds0 = (unsigned)(size_t)((const __attribute__((address_space(3))) unsigned char*)lds);
-  const unsigned ring0 = lds0 + 2u * Geo::PATCH;
+  const unsigned ring0 = lds0 + (unsigned)(Geo::PATCH0 + Geo::PATCH1);
   const unsigned lane16 = (unsigned)lane * 16u;
 
-  // ---- this lane's rows: patch entry under tap (0, 0), and which taps fall inside the image
-  unsigned e0[BM], okm[BM];
+  // ---- this lane's rows: region entry of its pixel under offset 0, and which taps fall inside the image
+  unsigned e0[2][BM], okm[BM];
 #pragma unroll
   for (int bi = 0; bi < BM; ++bi) {
     const int t = 32 * BM * wave + 32 * bi + li;
     const int dy = GROUPED ? t >> 6 : t >> 4, dx = GROUPED ? (t >> 3) & 7 : t & 15, r = GROUPED ? t & 7 : 0;
-    e0[bi] = (unsigned)(r * Geo::IMG + dy * Geo::PW + dx);
+    e0[0][bi] = (unsigned)(r * Geo::IMG0 + dy * Geo::RW + dx);
+    e0[1][bi] = (unsigned)(r * Geo::IMG1 + dy * Geo::RW + dx);
     unsigned m = 0;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int iy = oy0 + dy + tap / 3 - 1, ix = ox0 + dx + tap % 3 - 1;
-      m |= (iy >= 0 && iy < Ho && ix >= 0 && ix < Wo) ? 1u << tap : 0u;
+      const int iy = S * (oy0 + dy) + tap / 3 - 1, ix = S * (ox0 + dx) + tap % 3 - 1;
+      m |= (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) ? 1u << tap : 0u;
     }
     okm[bi] = m;
   }
@@ -576,41 +606,57 @@ conv_halo_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
     for (int tap = 0; tap < 9; ++tap) zt |= __builtin_amdgcn_ballot_w64((miss >> tap) & 1u) != 0 ? 1u << tap : 0u;
   }
 
-  // ---- patch pieces of this wave: 4 i + wave; byte offset of each lane's 16 B from a.Ah (channel chunk 0)
-  unsigned psrc[Geo::PP];
-#pragma unroll
-  for (int i = 0; i < Geo::PP; ++i) {
+  // ---- patch pieces of this wave: 4 i + wave; byte offset of each lane's 16 B from a.Ah (channel chunk 0).
+  // Stride 1: one geometry for both buffers (psrc1 unused).
+  unsigned psrc0[Geo::PP0], psrc1[S == 1 ? 1 : Geo::PP1];
+  auto piece_src = [&](int reg, int i) {
+    const int IMG = reg ? Geo::IMG1 : Geo::IMG0, ENT = reg ? Geo::ENT1 : Geo::ENT0, RH = reg ? Geo::RH1 : Geo::RH0;
     const int L = (4 * i + wave) * 64 + lane;
     int e = L >> 2;
     const int p = (L & 3) ^ ((e >> 2) & 3);
-    e = e < Geo::ENTRIES ? e : Geo::ENTRIES - 1;
-    const int r = e / Geo::IMG;
-    int rem = e - r * Geo::IMG;
-    rem = rem < Geo::PW * Geo::PH ? rem : Geo::PW * Geo::PH - 1;
-    const int py = rem / Geo::PW, px = rem - py * Geo::PW;
-    int iy = oy0 + py - 1, ix = ox0 + px - 1;
-    iy = iy < 0 ? 0 : (iy >= Ho ? Ho - 1 : iy);
-    ix = ix < 0 ? 0 : (ix >= Wo ? Wo - 1 : ix);
+    e = e < ENT ? e : ENT - 1;
+    const int r = e / IMG;
+    int rem = e - r * IMG;
+    rem = rem < Geo::RW * RH ? rem : Geo::RW * RH - 1;
+    const int py = rem / Geo::RW, px = rem - py * Geo::RW;
+    int iy, ix;
+    if (S == 1) {
+      iy = oy0 + py - 1;
+      ix = ox0 + px - 1;
+    } else {                                        // even columns first, then the odd ones
+      const int c = px <= Geo::TW ? 2 * px : 2 * (px - Geo::TW - 1) + 1;
+      iy = 2 * (oy0 + py) - reg;
+      ix = 2 * ox0 - 1 + c;
+    }
+    iy = iy < 0 ? 0 : (iy >= Hin ? Hin - 1 : iy);
+    ix = ix < 0 ? 0 : (ix >= Win ? Win - 1 : ix);
     const int sy = a.conv.up ? iy >> 1 : iy, sx = a.conv.up ? ix >> 1 : ix;
     const int img = GROUPED ? 8 * b + r : b;
     const int64_t off = (((int64_t)img * a.conv.Hs + sy) * a.conv.Ws + sx) * g.lda + ((p >> 1) ? a.a_plane : 0) + 8 * (p & 1);
-    psrc[i] = (unsigned)(off * 2);                  // < 2^32: the launch checks
+    return (unsigned)(off * 2);                     // < 2^32: the launch checks
+  };
+#pragma unroll
+  for (int i = 0; i < Geo::PP0; ++i) psrc0[i] = piece_src(0, i);
+  if (S == 2) {
+#pragma unroll
+    for (int i = 0; i < Geo::PP1; ++i) psrc1[i] = piece_src(1, i);
   }
   const char* const a_base = reinterpret_cast<const char*>(a.Ah);
-  auto patch_piece = [&](int cc, int i) {           // piece i of this wave for chunk cc (wrapped past the end)
+  // piece i of this wave: channel chunk cc (wrapped past the end) into buffer / region reg
+  auto patch_piece = [&](int reg, int cc, int i) {
     const int c = cc >= ncc ? cc - ncc : cc;
-    stream_dma_piece(a_base, psrc[i] + (unsigned)c * 32u, lds0 + (unsigned)(cc & 1) * Geo::PATCH + (unsigned)(4 * i + wave) * 1024u);
+    const unsigned src = (S == 2 && reg) ? psrc1[S == 1 ? 0 : i] : psrc0[i];
+    stream_dma_piece(a_base, src + (unsigned)c * 32u, lds0 + (unsigned)reg * Geo::PATCH0 + (unsigned)(4 * i + wave) * 1024u);
   };
 
-  // ---- B: piece P = PB wave + i of a k-step = column block P / 2, plane P & 1
-  const unsigned b_voff = (unsigned)((li * (int)a.ldbh + 8 * h) * 2);
-  const char* const b_base = reinterpret_cast<const char*>(a.Bh) + (int64_t)n0 * a.ldbh * 2;
-  const int64_t b_lo = (a.Bl - a.Bh) * 2, b_blk = 32 * a.ldbh * 2;
-  auto b_piece = [&](int cc, int tap, int i) {      // k-step (cc, tap), cc possibly one past the end (wraps)
+  // ---- B: piece P = PB wave + i of a k-step = column block P / 2, plane P & 1 = one contiguous KiB of the stream-ordered
+  // copy (GemmF16Args::Bs: [column block][cc * 9 + tap][plane][lane])
+  const char* const b_base = reinterpret_cast<const char*>(a.Bs) + (int64_t)(n0 / 32) * (9 * ncc) * 2048;
+  auto b_piece = [&](int cc, int j, int tap, int i) {      // k-step j of chunk cc (cc possibly one past the end: wraps), weights of `tap`
     const int c = cc >= ncc ? cc - ncc : cc;
     const int P = Geo::PB * wave + i;
-    const char* src = b_base + (int64_t)(P >> 1) * b_blk + ((P & 1) ? b_lo : 0) + (int64_t)(tap * cin + c * 16) * 2;
-    stream_dma_piece(src, b_voff, ring0 + (unsigned)((cc * 9 + tap) & 3) * Geo::SLOT + (unsigned)P * 1024u);
+    const char* src = b_base + ((int64_t)(P >> 1) * (9 * ncc) + c * 9 + tap) * 2048 + (P & 1) * 1024;
+    stream_dma_piece(src, lane16, ring0 + (unsigned)((cc * 9 + j) & 3) * Geo::SLOT + (unsigned)P * 1024u);
   };
 
   f32x16 acc[BM][1][BN];
@@ -622,33 +668,35 @@ conv_halo_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
       for (int r = 0; r < 16; ++r) acc[bi][0][bj][r] = 0.0f;
 
   u32x4 ah[BM], al[BM], bh, bl;
-  auto a_frags = [&](int cc, int tap, u32x4 (&fh)[BM], u32x4 (&fl)[BM]) {
-    const unsigned pbuf = lds0 + (unsigned)(cc & 1) * Geo::PATCH;
+  auto a_frags = [&](int cc, auto J_c, u32x4 (&fh)[BM], u32x4 (&fl)[BM]) {       // fragments of k-step J of chunk cc
+    constexpr int j = decltype(J_c)::value;
+    constexpr int reg = Geo::region(j);
+    const unsigned pbuf = lds0 + (reg < 0 ? (unsigned)(cc & 1) : (unsigned)reg) * Geo::PATCH0;
 #pragma unroll
     for (int bi = 0; bi < BM; ++bi) {
-      const unsigned e = e0[bi] + (unsigned)((tap / 3) * Geo::PW + tap % 3);
+      const unsigned e = e0[reg > 0 ? 1 : 0][bi] + (unsigned)Geo::eoff(j);
       const unsigned ad = pbuf + e * 64u + ((((unsigned)h) ^ ((e >> 2) & 3u)) << 4);
       fh[bi] = stream_lds(ad)[0];
       fl[bi] = stream_lds(ad ^ 32u)[0];
     }
   };
 
-  // ---- prologue: chunk 0's patch, B of k-steps 0..2, the first publish
+  // ---- prologue: what chunk 0's first phase reads, B of k-steps 0..2, the first publish
 #pragma unroll
-  for (int i = 0; i < Geo::PP; ++i) patch_piece(0, i);
+  for (int i = 0; i < Geo::PP0; ++i) patch_piece(0, 0, i);
 #pragma unroll
   for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int i = 0; i < Geo::PB; ++i) b_piece(0, k, i);
+    for (int i = 0; i < Geo::PB; ++i) b_piece(0, k, Geo::wtap(k), i);
   stream_vm_wait<0>();
   __syncthreads();
-  a_frags(0, 0, ah, al);
+  a_frags(0, std::integral_constant<int, 0>{}, ah, al);
   bh = stream_lds(ring0 + lane16)[0];
   bl = stream_lds(ring0 + 1024u + lane16)[0];
 
-  auto kstep = [&](auto TAP_c, int cc) {
-    constexpr int tap = decltype(TAP_c)::value;
-    const int ks = cc * 9 + tap;
+  auto kstep = [&](auto J_c, int cc) {
+    constexpr int j = decltype(J_c)::value, tap = Geo::wtap(j);
+    const int ks = cc * 9 + j;
     const unsigned slot = ring0 + (unsigned)(ks & 3) * Geo::SLOT, slot_next = ring0 + (unsigned)((ks + 1) & 3) * Geo::SLOT;
     u32x4 nah[BM], nal[BM];
     if ((zt >> tap) & 1u) {      // wave-uniform
@@ -662,26 +710,38 @@ conv_halo_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
     }
 #pragma unroll
     for (int bj = 0; bj < BN; ++bj) {
-      if (bj == BN / 2 - 1) {
+      if (bj < BN / 2) {          // refill of the idle buffer / region: this k-step's pieces, spread over the first blocks
 #pragma unroll
-        for (int i = 0; i < Geo::ppk(tap); ++i) patch_piece(cc + 1, tap * Geo::PPK + i);
+        for (int i = 0; i < Geo::ppk(j); ++i) {
+          if (i % (BN / 2) != bj) continue;
+#ifdef NSR_ABL_HALO_NO_PATCH
+          continue;
+#endif
+          if (S == 1) patch_piece((cc + 1) & 1, cc + 1, Geo::first(j) + i);
+          else if (j < 3) patch_piece(1, cc, Geo::first(j) + i);          // the odd rows of this chunk
+          else patch_piece(0, cc + 1, Geo::first(j) + i);                 // the even rows of the next
+        }
       }
       if (bj == BN / 2) {
-        stream_vm_wait<Geo::publish_wait(tap)>();
+        stream_vm_wait<Geo::publish_wait(j)>();
+#ifndef NSR_ABL_HALO_NO_BARRIER
         asm volatile("s_barrier" ::: "memory");
+#endif
       }
       const unsigned nxt = (bj < BN - 1 ? slot + (unsigned)(2 * (bj + 1)) * 1024u : slot_next) + lane16;
       const u32x4 nbh = stream_lds(nxt)[0], nbl = stream_lds(nxt + 1024u)[0];
       if (bj == BN / 2) {
-        if (tap < 8) a_frags(cc, tap + 1, nah, nal);
-        else a_frags(cc + 1, 0, nah, nal);
+        if (j < 8) a_frags(cc, std::integral_constant<int, (j < 8 ? j + 1 : 0)>{}, nah, nal);
+        else a_frags(cc + 1, std::integral_constant<int, 0>{}, nah, nal);
       }
 #pragma unroll
       for (int bi = 0; bi < BM; ++bi) {
         acc[bi][0][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(stream_h8(al[bi]), stream_h8(bh), acc[bi][0][bj], 0, 0, 0);   // small terms first
         acc[bi][0][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(stream_h8(ah[bi]), stream_h8(bl), acc[bi][0][bj], 0, 0, 0);
         acc[bi][0][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(stream_h8(ah[bi]), stream_h8(bh), acc[bi][0][bj], 0, 0, 0);
-        if (bi == 0 && bj >= BN / 2) b_piece(cc + (tap + 3) / 9, (tap + 3) % 9, bj - BN / 2);
+#ifndef NSR_ABL_HALO_NO_BDMA
+        if (bi == 0 && bj >= BN / 2) b_piece(cc + (j + 3) / 9, (j + 3) % 9, Geo::wtap((j + 3) % 9), bj - BN / 2);
+#endif
       }
       bh = nbh;
       bl = nbl;
@@ -704,9 +764,21 @@ conv_halo_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
     kstep(std::integral_constant<int, 7>{}, cc);
     kstep(std::integral_constant<int, 8>{}, cc);
   }
-  (void)nks;
   stream_vm_wait<0>();     // the wrapped fetches of the last k-steps
 
+#ifdef NSR_ABL_HALO_NO_EPILOGUE     // what the k-steps alone cost: every accumulator stays live, nothing is stored
+  {
+    float sum = 0.0f;
+#pragma unroll
+    for (int bi = 0; bi < BM; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < BN; ++bj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[bi][0][bj][r];
+    if (sum == 12345.678f) a.Ch[0] = 1;
+    return;
+  }
+#endif
   const unsigned per = (unsigned)(Ho * Wo);
   epilogue_planes_relu<BN, BM, GROUPED>(a, [&](int bi, int bj) -> const f32x16& { return acc[bi][0][bj]; },
                                         [&](int bi, int rq, int64_t& r0, int64_t& q) {
@@ -771,25 +843,25 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   // column tiles, whole spatial blocks, 32-bit byte offsets into A (the 8 x 8 decoder layers, the stride-2 layers and the
   // 3-channel first layers stay on the staged tiles below)
 #ifndef NSR_GEMM_NO_HALO
-  if (a.Ah && a.Ch && a.conv.cin > 0 && a.conv.stride == 1 && (a.conv.cin % 16) == 0 && (g.N % 128) == 0 && g.n_valid == g.N && !g.mask &&
-      !g.col_sums && g.act == kActRelu && g.acc_scale != 0.0f && g.acc_scale != 1.0f && (a.group == 8 || a.group <= 1) &&
-      a.ldbh * 64 < (1 << 30)) {
-    const bool grouped = a.group == 8;
+  if (a.Ah && a.Ch && a.Bs && a.conv.cin > 0 && (a.conv.stride == 1 || a.conv.stride == 2) && (a.conv.cin % 16) == 0 && (g.N % 128) == 0 &&
+      g.n_valid == g.N && !g.mask && !g.col_sums && g.act == kActRelu && g.acc_scale != 0.0f && g.acc_scale != 1.0f &&
+      (a.group == 8 || a.group <= 1) && g.K == 9 * a.conv.cin && (reinterpret_cast<uintptr_t>(a.Bs) & 15) == 0) {
+    const bool grouped = a.group == 8, s2 = a.conv.stride == 2;      // stride 2: from 256 input channels (measured: the 128-channel layer is faster staged)
     const int64_t per_img = (int64_t)a.conv.Ho * a.conv.Wo;
     const int64_t in_rows = (g.M / per_img) * a.conv.Hs * a.conv.Ws;      // images x source pixels
-    const bool common = (g.M % (per_img * (grouped ? 8 : 1))) == 0 &&
-                        (a.conv.up ? (a.conv.Ho == 2 * a.conv.Hs && a.conv.Wo == 2 * a.conv.Ws) : (a.conv.Ho == a.conv.Hs && a.conv.Wo == a.conv.Ws)) &&
-                        (a.a_plane + in_rows * g.lda) * 2 < ((int64_t)1 << 32);
-    // Shapes (rows x columns of a workgroup): 256 x 256 where N allows it, else 512 x 128 -- the whole register file as the
-    // accumulator; 256 x 128 (half of it) where that wastes fewer CU-rounds: a 16 x 16 decoder layer is 338 of the big tiles,
-    // two rounds of 256 CUs with the second a third full, against three rounds of half-size tiles.
+    const bool geometry = s2 ? (!a.conv.up && a.conv.Hs == 2 * a.conv.Ho && a.conv.Ws == 2 * a.conv.Wo)
+                             : (a.conv.up ? (a.conv.Ho == 2 * a.conv.Hs && a.conv.Wo == 2 * a.conv.Ws) : (a.conv.Ho == a.conv.Hs && a.conv.Wo == a.conv.Ws));
+    const bool common = (g.M % (per_img * (grouped ? 8 : 1))) == 0 && geometry && (!s2 || a.conv.cin >= 256) && (a.a_plane + in_rows * g.lda) * 2 < ((int64_t)1 << 32);
+    // Shapes (rows x columns of a workgroup): 256 x 256 where N allows it, else 512 x 128 (stride 1) -- the whole register
+    // file as the accumulator; 256 x 128 (half of it) where that wastes fewer CU-rounds: a 16 x 16 decoder layer is 338 of the
+    // big tiles, two rounds of 256 CUs with the second a third full, against three rounds of half-size tiles.
     const int tw = grouped ? 8 : 16;
     auto fits = [&](int rows) { const int th = rows / (grouped ? 8 : 1) / tw; return (a.conv.Ho % th) == 0 && (a.conv.Wo % tw) == 0 && (g.M % rows) == 0; };
     const int n_cu = 256;
     auto rounds = [&](int64_t blocks) { return (double)((blocks + n_cu - 1) / n_cu); };
     const bool wide = (g.N % 256) == 0;
     const int big_rows = wide ? 256 : 512;
-    const bool big_ok = common && fits(big_rows), half_ok = common && fits(256);
+    const bool big_ok = common && fits(big_rows) && (wide || !s2), half_ok = common && fits(256);
     const int64_t big_blk = (g.M / big_rows) * (g.N / (wide ? 256 : 128)), half_blk = (g.M / 256) * (g.N / 128);
     // halo or staged is a matter of SHAPE only, never of M: the two sum K in different orders (channel-chunk-major here,
     // tap-major there), and a batch of one patch must give the bits it gives inside a batch of 256 (tests/test_gpu_refine.py);
@@ -800,16 +872,21 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
       const int64_t n_blk = use_half ? half_blk : big_blk;
       const int n_ct = use_half ? g.N / 128 : g.N / (wide ? 256 : 128);
       const dim3 hgrid((unsigned)(((n_blk + 7) / 8) * 8));
-      if (use_half) {
-        if (grouped) hipLaunchKernelGGL((conv_halo_kernel<4, 2, true>), hgrid, dim3(256), 0, st, a, n_ct, n_blk);
-        else hipLaunchKernelGGL((conv_halo_kernel<4, 2, false>), hgrid, dim3(256), 0, st, a, n_ct, n_blk);
+#define NSR_HALO_LAUNCH(BN_, BM_, S_)                                                                                         \
+  do {                                                                                                                        \
+    if (grouped) hipLaunchKernelGGL((conv_halo_kernel<BN_, BM_, true, S_>), hgrid, dim3(256), 0, st, a, n_ct, n_blk);       \
+    else hipLaunchKernelGGL((conv_halo_kernel<BN_, BM_, false, S_>), hgrid, dim3(256), 0, st, a, n_ct, n_blk);               \
+  } while (0)
+      if (s2) {
+        if (use_half) NSR_HALO_LAUNCH(4, 2, 2); else NSR_HALO_LAUNCH(8, 2, 2);
+      } else if (use_half) {
+        NSR_HALO_LAUNCH(4, 2, 1);
       } else if (wide) {
-        if (grouped) hipLaunchKernelGGL((conv_halo_kernel<8, 2, true>), hgrid, dim3(256), 0, st, a, n_ct, n_blk);
-        else hipLaunchKernelGGL((conv_halo_kernel<8, 2, false>), hgrid, dim3(256), 0, st, a, n_ct, n_blk);
+        NSR_HALO_LAUNCH(8, 2, 1);
       } else {
-        if (grouped) hipLaunchKernelGGL((conv_halo_kernel<4, 4, true>), hgrid, dim3(256), 0, st, a, n_ct, n_blk);
-        else hipLaunchKernelGGL((conv_halo_kernel<4, 4, false>), hgrid, dim3(256), 0, st, a, n_ct, n_blk);
+        NSR_HALO_LAUNCH(4, 4, 1);
       }
+#undef NSR_HALO_LAUNCH
       if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
       return NSR_OK;
     }

@@ -50,7 +50,13 @@ constexpr Layer kLayersV[2][NSR_REFINE_N_LAYERS] = {{
 constexpr int pad32(int n) { return (n + 31) & ~31; }
 constexpr int kpad(int v, int l) { return pad32(9 * kLayersV[v][l].cin); }
 constexpr int npad(int v, int l) { return pad32(kLayersV[v][l].cout); }
-constexpr int64_t layer_floats(int v, int l) { return (int64_t)npad(v, l) * kpad(v, l) + npad(v, l); }   // W' (npad x kpad) | b' (npad)
+// layers conv_halo_kernel can take (nsr_gemm_f16.hip; the shape decides at run time) carry a second, stream-ordered copy of
+// their split weights (GemmF16Args::Bs)
+constexpr bool streamed(int v, int l) {
+  return (kLayersV[v][l].cin % 16) == 0 && (kLayersV[v][l].cout % 128) == 0 && kLayersV[v][l].act == kActRelu && kpad(v, l) == 9 * kLayersV[v][l].cin;
+}
+// W' (npad x kpad) | b' (npad) | stream-ordered W' (same size; streamed layers)
+constexpr int64_t layer_floats(int v, int l) { return (int64_t)npad(v, l) * kpad(v, l) * (streamed(v, l) ? 2 : 1) + npad(v, l); }
 constexpr int64_t layer_offset(int v, int l) { return l == 0 ? 0 : layer_offset(v, l - 1) + layer_floats(v, l - 1); }
 constexpr int64_t pack_floats(int v) { return layer_offset(v, NSR_REFINE_N_LAYERS - 1) + layer_floats(v, NSR_REFINE_N_LAYERS - 1); }
 constexpr float kBnEps = 1e-5f;   // nn.BatchNorm2d default
@@ -96,6 +102,19 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, const float* __res
     }
     dst[idx] = v;
   }
+}
+
+// GemmF16Args::Bs from the packed (hi | lo) planes: one thread per 16 B
+__global__ void stream_order_kernel(const unsigned short* __restrict__ hl, int np, int kp, int cin, unsigned short* __restrict__ dst) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // ((nb * nks + ks) * 2 + plane) * 64 + lane
+  const int nks = kp / 16;
+  if (idx >= (int64_t)(np / 32) * nks * 128) return;
+  const int lane = (int)(idx & 63), plane = (int)((idx >> 6) & 1);
+  const int64_t u = idx >> 7;
+  const int nb = (int)(u / nks), ks = (int)(u % nks), cc = ks / 9, tap = ks % 9;
+  const int n = 32 * nb + (lane & 31), k = tap * cin + 16 * cc + 8 * (lane >> 5);
+  const uint4 v = *reinterpret_cast<const uint4*>(hl + (int64_t)plane * np * kp + (int64_t)n * kp + k);
+  *reinterpret_cast<uint4*>(dst + idx * 8) = v;
 }
 
 // im2col of a 3x3 / pad 1 convolution.  Source: NHWC with row stride `ld` (channels [0, cin) of a possibly wider
@@ -278,6 +297,7 @@ int conv(hipStream_t st, const float* packed, int precision, int v, int l, const
   a.Bh = reinterpret_cast<const unsigned short*>(wp);
   a.Bl = a.Bh + (int64_t)npad(v, l) * kp;
   a.ldbh = kp;
+  if (streamed(v, l)) a.Bs = a.Bh + 2 * ((int64_t)npad(v, l) * kp + npad(v, l));       // behind the bias
   if (implicit) {   // gather from the pre-split NHWC activation
     a.g.A = nullptr;
     a.Ah = hi_of(src);
@@ -350,10 +370,17 @@ int pack_weights(const float* const* t, void* packed, int precision, int v, void
       gamma = t[ti]; beta = t[ti + 1]; mean = t[ti + 2]; var = t[ti + 3];
       ti += 4;
     }
-    const int64_t n = layer_floats(v, l);
+    const int64_t n = (int64_t)npad(v, l) * kpad(v, l) + npad(v, l);
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nsr_stream(stream), w, b, gamma, beta,
                        mean, var, L.cin, L.cout, kpad(v, l), npad(v, l), precision == NSR_F16X3, dst + layer_offset(v, l));
     NSR_CHECK_LAUNCH();
+    if (precision == NSR_F16X3 && streamed(v, l)) {
+      const int64_t np = npad(v, l), kp = kpad(v, l), n16 = np * kp / 4;          // 16-byte pieces of both planes
+      unsigned short* hl = reinterpret_cast<unsigned short*>(dst + layer_offset(v, l));
+      hipLaunchKernelGGL(stream_order_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, nsr_stream(stream), hl, (int)np, (int)kp,
+                         L.cin, hl + 2 * (np * kp + np));
+      NSR_CHECK_LAUNCH();
+    }
   }
   return NSR_OK;
 }
