@@ -47,6 +47,24 @@ def test_refine_patch_64_vs_oracle(net):
     assert net(x[:0].cuda(), c[:0].cuda()).shape == (0, 3, 64, 64)
 
 
+@pytest.mark.parametrize("hw", [(128, 64), (64, 96), (48, 80)])
+def test_refine_other_patch_shapes_vs_oracle(net, hw):
+    """Patches that are not the reference's 64 x 64 square: several spatial blocks per image in x and in y (the LDS-patch
+    convolution kernel tiles an image into 16 x 16 / 16 x 32 / 8 x 4 / 8 x 8 pixel blocks, csrc/nsr_gemm_f16.hip), image
+    borders on some sides of a block only, and (48 x 80) scales whose size is not a multiple of the block -- those layers
+    take the staged kernels, the others the patch kernel, inside one forward pass."""
+    H, W = hw
+    gen = torch.Generator().manual_seed(11 + H)
+    x = torch.rand(1, 3, H, W, generator=gen) * 2 - 1
+    c = torch.rand(1, 8, 3, H, W, generator=gen) * 2 - 1
+    y = net(x.cuda(), c.cuda())
+    want = ro.forward(make_refine_state_dict(7), x, c, dtype=torch.float64)
+    assert float((y.cpu().double() - want).abs().max()) <= TOL
+    # two patch sets in one call: the same bits per patch set (the kernel choice depends on the shape, never on the batch)
+    y2 = net(torch.cat([x, x]).cuda(), torch.cat([c, c]).cuda())
+    assert torch.equal(y2[0], y[0]) and torch.equal(y2[1], y[0])
+
+
 @pytest.mark.parametrize("prec", ["f16x3", "fp32"])
 def test_not_use_ref_vs_reference_fixture_and_oracle(prec, golden_dir):
     """--not_use_ref (Model_VNPCAT_Decoder_NoPooling, networks.py:866-945): fixture from the reference's own module, and
