@@ -310,6 +310,7 @@ def refine_pass(img_wh, downscale, c2w, focal, o, dev, reps: int = 3):
     n_tiles = -(-W // 64) * -(-H // 64)
     flop = 2 * refine.refine_macs(64, 64, 8) * n_tiles
     ms = sum(t_ref) / len(t_ref)
+    busy, busy_src = refine_pmc_busy()
     inside = ((locs[..., 0] >= 0) & (locs[..., 0] < W) & (locs[..., 1] >= 0) & (locs[..., 1] < H)).double().mean()
     return {"what": f"depth warp + {n_tiles} tiles of 64 x 64 with 8 reference patches through the refinement network "
                     "(split-fp16 MFMA, fp32-grade) + stitch, one 800 x 800 frame",
@@ -319,8 +320,28 @@ def refine_pass(img_wh, downscale, c2w, focal, o, dev, reps: int = 3):
             "roofline": {"bound": "mfma", "kernel": "refinement network (implicit-im2col split-fp16 GEMMs)",
                          "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_TFLOPS["f16x3"], "unit": "TFLOP/s",
                          "frac": flop / (ms * 1e-3) / 1e12 / PEAK_TFLOPS["f16x3"], "traffic": None,
-                         "flop_per_pass": flop,
-                         "note": "true convolution MACs x 2; three MFMAs are issued per product (split-fp16)"}}
+                         "flop_per_pass": flop, "mfma_issued": 3 * flop / (ms * 1e-3) / 1e12,
+                         "mfma_busy_time_weighted": busy, "pmc_source": busy_src,
+                         "note": "true convolution MACs x 2; three MFMAs are issued per product (split-fp16); mfma_busy_time_weighted "
+                                 "= SQ_VALU_MFMA_BUSY_CYCLES share of the pass's GEMM kernels weighted by their time, a counter "
+                                 "constant (scripts/pmc_refine.py), null unless pmc_source.matches_this_build"}}
+
+
+def refine_pmc_busy():
+    """Time-weighted matrix-pipe busy share of the refinement pass's GEMM kernels from profiles/r4_refine_pmc.json (rocprofv3
+    --pmc passes, scripts/pmc_refine.py), valid for the build whose source hash it carries."""
+    from nerf_sr_amd import build as nsr_build
+    here = nsr_build.source_hash()
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r4_refine_pmc.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None, {"file": None, "matches_this_build": False}
+    ok = rec.get("csrc_sha256") == here
+    src = {"file": "profiles/r4_refine_pmc.json", "csrc_sha256": rec.get("csrc_sha256"), "this_build_sha256": here, "matches_this_build": ok}
+    ks = [v for k, v in rec.get("kernels", {}).items() if ("gemm" in k or "conv_halo" in k) and v.get("ms_under_pmc", 0) > 0]
+    t = sum(v["ms_under_pmc"] for v in ks)
+    return (sum(v["ms_under_pmc"] * v["mfma_busy"] for v in ks) / t if ok and t > 0 else None), src
 
 
 def main():

@@ -28,7 +28,12 @@ extern "C" {
 #endif
 
 /* precision: NSR_FP32 (explicit im2col + fp32-MFMA GEMM) or NSR_F16X3 (split-fp16 MFMA, products exact to ~2^-21, with
- * implicit im2col: no col matrix is materialised); 0 / NSR_ERR_UNSUPPORTED for anything else */
+ * implicit im2col: no col matrix is materialised); 0 / NSR_ERR_UNSUPPORTED for anything else.
+ * The blob holds, per layer, the folded weights (row-major, K = tap-major), the folded bias and -- for the layers the
+ * LDS-patch convolution kernel can take -- a second, fragment-ordered copy of the weights; its size is
+ * whatever this function returns, the layout is private to the library.
+ * Non-finite values travel as in torch: ReLU keeps NaN, the max over the reference patches propagates it, tanh(NaN) = NaN --
+ * a NaN input pixel comes out as NaN over its receptive field, nothing is masked (there is no status word on this path). */
 size_t nsr_refine_packed_bytes(int precision);
 /* tensors: HOST array of NSR_REFINE_N_TENSORS DEVICE pointers (order above); packed: DEVICE, 16-byte aligned */
 int nsr_refine_pack_weights(const float* const* tensors, void* packed, int precision, void* stream);

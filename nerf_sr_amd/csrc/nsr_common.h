@@ -50,6 +50,8 @@ __device__ __forceinline__ bool nsr_opt_gamma(const NsrTail& t) {
 }
 // torch.max over the reference patches propagates NaN (models/networks.py:980-983); fmaxf drops it
 __device__ __forceinline__ float nsr_max_nan(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
+// torch.relu keeps NaN (networks.py: nn.ReLU after every BatchNorm); fmaxf(NaN, 0) = 0 would hide a diverged feature
+__device__ __forceinline__ float nsr_relu_nan(float x) { return (x < 0.0f) ? 0.0f : x; }
 __device__ __forceinline__ bool nsr_finite(float x) { return fabsf(x) <= 3.402823466e38f; }   // false for inf and NaN
 // --gamma_correct: out_rgbs = pow(out_rgbs, 1 / 2.2) on the per-sample colours (nerf_downX_model.py:271-276)
 __device__ __forceinline__ float nsr_gamma(float c) { return powf(c, 1.0f / 2.2f); }

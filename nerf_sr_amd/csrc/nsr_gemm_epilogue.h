@@ -42,7 +42,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
         for (int e = 0; e < 4; ++e) {
           const int64_t m = mb + 8 * rq + e;
           float x = scaled ? fmaf(acc[bi][bj][4 * rq + e], g.acc_scale, bias) : acc[bi][bj][4 * rq + e] + bias;
-          if (g.act == kActRelu) x = fmaxf(x, 0.0f);
+          if (g.act == kActRelu) x = nsr_relu_nan(x);
           else if (g.act == kActSigmoid) x = 1.0f / (1.0f + expf(-x));
           else if (g.act == kActTanh) x = tanhf(x);
           if (g.mask) x = mk[4 * rq + e] > 0.0f ? x : 0.0f;

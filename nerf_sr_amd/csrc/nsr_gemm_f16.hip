@@ -98,7 +98,7 @@ __device__ __forceinline__ void epilogue_planes_t(const GemmF16Args& a, f32x16 (
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = scaled ? fmaf(acc[bi][bj][4 * rq + e], g.acc_scale, bias) : acc[bi][bj][4 * rq + e] + bias;
-          if (g.act == kActRelu) v = fmaxf(v, 0.0f);
+          if (g.act == kActRelu) v = nsr_relu_nan(v);
           else if (g.act == kActSigmoid) v = 1.0f / (1.0f + expf(-v));
           else if (g.act == kActTanh) v = tanhf(v);
           x[e] = v;
@@ -185,7 +185,7 @@ __device__ __forceinline__ void epilogue_planes_relu(const GemmF16Args& a, Acc a
       for (int bj = 0; bj < BN; ++bj) {
         float x[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] = fmaxf(fmaf(acc(bi, bj)[4 * rq + e], scale, bias[bj]), 0.0f);
+        for (int e = 0; e < 4; ++e) x[e] = nsr_relu_nan(fmaf(acc(bi, bj)[4 * rq + e], scale, bias[bj]));
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
           const float xa = x[2 * pr], xb = x[2 * pr + 1];

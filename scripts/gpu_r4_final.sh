@@ -22,6 +22,8 @@ rec = {"how": "scripts/pmc_train_traffic.sh: separate rocprofv3 --pmc FETCH_SIZE
 json.dump(rec, open("$R/profiles/r4_train_traffic.json", "w"), indent=1); json.dump(rec, open("$R/gpurun_out/r4final/r4_train_traffic.json", "w"), indent=1)
 print("train hbm bytes per step", rec["hbm_bytes_per_step"])
 PY
+timeout 600 python scripts/pmc_refine.py $O/r4_refine_pmc.json > $O/refine_pmc.log 2>&1; tail -2 $O/refine_pmc.log | cut -c1-300 | tee -a $O/summary.txt
+cp $O/r4_refine_pmc.json profiles/r4_refine_pmc.json
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.json | cut -c1-240 | tee -a $O/summary.txt
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o run -- python $R/bench.py --no-cpu-baseline --no-config4 --no-extras > $O/bench_traced.log 2>&1)
 cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv; head -4 $O/kernel_stats.csv | cut -c1-200 | tee -a $O/summary.txt; rm -rf $O/trace
@@ -31,4 +33,3 @@ cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/train_kernel_stats.cs
 timeout 300 python bench.py --config 5 --with-refine --no-cpu-baseline > $O/config5_refine.json 2>> $O/bench.err
 timeout 300 python bench.py --config 3 --no-cpu-baseline > $O/config3.json 2>> $O/bench.err
 timeout 300 python bench.py --precision fp32 --no-cpu-baseline --no-config4 --no-extras > $O/fp32_bench.json 2>> $O/bench.err
-timeout 600 python scripts/pmc_refine.py $O/r4_refine_pmc.json > $O/refine_pmc.log 2>&1; tail -2 $O/refine_pmc.log | cut -c1-300 | tee -a $O/summary.txt

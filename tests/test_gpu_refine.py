@@ -47,6 +47,23 @@ def test_refine_patch_64_vs_oracle(net):
     assert net(x[:0].cuda(), c[:0].cuda()).shape == (0, 3, 64, 64)
 
 
+def test_refine_nan_travels_like_torch(net):
+    """A NaN input pixel (synthesised patch, and one reference patch) poisons exactly the outputs torch poisons: nn.ReLU keeps
+    NaN, torch.max over the reference patches propagates it (networks.py:980-983), tanh(NaN) = NaN.  The epilogues' ReLU
+    was fmaxf (NaN -> 0: a diverged feature came out finite) until round 4."""
+    gen = torch.Generator().manual_seed(21)
+    x = torch.rand(2, 3, 64, 64, generator=gen) * 2 - 1
+    c = torch.rand(2, 8, 3, 64, 64, generator=gen) * 2 - 1
+    x[0, 1, 5, 60] = float("nan")
+    c[1, 3, 2, 40, 7] = float("nan")
+    y = net(x.cuda(), c.cuda()).cpu()
+    want = ro.forward(make_refine_state_dict(7), x, c, dtype=torch.float64)
+    assert bool(torch.isnan(want).any()) and not bool(torch.isnan(want).all())
+    assert torch.equal(torch.isnan(y), torch.isnan(want))
+    ok = ~torch.isnan(want)
+    assert float((y.double() - want)[ok].abs().max()) <= TOL
+
+
 @pytest.mark.parametrize("hw", [(128, 64), (64, 96), (48, 80)])
 def test_refine_other_patch_shapes_vs_oracle(net, hw):
     """Patches that are not the reference's 64 x 64 square: several spatial blocks per image in x and in y (the LDS-patch

@@ -1,4 +1,5 @@
-"""Host-side check of two properties the hand-written inline asm of the f16x3 kernels relies on (no GPU: hipcc -S):
+"""Host-side check of two properties the hand-written inline asm of the f16x3 kernels (the MLP kernels, the training chain,
+the refinement network's conv_halo_kernel) relies on (no GPU: hipcc -S):
 
 1. M0 stays under the asm's control: the LDS-DMA pieces 4q+1..4q+3 reuse the M0 their group's first piece wrote, so no
    other instruction of those kernels may write M0;
@@ -19,7 +20,7 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "nerf_sr_amd", "csrc")
-UNITS = ["nsr_mlp_f16.hip", "nsr_train_chain.hip"]
+UNITS = ["nsr_mlp_f16.hip", "nsr_train_chain.hip", "nsr_gemm_f16.hip"]      # the last: conv_halo_kernel (round 4)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
          "-S", "--cuda-device-only"]
 
