@@ -51,7 +51,19 @@ __device__ __forceinline__ bool nsr_opt_gamma(const NsrTail& t) {
 // torch.max over the reference patches propagates NaN (models/networks.py:980-983); fmaxf drops it
 __device__ __forceinline__ float nsr_max_nan(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
 // torch.relu keeps NaN (networks.py: nn.ReLU after every BatchNorm); fmaxf(NaN, 0) = 0 would hide a diverged feature
-__device__ __forceinline__ float nsr_relu_nan(float x) { return (x < 0.0f) ? 0.0f : x; }
+// (x <= 0: -0.0 becomes +0.0, so the result is +0, positive, +inf or NaN -- see nsr_max_relu)
+#ifdef NSR_ABL_RELU_FMAX   // ablation: what keeping NaN costs (profiles/r4_refine_halo.txt)
+__device__ __forceinline__ float nsr_relu_nan(float x) { return fmaxf(x, 0.0f); }
+#else
+__device__ __forceinline__ float nsr_relu_nan(float x) { return (x <= 0.0f) ? 0.0f : x; }
+#endif
+// NaN-propagating maximum of two nsr_relu_nan results in one instruction: on +0 / positive / +inf the unsigned order of the bit
+// patterns is the numeric order, and a NaN of either sign is above +inf.  (With the general nsr_max_nan the compiler wraps every
+// maximum of the epilogue in an EXEC-mask branch: 4,047 -> 8,089 instructions in conv_halo_kernel's grouped epilogue.)
+__device__ __forceinline__ float nsr_max_relu(float a, float b) {
+  const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+  return __builtin_bit_cast(float, __builtin_elementwise_max(ua, ub));      // v_max_u32
+}
 __device__ __forceinline__ bool nsr_finite(float x) { return fabsf(x) <= 3.402823466e38f; }   // false for inf and NaN
 // --gamma_correct: out_rgbs = pow(out_rgbs, 1 / 2.2) on the per-sample colours (nerf_downX_model.py:271-276)
 __device__ __forceinline__ float nsr_gamma(float c) { return powf(c, 1.0f / 2.2f); }

@@ -193,7 +193,7 @@ __device__ __forceinline__ void epilogue_planes_relu(const GemmF16Args& a, Acc a
           store_split_pair(ph, pl, lane_off + (unsigned)pr * pr_off + 64u * bj, odd ? got : xa, odd ? xb : got);
         }
         if (GROUPED) {
-          float mx = nsr_max_nan(nsr_max_nan(x[0], x[1]), nsr_max_nan(x[2], x[3]));
+          float mx = nsr_max_relu(nsr_max_relu(x[0], x[1]), nsr_max_relu(x[2], x[3]));      // NaN-propagating, like torch.max
           {
             // v_permlane32_swap: lanes 32-63 of the first register <-> lanes 0-31 of the second: r0 = the lower half's value in
             // every lane, r1 = the upper half's; lanes < 32 (which store) combine (own, partner) in epilogue_planes_t's order.
@@ -201,7 +201,7 @@ __device__ __forceinline__ void epilogue_planes_relu(const GemmF16Args& a, Acc a
             // the max with the partner disappears from the ISA); the nops cover the VALU -> permlane-swap wait states.
             float r0 = mx, r1 = mx;
             asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(r0), "+v"(r1));
-            mx = nsr_max_nan(r0, r1);
+            mx = nsr_max_relu(r0, r1);
           }
           const float nb = lane_xor1(mx);
           if (h == 0 && !odd) store_split_pair(mh, mh + a.m_plane * 2, (unsigned)li * 2u + 64u * bj, mx, nb);
