@@ -146,7 +146,7 @@ class NeRFDownXModel:
 
     @torch.no_grad()
     def render_image_sharded(self, c2w, focal: float, ndc: bool, near: float = 0.0, far: float = 1.0, group=None,
-                             lr_range=None, workspace=None, outs=None, gather: str = "lr"):
+                             lr_range=None, workspace=None, outs=None, gather: str = "lr", want_weights: bool = False):
         """One frame rendered by all ranks of ``group`` together (BASELINE config #4): the LR-pixel range
         is cut into contiguous blocks (``dist.shard_bounds``; an LR pixel's s*s sub-rays stay on one GPU), every rank
         GENERATES its own ray block on its device (nothing is scattered), runs the eval-mode ``forward_rays`` on it, and
@@ -162,6 +162,9 @@ class NeRFDownXModel:
             LR-pixel-major, so the gathered buffer IS the (n_lr * s*s, 3) ray-major tensor ``unflatten_reshape`` takes:
             every rank returns ``hr_rgb`` (H, W, 3), and ``lr_rgb`` as the s*s means of the gathered rays (the same
             arithmetic on the same values as the per-block means).  ``lr_depth`` is not part of this exchange.
+        ``want_weights`` (default False): a frame render does not use the per-sample ``weights`` arrays of the reference's
+        8-entry dict; leaving them out saves 195 of the 261 MB the fine-pass launch moves through HBM on config #2
+        (``forward_rays`` itself, the drop-in for the reference's method, still returns all eight).
         ``lr_range`` overrides this rank's block and skips the collective (single-process tests).  Returns the assembled
         arrays plus this rank's own outputs (``local``) and ``bytes_per_rank`` (payload of the collective)."""
         from . import dist as nsr_dist
@@ -175,7 +178,7 @@ class NeRFDownXModel:
         rays = ops.subpixel_rays(c2w, opt.img_wh, focal, s, ndc, near, far, self.device, lr_range=(lo, hi)).view(-1, 8)
         fine = opt.N_importance > 0
         out = ops.forward_rays(self.netCoarse, self.netFine if fine else None, rays, opt.N_coarse, opt.N_importance,
-                               opt.white_bkgd, opt.lindisp, workspace=workspace, outs=outs)
+                               opt.white_bkgd, opt.lindisp, workspace=workspace, outs=outs, want_weights=want_weights)
         tag = "fine" if fine else "coarse"
         cap = (lo, hi) if lr_range is not None else nsr_dist.shard_bounds(n_lr, world)[0]   # the block the payload is sized by
         if gather == "hr":
