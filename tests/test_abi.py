@@ -169,3 +169,31 @@ def test_integration_md_only_names_exported_entry_points(lib):
     declared = set(_declared_symbols())
     for n in named:
         assert n in declared and hasattr(lib, n) and n in _lib.SIGNATURES, f"INTEGRATION.md names {n}, which libnsr does not export"
+
+
+def test_headers_are_plain_c99_and_the_library_links_from_c(lib, tmp_path):
+    """The boundary is a C ABI (include/*.h: `extern "C"`, plain pointers and sizes): the five headers compile as pedantic C99,
+    and a C program linked against libnsr.so -- the way a cgo / JNI / N-API binding would -- calls the size / version / status
+    entry points (no GPU needed for those)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi_link.c"
+    src.write_text('#include <stdio.h>\n'
+                   + "".join(f'#include "{h}"\n' for h in ("nsr.h", "nsr_train.h", "nsr_warp.h", "nsr_refine.h", "nsr_image.h"))
+                   + 'int main(void) {\n'
+                     '  printf("%d %lu %lu %s\\n", nsr_version(), (unsigned long)nsr_packed_weights_bytes(NSR_F16X3),\n'
+                     '         (unsigned long)nsr_refine_packed_bytes(NSR_F16X3), nsr_status_string(NSR_ERR_INVALID_ARG));\n'
+                     '  return nsr_packed_weights_bytes(12345) == 0 ? 0 : 1;\n}\n')
+    exe = tmp_path / "abi_link"
+    libdir = os.path.join(root, "nerf_sr_amd")
+    subprocess.check_call([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-l:libnsr.so", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    ver, mlp_bytes, refine_bytes, msg = out.stdout.strip().split(" ", 3)
+    assert int(ver) == lib.nsr_version() and int(mlp_bytes) == lib.nsr_packed_weights_bytes(_lib.NSR_F16X3)
+    assert int(refine_bytes) == lib.nsr_refine_packed_bytes(_lib.NSR_F16X3) and "invalid argument" in msg
