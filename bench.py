@@ -144,13 +144,16 @@ def committed_pmc(precision: str):
                                  "matches_this_build": ok}
 
 
+TRAIN_TRAFFIC_FILE = os.path.join("profiles", "r5_train_traffic.json")
+
+
 def committed_train_traffic(R):
     """HBM bytes per training step from the committed PMC run (profiles/r4_train_traffic.json, measured at 2,048 rays by
     scripts/pmc_train_traffic.sh): a constant of the build it names (sha256 of the kernel sources), not a measurement of
     this run; None when the sources have changed since."""
     from nerf_sr_amd import build as nsr_build
     try:
-        with open(os.path.join(REPO, "profiles", "r4_train_traffic.json")) as f:
+        with open(os.path.join(REPO, TRAIN_TRAFFIC_FILE)) as f:
             d = json.load(f)
         if d.get("csrc_sha256") != nsr_build.source_hash():
             return None
@@ -219,20 +222,22 @@ def train_bench(args, rank, local, world, steps=None, warmup=None, cpu=True):
                          "note": "algorithmic flops = 3 x 593,408 MAC x 2 per sample point x 192 points per ray"},
             "losses": [float(x) for x in t.losses.tolist()],
         }
-        if args.train_precision == "f16x3" and not os.environ.get("NSR_TRAIN_PATH", "").startswith("g"):
-            # chain path: every product runs on the split-fp16 MFMA and the step is bound by the panels it
-            # moves through HBM.  Rows of 4-byte values per sample point: the forward kernel writes 2,816 (ten
-            # pre-activation panels + the two encodings), the backward chain writes 2,688, the weight-gradient kernels
-            # read 5,696 (each product reads its gradient panel and its input panel once).
-            rows = 2816 + 2688 + 5696
-            gb = 4.0 * rows * R * (N_COARSE + N_COARSE + N_IMPORTANCE) / 1e9
+        if args.train_precision == "f16x3":
+            # chain path: forward and input gradients run on the split-fp16 MFMA, the weight gradients on one
+            # fp16 MFMA per product, and the step is bound by the 2-byte panels it moves through HBM.  Rows of 2-byte values
+            # per sample point: the forward kernel writes 2,560 (ten activation panels + the two encodings), the backward
+            # chain writes 2,432, the weight-gradient kernels read 5,696 (each product reads its gradient panel and its
+            # input panel once); + 4 bytes of sign words per 32 pre-activations, written once and read once.
+            rows = 2560 + 2432 + 5696
+            gb = (2.0 * rows + 2 * 304) * R * (N_COARSE + N_COARSE + N_IMPORTANCE) / 1e9
             # TRUE algorithmic bytes of a step (what any implementation must move): rays + targets in, and per network the
             # weights read and written, the gradients written and read, Adam's two moments read and written (8 x 595,844 x 4 B)
             true_bytes = R * 32 + (R // 4) * 12 + 2 * 8 * 595844 * 4
             traffic = committed_train_traffic(R)
-            res["dtype"] = "f32 results from split-fp16 x3 MFMA products (forward, input and weight gradients; fp32-grade)"
+            res["dtype"] = ("f32 results; forward and input gradients from split-fp16 x3 MFMA products (fp32-grade), weight "
+                            "gradients from fp16 operands (11 bits) on one MFMA per product, fp32 accumulation")
             res["roofline"] = {"bound": "hbm", "kernel": "whole training step, chain path (mlp_f16x3_kernel TRAIN, "
-                                                          "chain_bwd_kernel, wgrad_f16x3_kernel)",
+                                                          "chain_bwd_kernel, wgrad_jobs_kernel)",
                                "achieved": gb / (dt / steps), "peak": 8000.0, "unit": "GB/s",
                                "frac": gb / (dt / steps) / 8000.0, "traffic": traffic,
                                "gbytes_per_step": gb,
@@ -242,11 +247,11 @@ def train_bench(args, rank, local, world, steps=None, warmup=None, cpu=True):
                                "traffic_over_true_algorithmic_bytes": (traffic / true_bytes) if traffic else None,
                                "mfma_frac_on_true_flops": achieved / PEAK_TFLOPS["f16x3"],
                                "mfma_tflops_true": achieved,
-                               "mfma_tflops_issued": 3 * achieved,
-                               "note": "algorithmic bytes = 44,800 B of panel traffic per sample point x 192 points per ray "
+                               "mfma_tflops_issued": achieved * 7.0 / 3.0,
+                               "note": "algorithmic bytes = 21,984 B of panel + sign traffic per sample point x 192 points per ray "
                                        "(split-K partial sums, weight streams and per-ray arrays excluded; traffic = PMC-measured HBM bytes of all kernels "
-                                       "of a step, profiles/r4_train_traffic.json, null if the kernel sources changed since); "
-                                       "mfma_tflops_issued = 3 fp16 MFMAs per product x 3 x the forward MACs"}
+                                       "of a step, " + TRAIN_TRAFFIC_FILE + ", null if the kernel sources changed since); "
+                                       "mfma_tflops_issued = 3 fp16 MFMAs per product in the forward and backward chains, 1 in the weight gradients"}
         if world == 1 and cpu and not args.no_cpu_baseline:
             from oracle import train_oracle as to     # checker/baseline only; never on the product path
             n = 256
@@ -357,7 +362,7 @@ def main():
                     help="render (default): the headline metric; train: one optimize_parameters iteration per step "
                          "(SURVEY §8f N1: forward + backward + Adam, fp32) on a 2,048-ray batch per GPU")
     ap.add_argument("--train-rays", type=int, default=2048, help="rays per GPU per training step (multiple of 4)")
-    ap.add_argument("--train-precision", default="f16x3", choices=["f16x3", "fp32"],
+    ap.add_argument("--train-precision", default="f16x3", choices=["f16x3", "fp32", "f16x3_gemm"],
                     help="training step: forward products on the split-fp16 MFMA (default, fp32-grade) or everything on the fp32 MFMA")
     ap.add_argument("--config", type=int, default=0, choices=[0] + sorted(RENDER_CONFIGS),
                     help="BASELINE.json render configuration; default: #2 (the one the metric is quoted on) at every N, with "

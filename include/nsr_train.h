@@ -11,9 +11,13 @@
  * pass `p.data_ptr()` / `p.grad.data_ptr()` of the reference's own parameters.
  *
  * Arithmetic: fp32 storage and accumulation throughout, like the reference.  precision = NSR_FP32: every contraction on
- * v_mfma_f32_32x32x2_f32, layer by layer.  precision = NSR_F16X3: every contraction (forward, input and weight gradients)
- * on split-fp16 v_mfma_f32_32x32x16_f16 with fp32-grade products (hi/lo operands, three MFMAs per product; gradients
- * scaled by exact powers of two per point / per tensor), the network as two fused chain launches per pass -- DESIGN 7.1.
+ * v_mfma_f32_32x32x2_f32, layer by layer.  precision = NSR_F16X3: the network as two fused chain launches per pass
+ * (DESIGN 7.1): forward pass and input gradients on split-fp16 v_mfma_f32_32x32x16_f16 with fp32-grade products (hi/lo
+ * operands, three MFMAs per product; gradients scaled by exact powers of two per point); the WEIGHT gradients contract
+ * the chain's fp16 `hi` operands (activation and input gradient rounded to 11 bits, one MFMA per product, fp32
+ * accumulation over the sample points: a gradient tensor moves by < 1e-4 of its norm, less than fp32-vs-fp64 of the
+ * reference's own arithmetic).  precision = NSR_F16X3_GEMM: layer-by-layer GEMMs, forward products split-fp16, every
+ * gradient on the fp32 MFMA (round 1's design; the chain path's A/B partner).
  */
 #ifndef NSR_TRAIN_H_
 #define NSR_TRAIN_H_
@@ -24,14 +28,17 @@
 extern "C" {
 #endif
 
+/* A third `precision` value, valid for the training entry points only (nsr_precision in nsr.h holds the others). */
+#define NSR_F16X3_GEMM 18
+
 /* Workspace for one pass over `ray_chunk` rays (activations of one network, gradient buffers, padded weight copies,
- * split-K partials; for NSR_F16X3 the pre-activation / gradient panels, ~35 KB per sample point in all).  0 on invalid
+ * split-K partials; for NSR_F16X3 the activation / gradient panels, ~24 KB per sample point in all).  0 on invalid
  * arguments. */
 size_t nsr_train_workspace_bytes(int64_t ray_chunk, int n_coarse, int n_importance);
-/* The same for the path `precision` selects (what nsr_train_loss_and_grads checks): NSR_F16X3 -> the chain path's panels,
- * sign words and weight streams without the per-layer activation / gradient matrices of the GEMM path (~22 KB per sample
- * point instead of ~33); NSR_FP32 (or NSR_F16X3 under NSR_TRAIN_PATH=gemm) -> the GEMM path's buffers without the panels
- * (~13 KB).  nsr_train_workspace_bytes is the union: sufficient whatever runs. */
+/* The same for the path `precision` selects (what nsr_train_loss_and_grads checks): NSR_F16X3 -> the chain path's 2-byte
+ * panels, sign words and weight streams without the per-layer activation / gradient matrices of the GEMM path (~11 KB per
+ * sample point); NSR_FP32 / NSR_F16X3_GEMM -> the GEMM path's buffers without the panels (~13 KB).
+ * nsr_train_workspace_bytes is the union: sufficient whatever runs.  Both depend on their arguments only. */
 size_t nsr_train_workspace_bytes_for(int precision, int64_t ray_chunk, int n_coarse, int n_importance);
 
 /* Losses and d(loss_tot)/d(weights) of one batch.
@@ -44,9 +51,10 @@ size_t nsr_train_workspace_bytes_for(int precision, int64_t ray_chunk, int n_coa
  * (R, Nc), noise_fine (R, Nc + Ni) standard normal, scaled by noise_std.  NULL selects the deterministic
  * branch of the corresponding stage (randomized = False / noise off).
  * g_coarse / g_fine: 24 gradient tensors each, OVERWRITTEN.
- * precision: NSR_FP32 = every product on the fp32 MFMA; NSR_F16X3 = every product on the split-fp16 MFMA (exact to
- * ~2^-21, the inference path's scheme; the environment variable NSR_TRAIN_PATH=gemm selects round 1's variant of it:
- * per-layer GEMMs, forward products split-fp16, gradients on the fp32 MFMA).
+ * precision: NSR_FP32 = every product on the fp32 MFMA; NSR_F16X3 = the chain kernels (forward and input gradients on the
+ * split-fp16 MFMA, exact to ~2^-21, the inference path's scheme; weight gradients on one fp16 MFMA per product);
+ * NSR_F16X3_GEMM = round 1's variant: per-layer GEMMs, forward products split-fp16, gradients on the fp32 MFMA.  The
+ * path is a function of this argument alone: no environment variable, no process state.
  * ray_chunk: rays per pass (bounds the workspace; multiple of s2; 0 = R); gradients and losses of the passes
  * are accumulated, the result does not depend on the chunking beyond fp32 summation order.  Every pass -- the
  * shorter last one included -- must hold a multiple of 32 sample points in both networks
@@ -72,7 +80,8 @@ int nsr_train_loss_and_grads(const float* const* w_coarse, const float* const* w
  * activation left the fp16 operand range: products degrade to 11 bits) and NSR_FLAG_OUTPUT_NONFINITE into its first word,
  * exactly as the inference entry points do into a packed network's tail (nsr.h).  Nothing is synchronised by the step.
  * nsr_train_status_reset zeroes the block (call it once when the workspace is allocated: the step never clears it);
- * nsr_train_status copies the word to the host (waits for the stream) and optionally clears it.  NSR_FP32 raises nothing. */
+ * nsr_train_status copies the word to the host (waits for the stream) and optionally clears it.  NSR_FP32 and
+ * NSR_F16X3_GEMM raise nothing (the word stays as nsr_train_status_reset left it). */
 int nsr_train_status_reset(void* workspace, void* stream);
 int nsr_train_status(void* workspace, int clear, unsigned* flags_out, void* stream);
 

@@ -18,7 +18,9 @@ NSR_FP32, NSR_BF16, NSR_F16X3, NSR_F16 = 0, 1, 2, 3
 NSR_ERR_RANGE = -5
 # numerics status word of a packed network (include/nsr.h)
 FLAGS = {1: "WEIGHT_RANGE", 2: "INPUT_RANGE", 4: "ACTIVATION_RANGE", 8: "OUTPUT_NONFINITE"}
+NSR_F16X3_GEMM = 18   # include/nsr_train.h: training entry points only
 PRECISIONS = {"fp32": NSR_FP32, "bf16": NSR_BF16, "f16x3": NSR_F16X3, "f16": NSR_F16}
+TRAIN_PRECISIONS = {"fp32": NSR_FP32, "f16x3": NSR_F16X3, "f16x3_gemm": NSR_F16X3_GEMM}
 
 # symbol -> (restype, argtypes); must list every function of include/*.h
 SIGNATURES = {

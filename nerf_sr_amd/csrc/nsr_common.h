@@ -15,10 +15,10 @@
 
 static inline hipStream_t nsr_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Development switches (A/B runs on one box: NSR_GEMM_TILE / NSR_GEMM_TK / NSR_GEMM_FULLN / NSR_REFINE_SEPARATE_MAX /
-// NSR_WGRAD_JOBS) are environment reads, and getenv is not safe against a concurrent setenv: the release library does
-// not contain them (include/nsr.h promises no ambient process state); build with -DNSR_DEV_SWITCHES to get them back.
-// The one documented run-time switch, NSR_TRAIN_PATH (include/nsr_train.h), stays.
+// Development switches (A/B runs on one box: NSR_GEMM_TILE / NSR_GEMM_TK / NSR_GEMM_FULLN / NSR_REFINE_SEPARATE_MAX) are
+// environment reads, and getenv is not safe against a concurrent setenv: the release library does not contain them
+// (include/nsr.h promises no ambient process state; tests/test_abi.py checks that `getenv` is not even imported); build
+// with -DNSR_DEV_SWITCHES to get them back.  The training step's path is an argument (NSR_F16X3_GEMM, include/nsr_train.h).
 #ifdef NSR_DEV_SWITCHES
 static inline const char* nsr_dev_env(const char* name) { return getenv(name); }
 #else

@@ -4,6 +4,7 @@
 #pragma once
 #include "nsr_common.h"
 #include "nsr_mlp_layout.h"
+#include "nsr_panels.h"
 
 using namespace nsr;
 using namespace nsr::hx;
@@ -375,57 +376,50 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
 }
 
 // ---------------------------------------------------------------------------
-// Training panels.  The chain kernels of the training step (the TRAIN instantiation of the inference kernel and
-// nsr_train_chain.hip) keep per-layer tensors as "blocked transposed" panels: [group of 32 points][feature][32 points]
-// floats.  The 32 points of a wave are one group, so an accumulator register -- one feature of 32 points per lane half
-// -- goes out as one dword store that fills two whole 128 B lines, and the 32 features of an output block sit within
-// the 4 KiB the instruction's immediate offset reaches (one scalar base per block).  The weight-gradient GEMM reads
-// the same panels as K-contiguous operands (nsr_gemm.h, a_blk / b_blk).
-// A panel set is twelve panels back to back: 0..7 = trunk layers 1..8, 8 = xyz_encoding_final, 9 = dir_encoding (128
-// rows); forward sets only: 10 = the encoded position (64 rows: register t of lane half h in row t + 32 h, i.e. column
-// pecol(t, h) of the 63), 11 = the encoded direction (64 rows of which 32 are written: row t + 16 h = column
-// dircol(t, h) of the 27; the rest pads the panel to the weight-gradient kernel's narrowest tile), both at true scale.
+// Training panels (round 5: 2 bytes per value).  The chain kernels of the training step (the TRAIN instantiation of the
+// inference kernel and nsr_train_chain.hip) keep, per layer, exactly what the weight-gradient contraction
+//     dW_l = sum over the points of  dz_l (x) a_{l-1}
+// needs of them: the fp16 `hi` operand registers they have already made for their own next layer -- the activation
+// a = relu(z) (forward) and the masked input gradient x * phi (backward; phi = the point's power-of-two operand scale).
+// One 32-feature output block of a wave's 32 points is two "units" of 1 KiB (64 lanes x 16 B): unit u = the packed pairs
+// 4u .. 4u+3 of the block = the u32x4 that is k-step 2 nb + u of the consuming layer's B operand; lane (m, h) holds, for
+// point m, the block's features 16u + 4h + {0..3} (first 8 bytes) and 16u + 8 + 4h + {0..3} (second 8 bytes).
+// A unit leaves as ONE global_store_dwordx4 per lane (2 stores per block instead of the 16 dword stores of the fp32
+// panels of rounds 2-4: the chain kernels were store-ISSUE bound), into slot ((2m + h) ^ 8u) of the unit -- a full,
+// contiguous KiB per wave instruction, permuted so that the weight-gradient kernel's LDS image of it (a plain LDS-DMA copy)
+// is read conflict-free by ds_read_b64_tr_b16 (nsr_wgrad_f16.hip: the transposing read turns [point][4 features] into the
+// MFMA operand's [feature][4 points]; feature 16u + l of the block arrives in lane l of a 16-lane group, natural order).
+// A panel set is twelve panels back to back, panel-major: 0..7 = trunk layers 1..8, 8 = xyz_encoding_final (no relu),
+// 9 = dir_encoding (128 rows); forward sets only: 10 = the encoded position (64 rows), 11 = the encoded direction (64 rows,
+// 32 of them zero); row order of the two encodings: enc_row() below.  Per sample point 2,560 rows x 2 B = 5 KiB forward,
+// 2,432 x 2 B backward (rounds 2-4: 11.3 + 10.8 KB).
 // ---------------------------------------------------------------------------
-constexpr int64_t kPanelGroupFloats = 256 * 32;   // a 256-row panel's stride between point groups
-__device__ __host__ __forceinline__ int panel_rows(int panel) { return panel < 9 ? 256 : (panel == 9 ? 128 : 64); }
-__device__ __host__ __forceinline__ int64_t panel_offset(int64_t n_groups, int panel) {   // floats
-  const int64_t rows_before = panel <= 9 ? 256 * (int64_t)panel : (panel == 10 ? 2304 + 128 : (panel == 11 ? 2304 + 192 : 2304 + 256));
-  return rows_before * 32 * n_groups;
-}
-__device__ __host__ __forceinline__ int64_t panel_set_floats(int64_t n_groups) { return panel_offset(n_groups, 12); }
 struct PanelRef {
-  float* base;        // panel set
+  char* base;         // panel set
   int64_t n_groups;   // ceil(P / 128) * 4
   int64_t group;      // this wave's point group (wave-uniform)
   unsigned* sgn;      // sign panels (see below)
 };
-// first float of output block `blk` of `panel` for this wave's points
-__device__ __forceinline__ float* panel_block(const PanelRef& t, int panel, int blk) {
-  return t.base + panel_offset(t.n_groups, panel) + (t.group * panel_rows(panel) + 32 * blk) * 32;
+// first byte of output block `blk` of `panel` for this wave's points (its two units follow each other)
+__device__ __forceinline__ const char* panel_block(const PanelRef& t, int panel, int blk) {
+  return t.base + panel_offset_bytes(t.n_groups, panel) + (t.group * panel_rows(panel) + 32 * blk) * kPanelRowBytes;
 }
-// accumulator register R of a lane (m, h) holds feature 8 (R >> 2) + (R & 3) + 4 h of the block; voff = 4 (m + 128 h) bytes
-// cache policy of the panel stores: write-once streams far larger than the caches, so non-temporal (same box, 2,048-ray
-// training step: default policy 7.51-7.54 ms, "sc0 sc1" 7.38 ms, "nt" 6.50 ms)
+// this lane's byte offset inside unit U (0 / 1) of a block: slot (2m + h) ^ 8U
+__device__ __forceinline__ unsigned unit_voff(int m, int h, int u) { return 16u * (unsigned)((2 * m + h) ^ (8 * u)); }
+// cache policy of the panel stores: write-once streams far larger than the caches, so non-temporal (round 2, same box,
+// 2,048-ray training step: default policy 7.51-7.54 ms, "sc0 sc1" 7.38 ms, "nt" 6.50 ms)
 #ifndef NSR_PANEL_STORE_POLICY
 #define NSR_PANEL_STORE_POLICY " nt"
 #endif
-template <int R>
-__device__ __forceinline__ void panel_store_r(float v, const float* blk, unsigned voff) {
-  // base through an in-statement SALU copy: see glds16_asm (VALU-restored SGPR -> VMEM hazard behind inline asm)
-  unsigned long long tmp;
-  asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0 offset:%4" NSR_PANEL_STORE_POLICY : "=&s"(tmp) : "v"(voff), "v"(v), "s"(blk), "n"((8 * (R >> 2) + (R & 3)) * 128) : "memory");
-}
-__device__ __forceinline__ void panel_store(int r, const Acc& p, const float* blk, unsigned voff) {
+// unit U of the block at `blk`: v = the four packed pairs, voff = unit_voff(m, h, U)
+template <int U>
+__device__ __forceinline__ void unit_store(const u32x4& v, const char* blk, unsigned voff) {
 #ifdef NSR_ABL_FWD_NO_STORE   // ablation (scripts/): how much of the TRAIN forward kernel is its panel writes
   if (voff != 0xffffffffu) return;
 #endif
-  switch (r) {
-#define NSR_PS(R) case R: panel_store_r<R>(p.m[R], blk, voff); break;
-    NSR_PS(0) NSR_PS(1) NSR_PS(2) NSR_PS(3) NSR_PS(4) NSR_PS(5) NSR_PS(6) NSR_PS(7)
-    NSR_PS(8) NSR_PS(9) NSR_PS(10) NSR_PS(11) NSR_PS(12) NSR_PS(13) NSR_PS(14) NSR_PS(15)
-#undef NSR_PS
-    default: break;
-  }
+  // base through an in-statement SALU copy: see glds16_asm (VALU-restored SGPR -> VMEM hazard behind inline asm)
+  unsigned long long tmp;
+  asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx4 %1, %2, %0 offset:%4" NSR_PANEL_STORE_POLICY : "=&s"(tmp) : "v"(voff), "v"(v), "s"(blk), "n"(U * 1024) : "memory");
 }
 
 // Sign panels: one bit per pre-activation ([z < 0], i.e. "the ReLU zeroes it"; +0.0 counts as active), the only thing the
@@ -443,22 +437,4 @@ __device__ __forceinline__ void sign_push(unsigned& bits, float v) {
 __device__ __forceinline__ void sign_store(unsigned bits, const unsigned* blk, unsigned lane4) {
   unsigned long long tmp;
   asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0" : "=&s"(tmp) : "v"(lane4), "v"(bits), "s"(blk) : "memory");
-}
-
-// value v of this lane into row T (0..31) of a panel block: row pitch 128 B, voff = this lane's byte offset inside the block
-template <int T>
-__device__ __forceinline__ void row_store_t(float v, const float* blk, unsigned voff) {
-  unsigned long long tmp;
-  asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dword %1, %2, %0 offset:%4" NSR_PANEL_STORE_POLICY : "=&s"(tmp) : "v"(voff), "v"(v), "s"(blk), "n"(T * 128) : "memory");
-}
-__device__ __forceinline__ void row_store(int t, float v, const float* blk, unsigned voff) {
-  switch (t) {
-#define NSR_RS(T) case T: row_store_t<T>(v, blk, voff); break;
-    NSR_RS(0) NSR_RS(1) NSR_RS(2) NSR_RS(3) NSR_RS(4) NSR_RS(5) NSR_RS(6) NSR_RS(7)
-    NSR_RS(8) NSR_RS(9) NSR_RS(10) NSR_RS(11) NSR_RS(12) NSR_RS(13) NSR_RS(14) NSR_RS(15)
-    NSR_RS(16) NSR_RS(17) NSR_RS(18) NSR_RS(19) NSR_RS(20) NSR_RS(21) NSR_RS(22) NSR_RS(23)
-    NSR_RS(24) NSR_RS(25) NSR_RS(26) NSR_RS(27) NSR_RS(28) NSR_RS(29) NSR_RS(30) NSR_RS(31)
-#undef NSR_RS
-    default: break;
-  }
 }

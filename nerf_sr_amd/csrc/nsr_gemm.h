@@ -82,27 +82,23 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st);
 // v = kSplitScale * w[i];  hi[i] = fp16(v), lo[i] = fp16(v - hi[i])   (round to nearest)
 NSR_INTERNAL int split_f16(const float* w, int64_t n, unsigned short* hi, unsigned short* lo, hipStream_t st);
 
-// ---- weight gradient from two training panels on the split-fp16 MFMA (nsr_wgrad_f16.hip): partial[z] (M x 256) =
-// out_scale * sum over slice z of the points of A[p][0..M) max(B[p][0..256), lower)^T, M = 256 or 128, both operands
-// "blocked transposed" fp32 panels (nsr_f16x3_core.h).  A is pre-scaled by a power of two derived from *a_max_bits
-// (float bits of the panel's largest magnitude, device memory); the scale is removed again before the store.
+// ---- weight gradient from two training panels on the fp16 MFMA (nsr_wgrad_f16.hip): partial[z] (M x N) =
+// sum over slice z of the points of A[p][0..M) B[p][0..N)^T, M = 256 or 128, N = 256 or 64, both operands 2-byte panels
+// in the chain kernels' unit layout (nsr_f16x3_core.h).  A's stored values x a_pscale[p] (a power of two per point) are the
+// true gradients; they are brought into fp16's range by a further power of two derived from *a_max_bits (float bits of the
+// panel's largest true magnitude, device memory), removed again before the store.
 struct WgradArgs {
-  const float* A; int64_t a_gstride; int M;   // gradient panel, floats between two point groups (32 M)
-  const float* B; int64_t b_gstride; int N;   // forward panel (N = 256)
-  int b_relu;
-  int64_t P;                                  // points, multiple of 32
+  const void* A; int64_t a_gbytes; int M;     // gradient panel, bytes between two point groups (64 M)
+  const void* B; int64_t b_gbytes; int N;     // forward panel (64 N)
   const unsigned* a_max_bits;
-  const float* a_pscale;                      // may be null: per point, A's stored values x a_pscale = the true values
-  float out_scale;
-  float* partial; int64_t split_stride; int splits;
-  float* row_sums;                            // may be null: (splits, M) sums of A's rows over the slice (fp32, true scale)
+  const float* a_pscale;                      // (points): A's stored values x a_pscale = the true values
+  float* partial; int64_t split_stride;       // slot s of the product: partial + s * split_stride (M x N floats)
+  float* row_sums;                            // may be null: slot s at row_sums + s * M: sums of A's rows over the slice (true scale)
 };
-NSR_INTERNAL int wgrad_f16x3(const WgradArgs& w, hipStream_t st);
 
-// All products of one network pass as ONE launch (nsr_wgrad_f16.hip, wgrad_jobs_kernel).  Fill j[0..n).w (P, splits and
-// of the entries are ignored: every product has jobs.n_groups point groups; slot s of product p is the M x N tile at
-// w.partial + s * w.split_stride, its row sums at w.row_sums + s * M), call wgrad_jobs_plan, hand out the partial /
-// row-sum slots (n_slots of each job), launch with the workgroup count the plan returned.
+// All products of one network pass as ONE launch (nsr_wgrad_f16.hip, wgrad_jobs_kernel).  Fill j[0..n).w (every product
+// has jobs.n_groups point groups), call wgrad_jobs_plan, hand out the partial / row-sum slots (n_slots of each job),
+// launch with the workgroup count the plan returned.
 struct WgradJob {
   WgradArgs w;
   int64_t cost0;      // start of the product in the work list (plan)
@@ -117,6 +113,6 @@ struct WgradJobs {
   int64_t n_groups, total_cost, per_wg;
 };
 NSR_INTERNAL int wgrad_jobs_plan(WgradJobs& jobs, int64_t P, int n_wg);
-NSR_INTERNAL int wgrad_jobs_f16x3(const WgradJobs& jobs, int n_wg, hipStream_t st);
+NSR_INTERNAL int wgrad_jobs_f16(const WgradJobs& jobs, int n_wg, hipStream_t st);
 
 }  // namespace nsr

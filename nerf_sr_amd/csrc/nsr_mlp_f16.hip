@@ -279,6 +279,33 @@ __device__ __forceinline__ void rgb_gap(int s, int g, const Acc& p, const float*
 }
 
 
+// TRAIN: vector-memory operations a block issues behind its last DMA piece (two unit stores + the sign word)
+constexpr int kTrainYoung = 3;
+// TRAIN: dir_encoding's blocks feed the colour head from their fp32 accumulators (rgb_gap), so nothing makes their fp16
+// operand form -- but the colour head's weight gradient wants it like any other layer's input: hi of pair P = RNE_f16 of
+// relu(acc) / 64, the re-split's first half
+template <int P>
+__device__ __forceinline__ void relu_hi_pair(const Acc& p, u32x4& d0, u32x4& d1) {
+  float x0, x1;
+  unsigned hi;
+  asm volatile(
+      "v_max_f32 %0, %3, 0\n\t"
+      "v_max_f32 %1, %4, 0\n\t"
+      "v_cvt_pk_f16_f32 %2, %0, %1\n\t"
+      "v_pk_sub_u16 %2, %2, %5 clamp"
+      : "=&v"(x0), "=&v"(x1), "=&v"(hi)
+      : "v"(p.m[2 * P]), "v"(p.m[2 * P + 1]), "v"(0x18001800u));
+  put<P>(hi, d0, d1);
+}
+__device__ __forceinline__ void relu_hi_step(int P, const Acc& p, u32x4& d0, u32x4& d1) {
+  switch (P) {
+#define NSR_RH(Q) case Q: relu_hi_pair<Q>(p, d0, d1); break;
+    NSR_RH(0) NSR_RH(1) NSR_RH(2) NSR_RH(3) NSR_RH(4) NSR_RH(5) NSR_RH(6) NSR_RH(7)
+#undef NSR_RH
+    default: break;
+  }
+}
+
 constexpr int kConvStep0 = 6;   // colour head: pending dir block is consumed in k-steps 6..13 (one pair each)
 
 // prefetch of the NEXT chunk (sequence position j+1) during the last three k-steps of chunk j
@@ -511,19 +538,19 @@ __device__ __forceinline__ void enc_all(Enc& e, const EncIn& in) {
 // finished last (block 7 of the previous layer on entry; block 7 of this layer on exit): it is
 // activated and re-split in the MFMA shadow of the FOLLOWING block's k-steps 0..13.  `pre` carries the
 // prefetched head of the next chunk across chunk (and layer) boundaries.
-// TRAIN: the pending block's raw accumulators (64 x the pre-activation) are also written to the training panels
-// (panel L - 1 holds trunk layer L's output, see nsr_f16x3_core.h): 16 dword stores in k-steps 14 and 15 (+ the block's
-// sign word), i.e. BEHIND the chunk's last DMA piece (k-step 13).  Vector-memory operations complete in issue order, so
-// the next publish point -- which must see that DMA landed -- may leave those 17 stores in flight (block_mma's YOUNGER);
-// they have a whole further chunk to reach HBM.  (Spread over k-steps 8..15 and covered by the publish point's
-// vmcnt(0), they stalled the wave on write latency every chunk.)
+// TRAIN: the pending block's fp16 `hi` operand registers -- the activation the next layer multiplies, which is also the
+// operand of the weight gradients -- are written to the training panels (panel L - 1 holds trunk layer L's output, see
+// nsr_f16x3_core.h): its two units as two 16-byte stores in k-steps 14 and 15 (+ the block's sign word), i.e. BEHIND the
+// chunk's last DMA piece (k-step 13).  Vector-memory operations complete in issue order, so the next publish point --
+// which must see that DMA landed -- may leave those 3 stores in flight (block_mma's YOUNGER); they have a whole further
+// chunk to reach HBM.  (Rounds 2-4 stored the sixteen raw fp32 accumulators of a block here.)
 // ENC: the layer's gap-0 slots also carry encoding pieces of the next tile's point: 1 (L8) = the loads (piece 0) in the
 // last chunk, 2 (xyz_encoding_final) = slots 16 nb + s of the piece schedule (enc_slot).
 template <bool RELU_OUT, bool TRAIN = false, int ENC = 0>   // relu on L2..L8 (true), none on xyz_encoding_final (L == 8: false)
 __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[16], u32x4 (&oh)[16], u32x4 (&ol)[16],
                                             const u32x4* stash, Loader& ld, int h, Acc& pend, Pre& pre,
                                             const ChunkRef& after0, const ChunkRef& after1, float& amax,
-                                            const PanelRef& tr = PanelRef{}, unsigned voff = 0, Enc* enc = nullptr,
+                                            const PanelRef& tr = PanelRef{}, unsigned voff0 = 0, unsigned voff1 = 0, Enc* enc = nullptr,
                                             const EncIn* ein = nullptr
 #ifdef NSR_ABL_TIMELINE
                                             , unsigned long long* ld_tk_buf = nullptr
@@ -569,7 +596,7 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
       }
       a_addr += 8 * 1024;
     }
-    block_mma3<16, kBar, (TRAIN ? 17 : 0)>(
+    block_mma3<16, kBar, (TRAIN ? kTrainYoung : 0)>(
         cur, pre, a_addr, ld, c2, [&](int s, int part) -> u32x4 { return part ? bl[s] : bh[s]; },
         [&](int s, int g) {
           if (ENC == 1 && g == 0 && nb == 7 && s == 0) enc_piece(0, 2, *enc, *ein);
@@ -581,10 +608,14 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
           else
             pending_gap<RELU_OUT>(s, g, pend, ptmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1], amax);
           if (TRAIN && s >= 8 && g == 2) {
-            const float* blk = (nb == 0) ? panel_block(tr, L - 1, 7) : panel_block(tr, L, nb - 1);
-            if (s >= 14) {
-#pragma unroll
-              for (int r = 0; r < 8; ++r) panel_store(8 * (s - 14) + r, pend, blk, voff);
+            const char* blk = (nb == 0) ? panel_block(tr, L - 1, 7) : panel_block(tr, L, nb - 1);
+            // the pending block's hi registers were finished in k-step 7 (half-step 15)
+            if (nb == 0) {
+              if (s == 14) unit_store<0>(bh[14], blk, voff0);
+              if (s == 15) unit_store<1>(bh[15], blk, voff1);
+            } else {
+              if (s == 14) unit_store<0>(oh[2 * nb - 2], blk, voff0);
+              if (s == 15) unit_store<1>(oh[2 * nb - 1], blk, voff1);
             }
             sign_push(sbits, pend.m[2 * (s - 8)]);
             sign_push(sbits, pend.m[2 * (s - 8) + 1]);
@@ -687,7 +718,9 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   const int64_t n_tiles = (P + 127) / 128;
   const int samples = (NS > 0) ? NS : N;
   const bool gamma = !TRAIN && nsr_opt_gamma(tail);
-  const unsigned voff = 4u * (unsigned)(m + 128 * h);   // panel stores: point m of the group, lane half h = 4 rows on
+  // (the inference instantiations never use them; their voff0 is the expression rounds 2-4 had here, which keeps the register
+  // allocation -- and with it the whole ISA of those kernels -- bit-identical to the measured round-4 build)
+  const unsigned voff0 = TRAIN ? unit_voff(m, h, 0) : 4u * (unsigned)(m + 128 * h), voff1 = TRAIN ? unit_voff(m, h, 1) : 0u;   // panel stores: this lane's slot in either unit of a block
   // the wave's stash of the split position encoding: L5 (skip) re-reads it, which frees 32 registers in the loop
   u32x4* stash = reinterpret_cast<u32x4*>(ring + kStash0) + wave * 8 * 64 + lane;
   u32x4 deh[2], del[2];
@@ -735,7 +768,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   const int64_t pc = p < P ? p : P - 1;
   PanelRef tr{};
   if (TRAIN) {
-    tr.base = pan;
+    tr.base = reinterpret_cast<char*>(pan);
     tr.n_groups = n_tiles * 4;
     tr.group = tile * 4 + wave;
     tr.sgn = sgn;
@@ -827,14 +860,19 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   }
 
 
-  if (TRAIN) {   // the encodings themselves: operands of the weight gradients of L1, L5 (skip part) and dir_encoding
-    const float* pblk = tr.base + panel_offset(tr.n_groups, 10) + tr.group * (64 * 32);
-    const float* dblk = tr.base + panel_offset(tr.n_groups, 11) + tr.group * (64 * 32);
-    const unsigned voff_pe = 4u * (unsigned)(m + 1024 * h), voff_de = 4u * (unsigned)(m + 512 * h);
-#pragma unroll
-    for (int t = 0; t < 32; ++t) row_store(t, pe[t], pblk, voff_pe);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) row_store(t, de[t], dblk, voff_de);
+  if (TRAIN) {   // the encodings themselves (their hi halves): operands of the weight gradients of L1, L5 (skip part) and
+                 // dir_encoding; the direction panel's second 32 rows are zeros (the narrowest weight-gradient tile is 64)
+    const char* pblk = panel_block(tr, 10, 0);
+    const char* dblk = panel_block(tr, 11, 0);
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    unit_store<0>(peh[0], pblk, voff0);
+    unit_store<1>(peh[1], pblk, voff1);
+    unit_store<0>(peh[2], pblk + 2048, voff0);
+    unit_store<1>(peh[3], pblk + 2048, voff1);
+    unit_store<0>(deh[0], dblk, voff0);
+    unit_store<1>(deh[1], dblk, voff1);
+    unit_store<0>(zero4, dblk + 2048, voff0);
+    unit_store<1>(zero4, dblk + 2048, voff1);
   }
 
   // park the split position encoding in LDS for L5
@@ -893,9 +931,10 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
               for (int q = 0; q < count; ++q)
                 pending_half<true>(first + q, pend, ptmp, bh[2 * nb - 2], bl[2 * nb - 2], bh[2 * nb - 1], bl[2 * nb - 1], amax);
               if (TRAIN && gp == 2) {
-                const float* blk = panel_block(tr, 0, nb - 1);
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) panel_store(4 * s + q4, pend, blk, voff);
+                const char* blk = panel_block(tr, 0, nb - 1);
+                // hi of pairs 0..3 is complete after k-step 1 (half-step 7), of pairs 4..7 after gap 1 of k-step 3 (half-step 15)
+                if (s == 2) unit_store<0>(bh[2 * nb - 2], blk, voff0);
+                if (s == 3) unit_store<1>(bh[2 * nb - 1], blk, voff1);
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) sign_push(sbits, pend.m[4 * s + q4]);
                 if (s == 3) sign_store(sbits, sign_block(tr.sgn, tr.group, 0, nb - 1), ld.lane_off >> 2);
@@ -925,20 +964,20 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
 #pragma unroll 1
   for (int pair = 0; pair < 3; ++pair) {
     const int L = 1 + 2 * pair;
-    trunk_layer<true, TRAIN>(L, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(L + 1, 0, wave), layer_ref(L + 1, 1, wave), amax, tr, voff);
+    trunk_layer<true, TRAIN>(L, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(L + 1, 0, wave), layer_ref(L + 1, 1, wave), amax, tr, voff0, voff1);
     trunk_layer<true, TRAIN>(L + 1, oh, ol, bh, bl, stash, ld, h, pend, pre, layer_ref(L + 2, 0, wave), layer_ref(L + 2, 1, wave), amax,
-                             tr, voff);
+                             tr, voff0, voff1);
   }
   if (SIGMA_ONLY) {   // xyz_encoding_final is not evaluated: L8 is followed by the density head, then nothing
     trunk_layer<true>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, sigma_ref(wave), first_ref(0, wave), amax);
   } else {
 #ifdef NSR_ABL_TIMELINE
-    trunk_layer<true, TRAIN, (OVERLAP ? 1 : 0)>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave), amax, tr, voff, &enc, &ein, tk);
+    trunk_layer<true, TRAIN, (OVERLAP ? 1 : 0)>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave), amax, tr, voff0, voff1, &enc, &ein, tk);
     ld.tk = nullptr;
 #else
-    trunk_layer<true, TRAIN, (OVERLAP ? 1 : 0)>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave), amax, tr, voff, &enc, &ein);
+    trunk_layer<true, TRAIN, (OVERLAP ? 1 : 0)>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave), amax, tr, voff0, voff1, &enc, &ein);
 #endif
-    trunk_layer<false, TRAIN, (OVERLAP ? 2 : 0)>(8, oh, ol, bh, bl, stash, ld, h, pend, pre, sigma_ref(wave), dir_ref(0, wave), amax, tr, voff, &enc, &ein);
+    trunk_layer<false, TRAIN, (OVERLAP ? 2 : 0)>(8, oh, ol, bh, bl, stash, ld, h, pend, pre, sigma_ref(wave), dir_ref(0, wave), amax, tr, voff0, voff1, &enc, &ein);
   }
 
   NSR_TL(3);
@@ -952,7 +991,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     Resplit ptmp;
     const unsigned next_bias = 36u * 1024u;       // dir_encoding chunks: 36 weight pieces, then the bias
     Pre nxt;
-    block_mma3<16, kBar, (TRAIN ? 17 : 0)>(
+    block_mma3<16, kBar, (TRAIN ? kTrainYoung : 0)>(
         cur, pre, ld.slot_cur + ld.lane_off, ld, SIGMA_ONLY ? first_ref(1, wave) : dir_ref(1, wave),
         [&](int s, int part) -> u32x4 { return part ? ol[s] : oh[s]; },
         [&](int s, int g) {
@@ -962,9 +1001,9 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
           else
             pending_gap<false>(s, g, pend, ptmp, bh[14], bl[14], bh[15], bl[15], amax);
           if (TRAIN && s >= 14 && g == 2) {   // xyz_encoding_final's last block (no sign bits: nothing is masked by it)
-            const float* blk = panel_block(tr, 8, 7);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) panel_store(8 * (s - 14) + r, pend, blk, voff);
+            const char* blk = panel_block(tr, 8, 7);
+            if (s == 14) unit_store<0>(bh[14], blk, voff0);
+            else unit_store<1>(bh[15], blk, voff1);
           }
         },
         [&](int k, int g) {
@@ -993,9 +1032,10 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     Acc cur;
     cur.m = pre.bias;
     unsigned sbits = 0u;
+    u32x4 dh0 = {0u, 0u, 0u, 0u}, dh1 = {0u, 0u, 0u, 0u};   // TRAIN: hi halves of the pending dir block (relu_hi_pair)
     const unsigned next_bias = 36u * 1024u;
     Pre nxt;
-    // in flight behind the previous block's DMA: the density block's 16 stores | nothing | a dir block's 16 + sign word
+    // in flight behind the previous block's DMA: the density block's 2 stores | nothing | a dir block's 2 + sign word
     const unsigned a_seq = ld.slot_cur + ld.lane_off;
     const ChunkRef c2 = nb < 2 ? dir_ref(nb + 2, wave) : first_ref(nb - 2, wave);   // ... then the next tile's L1
     auto b_of = [&](int s, int part) -> u32x4 {
@@ -1005,12 +1045,11 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
       if (OVERLAP && nb == 0 && g == 0) enc_slot(144 + s, enc, ein);
       // the pending dir block is consumed in k-steps 6..13, one pair per k-step, one colour channel per gap
       if (nb > 0) rgb_gap<kConvStep0>(s, g, pend, aux + hx::kAuxRgbW + 32 * (nb - 1), h, rgb, w2);
+      if (TRAIN && nb > 0 && s < 8 && g == 1) relu_hi_step(s, pend, dh0, dh1);
       if (TRAIN && nb > 0 && s >= 8 && s < 16 && g == 2) {
-        const float* blk = panel_block(tr, 9, nb - 1);
-        if (s >= 14) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) panel_store(8 * (s - 14) + r, pend, blk, voff);
-        }
+        const char* blk = panel_block(tr, 9, nb - 1);
+        if (s == 14) unit_store<0>(dh0, blk, voff0);
+        if (s == 15) unit_store<1>(dh1, blk, voff1);
         sign_push(sbits, pend.m[2 * (s - 8)]);
         sign_push(sbits, pend.m[2 * (s - 8) + 1]);
         if (s == 15) sign_store(sbits, sign_block(tr.sgn, tr.group, 9, nb - 1), ld.lane_off >> 2);
@@ -1023,10 +1062,10 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     constexpr bool kFetch = PERSIST;
     if (nb >= 2 && !kFetch) {
       if (!TRAIN) block_mma3<18, kBar, 0, false>(cur, pre, a_seq, ld, c2, b_of, hook, next);
-      else block_mma3<18, kBar, 17, false>(cur, pre, a_seq, ld, c2, b_of, hook, next);
+      else block_mma3<18, kBar, kTrainYoung, false>(cur, pre, a_seq, ld, c2, b_of, hook, next);
     } else if (!TRAIN || nb == 1) block_mma3<18, kBar>(cur, pre, a_seq, ld, c2, b_of, hook, next);
-    else if (nb == 0) block_mma3<18, kBar, 16>(cur, pre, a_seq, ld, c2, b_of, hook, next);
-    else block_mma3<18, kBar, 17>(cur, pre, a_seq, ld, c2, b_of, hook, next);
+    else if (nb == 0) block_mma3<18, kBar, 2>(cur, pre, a_seq, ld, c2, b_of, hook, next);
+    else block_mma3<18, kBar, kTrainYoung>(cur, pre, a_seq, ld, c2, b_of, hook, next);
     pend = cur;
     pre = nxt;
     loader_advance(ld);
@@ -1041,14 +1080,16 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
 #pragma unroll
       for (int g = 0; g < 3; ++g) rgb_gap<0>(s, g, pend, w32, h, rgb, w2);
   }
-  if (TRAIN) {
-    const float* blk = panel_block(tr, 9, 3);
+  if (TRAIN) {   // the last dir block (its accumulators were read by the colour head just above: no MFMA is in flight)
+    const char* blk = panel_block(tr, 9, 3);
     unsigned sbits = 0u;
+    u32x4 dh0, dh1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      panel_store(r, pend, blk, voff);
-      sign_push(sbits, pend.m[r]);
-    }
+    for (int P = 0; P < 8; ++P) relu_hi_step(P, pend, dh0, dh1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sign_push(sbits, pend.m[r]);
+    unit_store<0>(dh0, blk, voff0);
+    unit_store<1>(dh1, blk, voff1);
     sign_store(sbits, sign_block(tr.sgn, tr.group, 9, 3), ld.lane_off >> 2);
   }
 #pragma unroll
@@ -1155,18 +1196,18 @@ extern "C" NSR_INTERNAL int nsr_f16x3_render_composite(const void* packed, const
 }
 
 // forward pass of the training step: raw (R * N, 4) network outputs + the training panels (see nsr_f16x3_core.h);
-// `pan` holds 10 panels of ceil(R N / 128) * 4 point groups (nsr_f16x3_train_panel_floats)
-extern "C" NSR_INTERNAL int64_t nsr_f16x3_train_panel_floats(int64_t P) {
+// `pan` holds the twelve fp16 panels of ceil(R N / 128) * 4 point groups (nsr_f16x3_train_panel_bytes)
+extern "C" NSR_INTERNAL int64_t nsr_f16x3_train_panel_bytes(int64_t P) {
   const int64_t n_groups = ((P + 127) / 128) * 4;
-  return panel_set_floats(n_groups);
+  return panel_set_bytes(n_groups);
 }
 extern "C" NSR_INTERNAL int64_t nsr_f16x3_train_sign_words(int64_t P) { return sign_panel_words(((P + 127) / 128) * 4); }
 extern "C" NSR_INTERNAL int nsr_f16x3_train_forward(const void* packed, const float* rays, int ray_stride, const float* z, int64_t R,
-                                                    int N, float* raw, float* pan, unsigned* sgn, unsigned* status, void* stream) {
+                                                    int N, float* raw, void* pan, unsigned* sgn, unsigned* status, void* stream) {
   const int64_t P = R * N;
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   hipLaunchKernelGGL((mlp_f16x3_kernel<1, false, 0, false, true>), grid, block, 0, nsr_stream(stream),
-                     static_cast<const float*>(packed), rays, z, P, N, ray_stride, raw, NsrTail{status}, NsrCompOut{}, pan, sgn);
+                     static_cast<const float*>(packed), rays, z, P, N, ray_stride, raw, NsrTail{status}, NsrCompOut{}, static_cast<float*>(pan), sgn);
   if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
   return NSR_OK;
 }

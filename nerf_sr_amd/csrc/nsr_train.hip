@@ -17,18 +17,18 @@
 //
 // CHAIN path (precision NSR_F16X3, the default there): the network is a per-point chain, so its forward pass and its
 // input gradients do not need per-layer GEMMs at all.  The forward pass is the inference kernel (nsr_mlp_f16.hip, TRAIN)
-// that additionally keeps every layer's pre-activations; the input gradients are one launch of the backward chain
-// (nsr_train_chain.hip).  Both write "panels" ([group of 32 points][feature][32 points], nsr_f16x3_core.h) that the
-// weight-gradient GEMMs read as K-contiguous operands; those GEMMs also sum the bias gradients while they stage the
-// pre-activation gradients.  Only the weight gradients stay on the fp32 MFMA.  NSR_TRAIN_PATH=gemm selects the
-// layer-by-layer path above for NSR_F16X3 as well (the A/B switch of profiles/; NSR_FP32 always takes it).
+// that additionally keeps every layer's activation as the fp16 operand it makes anyway; the input gradients are one launch
+// of the backward chain (nsr_train_chain.hip), which keeps its fp16 operands likewise.  Both write 2-byte "panels" in
+// 1 KiB units (nsr_f16x3_core.h) that the weight-gradient kernel (nsr_wgrad_f16.hip) copies into LDS as they are and
+// multiplies on ONE fp16 MFMA per product; it also sums the bias gradients.  precision NSR_F16X3_GEMM selects the
+// layer-by-layer path above with split-fp16 forward products (the A/B partner of profiles/; NSR_FP32 always takes it).
 // Per-ray stages (sampling, compositing, resampling) are the inference kernels (nsr_rays.hip / nsr_render.hip);
 // the compositing backward is a one-wave-per-ray kernel like its forward.
 #include "nsr_common.h"
 #include "nsr_gemm.h"
 #include "nsr_train_chain.h"
+#include "nsr_panels.h"
 #include "../../include/nsr_train.h"
-#include <cstdlib>
 
 using namespace nsr;
 
@@ -310,18 +310,11 @@ __global__ void __launch_bounds__(256) sum_finish_kernel(const double* __restric
 // dst[i * dst_ld + dc0 + j] (+)= sum_z partial[z * stride + (pr0 + i) * p_ld + pc0 + j]
 __global__ void __launch_bounds__(256) reduce_place_kernel(float* __restrict__ dst, int dst_ld, int dc0, int rows, int cols,
                                                            const float* __restrict__ partial, int splits, int64_t stride,
-                                                           int p_ld, int pr0, int pc0, int accumulate, float scale,
-                                                           int enc_rows) {
+                                                           int p_ld, int pr0, int pc0, int accumulate, float scale) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * cols) return;
   const int i = idx / cols, j = idx % cols;
-  // enc_rows: the partial's columns are rows of an encoding panel, i.e. in register order (nsr_f16x3_core.h).
-  // 1: encoded position, register t of lane half h in row t + 32 h = column pecol(t, h): column j of the 63 sits at
-  //    0, 1, 32 (x, y, z), j - 1 (j < 33) or j + 1;   2: encoded direction, row t + 16 h = column dircol(t, h): column j of
-  //    the 27 sits at 0, 1, 16, j - 1 (j < 15) or j + 3
-  const int js = enc_rows == 1 ? (j < 2 ? j : (j == 2 ? 32 : (j < 33 ? j - 1 : j + 1)))
-               : enc_rows == 2 ? (j < 2 ? j : (j == 2 ? 16 : (j < 15 ? j - 1 : j + 3))) : j;
-  const float* src = partial + (int64_t)(pr0 + i) * p_ld + pc0 + js;
+  const float* src = partial + (int64_t)(pr0 + i) * p_ld + pc0 + j;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four independent chains: the loads of a round are all in flight
   int zc = 0;
   for (; zc + 4 <= splits; zc += 4) {
@@ -335,52 +328,69 @@ __global__ void __launch_bounds__(256) reduce_place_kernel(float* __restrict__ d
   float* d = dst + (int64_t)i * dst_ld + dc0 + j;
   *d = (accumulate ? *d : 0.0f) + (float)(s * (double)scale);   // scale: a power of two (pre-scaled operands)
 }
-// sums over the points of  w[p][c] * max(panel[p][row], lower)  for c < NW weights per point -- the weight gradients of
-// the 1- and 3-row heads (sigma over h8, rgb over dir_encoding's output), whose "GEMM" is a stream over one panel:
-// partial[z][c * R + row] = scale * sum over slice z.  The panel run of a point group is contiguous (R x 32 floats);
-// thread t takes its float4 number t + 256 i = row (t >> 3) + 32 i, points 4 (t & 7) ..+3.
+// sums over the points of  w[p][c] * panel[p][row]  for c < NW weights per point -- the weight gradients of the 1- and
+// 3-row heads (sigma over h8 = forward panel 7, rgb over dir_encoding's output = forward panel 9), whose "GEMM" is a stream
+// over one 2-byte panel:  partial[z][c * R + row] = sum over slice z.  The run of a point group is R / 16 units of 1 KiB
+// (nsr_f16x3_core.h): 16-byte slot sl of unit U holds, for point m = ((sl ^ 8 (U & 1)) >> 1) and lane half h = sl & 1,
+// the features 32 (U >> 1) + 16 (U & 1) + 4 h + {0..3} and + 8 + {0..3}.  Thread t owns slot t & 63 of the units
+// (t >> 6) + 4 i: its eight features are the same for every point group, its point is m.
 template <int R, int NW>
-__global__ void __launch_bounds__(256) panel_wsums_kernel(const float* __restrict__ panel, int64_t P, const float* __restrict__ w,
-                                                          int w_stride, float lower, float scale, int64_t groups_per_slice,
-                                                          float* __restrict__ partial) {
-  constexpr int NI = R * 8 / 256;
-  const int tid = threadIdx.x, c4 = tid & 7, z = blockIdx.x;
+__global__ void __launch_bounds__(256) panel_wsums_kernel(const char* __restrict__ panel, int64_t P, const float* __restrict__ w,
+                                                          int w_stride, int64_t groups_per_slice, float* __restrict__ partial) {
+  constexpr int NI = R / 64;               // units per thread and point group
+  typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+  const int tid = threadIdx.x, sl = tid & 63, u0 = tid >> 6, z = blockIdx.x;
   const int64_t n_groups = P / 32;
   const int64_t g0 = (int64_t)z * groups_per_slice;
   const int64_t g1 = (g0 + groups_per_slice < n_groups) ? g0 + groups_per_slice : n_groups;
-  float acc[NI][NW];
+  float acc[NI][8][NW];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int c = 0; c < NW; ++c) acc[i][c] = 0.0f;
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int c = 0; c < NW; ++c) acc[i][e][c] = 0.0f;
   for (int64_t g = g0; g < g1; ++g) {
-    const float4* run = reinterpret_cast<const float4*>(panel + g * (int64_t)(R * 32));
-    float wk[4][NW];
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int c = 0; c < NW; ++c) wk[e][c] = w[(g * 32 + 4 * c4 + e) * w_stride + c];
+    const char* run = panel + g * (int64_t)(R * 64);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const float4 v = run[tid + 256 * i];
-      const float x[4] = {fmaxf(v.x, lower), fmaxf(v.y, lower), fmaxf(v.z, lower), fmaxf(v.w, lower)};
+      const int U = u0 + 4 * i;
+      const int m = (sl ^ (8 * (U & 1))) >> 1;
+      const h8v v = __builtin_nontemporal_load(reinterpret_cast<const h8v*>(run + U * 1024 + sl * 16));
+      float wk[NW];
 #pragma unroll
-      for (int c = 0; c < NW; ++c)
-        acc[i][c] += (x[0] * wk[0][c] + x[1] * wk[1][c]) + (x[2] * wk[2][c] + x[3] * wk[3][c]);
+      for (int c = 0; c < NW; ++c) wk[c] = w[(g * 32 + m) * w_stride + c];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int c = 0; c < NW; ++c) acc[i][e][c] = fmaf((float)v[e], wk[c], acc[i][e][c]);
     }
   }
+  // the 32 points of a (unit, lane half) are the slots of one parity: sum over slot bits 1..5
 #pragma unroll
-  for (int i = 0; i < NI; ++i)
+  for (int i = 0; i < NI; ++i) {
+    const int U = u0 + 4 * i, h = sl & 1;
 #pragma unroll
-    for (int c = 0; c < NW; ++c) {
-      float s = acc[i][c];
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
-      if (c4 == 0) partial[(int64_t)z * (NW * R) + c * R + (tid >> 3) + 32 * i] = s * scale;
-    }
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int c = 0; c < NW; ++c) {
+        float s = acc[i][e][c];
+#pragma unroll
+        for (int o = 2; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+        const int row = 32 * (U >> 1) + 16 * (U & 1) + 8 * (e >> 2) + 4 * h + (e & 3);
+        if ((sl >> 1) == 0) partial[(int64_t)z * (NW * R) + c * R + row] = s;
+      }
+  }
 }
 
+// enc_rows: the partial's columns are rows of an encoding panel (nsr_f16x3_core.h, enc_row): 1 = the encoded position,
+// column j of the 63 is register t of lane half h with pecol(t, h) == j; 2 = the encoded direction, dircol(t, h) == j
+__device__ __forceinline__ int enc_panel_row(int enc_rows, int j) {
+  if (enc_rows == 0) return j;
+  const int per = enc_rows == 1 ? 30 : 12;           // columns per lane half behind the three raw coordinates
+  const int t = j < 2 ? j : (j == 2 ? 0 : (j - 3) % per + 2), h = j < 2 ? 0 : (j == 2 ? 1 : (j - 3) / per);
+  return enc_row(t, h);
+}
 // All second passes of one network's weight / bias gradients in ONE launch (chain path): blockIdx.y = job.
 //   kind 0: dst[i * dst_ld + dc0 + j] (+)= scale * sum_z partial[z * stride + i * p_ld + col(j)]   (reduce_place_kernel)
 //   kind 1: dst[i] (+)= sum_z partial[z * rows + i]                                                 (rowsum_finish_kernel)
@@ -407,8 +417,7 @@ __global__ void __launch_bounds__(256) finish_jobs_kernel(FinishJobs jobs) {
   float* d;
   if (q.kind == 0) {
     const int i = idx / q.cols, j = idx % q.cols;
-    const int js = q.enc_rows == 1 ? (j < 2 ? j : (j == 2 ? 32 : (j < 33 ? j - 1 : j + 1)))
-                 : q.enc_rows == 2 ? (j < 2 ? j : (j == 2 ? 16 : (j < 15 ? j - 1 : j + 3))) : j;   // see reduce_place_kernel
+    const int js = enc_panel_row(q.enc_rows, j);
     src = q.partial + (int64_t)i * q.p_ld + js;
     stride = q.stride;
     d = q.dst + (int64_t)i * q.dst_ld + q.dc0 + j;
@@ -471,9 +480,10 @@ struct Work {   // per-pass buffers, sized for P_max = chunk * (Nc + Ni) sample 
   float *z_c, *z_f, *w_c, *comp, *g_comp, *partial, *scratch_out;
   double *block_sums, *carry;
   WeightPack pack[2];
-  // chain path (NSR_F16X3): pre-activation panels of the forward pass, gradient panels of the backward chain
-  // (nsr_f16x3_core.h), the two weight streams per network, per-slice row sums of the weight-gradient GEMMs
-  float *zpan, *dpan, *row_part, *slots;
+  // chain path (NSR_F16X3): activation panels of the forward pass, gradient panels of the backward chain (2 bytes per
+  // value, nsr_f16x3_core.h), the two weight streams per network, per-slice row sums of the weight-gradient products
+  char *zpan, *dpan;
+  float *row_part, *slots;
   float *stream_f[2], *stream_b[2];
   unsigned* sgn;    // sign panels of the forward pass (nsr_f16x3_core.h)
   float* pscale;    // per gradient panel and point: stored value x pscale = true gradient (written by the backward chain)
@@ -520,8 +530,8 @@ int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base, int mod
     q.wrgbp = take(32 * 128);   q.b9p = take(320);   q.brgbp = take(64);
     q.split = reinterpret_cast<unsigned short*>(take((kSplitHalves + 1) / 2));
   }
-  const int64_t pan = nsr_f16x3_train_panel_floats(P);
-  k.zpan = take_if(chain_path, pan);   k.dpan = take_if(chain_path, pan);
+  const int64_t pan = nsr_f16x3_train_panel_bytes(P) / 4;
+  k.zpan = reinterpret_cast<char*>(take_if(chain_path, pan));   k.dpan = reinterpret_cast<char*>(take_if(chain_path, pan));
   k.row_part = take_if(chain_path, kChainRowSlots * sp_max * 256);
   k.gmax = reinterpret_cast<unsigned*>(take_if(chain_path, 64));
   k.pscale = take_if(chain_path, 10 * ((P + 127) / 128) * 128);
@@ -621,10 +631,10 @@ int lin_wgrad(hipStream_t st, const float* dy, int64_t lddy, int M, const float*
   return gemm(g, st);
 }
 int reduce_place(hipStream_t st, float* dst, int dst_ld, int dc0, int rows, int cols, const float* partial, int splits,
-                 int p_ld, int pr0, int pc0, int accumulate, float scale = 1.0f, int enc_rows = 0) {
+                 int p_ld, int pr0, int pc0, int accumulate, float scale = 1.0f) {
   const int n = rows * cols;
   hipLaunchKernelGGL(reduce_place_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dst, dst_ld, dc0, rows, cols, partial,
-                     splits, kPartialFloats, p_ld, pr0, pc0, accumulate, scale, enc_rows);
+                     splits, kPartialFloats, p_ld, pr0, pc0, accumulate, scale);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
@@ -713,31 +723,24 @@ int net_backward(hipStream_t st, const float* const* w, const WeightPack& q, con
 
 // ---- chain path ------------------------------------------------------------------------------------------
 int64_t n_groups_of(int64_t P) { return ((P + 127) / 128) * 4; }
-float* panel_of(float* set, int64_t P, int panel) {   // nsr_f16x3_core.h: panel_offset
-  const int64_t rows_before = panel <= 9 ? 256 * (int64_t)panel : (panel == 10 ? 2304 + 128 : 2304 + 192);
-  return set + rows_before * 32 * n_groups_of(P);
-}
+char* panel_of(char* set, int64_t P, int panel) { return set + panel_offset_bytes(n_groups_of(P), panel); }
 
-// weight and bias gradients from the panels: zpan = forward pre-activations x 2^6 (kWScale), dpan = true-scale
-// gradients of the pre-activations; d_rgb_pre in k.drgb (P, 32), d_sigma in column 256 of k.g1 (P, 288).
-// The 14 panel x panel products of the network are ONE launch (wgrad_jobs_kernel, nsr_wgrad_f16.hip): ~256 workgroups
-// share the products' point groups by bytes, a 256 x 256 product ends up with ~21 partial tiles instead of the 256 a
-// launch of its own needed to fill the chip -- 12 x fewer partial sums to write, and for finish_jobs_kernel to read
-// back.  NSR_WGRAD_JOBS=0 selects the per-product launches (round 2; kept for A/B runs).
+// weight and bias gradients from the panels: zpan = the forward activations, dpan = the input gradients at each point's
+// power-of-two scale (k.pscale), both fp16 (nsr_f16x3_core.h); d_rgb_pre in k.drgb (P, 32), d_sigma in column 256 of k.g1
+// (P, 288).  The 12 panel x panel products of the network are ONE launch (wgrad_jobs_kernel, nsr_wgrad_f16.hip): ~256
+// workgroups share the products' point groups by bytes, a 256 x 256 product ends up with ~21 partial tiles instead of the
+// 256 a launch of its own needed to fill the chip -- 12 x fewer partial sums to write, and for finish_jobs_kernel to read
+// back.
 int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g, int acc) {
   const int sp = n_splits(P);
   const int64_t sp_max = sp;   // the workspace's slots are sized for the largest pass (work_floats): at least this one's
-  constexpr float kInv = 1.0f / 64.0f;
-  const char* env = nsr_dev_env("NSR_WGRAD_JOBS");
-  const bool one_launch = !(env && env[0] == '0');
   FinishJobs jobs{};
   WgradJobs wj{};
   struct Placed { int job, fin; };     // finish job `fin` reduces the partial tiles (fin >= 0) / row sums (~fin) of product `job`
   Placed placed[2 * kMaxFinishJobs];
   int n_placed = 0;
-  int n_big = 0, n_row = 0;
+  int n_big = 0;
   auto big_slot = [&]() { return k.slots + (int64_t)(n_big++) * sp * 256 * 256; };     // sp <= the workspace's sp_max
-  auto row_slot = [&]() { return k.row_part + (int64_t)(n_row++) * sp * 256; };
   // second passes, executed by finish_jobs_kernel at the end
   auto place = [&](float* dst, int dst_ld, int dc0, int rows, int cols, const float* partial, int p_ld, int enc_rows) {
     FinishJob& q = jobs.j[jobs.n++];
@@ -750,115 +753,99 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
     q.kind = 1; q.dst = dst; q.rows = rows; q.cols = 1; q.partial = partial; q.splits = sp; q.accumulate = acc; q.scale = 1.0f;
     return jobs.n - 1;
   };
-  // product of gradient panel a with forward panel b (+ the bias row sums of a): a launch of its own into a fresh slot, or
-  // an entry of the job table (slots are handed out after the plan); returns the product's index
-  auto product = [&](int a_panel, int b_panel, int b_relu, float** part, float** rs) -> int {
+  // product of gradient panel a with forward panel b (+ the bias row sums of a): an entry of the job table (slots are
+  // handed out after the plan); returns the product's index
+  auto product = [&](int a_panel, int b_panel, bool row_sums) -> int {
+    if (wj.n >= kMaxWgradJobs) return -1;
     WgradArgs w{};
-    w.A = panel_of(k.dpan, P, a_panel); w.M = a_panel == 9 ? 128 : 256; w.a_gstride = 32 * w.M;
-    w.B = panel_of(k.zpan, P, b_panel); w.N = b_panel >= 10 ? 64 : 256; w.b_gstride = 32 * w.N; w.b_relu = b_relu;
-    w.P = P; w.a_max_bits = k.gmax + a_panel;
+    w.A = panel_of(k.dpan, P, a_panel); w.M = panel_rows(a_panel); w.a_gbytes = (int64_t)kPanelRowBytes * w.M;
+    w.B = panel_of(k.zpan, P, b_panel); w.N = panel_rows(b_panel); w.b_gbytes = (int64_t)kPanelRowBytes * w.N;
+    w.a_max_bits = k.gmax + a_panel;
     w.a_pscale = k.pscale + (int64_t)a_panel * n_groups_of(P) * 32;
-    w.out_scale = b_panel >= 10 ? 1.0f : kInv;    // the encodings are stored at true scale, the pre-activations x 2^6
-    w.split_stride = (int64_t)256 * 256; w.splits = sp;
-    if (one_launch) {
-      if (wj.n >= kMaxWgradJobs) return -1;
-      w.partial = k.slots;                       // placeholder (validated non-null); real slots after the plan
-      w.row_sums = rs ? k.row_part : nullptr;
-      wj.j[wj.n].w = w;
-      *part = nullptr;
-      if (rs) *rs = nullptr;
-      return wj.n++;
-    }
-    *part = big_slot();
-    float* r = rs ? row_slot() : nullptr;
-    if (rs) *rs = r;
-    w.partial = *part; w.row_sums = r;
-    return wgrad_f16x3(w, st) == NSR_OK ? 0 : -1;
+    w.split_stride = (int64_t)256 * 256;
+    w.partial = k.slots;                       // placeholders (validated non-null); real slots after the plan
+    w.row_sums = row_sums ? k.row_part : nullptr;
+    wj.j[wj.n].w = w;
+    return wj.n++;
   };
   auto note = [&](int job, int fin) { placed[n_placed++] = Placed{job, fin}; };
-  float *part, *rs;
+  float* part;
   int pj;
   const int64_t per = (P / 32 + sp - 1) / sp;
   // rgb head: d_rgb_pre^T relu(zcc), a stream over the panel
   part = big_slot();
-  hipLaunchKernelGGL((panel_wsums_kernel<128, 3>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 9), P, k.drgb, kRgbPad, 0.0f,
-                     kInv, per, part);
+  hipLaunchKernelGGL((panel_wsums_kernel<128, 3>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 9), P, k.drgb, kRgbPad, per, part);
   NSR_CHECK_LAUNCH();
   sum_rows(g[kRgbW], 3 * 128, part);
   NSR_TRY(colsum(st, k.drgb, kRgbPad, P, 0, 3, g[kRgbB], acc, k.partial));
   // dir_encoding: dzc^T [g | de]
-  if ((pj = product(9, 8, 0, &part, &rs)) < 0) return NSR_ERR_LAUNCH;
-  note(pj, place(g[kDirW], 283, 0, 128, 256, part, kW, 0));
-  note(pj, ~sum_rows(g[kDirB], kDirOut, rs));
-  if ((pj = product(9, 11, 0, &part, nullptr)) < 0) return NSR_ERR_LAUNCH;
-  note(pj, place(g[kDirW], 283, 256, 128, 27, part, kPe, 2));
+  if ((pj = product(9, 8, true)) < 0) return NSR_ERR_LAUNCH;
+  note(pj, place(g[kDirW], 283, 0, 128, 256, nullptr, kW, 0));
+  note(pj, ~sum_rows(g[kDirB], kDirOut, nullptr));
+  if ((pj = product(9, 11, false)) < 0) return NSR_ERR_LAUNCH;
+  note(pj, place(g[kDirW], 283, 256, 128, 27, nullptr, kPe, 2));
   // xyz_encoding_final: dg^T relu(z8); sigma: d_sigma^T relu(z8)
-  if ((pj = product(8, 7, 1, &part, &rs)) < 0) return NSR_ERR_LAUNCH;
-  note(pj, place(g[kFinalW], 256, 0, 256, 256, part, kW, 0));
-  note(pj, ~sum_rows(g[kFinalB], kW, rs));
+  if ((pj = product(8, 7, true)) < 0) return NSR_ERR_LAUNCH;
+  note(pj, place(g[kFinalW], 256, 0, 256, 256, nullptr, kW, 0));
+  note(pj, ~sum_rows(g[kFinalB], kW, nullptr));
   part = big_slot();
-  hipLaunchKernelGGL((panel_wsums_kernel<256, 1>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 7), P, k.g1 + kSigmaCol, kGs,
-                     0.0f, kInv, per, part);
+  hipLaunchKernelGGL((panel_wsums_kernel<256, 1>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 7), P, k.g1 + kSigmaCol, kGs, per, part);
   NSR_CHECK_LAUNCH();
   sum_rows(g[kSigmaW], 256, part);
   NSR_TRY(colsum(st, k.g1, kGs, P, 256, 1, g[kSigmaB], acc, k.partial));
   // trunk layers 8..1: dz_L^T (input of layer L)
   for (int L = 8; L >= 1; --L) {
     float* gw = g[2 * (L - 1)];
-    rs = nullptr;
     int pj_rs = -1;
     if (L > 1) {
-      if ((pj = product(L - 1, L - 2, 1, &part, &rs)) < 0) return NSR_ERR_LAUNCH;
-      note(pj, place(gw, L == 5 ? 319 : 256, L == 5 ? 63 : 0, 256, 256, part, kW, 0));
+      if ((pj = product(L - 1, L - 2, true)) < 0) return NSR_ERR_LAUNCH;
+      note(pj, place(gw, L == 5 ? 319 : 256, L == 5 ? 63 : 0, 256, 256, nullptr, kW, 0));
       pj_rs = pj;
     }
     if (L == 1 || L == 5) {   // over the encoded position (panel 10, 64 rows in register order)
-      if ((pj = product(L - 1, 10, 0, &part, L == 1 ? &rs : nullptr)) < 0) return NSR_ERR_LAUNCH;
-      note(pj, place(gw, L == 1 ? 63 : 319, 0, 256, 63, part, kPe, 1));
+      if ((pj = product(L - 1, 10, L == 1)) < 0) return NSR_ERR_LAUNCH;
+      note(pj, place(gw, L == 1 ? 63 : 319, 0, 256, 63, nullptr, kPe, 1));
       if (L == 1) pj_rs = pj;
     }
-    note(pj_rs, ~sum_rows(g[2 * (L - 1) + 1], kW, rs));
+    note(pj_rs, ~sum_rows(g[2 * (L - 1) + 1], kW, nullptr));
   }
-  if (n_big > kChainSlots || n_row > kChainRowSlots || jobs.n > kMaxFinishJobs) return NSR_ERR_UNSUPPORTED;   // cannot happen
-  if (one_launch) {
-    // as many workgroups as there are CUs -- fewer for a small pass, so that the partial tiles fit the slots the
-    // workspace holds (sized by sp_max) and a workgroup always has a few point groups to sweep
-    int64_t want = 10 * (sp_max - 1);
-    want = want < 1 ? 1 : (want > 256 ? 256 : want);
-    const int n_wg = wgrad_jobs_plan(wj, P, (int)want);
-    float* next_big = k.slots + (int64_t)n_big * sp * 256 * 256;          // behind the two head slots taken above
-    float* next_row = k.row_part;
-    const float* big_end = k.slots + (int64_t)kChainSlots * sp_max * 256 * 256;
-    const float* row_end = k.row_part + (int64_t)kChainRowSlots * sp_max * 256;
-    for (int p = 0; p < wj.n; ++p) {
-      WgradJob& q = wj.j[p];
-      q.w.partial = next_big;
-      next_big += (int64_t)q.n_slots * 256 * 256;
-      if (q.w.row_sums) {
-        q.w.row_sums = next_row;
-        next_row += (int64_t)q.n_slots * q.w.M;
-      }
+  if (n_big > kChainSlots || jobs.n > kMaxFinishJobs) return NSR_ERR_UNSUPPORTED;   // cannot happen
+  // as many workgroups as there are CUs -- fewer for a small pass, so that the partial tiles fit the slots the
+  // workspace holds (sized by sp_max) and a workgroup always has a few point groups to sweep
+  int64_t want = 10 * (sp_max - 1);
+  want = want < 1 ? 1 : (want > 256 ? 256 : want);
+  const int n_wg = wgrad_jobs_plan(wj, P, (int)want);
+  float* next_big = k.slots + (int64_t)n_big * sp * 256 * 256;          // behind the two head slots taken above
+  float* next_row = k.row_part;
+  const float* big_end = k.slots + (int64_t)kChainSlots * sp_max * 256 * 256;
+  const float* row_end = k.row_part + (int64_t)kChainRowSlots * sp_max * 256;
+  for (int p = 0; p < wj.n; ++p) {
+    WgradJob& q = wj.j[p];
+    q.w.partial = next_big;
+    next_big += (int64_t)q.n_slots * 256 * 256;
+    if (q.w.row_sums) {
+      q.w.row_sums = next_row;
+      next_row += (int64_t)q.n_slots * q.w.M;
     }
-    if (next_big > big_end || next_row > row_end) return NSR_ERR_WORKSPACE;   // cannot happen (see `want`)
-    for (int i = 0; i < n_placed; ++i) {
-      const WgradJob& q = wj.j[placed[i].job];
-      const bool rows = placed[i].fin < 0;
-      FinishJob& f = jobs.j[rows ? ~placed[i].fin : placed[i].fin];
-      f.partial = rows ? q.w.row_sums : q.w.partial;
-      f.splits = q.n_slots;
-    }
-    NSR_TRY(wgrad_jobs_f16x3(wj, n_wg, st));
   }
+  if (next_big > big_end || next_row > row_end) return NSR_ERR_WORKSPACE;   // cannot happen (see `want`)
+  for (int i = 0; i < n_placed; ++i) {
+    const WgradJob& q = wj.j[placed[i].job];
+    const bool rows = placed[i].fin < 0;
+    FinishJob& f = jobs.j[rows ? ~placed[i].fin : placed[i].fin];
+    f.partial = rows ? q.w.row_sums : q.w.partial;
+    f.splits = q.n_slots;
+  }
+  NSR_TRY(wgrad_jobs_f16(wj, n_wg, st));
   hipLaunchKernelGGL(finish_jobs_kernel, dim3(256, jobs.n), dim3(256), 0, st, jobs);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
 
-bool chain_selected(int precision) {
-  if (precision != NSR_F16X3) return false;
-  const char* e = getenv("NSR_TRAIN_PATH");
-  return !(e && e[0] == 'g');   // "gemm": the layer-by-layer path
-}
+// which implementation a precision value selects (include/nsr_train.h): the chain kernels or the layer-by-layer GEMMs
+bool chain_selected(int precision) { return precision == NSR_F16X3; }
+bool train_precision_ok(int precision) { return precision == NSR_FP32 || precision == NSR_F16X3 || precision == NSR_F16X3_GEMM; }
+int gemm_precision(int precision) { return precision == NSR_F16X3_GEMM ? NSR_F16X3 : precision; }   // what the GEMM path's helpers expect
 
 int composite_bwd(hipStream_t st, const Work& k, const float* z, int64_t R, int N, int white) {
   const dim3 block(256), grid((unsigned)((R + 3) / 4));
@@ -881,7 +868,7 @@ int composite_bwd(hipStream_t st, const Work& k, const float* z, int64_t R, int 
 
 extern "C" size_t nsr_train_workspace_bytes_for(int precision, int64_t ray_chunk, int n_coarse, int n_importance) {
   if (ray_chunk <= 0 || n_coarse < 2 || n_importance < 1 || n_coarse + n_importance > 256) return 0;
-  if (precision != NSR_FP32 && precision != NSR_F16X3) return 0;
+  if (!train_precision_ok(precision)) return 0;
   return (size_t)work_floats(ray_chunk, n_coarse, n_importance, nullptr, nullptr, chain_selected(precision) ? 2 : 1) * sizeof(float);
 }
 
@@ -901,7 +888,7 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
   if (!w_coarse || !w_fine || !g_coarse || !g_fine || !outs || R < 0 || s2 <= 0 || !nsr_ray_stride_ok(ray_stride))
     return NSR_ERR_INVALID_ARG;
   if (n_coarse < 2 || n_importance < 1 || n_coarse + n_importance > 256) return NSR_ERR_UNSUPPORTED;
-  if (precision != NSR_FP32 && precision != NSR_F16X3) return NSR_ERR_UNSUPPORTED;
+  if (!train_precision_ok(precision)) return NSR_ERR_UNSUPPORTED;
   if (R % s2 != 0) return NSR_ERR_INVALID_ARG;
   if (ray_chunk <= 0 || ray_chunk > R) ray_chunk = R;
   if (ray_chunk % s2 != 0) return NSR_ERR_INVALID_ARG;
@@ -937,8 +924,8 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
       NSR_TRY(nsr_chain_bwd_pack(net ? w_fine : w_coarse, k.stream_b[net], stream));
     }
   } else {
-    NSR_TRY(prepare_weights(st, w_coarse, k.pack[0], precision));
-    NSR_TRY(prepare_weights(st, w_fine, k.pack[1], precision));
+    NSR_TRY(prepare_weights(st, w_coarse, k.pack[0], gemm_precision(precision)));
+    NSR_TRY(prepare_weights(st, w_fine, k.pack[1], gemm_precision(precision)));
   }
   if (hipMemsetAsync(k.carry, 0, 4 * sizeof(double), st) != hipSuccess) return NSR_ERR_LAUNCH;
 
@@ -967,7 +954,7 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
         NSR_CHECK_LAUNCH();
       }
       if (chain) NSR_TRY(nsr_f16x3_train_forward(k.stream_f[net], rays_c, ray_stride, z, rc, N, k.rgb, k.zpan, k.sgn, k.status, stream));
-      else NSR_TRY(net_forward(st, w, k.pack[net], k, P, precision));
+      else NSR_TRY(net_forward(st, w, k.pack[net], k, P, gemm_precision(precision)));
       const float* noise = net ? noise_fine : noise_coarse;
       hipLaunchKernelGGL(sigma_noise_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st,
                          chain ? k.rgb + 3 : k.gs + kSigmaCol, chain ? 4 : kGs, (noisy && noise) ? noise + r0 * N : nullptr,

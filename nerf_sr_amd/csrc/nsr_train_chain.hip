@@ -15,12 +15,13 @@
 //   layers 2..8      dz_{l-1} = (W_l^T dz_l) * [z_{l-1} > 0], l = 8..2     (l = 5: the h4 columns of the skip layer)
 //
 // Inputs: the sign panels of the forward pass (one bit per pre-activation, nsr_f16x3_core.h) for the ReLU masks;
-// outputs: gradient panels in the forward panels' layout, TRUE scale fp32 -- the A operands of the weight-gradient
-// kernel (nsr_wgrad_f16.hip), whose staging also sums them into the bias gradients -- and, per panel, the largest
-// magnitude written (that kernel's fp16 pre-scale).
-// Vector-memory choreography per 16-k-step block: weight DMA of the chunk after next in k-steps 8..13, then the 16
+// outputs: gradient panels in the forward panels' layout (round 5: the fp16 `hi` operand registers this kernel makes for
+// its own next layer, two 16-byte unit stores per block; stored value x the point's power-of-two `pscale` = the true
+// gradient rounded to 11 bits) -- the A operands of the weight-gradient kernel (nsr_wgrad_f16.hip), which also sums them
+// into the bias gradients -- and, per panel, the largest TRUE magnitude written (that kernel's fp16 pre-scale).
+// Vector-memory choreography per 16-k-step block: weight DMA of the chunk after next in k-steps 8..13, then the 2
 // stores of the pending block and the sign-word load of the next one in k-steps 14, 15 -- behind the DMA, so the next
-// publish point (s_waitcnt vmcnt(17)) does not have to wait for them.
+// publish point (s_waitcnt vmcnt(3)) does not have to wait for them.
 //
 // Range: gradients sit far below fp16's range and differ by orders of magnitude from point to point, so every point
 // (lane pair) carries its own power-of-two scale: the prologue scales the point's inputs to max 2^1..2^2, and each
@@ -134,9 +135,8 @@ __device__ __forceinline__ void stage_factors(Scale& cur, const Scale& prev) {
 // re-split of a finished gradient block (in place in its accumulator registers)
 //   MASK:  x = acc * [z > 0]                         (v_cmp + v_cndmask per element)
 //   CONV:  hi = RNE_f16(x) * phi (v_cvt_pk, v_pk_mul), lo = RNE_f16(x phi - hi) (v_fma_mix), max |x| tracked
-//   the masked accumulator x itself is what the caller stores to the gradient panel: x = the true gradient / cinv with
-//   the POINT's power-of-two cinv of this layer, kept once per point and panel (pscale) and applied by the consumer --
-//   the weight-gradient kernel multiplies every staged value by a scale anyway (16 fewer VALU per block here)
+//   hi is also what the caller stores to the gradient panel: hi = RNE_f16(the true gradient / cinv) * phi with the POINT's
+//   powers of two cinv, phi of this layer; pscale = cinv / phi is kept once per point and panel and applied by the consumer
 // 17 half-steps as in the forward kernel: half-step 2P = first part of pair P, 2P + 1 = second part of pair P and the
 // lo of pair P - 1.
 // ---------------------------------------------------------------------------------------------------------
@@ -159,21 +159,12 @@ __device__ __forceinline__ void bsplit_a(Acc& p, unsigned mz, Scale& sc, BwdTmp&
         "v_max3_f32 %3, |%0|, |%1|, %3"
         : "+v"(p.m[2 * P]), "+v"(p.m[2 * P + 1]), "=&v"(hi), "+v"(sc.mx), "=&v"(t0), "=&v"(t1)
         : "v"(mz), "n"(15 - 2 * P), "n"(14 - 2 * P));
-  else if (CONV)
+  else
     asm volatile(
         "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
         "v_max3_f32 %1, |%2|, |%3|, %1"
         : "=&v"(hi), "+v"(sc.mx)
         : "v"(p.m[2 * P]), "v"(p.m[2 * P + 1]));
-  else   // last layer: mask and scale only
-    asm volatile(
-        "v_bfe_i32 %3, %5, %7, 1\n\t"
-        "v_bfe_i32 %4, %5, %8, 1\n\t"
-        "v_bfi_b32 %0, %3, 0, %0\n\t"
-        "v_bfi_b32 %1, %4, 0, %1\n\t"
-        "v_max3_f32 %2, |%0|, |%1|, %2"
-        : "+v"(p.m[2 * P]), "+v"(p.m[2 * P + 1]), "+v"(sc.mx), "=&v"(t0), "=&v"(t1)
-        : "v"(mz), "v"(sc.cinv), "n"(15 - 2 * P), "n"(14 - 2 * P));
 }
 template <int P>
 __device__ __forceinline__ void bput(unsigned v, u32x4& d0, u32x4& d1) {
@@ -229,26 +220,26 @@ __device__ __forceinline__ void bwd_step(int s, Acc& p, unsigned mz, Scale& sc, 
     bwd_half<MASK, CONV>(s + 3, p, mz, sc, t, h0, l0, h1, l1);
   }
 }
-// Stores of the pending block: all 16 in k-steps 14 and 15 (the block is final, true scale, after half-step 16 =
-// k-step 13), i.e. BEHIND the chunk's last DMA piece (k-step 13).  Vector-memory operations complete in issue order, so
+// Stores of the pending block: its two units in k-steps 14 and 15 (the hi registers are final after half-step 15 =
+// k-step 12), i.e. BEHIND the chunk's last DMA piece (k-step 13).  Vector-memory operations complete in issue order, so
 // the next publish point -- which must see that DMA landed -- can leave these stores in flight (block_mma's YOUNGER
 // count); they only have to be done one block later.  (With the stores spread over k-steps 8..13 the publish point's
 // wait covered them too and the wave stalled on HBM write latency every block.)
 // These are PLAIN (compiler-visible, non-temporal) stores, unlike the forward kernel's asm ones: the kernel also has
 // compiler-visible loads (the mask words), and the compiler's vmcnt for a load only counts the younger operations it
 // can see -- with invisible stores behind the load its wait would cover them as well.
-__device__ __forceinline__ void bwd_panel_store(int r, const Acc& p, const float* blk, unsigned voff) {
+template <int U>
+__device__ __forceinline__ void bwd_unit_store(const u32x4& v, const char* blk, unsigned voff) {
 #ifdef NSR_ABL_BWD_NO_STORE   // ablation (scripts/): how much of the kernel is its panel writes
   if (voff != 0xffffffffu) return;
 #endif
-  float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(const_cast<float*>(blk)) + voff + (8 * (r >> 2) + (r & 3)) * 128);
-  __builtin_nontemporal_store(p.m[r], dst);
+  u32x4* dst = reinterpret_cast<u32x4*>(const_cast<char*>(blk) + U * 1024 + voff);
+  __builtin_nontemporal_store(v, dst);
 }
-__device__ __forceinline__ void bwd_store_step(int s, const Acc& p, const float* blk, unsigned voff) {
-  if (s >= 14) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) bwd_panel_store(8 * (s - 14) + r, p, blk, voff);
-  }
+__device__ __forceinline__ void bwd_store_step(int s, const u32x4& h0, const u32x4& h1, const char* blk, unsigned voff0,
+                                               unsigned voff1) {
+  if (s == 14) bwd_unit_store<0>(h0, blk, voff0);
+  if (s == 15) bwd_unit_store<1>(h1, blk, voff1);
 }
 
 // Mask load: the sign word this lane needs to mask block X is fetched during block X - 1, k-step 14 -- a whole block
@@ -262,7 +253,7 @@ __device__ __forceinline__ void mask_load_step(int s, unsigned& mz, const unsign
 struct BwdCtx {
   const unsigned* sgn;   // sign panels of the forward pass (masks)
   PanelRef dp;           // gradient panels
-  unsigned voff;
+  unsigned voff0, voff1; // this lane's slot in unit 0 / 1 of a block (unit_voff)
   int lane;
   unsigned* lmax;     // LDS, 16 words: per gradient panel, float bits of the largest magnitude this workgroup wrote
   float* pscale;      // (10 panels, padded points): stored value x pscale = true gradient
@@ -283,7 +274,7 @@ __device__ __forceinline__ void publish_max(const BwdCtx& cx, int panel, float v
 //   MASK: this layer's outputs are masked by forward panel `panel` (and written to gradient panel `panel`)
 //   ADD: this layer's finished blocks get the density head's rank-1 term, acc += wsigma[feature] * sig (sig = d_sigma at
 //        the accumulators' scale) -- 16 FMAs per block of layer 1 instead of streaming a (mostly zero) k-step for it
-//   LAST: outputs are not converted (nothing consumes them in this kernel)
+//   LAST: the last layer (nothing consumes its operands in this kernel, but they are what is stored)
 //   NEXT_MASK / next_panel: the layer after this one, whose first block's masks are fetched during this layer's last block
 //   FIRST: no layer before this one (layer 0): block 0 has nothing pending to convert or store
 template <bool PREV_MASK, bool MASK, bool ADD, bool LAST, bool NEXT_MASK, bool FIRST = false>
@@ -306,7 +297,7 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
     if (nb == 1) {                             // the previous layer's last block was measured during block 0
       if (prev_panel >= 0) publish_max(cx, prev_panel, prev.mx * prev.cinv);
       stage_factors(cur, prev);
-      store_pscale(cx, panel, cur.cinv);
+      store_pscale(cx, panel, cur.cinv * (1.0f / cur.phi));   // phi is a power of two >= 2^-14: exact
     }
     // masks of the block AFTER this one (loaded here), of the PENDING block (loaded two blocks ago, same buffer parity)
     const bool load_next = (nb < 7) ? MASK : NEXT_MASK;
@@ -318,7 +309,7 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
     unsigned& mz_next = mz[(nb + 1) & 1];   // block nb + 1; free again once the pending block (nb - 1) is done (k-step 13)
     // younger than the DMA this chunk's publish point waits for: what the block before issued in its k-steps 14, 15,
     // behind its last DMA piece (k-step 13): the 16 stores of ITS pending block and the mask load for THIS block
-    const int kYoung = ((FIRST && nb <= 1) ? 0 : 16) + ((MASK && !(FIRST && nb == 0)) ? 1 : 0);
+    const int kYoung = ((FIRST && nb <= 1) ? 0 : 2) + ((MASK && !(FIRST && nb == 0)) ? 1 : 0);
     auto mma = [&](auto young) {
     block_mma<16, kBar, decltype(young)::value>(
         acc, pre, a_addr, ld, c2, [&](int s, int part) -> u32x4 { return part ? bl[s] : bh[s]; },
@@ -326,17 +317,17 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
           if (nb == 0) {
             // block 7 of the layer before -> k-steps 14, 15 of THIS layer's input
             bwd_step<PREV_MASK, true>(s, pend, mz_pend, prev, tmp, bh[14], bl[14], bh[15], bl[15]);
-            if (prev_panel >= 0) bwd_store_step(s, pend, panel_block(cx.dp, prev_panel, 7), cx.voff);
+            if (prev_panel >= 0) bwd_store_step(s, bh[14], bh[15], panel_block(cx.dp, prev_panel, 7), cx.voff0, cx.voff1);
           } else {
-            bwd_step<MASK, !LAST>(s, pend, mz_pend, cur, tmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1]);
-            bwd_store_step(s, pend, panel_block(cx.dp, panel, nb - 1), cx.voff);
+            bwd_step<MASK, true>(s, pend, mz_pend, cur, tmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1]);
+            bwd_store_step(s, oh[2 * nb - 2], oh[2 * nb - 1], panel_block(cx.dp, panel, nb - 1), cx.voff0, cx.voff1);
           }
           if (load_next) mask_load_step(s, mz_next, next_blk, cx.lane);
         },
         [&](int k) { prefetch_frag(nxt, k, ld.slot_next + ld.lane_off); });
     };
-    if (kYoung == 17) mma(std::integral_constant<int, 17>{});
-    else if (kYoung == 16) mma(std::integral_constant<int, 16>{});
+    if (kYoung == 3) mma(std::integral_constant<int, 3>{});
+    else if (kYoung == 2) mma(std::integral_constant<int, 2>{});
     else if (kYoung == 1) mma(std::integral_constant<int, 1>{});
     else mma(std::integral_constant<int, 0>{});
     if (ADD) {   // plain C++ on purpose: the compiler inserts the MFMA -> VALU wait states
@@ -351,7 +342,7 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
 }
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ sgn, float* __restrict__ dpan,
+chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ sgn, char* __restrict__ dpan,
                  const float* __restrict__ d_rgb, int d_rgb_stride, const float* __restrict__ d_sigma, int d_sigma_stride,
                  int64_t P, unsigned* __restrict__ gmax, float* __restrict__ pscale) {
   constexpr int kAux0 = 3 * kSlotFloats;
@@ -386,13 +377,13 @@ chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ 
   cx.dp.n_groups = (int64_t)gridDim.x * 4;
   cx.dp.group = (int64_t)blockIdx.x * 4 + wave;
   cx.dp.sgn = nullptr;
-  cx.voff = 4u * (unsigned)(m + 128 * h);
+  cx.voff0 = unit_voff(m, h, 0);
+  cx.voff1 = unit_voff(m, h, 1);
   cx.lane = lane;
   cx.lmax = lmax;
   cx.pscale = pscale;
   cx.pidx = cx.dp.group * 32 + m;
   cx.writer = h == 0;
-  store_pscale(cx, 9, 1.0f);   // the colour head's input gradient (prologue) is written at true scale
 
   // ---- prologue: the colour head's input gradient on the VALU (K = 3), masked by dir_encoding's ReLU
   const float g0 = d_rgb[pc * d_rgb_stride + 0], g1 = d_rgb[pc * d_rgb_stride + 1], g2 = d_rgb[pc * d_rgb_stride + 2];
@@ -421,17 +412,7 @@ chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ 
   mxin = fmaxf(mxin, __shfl_xor(mxin, 32, 64));
   // the point's scale: its largest input lands in [2, 4)
   const float S = mxin > 0.0f ? pow2f(1 - floor_log2(mxin)) : 1.0f;
-  {
-    Acc tmp;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tmp.m[r] = dz[16 * b + r];
-      const float* blk = panel_block(cx.dp, 9, b);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) panel_store(r, tmp, blk, cx.voff);
-    }
-  }
+  store_pscale(cx, 9, 1.0f / S);   // the colour head's input gradient (prologue) is stored as hi of dz * S
   u32x4 bh[16], bl[16], oh[16], ol[16];
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
@@ -445,6 +426,13 @@ chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ 
   for (int s = 8; s < 16; ++s) {
     bh[s] = u32x4{0u, 0u, 0u, 0u};
     bl[s] = u32x4{0u, 0u, 0u, 0u};
+  }
+  // gradient panel 9: the operand registers just made (block b = k-steps 2b, 2b + 1)
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const char* blk = panel_block(cx.dp, 9, b);
+    unit_store<0>(bh[2 * b], blk, cx.voff0);
+    unit_store<1>(bh[2 * b + 1], blk, cx.voff1);
   }
   const float* wsig_h = ring + kAux0 + 512 + 4 * h;   // sigma.weight, this lane half's features (+ 32 nb + 8 (r >> 2) + (r & 3))
   // "previous stage" of layer 0 = the prologue: operands at scale S with max in [2, 4)
@@ -481,21 +469,18 @@ chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ 
                                               prev, cx);
   }
   bwd_layer<true, true, false, true, false>(8, 1, 0, -1, bh, bl, oh, ol, wsig_h, gs, ld, pend, pre, mz, prev, cx);
-  // the last block of dz1: mask, true scale, store
+  // the last block of dz1: mask, convert with the last layer's factors (`prev` now), store
   {
-    Scale last{};
-    last.cinv = prev.cinv;
     BwdTmp tmp;
     // the accumulators were written by the MFMA just issued, and the hazard recognizer does not look inside inline asm:
     // give the matrix pipe its write-back latency (18 wait states for a 16-pass MFMA) before the asm below reads them
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    last.mx = prev.mx;
 #pragma unroll
-    for (int hs = 0; hs < 16; hs += 2) bwd_half<true, false>(hs, pend, mz[1], last, tmp, bh[0], bl[0], bh[1], bl[1]);
-    publish_max(cx, 0, last.mx * last.cinv);
-    const float* blk = panel_block(cx.dp, 0, 7);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) panel_store(r, pend, blk, cx.voff);
+    for (int hs = 0; hs < 17; ++hs) bwd_half<true, true>(hs, pend, mz[1], prev, tmp, bh[0], bl[0], bh[1], bl[1]);
+    publish_max(cx, 0, prev.mx * prev.cinv);
+    const char* blk = panel_block(cx.dp, 0, 7);
+    unit_store<0>(bh[0], blk, cx.voff0);
+    unit_store<1>(bh[1], blk, cx.voff1);
   }
   dma_drain();   // no LDS-DMA may be in flight when the workgroup's LDS is released
   __syncthreads();
@@ -519,13 +504,13 @@ extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* pack
   return NSR_OK;
 }
 
-extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const unsigned* sgn, float* dpan, const float* d_rgb, int d_rgb_stride,
+extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const unsigned* sgn, void* dpan, const float* d_rgb, int d_rgb_stride,
                                           const float* d_sigma, int d_sigma_stride, int64_t P, unsigned* gmax,
                                           float* pscale, void* stream) {
   if (P <= 0) return NSR_OK;
   if (hipMemsetAsync(gmax, 0, 10 * sizeof(unsigned), nsr_stream(stream)) != hipSuccess) return NSR_ERR_LAUNCH;
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
-  hipLaunchKernelGGL(chain_bwd_kernel, grid, block, 0, nsr_stream(stream), static_cast<const float*>(packed), sgn, dpan, d_rgb,
+  hipLaunchKernelGGL(chain_bwd_kernel, grid, block, 0, nsr_stream(stream), static_cast<const float*>(packed), sgn, static_cast<char*>(dpan), d_rgb,
                      d_rgb_stride, d_sigma, d_sigma_stride, P, gmax, pscale);
   NSR_CHECK_LAUNCH();
   return NSR_OK;

@@ -1,66 +1,91 @@
-// Weight gradient of a linear layer from two training panels on the split-fp16 matrix pipe (nsr_gemm.h: wgrad_f16x3).
+// Weight gradient of a linear layer from two training panels on the fp16 matrix pipe (nsr_gemm.h: WgradArgs).
 //
-//   partial[z] (M x N) = mult * sum over slice z of the points p of  A[p][0..M) B[p][0..N)^T
+//   partial[z] (M x N) = sum over slice z of the points p of  dz[p][0..M) a[p][0..N)^T
 //
-// A = a gradient panel (true-scale fp32, nsr_train_chain.hip), B = a forward panel (pre-activations x 2^6, read through
-// max(., 0) when the consumer saw them behind a ReLU).  Both are "blocked transposed" ([group of 32 points][row][32],
-// nsr_f16x3_core.h), so the K tile of one point group is ONE contiguous rows x 128 B run of each panel: the staging
-// loads are perfectly coalesced float4 streams and every byte of both panels is read exactly once by exactly one
-// workgroup (tile = all M x all N columns; PMC: 8.36 GB fetched per 2,048-ray step against 8.36 GB of panels,
-// profiles/r2_train_traffic.json).  Each value is split into fp16 (hi, lo) on its way from registers to LDS
-// and each product is a_hi b_hi + a_hi b_lo + a_lo b_hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation: 3/16 of the
-// fp32-MFMA cycles, which turns the product from matrix-pipe bound (68 % of the fp32 peak, 0.32 ms per fine-pass layer)
-// into HBM bound (two panels of P KiB each).
-// Range: gradients are tiny (1e-8 .. 1e-3), so A is multiplied by a power of two S that puts the panel's largest
-// magnitude (kept by the backward chain: an LDS atomicMax per lane and layer, a global one per workgroup) at 2^13..2^14; elements far below the
-// maximum lose relative precision against fp16's subnormal floor (2^-24 / S absolute), which is 2^-38 of the panel's
-// maximum -- nothing a sum over the points can see.  S and B's 2^6 are removed from the accumulators (exactly) before
-// the partial sums are written; the split-K reduction is the deterministic second pass of the fp32 path.
-// While a thread stages its A values it also sums them per row in fp32: the bias gradient of the layer.
+// Round 5: both operands are the 2-byte panels the chain kernels write (nsr_f16x3_core.h): A = a gradient panel -- the
+// backward chain's own fp16 `hi` operand, i.e. the input gradient rounded to 11 bits at the POINT's power-of-two scale
+// (stored x pscale[p] = true) --, B = a forward panel -- the activation relu(z) (or g, for xyz_encoding_final) rounded to
+// 11 bits.  ONE v_mfma_f32_32x32x16_f16 per product, fp32 accumulation: the contraction runs over hundreds of thousands of
+// points whose rounding errors are independent, so a weight-gradient tensor moves by 1e-5 .. 8e-5 of its norm -- less than
+// running the reference's own arithmetic in fp32 instead of fp64 does (profiles/r4_train_fp16_wgrad_study.txt).  Rounds
+// 2-4 read fp32 panels (twice the bytes) and issued three MFMAs per product after splitting every value on the VALU.
+//
+// HBM-bound by design: every byte of both panels is read exactly once by exactly one workgroup (tile = all M x all N).
+// Data path: a point group's rows of either panel are one contiguous run of 1 KiB units; LDS-DMA copies them, unit for
+// unit, into a 4-stage LDS ring (three point groups in flight per CU), no register staging, no VALU on the way.  The units
+// hold [point][4 features] (what a chain kernel's lane owns); the MFMA wants, per lane, one feature x 8 consecutive points:
+// ds_read_b64_tr_b16 transposes on the way out of LDS -- a 16-lane group reads sixteen 8-byte pieces (4 points x 4 feature
+// runs) and lane l receives feature l of 4 points.  The slot permutation the chain kernels store with, (2m + h) ^ 8u, makes
+// the 32 pieces of a half-wave fall on 32 distinct 8-byte bank pairs.
+// Range: the per-point factor pscale[p] * S (S = the power of two that puts the panel's largest true magnitude, kept by the
+// backward chain, at 2^13 .. 2^14) is applied to the A fragments as two exact v_pk_mul_f16 (2^ceil(e/2) * 2^floor(e/2):
+// neither the factors nor the intermediate can leave fp16's range while the result is inside it); elements far below the
+// panel's maximum meet fp16's subnormal floor at 2^-38 of that maximum -- nothing a sum over the points can see.  All
+// factors are powers of two: multiplying the loss by 2^k multiplies every gradient by exactly 2^k.
+// The bias gradient (row sums of A at true scale) rides along: v_dot2_f32_f16 of the scaled fragments with ones.
 #include "nsr_gemm.h"
+#include "nsr_f16x3_core.h"
 
 namespace nsr {
 namespace {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// the panels are read once: non-temporal staging loads (same box, 2,048-ray training step: 6.02-6.03 ms with plain
-// loads, 5.94 ms with these)
-#ifdef NSR_WGRAD_PLAIN_LOADS
-#define NSR_WGRAD_LOAD(p) (*(p))
-#else
-#define NSR_WGRAD_LOAD(p) __builtin_nontemporal_load(p)
-#endif
+typedef __fp16 fp4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef NSR_SLICE_INLINE
 #define NSR_SLICE_INLINE __forceinline__
 #endif
-constexpr int kTK = 32, kLd = kTK + 8;   // one point group per K tile; LDS row stride in halves (80 B: conflict-free b128 reads)
-constexpr int kNT = 512;                 // 8 waves, each a (32 BM) x (32 BN) tile of the TM x TN product
+constexpr int kNT = 512;                       // 8 waves, each a (32 BM) x (32 BN) tile of the TM x TN product
+constexpr int kStages = 4;                     // LDS ring: the group being multiplied + three in flight
+constexpr int kStageData = 32 * 1024;          // A rows then B rows of one point group (256 + 256 rows x 64 B at most)
+constexpr int kStageBytes = kStageData + 256;  // + the group's pscale (one 256-byte DMA piece: 32 floats, twice)
+constexpr int kFac0 = kStages * kStageBytes;   // per wave: F1[32], F2[32] fp16 factors of the current group
+constexpr int kLdsBytes = kFac0 + 8 * 128;
+
+// 64 lanes x 4 B, lane-linear, global -> LDS (the dword form of glds16_asm, nsr_f16x3_core.h)
+__device__ __forceinline__ void glds4_asm(const char* base_uniform, unsigned lane_off, unsigned lds_dst_uniform) {
+  unsigned long long tmp;
+  asm volatile(
+      "s_mov_b32 m0, %3\n\t"
+      "s_mov_b64 %0, %2\n\t"
+      "global_load_lds_dword %1, %0"
+      : "=&s"(tmp)
+      : "v"(lane_off), "s"(base_uniform), "s"(lds_dst_uniform)
+      : "memory");
+}
+// the transposing LDS read: lane l of a 16-lane group receives, of the sixteen 8-byte pieces the group's lanes address,
+// half (l & 3) of the pieces of lanes (l >> 2), 4 + (l >> 2), 8 + (l >> 2), 12 + (l >> 2)
+__device__ __forceinline__ h4 tr16(unsigned byte_addr) {
+  return __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp4*)(size_t)byte_addr));
+}
+__device__ __forceinline__ u32x2 lds_u2(unsigned byte_addr) {
+  return *(const __attribute__((address_space(3))) u32x2*)(size_t)byte_addr;
+}
 
 // TM x TN (BM, BN) = 256 x 256 (4, 2): trunk layers; 128 x 256 (2, 2): dir_encoding over g; 256 x 64 (1, 2): a trunk
 // layer over the encoded position; 128 x 64 (1, 1): dir_encoding over the encoded direction
-// One slice of one product: the point groups [g_begin, g_end) of w's panels -> partial slot `slot` (+ row sums).  `lds`:
-// 2 * TM * kLd + 2 * kTN * kLd halves.  Ends behind a workgroup barrier (the caller may re-use the LDS at once).
+// One slice of one product: the point groups [g_begin, g_end) of w's panels -> partial slot `slot` (+ row sums).
+// Ends drained and behind a workgroup barrier (the caller may re-use the LDS at once).
 template <int TM, int kTN, int BM, int BN>
-__device__ NSR_SLICE_INLINE void wgrad_slice(const WgradArgs& w, int64_t g_begin, int64_t g_end, int64_t slot, _Float16* lds) {
+__device__ NSR_SLICE_INLINE void wgrad_slice(const WgradArgs& w, int64_t g_begin, int64_t g_end, int64_t slot, unsigned lds0) {
   constexpr int WM = TM / (32 * BM), WN = kTN / (32 * BN);   // wave grid
   static_assert(WM * WN == 8, "tile does not split over 8 waves");
-  constexpr int kArrA = TM * kLd, kArrB = kTN * kLd;
-  constexpr int NA = TM * kTK / 4 / kNT, NB = kTN * kTK / 4 / kNT;   // float4 per thread and K tile: 4 (2) and 4
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int kPiecesA = TM / 16, kPieces = (TM + kTN) / 16;   // 1 KiB units of a point group
+  constexpr int PW = (kPieces + 7) / 8;                           // DMA pieces a wave issues per stage (the surplus re-fetches
+                                                                  // the last piece: same bytes to the same place)
+  static_assert((TM + kTN) * 64 <= kStageData, "stage too small");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WM, wn = wave / WM, li = lane & 31, h = lane >> 5;
-  const int64_t z = slot;
 
-  // power-of-two pre-scale of A from the panel's maximum magnitude
+  // power-of-two pre-scale of A from the panel's largest true magnitude
   const float amax = __uint_as_float(*w.a_max_bits);
-  int e = 13 - ((int)((__float_as_uint(amax) >> 23) & 255u) - 127);
-  e = e < -100 ? -100 : (e > 100 ? 100 : e);
-  const float S = amax > 0.0f ? __uint_as_float((unsigned)(e + 127) << 23) : 1.0f;
-  const float b_lower = w.b_relu ? 0.0f : -__builtin_inff();
+  int eS = 13 - ((int)((__float_as_uint(amax) >> 23) & 255u) - 127);
+  eS = eS < -100 ? -100 : (eS > 100 ? 100 : eS);
+  if (!(amax > 0.0f)) eS = 0;
+  const float inv_S = __uint_as_float((unsigned)(127 - eS) << 23);
 
   f32x16 acc[BM][BN];
 #pragma unroll
@@ -69,83 +94,115 @@ __device__ NSR_SLICE_INLINE void wgrad_slice(const WgradArgs& w, int64_t g_begin
     for (int bj = 0; bj < BN; ++bj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.0f;
+  float rs[BM];
+#pragma unroll
+  for (int bi = 0; bi < BM; ++bi) rs[bi] = 0.0f;
 
-  // staging: float4 number tid + 512 i of the group's contiguous (rows x 32) run = row (tid >> 3) + 64 i, k = 4 (tid & 7)
-  f32x4 sa[NA], sb[NB];
-  f32x4 ps = {1.0f, 1.0f, 1.0f, 1.0f};   // per-point scales of this thread's four points (the same for all its rows)
-  float rs[NA];
+  if (g_begin < g_end) {
+    // ---- DMA of point group g into ring stage st (all operands wave-uniform but the lane offset); the panel descriptors
+    // are copied out of the argument block once: the asm statements clobber memory, and the compiler would re-load them
+    // from the kernel arguments (s_load + lgkmcnt(0), which also waits for the LDS reads) in every trip
+    const unsigned lane16 = (unsigned)lane * 16u, lane4 = (unsigned)(lane & 31) * 4u;
+    const char* src0[PW];
+    int64_t gstep[PW];
+    unsigned dst0[PW];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) rs[i] = 0.0f;
-  auto load = [&](int64_t g) {
-    const f32x4* ap = reinterpret_cast<const f32x4*>(w.A + g * w.a_gstride);
-    const f32x4* bp = reinterpret_cast<const f32x4*>(w.B + g * w.b_gstride);
-#pragma unroll
-    for (int i = 0; i < NA; ++i) sa[i] = NSR_WGRAD_LOAD(ap + tid + kNT * i);
-#pragma unroll
-    for (int i = 0; i < NB; ++i) sb[i] = NSR_WGRAD_LOAD(bp + tid + kNT * i);
-    if (w.a_pscale) ps = reinterpret_cast<const f32x4*>(w.a_pscale + g * 32)[tid & 7];
-  };
-  auto split_store = [&](const f32x4& v, _Float16* hi_arr, _Float16* lo_arr, int row) {
-    h4 hi, lo;
-#pragma unroll
-    for (int e4 = 0; e4 < 4; ++e4) {
-      const _Float16 x = (_Float16)v[e4];
-      hi[e4] = x;
-      lo[e4] = (_Float16)(v[e4] - (float)x);
+    for (int j = 0; j < PW; ++j) {
+      int q = wave + 8 * j;
+      if (q >= kPieces) q = kPieces - 1;
+      const bool is_a = q < kPiecesA;
+      src0[j] = is_a ? static_cast<const char*>(w.A) + q * 1024 : static_cast<const char*>(w.B) + (q - kPiecesA) * 1024;
+      gstep[j] = is_a ? w.a_gbytes : w.b_gbytes;
+      dst0[j] = (unsigned)q * 1024u;
     }
-    const int off = row * kLd + 4 * (tid & 7);
-    *reinterpret_cast<h4*>(hi_arr + off) = hi;
-    *reinterpret_cast<h4*>(lo_arr + off) = lo;
-  };
-  auto store = [&]() {
+    const char* ps0 = reinterpret_cast<const char*>(w.a_pscale);
+    auto issue = [&](int64_t g, int st) {
+      if (g >= g_end) g = g_end - 1;     // tail: keep the per-stage operation count uniform (the vmcnt below relies on it)
+      const unsigned dst = lds0 + (unsigned)st * kStageBytes;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const f32x4 t = sa[i] * ps;           // true gradients
-      rs[i] += (t[0] + t[1]) + (t[2] + t[3]);
-      split_store(t * S, lds, lds + kArrA, (tid >> 3) + 64 * i);
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      f32x4 v = sb[i];
-#pragma unroll
-      for (int e4 = 0; e4 < 4; ++e4) v[e4] = fmaxf(v[e4], b_lower);
-      split_store(v, lds + 2 * kArrA, lds + 2 * kArrA + kArrB, (tid >> 3) + 64 * i);
-    }
-  };
+      for (int j = 0; j < PW; ++j) glds16_asm<0>(src0[j] + g * gstep[j], lane16, dst + dst0[j]);
+      glds4_asm(ps0 + g * 128, lane4, dst + kStageData);   // every wave: the same 128 B twice
+    };
+    // this lane's piece addresses inside a 2 KiB block for the transposing reads (see the header): 16-lane group g4 =
+    // (unit u, k half hh); source lane i = lane & 15 addresses point 16 s + 8 hh + 4 t + (i >> 2), feature run i & 3
+    const int g4 = lane >> 4, u = g4 & 1, hh = g4 >> 1, i16 = lane & 15;
+    const unsigned c0 = (unsigned)(u * 1024 + 256 * hh + 32 * (i16 >> 2) + 16 * (i16 & 1) + 8 * ((i16 >> 1) & 1));
+    const unsigned rd_t0 = c0 + 128u * (unsigned)u, rd_t1 = c0 + 128u * (unsigned)(1 - u);
+    const unsigned fac = lds0 + kFac0 + (unsigned)wave * 128u;
+    const h2 ones = {(_Float16)1.0f, (_Float16)1.0f};
 
-  if (g_begin < g_end) load(g_begin);
-  for (int64_t g = g_begin; g < g_end; ++g) {
-    store();
-    __syncthreads();
-    if (g + 1 < g_end) load(g + 1);
-    const _Float16* ap = lds + (32 * BM * wm + li) * kLd + 8 * h;
-    const _Float16* bp = lds + 2 * kArrA + (32 * BN * wn + li) * kLd + 8 * h;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      h8 bh[BN], bl[BN];
-#pragma unroll
-      for (int bj = 0; bj < BN; ++bj) {
-        bh[bj] = *reinterpret_cast<const h8*>(bp + 32 * bj * kLd + 16 * s);
-        bl[bj] = *reinterpret_cast<const h8*>(bp + kArrB + 32 * bj * kLd + 16 * s);
+    for (int i = 0; i < kStages - 1; ++i) issue(g_begin + i, i);
+    int st = 0;
+    for (int64_t g = g_begin; g < g_end; ++g) {
+      // this wave's pieces of group g have landed (two younger stages may stay in flight); then everybody's have, and
+      // everybody has left the stage that is refilled next
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"(2 * (PW + 1)) : "memory");
+      issue(g + kStages - 1, (st + kStages - 1) & (kStages - 1));
+      const unsigned sb = lds0 + (unsigned)st * kStageBytes;
+      // ---- per-point factors of this group, made once per wave: e = log2(pscale * S) as 2^(e >> 1) * 2^(e - (e >> 1))
+      if (lane < 32) {
+        const unsigned pb = *(const __attribute__((address_space(3))) unsigned*)(size_t)(sb + kStageData + 4u * (unsigned)lane);
+        int e = (int)((pb >> 23) & 255u) - 127 + eS;
+        e = e < -28 ? -28 : (e > 28 ? 28 : e);
+        const int e1 = e >> 1, e2 = e - e1;
+        *(__attribute__((address_space(3))) unsigned short*)(size_t)(fac + 2u * (unsigned)lane) = (unsigned short)((15 + e1) << 10);
+        *(__attribute__((address_space(3))) unsigned short*)(size_t)(fac + 64u + 2u * (unsigned)lane) = (unsigned short)((15 + e2) << 10);
       }
+      asm volatile("" ::: "memory");   // the wave's own LDS writes are seen by its later reads (DS operations stay in order)
+      h2 f1[2][2][2], f2[2][2][2];     // [k-step][t][pair]
 #pragma unroll
-      for (int bi = 0; bi < BM; ++bi) {
-        const h8 ah = *reinterpret_cast<const h8*>(ap + 32 * bi * kLd + 16 * s);
-        const h8 al = *reinterpret_cast<const h8*>(ap + kArrA + 32 * bi * kLd + 16 * s);
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const unsigned o = 2u * (unsigned)(16 * s + 8 * hh + 4 * t);
+          const u32x2 a = lds_u2(fac + o), b = lds_u2(fac + 64u + o);
+          // through scalars: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0 whatever the index
+          // (hipcc 7.2; found in the ISA: one ds_read_b32 per pair of points)
+          const unsigned a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+          f1[s][t][0] = __builtin_bit_cast(h2, a0);
+          f1[s][t][1] = __builtin_bit_cast(h2, a1);
+          f2[s][t][0] = __builtin_bit_cast(h2, b0);
+          f2[s][t][1] = __builtin_bit_cast(h2, b1);
+        }
+      const unsigned a_base = sb + (unsigned)(BM * wm) * 2048u, b_base = sb + (unsigned)(TM * 64) + (unsigned)(BN * wn) * 2048u;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        h8 bf[BN];
 #pragma unroll
         for (int bj = 0; bj < BN; ++bj) {
-          acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[bj], acc[bi][bj], 0, 0, 0);   // small terms first
-          acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[bj], acc[bi][bj], 0, 0, 0);
-          acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[bj], acc[bi][bj], 0, 0, 0);
+          const h4 b0 = tr16(b_base + rd_t0 + (unsigned)(bj * 2048 + 512 * s));
+          const h4 b1 = tr16(b_base + rd_t1 + (unsigned)(bj * 2048 + 512 * s));
+          bf[bj] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int bi = 0; bi < BM; ++bi) {
+          h4 a0 = tr16(a_base + rd_t0 + (unsigned)(bi * 2048 + 512 * s));
+          h4 a1 = tr16(a_base + rd_t1 + (unsigned)(bi * 2048 + 512 * s));
+          h2 p00 = {a0[0], a0[1]}, p01 = {a0[2], a0[3]}, p10 = {a1[0], a1[1]}, p11 = {a1[2], a1[3]};
+          p00 = (p00 * f1[s][0][0]) * f2[s][0][0];
+          p01 = (p01 * f1[s][0][1]) * f2[s][0][1];
+          p10 = (p10 * f1[s][1][0]) * f2[s][1][0];
+          p11 = (p11 * f1[s][1][1]) * f2[s][1][1];
+          if (wn == 0) {   // wave-uniform: one wave column sums the rows (the bias gradient)
+            rs[bi] = __builtin_amdgcn_fdot2(p00, ones, rs[bi], false);
+            rs[bi] = __builtin_amdgcn_fdot2(p01, ones, rs[bi], false);
+            rs[bi] = __builtin_amdgcn_fdot2(p10, ones, rs[bi], false);
+            rs[bi] = __builtin_amdgcn_fdot2(p11, ones, rs[bi], false);
+          }
+          const h8 af = {p00[0], p00[1], p01[0], p01[1], p10[0], p10[1], p11[0], p11[1]};
+#pragma unroll
+          for (int bj = 0; bj < BN; ++bj) acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[bj], acc[bi][bj], 0, 0, 0);
         }
       }
+      st = (st + 1) & (kStages - 1);
     }
-    __syncthreads();
+    // the tail's surplus fetches must have landed before the ring is handed on (or the workgroup's LDS released)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   }
 
   // partial sums at true scale: D lane (column li, half h) of block (bi, bj) holds rows 8 (r >> 2) + 4 h + (r & 3)
-  const float mult = w.out_scale / S;
-  float* C = w.partial + (int64_t)z * w.split_stride;
+  float* C = w.partial + slot * w.split_stride;
 #pragma unroll
   for (int bi = 0; bi < BM; ++bi)
 #pragma unroll
@@ -154,42 +211,28 @@ __device__ NSR_SLICE_INLINE void wgrad_slice(const WgradArgs& w, int64_t g_begin
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = 32 * BM * wm + 32 * bi + 8 * (r >> 2) + 4 * h + (r & 3);
-        C[(int64_t)m * kTN + n] = acc[bi][bj][r] * mult;
+        C[(int64_t)m * kTN + n] = acc[bi][bj][r] * inv_S;
       }
     }
-  if (w.row_sums) {   // the 8 threads that stage one row are neighbours
+  if (w.row_sums && wn == 0) {   // lane (li, h) summed row li of its blocks over the points 8 h .. 8 h + 7 (mod 16)
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      float s = rs[i];
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
-      if ((tid & 7) == 0) w.row_sums[(int64_t)z * TM + (tid >> 3) + 64 * i] = s;
+    for (int bi = 0; bi < BM; ++bi) {
+      const float s2 = rs[bi] + __shfl_xor(rs[bi], 32, 64);
+      if (h == 0) w.row_sums[slot * TM + 32 * BM * wm + 32 * bi + li] = s2 * inv_S;
     }
   }
-}
-
-constexpr int kLdsHalves = 2 * 256 * kLd + 2 * 256 * kLd;   // the largest tile (256 x 256)
-
-template <int TM, int kTN, int BM, int BN>
-__global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2)))
-wgrad_f16x3_kernel(WgradArgs w, int64_t groups_per_slice) {
-  __shared__ __attribute__((aligned(16))) _Float16 lds[2 * TM * kLd + 2 * kTN * kLd];   // A hi | A lo | B hi | B lo
-  const int64_t n_groups = w.P / 32;
-  const int64_t g_begin = (int64_t)blockIdx.x * groups_per_slice;
-  const int64_t g_end = (g_begin + groups_per_slice < n_groups) ? g_begin + groups_per_slice : n_groups;
-  wgrad_slice<TM, kTN, BM, BN>(w, g_begin, g_end, blockIdx.x, lds);
 }
 
 // ALL weight-gradient products of one network pass in ONE launch (WgradJobs, nsr_gemm.h).  The products' point groups
 // form one work list, product after product, a group of product p costing cost_p = M + N panel rows (the kernel is HBM
 // bound: a group's time is the bytes it reads).  Workgroup w owns the cost range [w, w + 1) * per_wg of that list, i.e.
 // for every product it overlaps the groups whose start cost falls inside -- so the ~256 resident workgroups (one per CU)
-// carry the same number of bytes, each sweeps a few hundred point groups before it writes a partial tile instead of the
-// 16-32 a per-product launch with 256 slices each allowed, and a product owns about as many partial slots as its share
-// of the bytes (21 for a 256 x 256 trunk product instead of 256).  Deterministic: the mapping is static, no atomics.
+// carry the same number of bytes, each sweeps a few hundred point groups before it writes a partial tile, and a product
+// owns about as many partial slots as its share of the bytes (21 for a 256 x 256 trunk product).  Deterministic: the
+// mapping is static, no atomics.
 __global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) wgrad_jobs_kernel(WgradJobs jobs) {
-  __shared__ __attribute__((aligned(16))) _Float16 lds[kLdsHalves];
+  __shared__ __attribute__((aligned(1024))) char lds[kLdsBytes];
+  const unsigned lds0 = lds_addr(lds);
   const int64_t lo = (int64_t)blockIdx.x * jobs.per_wg;
   const int64_t hi = (lo + jobs.per_wg < jobs.total_cost) ? lo + jobs.per_wg : jobs.total_cost;
   for (int p = 0; p < jobs.n; ++p) {
@@ -201,39 +244,21 @@ __global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))
     int64_t g_end = (b + q.cost - 1) / q.cost;
     if (g_end > jobs.n_groups) g_end = jobs.n_groups;
     const int64_t slot = (int64_t)blockIdx.x - q.w_first;
-    const WgradArgs& w = q.w;               // the slices never read w.P / w.splits
-    if (w.M == 256 && w.N == 256) wgrad_slice<256, 256, 4, 2>(w, g_begin, g_end, slot, lds);
-    else if (w.M == 128 && w.N == 256) wgrad_slice<128, 256, 2, 2>(w, g_begin, g_end, slot, lds);
-    else if (w.M == 256 && w.N == 64) wgrad_slice<256, 64, 1, 2>(w, g_begin, g_end, slot, lds);
-    else wgrad_slice<128, 64, 1, 1>(w, g_begin, g_end, slot, lds);
+    const WgradArgs& w = q.w;
+    if (w.M == 256 && w.N == 256) wgrad_slice<256, 256, 4, 2>(w, g_begin, g_end, slot, lds0);
+    else if (w.M == 128 && w.N == 256) wgrad_slice<128, 256, 2, 2>(w, g_begin, g_end, slot, lds0);
+    else if (w.M == 256 && w.N == 64) wgrad_slice<256, 64, 1, 2>(w, g_begin, g_end, slot, lds0);
+    else wgrad_slice<128, 64, 1, 1>(w, g_begin, g_end, slot, lds0);
   }
 }
 
 }  // namespace
 
-static int wgrad_shape(const WgradArgs& w) {
-  return (w.N == 256 ? 0 : (w.N == 64 ? 2 : -8)) + (w.M == 256 ? 0 : (w.M == 128 ? 1 : -8));
-}
 static bool wgrad_args_ok(const WgradArgs& w) {
-  if (!w.A || !w.B || !w.partial || !w.a_max_bits || wgrad_shape(w) < 0) return false;
-  if (w.a_gstride % 4 || w.b_gstride % 4) return false;
+  if (!w.A || !w.B || !w.partial || !w.a_max_bits || !w.a_pscale) return false;
+  if (!((w.M == 256 || w.M == 128) && (w.N == 256 || w.N == 64))) return false;
+  if (w.a_gbytes % 1024 || w.b_gbytes % 1024) return false;
   return !((reinterpret_cast<uintptr_t>(w.A) & 15) || (reinterpret_cast<uintptr_t>(w.B) & 15));
-}
-
-NSR_INTERNAL int wgrad_f16x3(const WgradArgs& w, hipStream_t st) {
-  const int shape = wgrad_shape(w);
-  if (!wgrad_args_ok(w) || w.splits < 1) return NSR_ERR_INVALID_ARG;
-  if (w.P < 0 || w.P % 32 != 0) return NSR_ERR_INVALID_ARG;
-  if (w.P == 0) return NSR_OK;
-  const int64_t n_groups = w.P / 32;
-  const int64_t per = (n_groups + w.splits - 1) / w.splits;
-  const dim3 grid((unsigned)w.splits), block(kNT);
-  if (shape == 0) hipLaunchKernelGGL((wgrad_f16x3_kernel<256, 256, 4, 2>), grid, block, 0, st, w, per);
-  else if (shape == 1) hipLaunchKernelGGL((wgrad_f16x3_kernel<128, 256, 2, 2>), grid, block, 0, st, w, per);
-  else if (shape == 2) hipLaunchKernelGGL((wgrad_f16x3_kernel<256, 64, 1, 2>), grid, block, 0, st, w, per);
-  else hipLaunchKernelGGL((wgrad_f16x3_kernel<128, 64, 1, 1>), grid, block, 0, st, w, per);
-  if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
-  return NSR_OK;
 }
 
 // fills cost0 / w_first / n_slots of every job and the work-list totals for `n_wg` workgroups; returns the number of
@@ -259,7 +284,7 @@ NSR_INTERNAL int wgrad_jobs_plan(WgradJobs& jobs, int64_t P, int n_wg) {
   return (int)((c + jobs.per_wg - 1) / jobs.per_wg);
 }
 
-NSR_INTERNAL int wgrad_jobs_f16x3(const WgradJobs& jobs, int n_wg, hipStream_t st) {
+NSR_INTERNAL int wgrad_jobs_f16(const WgradJobs& jobs, int n_wg, hipStream_t st) {
   if (jobs.n < 0 || jobs.n > kMaxWgradJobs || jobs.n_groups < 0) return NSR_ERR_INVALID_ARG;
   for (int p = 0; p < jobs.n; ++p)
     if (!wgrad_args_ok(jobs.j[p].w)) return NSR_ERR_INVALID_ARG;

@@ -80,10 +80,11 @@ class Trainer:
             # training too; the training kernels have no such branch, and ignoring the option would train another model
             raise ValueError("training with gamma_correct=True is not built (the HIP training step has no gamma branch); "
                              "the render path supports it (VanillaMLP.set_gamma_correct)")
-        if precision not in ("fp32", "f16x3"):
-            raise ValueError("precision must be 'fp32' (every product on the fp32 MFMA, layer by layer) or 'f16x3' (every "
-                             "product -- forward, input and weight gradients -- on the split-fp16 MFMA, fp32-grade)")
-        self.precision, self._prec = precision, _lib.PRECISIONS[precision]
+        if precision not in _lib.TRAIN_PRECISIONS:
+            raise ValueError("precision must be 'fp32' (every product on the fp32 MFMA, layer by layer), 'f16x3' (the chain "
+                             "kernels: forward and input gradients on the split-fp16 MFMA, weight gradients on one fp16 MFMA "
+                             "per product) or 'f16x3_gemm' (layer by layer, forward products split-fp16, gradients fp32)")
+        self.precision, self._prec = precision, _lib.TRAIN_PRECISIONS[precision]
         self.device = torch.device(device)
         self.params = [_to_dev(sd_coarse, self.device), _to_dev(sd_fine, self.device)]
         flat = [_flat_like(p) for p in self.params]
@@ -149,8 +150,11 @@ class Trainer:
         if need == 0:
             raise _lib.NsrError("sample counts outside the built path")
         if self._ws is None or self._ws.numel() < need:
+            carried = self.status() if self._ws is not None else 0     # a regrown workspace keeps the sticky flags
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             _lib.check(_lib.load().nsr_train_status_reset(_p(self._ws), _stream()), "nsr_train_status_reset")
+            if carried:
+                self._ws[:4].copy_(torch.tensor([carried], dtype=torch.int32).view(torch.uint8))
         dev = self.device
         o = {"coarse_comp_rgbs": torch.empty(R, 3, device=dev), "coarse_depth": torch.empty(R, device=dev),
              "coarse_opacity": torch.empty(R, device=dev), "coarse_weights": torch.empty(R, nc, device=dev),
@@ -221,7 +225,7 @@ class Trainer:
                 raise FloatingPointError(
                     f"non-finite training loss at step {self.step + 1} (this rank: {self.losses.tolist()}): the run diverged"
                     + (" or left the fp16 range of the split-fp16 forward; retry with precision='fp32'"
-                       if self.precision == "f16x3" else ""))
+                       if self.precision != "fp32" else ""))
         self.all_reduce_grads()
         self.optimizer_step()
         return self.losses

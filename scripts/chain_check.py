@@ -1,5 +1,5 @@
 """Development aid: the training step's CHAIN path (fused forward + backward chain, nsr_train_chain.hip) against the
-layer-by-layer GEMM path (NSR_TRAIN_PATH=gemm) and the fp64 CPU oracle, tensor by tensor, then the step time of both."""
+layer-by-layer GEMM path (precision f16x3_gemm) and the fp64 CPU oracle, tensor by tensor, then the step time of both."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,11 +9,8 @@ from oracle import train_oracle as to
 from tests.util import train_draws
 
 
-def run(path, g, sd_c, sd_f, draws, precision="f16x3"):
-    if path == "gemm":
-        os.environ["NSR_TRAIN_PATH"] = "gemm"
-    else:
-        os.environ.pop("NSR_TRAIN_PATH", None)
+def run(path, g, sd_c, sd_f, draws, precision=None):
+    precision = precision or ("f16x3_gemm" if path == "gemm" else "f16x3")
     t = tr.Trainer(sd_c, sd_f, white_bkgd=bool(g["white_bkgd"]), downscale=int(round(int(g["s2"]) ** 0.5)),
                    randomized=bool(g["randomized"]), noise_std=float(g["noise_std"]), lr=float(g["lr"]), beta1=float(g["beta1"]),
                    precision=precision)
@@ -54,11 +51,8 @@ from nerf_sr_amd import ops, cameras
 R = 2048
 rays = ops.subpixel_rays(cameras.spiral_pose(0.4), (504, 378), cameras.llff_focal(504), 2, True).reshape(-1, 8)[:R].contiguous()
 for p in ("gemm", "chain"):
-    if p == "gemm":
-        os.environ["NSR_TRAIN_PATH"] = "gemm"
-    else:
-        os.environ.pop("NSR_TRAIN_PATH", None)
-    t = tr.Trainer(make_state_dict(99), make_state_dict(100), N_importance=128, randomized=True, noise_std=1.0)
+    t = tr.Trainer(make_state_dict(99), make_state_dict(100), N_importance=128, randomized=True, noise_std=1.0,
+                   precision="f16x3_gemm" if p == "gemm" else "f16x3")
     t.set_input(rays, torch.rand(R // 4, 3, device="cuda"))
     for i in range(3):
         t.optimize_parameters()

@@ -96,6 +96,30 @@ def test_invalid_arguments_are_rejected_before_any_launch(lib):
     assert lib.nsr_composite(one, 3, one, 1, one, 0, 64, 0, null, null, null, null, null) == 0
 
 
+def test_release_library_reads_no_environment(lib):
+    """include/nsr.h: "no global mutable state".  The release library must not even import getenv (round 4 still read
+    NSR_TRAIN_PATH on every training call; the path is the precision argument now, include/nsr_train.h NSR_F16X3_GEMM), and
+    the workspace size of a training precision is a function of its arguments whatever the environment says."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    imported = {line.split()[-1].split("@")[0] for line in out.splitlines() if line.strip()}
+    assert not ({"getenv", "secure_getenv", "setenv", "putenv"} & imported), sorted(imported & {"getenv", "secure_getenv"})
+    a = lib.nsr_train_workspace_bytes_for(_lib.NSR_F16X3, 2048, 64, 64)
+    b = lib.nsr_train_workspace_bytes_for(_lib.NSR_F16X3_GEMM, 2048, 64, 64)
+    old = os.environ.get("NSR_TRAIN_PATH")
+    os.environ["NSR_TRAIN_PATH"] = "gemm"
+    try:
+        assert lib.nsr_train_workspace_bytes_for(_lib.NSR_F16X3, 2048, 64, 64) == a
+    finally:
+        if old is None:
+            del os.environ["NSR_TRAIN_PATH"]
+        else:
+            os.environ["NSR_TRAIN_PATH"] = old
+    assert a > 0 and b > 0 and a != b
+    assert b == lib.nsr_train_workspace_bytes_for(_lib.NSR_FP32, 2048, 64, 64)
+    assert lib.nsr_train_workspace_bytes_for(7, 2048, 64, 64) == 0
+
+
 def test_product_has_no_cpu_fallback():
     import torch
     from nerf_sr_amd import ops

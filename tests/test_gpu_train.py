@@ -215,30 +215,26 @@ def test_config1_vanilla_model_iteration(tr):
 
 
 # ---- chain path (fused forward / backward chain / split-fp16 weight gradients) against the layer-by-layer GEMM path ----
-def _both_paths(tr, g, monkeypatch, **kw):
+def _both_paths(tr, g, **kw):
+    """The path is an argument of the C entry point (precision NSR_F16X3 vs NSR_F16X3_GEMM), not process state."""
     out = {}
-    for path in ("gemm", "chain"):
-        if path == "gemm":
-            monkeypatch.setenv("NSR_TRAIN_PATH", "gemm")
-        else:
-            monkeypatch.delenv("NSR_TRAIN_PATH", raising=False)
-        t, _, _ = _trainer(tr, g, **kw)
+    for path, prec in (("gemm", "f16x3_gemm"), ("chain", "f16x3")):
+        t, _, _ = _trainer(tr, g, precision=prec, **kw)
         t.loss_and_grads(_draws(g))
         torch.cuda.synchronize()
         out[path] = t
-    monkeypatch.delenv("NSR_TRAIN_PATH", raising=False)
     return out["gemm"], out["chain"]
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_chain_path_matches_gemm_path(name, golden_dir, tr, monkeypatch):
+def test_chain_path_matches_gemm_path(name, golden_dir, tr):
     """The two implementations of the NSR_F16X3 step -- per-layer GEMMs (forward products split-fp16, gradients on the
     fp32 MFMA) and the chain kernels (everything split-fp16, per-point / per-panel power-of-two scaling) -- agree far
     inside the tolerance either has against the oracle: forward outputs to 2e-6, every gradient tensor to 1e-3 of its norm
     (the two forward passes round differently, so a ReLU mask can flip between them -- see the module docstring; measured:
     3e-4 on xyz_encoding_1.weight of `llff_det`, where the GEMM path has the flip, <= 6e-5 everywhere else)."""
     g = np.load(os.path.join(golden_dir, f"train_{name}.npz"))
-    a, b = _both_paths(tr, g, monkeypatch)
+    a, b = _both_paths(tr, g)
     assert float((a.losses - b.losses).abs().max()) < 2e-6
     for k in ("coarse_comp_rgbs", "lr_coarse"):
         assert float((a.out[k] - b.out[k]).abs().max()) < 2e-6, k
@@ -292,7 +288,7 @@ def test_chain_path_ragged_tiles_and_sample_counts(tr):
         assert (num / den) ** 0.5 < (1e-3 if n == 0 else 5e-3), (n, (num / den) ** 0.5)
 
 
-def test_chain_path_matches_gemm_path_at_bench_scale(tr, monkeypatch):
+def test_chain_path_matches_gemm_path_at_bench_scale(tr):
     """The bench's training batch (2,048 rays, 64 + 128 samples = 393,216 sample points, randomized sampling, density
     noise): the chain path against the layer-by-layer path (gradients on the fp32 MFMA) on identical draws -- the
     fixtures above hold 96 rays, this is where the split-K factors, multi-tile panels and per-panel scales are at
@@ -304,12 +300,8 @@ def test_chain_path_matches_gemm_path_at_bench_scale(tr, monkeypatch):
     rays = frame[sel].reshape(-1, 8).contiguous()
     tgt = torch.rand(R // 4, 3, generator=torch.Generator().manual_seed(4)).cuda()
     res = {}
-    for path in ("gemm", "chain"):
-        if path == "gemm":
-            monkeypatch.setenv("NSR_TRAIN_PATH", "gemm")
-        else:
-            monkeypatch.delenv("NSR_TRAIN_PATH", raising=False)
-        t = tr.Trainer(make_state_dict(99), make_state_dict(100), randomized=True, noise_std=1.0, ray_chunk=R)
+    for path, prec in (("gemm", "f16x3_gemm"), ("chain", "f16x3")):
+        t = tr.Trainer(make_state_dict(99), make_state_dict(100), randomized=True, noise_std=1.0, ray_chunk=R, precision=prec)
         t.set_input(rays, tgt)
         torch.manual_seed(77)                      # identical draws for both paths
         t.loss_and_grads()
