@@ -422,13 +422,17 @@ __device__ __forceinline__ void unit_store(const u32x4& v, const char* blk, unsi
   asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx4 %1, %2, %0 offset:%4" NSR_PANEL_STORE_POLICY : "=&s"(tmp) : "v"(voff), "v"(v), "s"(blk), "n"(U * 1024) : "memory");
 }
 
-// Sign panels: one bit per pre-activation ([z < 0], i.e. "the ReLU zeroes it"; +0.0 counts as active), the only thing the
-// backward chain needs from the forward pass.  Per point group 76 blocks (8 per 256-row panel, 4 for panel 9) of 64 dwords:
-// lane (m, h) keeps the 16 bits of its 16 accumulator registers of a block, register r in bit 15 - r.
-constexpr int kSignBlocks = 76;
-__device__ __host__ __forceinline__ int64_t sign_panel_words(int64_t n_groups) { return n_groups * kSignBlocks * 64; }
+// Sign panels: one bit per pre-activation ([z < 0], i.e. "the ReLU zeroes it"; +0.0 counts as active) of the layers whose
+// ReLU the backward chain masks with (panels 0..7 and 9; xyz_encoding_final has none) -- the only thing the backward chain
+// needs from the forward pass.  Two consecutive blocks (2q, 2q + 1) of a panel share one dword per lane: lane (m, h) keeps
+// the 16 sign bits of its 16 accumulator registers of block 2q in bits 31..16 (register r in bit 31 - r) and of block
+// 2q + 1 in bits 15..0 (bit 15 - r) -- what 32 sign_push in block order leave behind.  Per point group 34 pair blocks (4 per
+// 256-row panel, 2 for panel 9) of 64 dwords: 272 bytes per sample point (rounds 2-4: one half-used dword per block, 608).
+constexpr int kSignPairs = 34;
+__device__ __host__ __forceinline__ int64_t sign_panel_words(int64_t n_groups) { return n_groups * kSignPairs * 64; }
+// the dword block that holds the signs of output block `blk` of `panel` (shared with block blk ^ 1)
 __device__ __forceinline__ unsigned* sign_block(unsigned* base, int64_t group, int panel, int blk) {
-  return base + (group * kSignBlocks + 8 * panel + blk) * 64;
+  return base + (group * kSignPairs + (panel == 9 ? 32 : 4 * panel) + (blk >> 1)) * 64;
 }
 // bits = (bits << 1) | sign(v)
 __device__ __forceinline__ void sign_push(unsigned& bits, float v) {

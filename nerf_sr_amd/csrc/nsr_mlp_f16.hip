@@ -279,8 +279,10 @@ __device__ __forceinline__ void rgb_gap(int s, int g, const Acc& p, const float*
 }
 
 
-// TRAIN: vector-memory operations a block issues behind its last DMA piece (two unit stores + the sign word)
-constexpr int kTrainYoung = 3;
+// TRAIN: vector-memory operations EVERY storing block issues behind its last DMA piece: the two unit stores (every second
+// block adds the sign dword; counting it would let the publish point's vmcnt leave a DMA piece in flight after the blocks
+// that do not -- under-counting only waits for a store that is a whole chunk old)
+constexpr int kTrainYoung = 2;
 // TRAIN: dir_encoding's blocks feed the colour head from their fp32 accumulators (rgb_gap), so nothing makes their fp16
 // operand form -- but the colour head's weight gradient wants it like any other layer's input: hi of pair P = RNE_f16 of
 // relu(acc) / 64, the re-split's first half
@@ -542,14 +544,14 @@ __device__ __forceinline__ void enc_all(Enc& e, const EncIn& in) {
 // operand of the weight gradients -- are written to the training panels (panel L - 1 holds trunk layer L's output, see
 // nsr_f16x3_core.h): its two units as two 16-byte stores in k-steps 14 and 15 (+ the block's sign word), i.e. BEHIND the
 // chunk's last DMA piece (k-step 13).  Vector-memory operations complete in issue order, so the next publish point --
-// which must see that DMA landed -- may leave those 3 stores in flight (block_mma's YOUNGER); they have a whole further
+// which must see that DMA landed -- may leave those stores in flight (block_mma's YOUNGER); they have a whole further
 // chunk to reach HBM.  (Rounds 2-4 stored the sixteen raw fp32 accumulators of a block here.)
 // ENC: the layer's gap-0 slots also carry encoding pieces of the next tile's point: 1 (L8) = the loads (piece 0) in the
 // last chunk, 2 (xyz_encoding_final) = slots 16 nb + s of the piece schedule (enc_slot).
 template <bool RELU_OUT, bool TRAIN = false, int ENC = 0>   // relu on L2..L8 (true), none on xyz_encoding_final (L == 8: false)
 __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[16], u32x4 (&oh)[16], u32x4 (&ol)[16],
                                             const u32x4* stash, Loader& ld, int h, Acc& pend, Pre& pre,
-                                            const ChunkRef& after0, const ChunkRef& after1, float& amax,
+                                            const ChunkRef& after0, const ChunkRef& after1, float& amax, unsigned& sbits,
                                             const PanelRef& tr = PanelRef{}, unsigned voff0 = 0, unsigned voff1 = 0, Enc* enc = nullptr,
                                             const EncIn* ein = nullptr
 #ifdef NSR_ABL_TIMELINE
@@ -569,7 +571,6 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
     Acc cur;
     cur.m = pre.bias;
     Resplit ptmp;
-    unsigned sbits = 0u;
     unsigned a_addr = ld.slot_cur + ld.lane_off;
 #ifdef NSR_ABL_TIMELINE
     ld.tk = (L == 7 && nb == 3) ? ld_tk_buf : nullptr;
@@ -617,11 +618,16 @@ __device__ __forceinline__ void trunk_layer(int L, u32x4 (&bh)[16], u32x4 (&bl)[
               if (s == 14) unit_store<0>(oh[2 * nb - 2], blk, voff0);
               if (s == 15) unit_store<1>(oh[2 * nb - 1], blk, voff1);
             }
-            sign_push(sbits, pend.m[2 * (s - 8)]);
-            sign_push(sbits, pend.m[2 * (s - 8) + 1]);
-            if (s == 15)
-              sign_store(sbits, (nb == 0) ? sign_block(tr.sgn, tr.group, L - 1, 7) : sign_block(tr.sgn, tr.group, L, nb - 1),
-                         ld.lane_off >> 2);
+            // sign bits of the pending block if a ReLU follows it (block 7 of the previous layer always does; this layer's
+            // blocks do unless it is xyz_encoding_final); `sbits` runs on across blocks and layers, the dword is stored when
+            // its second (odd) block is complete
+            if (nb == 0 || RELU_OUT) {
+              sign_push(sbits, pend.m[2 * (s - 8)]);
+              sign_push(sbits, pend.m[2 * (s - 8) + 1]);
+              if (s == 15 && (nb == 0 || ((nb - 1) & 1)))
+                sign_store(sbits, (nb == 0) ? sign_block(tr.sgn, tr.group, L - 1, 7) : sign_block(tr.sgn, tr.group, L, nb - 1),
+                           ld.lane_off >> 2);
+            }
           }
         },
         [&](int k, int g) { prefetch_next_chunk(nxt, k, g, ld, next_bias, h); },
@@ -896,6 +902,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   u32x4 bh[16], bl[16], oh[16], ol[16];
   Acc pend;
   Pre pre;
+  unsigned sbits = 0u;     // TRAIN: sign bits of the pending blocks, two blocks per stored dword (nsr_f16x3_core.h)
 
   NSR_TL(1);
   // ---- L1: two chunks of four output blocks, 4 k-steps each; block b is re-split during block b+1 (17 half-steps
@@ -917,7 +924,6 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
       Acc cur;
       cur.m = l1pre.bias;
       Resplit ptmp;
-      unsigned sbits = 0u;
       block_mma3<4, -1>(
           cur, l1pre, a_addr, ld, first_ref(0, wave), [&](int s, int part) -> u32x4 { return part ? pel[s] : peh[s]; },
           [&](int s, int gp) {
@@ -937,7 +943,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
                 if (s == 3) unit_store<1>(bh[2 * nb - 1], blk, voff1);
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) sign_push(sbits, pend.m[4 * s + q4]);
-                if (s == 3) sign_store(sbits, sign_block(tr.sgn, tr.group, 0, nb - 1), ld.lane_off >> 2);
+                if (s == 3 && ((nb - 1) & 1)) sign_store(sbits, sign_block(tr.sgn, tr.group, 0, nb - 1), ld.lane_off >> 2);
               }
             }
           },
@@ -964,20 +970,20 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
 #pragma unroll 1
   for (int pair = 0; pair < 3; ++pair) {
     const int L = 1 + 2 * pair;
-    trunk_layer<true, TRAIN>(L, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(L + 1, 0, wave), layer_ref(L + 1, 1, wave), amax, tr, voff0, voff1);
+    trunk_layer<true, TRAIN>(L, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(L + 1, 0, wave), layer_ref(L + 1, 1, wave), amax, sbits, tr, voff0, voff1);
     trunk_layer<true, TRAIN>(L + 1, oh, ol, bh, bl, stash, ld, h, pend, pre, layer_ref(L + 2, 0, wave), layer_ref(L + 2, 1, wave), amax,
-                             tr, voff0, voff1);
+                             sbits, tr, voff0, voff1);
   }
   if (SIGMA_ONLY) {   // xyz_encoding_final is not evaluated: L8 is followed by the density head, then nothing
-    trunk_layer<true>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, sigma_ref(wave), first_ref(0, wave), amax);
+    trunk_layer<true>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, sigma_ref(wave), first_ref(0, wave), amax, sbits);
   } else {
 #ifdef NSR_ABL_TIMELINE
-    trunk_layer<true, TRAIN, (OVERLAP ? 1 : 0)>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave), amax, tr, voff0, voff1, &enc, &ein, tk);
+    trunk_layer<true, TRAIN, (OVERLAP ? 1 : 0)>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave), amax, sbits, tr, voff0, voff1, &enc, &ein, tk);
     ld.tk = nullptr;
 #else
-    trunk_layer<true, TRAIN, (OVERLAP ? 1 : 0)>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave), amax, tr, voff0, voff1, &enc, &ein);
+    trunk_layer<true, TRAIN, (OVERLAP ? 1 : 0)>(7, bh, bl, oh, ol, stash, ld, h, pend, pre, layer_ref(8, 0, wave), layer_ref(8, 1, wave), amax, sbits, tr, voff0, voff1, &enc, &ein);
 #endif
-    trunk_layer<false, TRAIN, (OVERLAP ? 2 : 0)>(8, oh, ol, bh, bl, stash, ld, h, pend, pre, sigma_ref(wave), dir_ref(0, wave), amax, tr, voff0, voff1, &enc, &ein);
+    trunk_layer<false, TRAIN, (OVERLAP ? 2 : 0)>(8, oh, ol, bh, bl, stash, ld, h, pend, pre, sigma_ref(wave), dir_ref(0, wave), amax, sbits, tr, voff0, voff1, &enc, &ein);
   }
 
   NSR_TL(3);
@@ -1031,7 +1037,6 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   for (int nb = 0; nb < 4; ++nb) {
     Acc cur;
     cur.m = pre.bias;
-    unsigned sbits = 0u;
     u32x4 dh0 = {0u, 0u, 0u, 0u}, dh1 = {0u, 0u, 0u, 0u};   // TRAIN: hi halves of the pending dir block (relu_hi_pair)
     const unsigned next_bias = 36u * 1024u;
     Pre nxt;
@@ -1052,7 +1057,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
         if (s == 15) unit_store<1>(dh1, blk, voff1);
         sign_push(sbits, pend.m[2 * (s - 8)]);
         sign_push(sbits, pend.m[2 * (s - 8) + 1]);
-        if (s == 15) sign_store(sbits, sign_block(tr.sgn, tr.group, 9, nb - 1), ld.lane_off >> 2);
+        if (s == 15 && ((nb - 1) & 1)) sign_store(sbits, sign_block(tr.sgn, tr.group, 9, nb - 1), ld.lane_off >> 2);
       }
     };
     auto next = [&](int k, int g) {   // the last block hands over to the next tile's L1 (bias behind 32 weight pieces)
@@ -1082,7 +1087,6 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
   }
   if (TRAIN) {   // the last dir block (its accumulators were read by the colour head just above: no MFMA is in flight)
     const char* blk = panel_block(tr, 9, 3);
-    unsigned sbits = 0u;
     u32x4 dh0, dh1;
 #pragma unroll
     for (int P = 0; P < 8; ++P) relu_hi_step(P, pend, dh0, dh1);

@@ -174,9 +174,10 @@ __global__ void __launch_bounds__(256) loss_finish_kernel(const double* __restri
 //   dL/dalpha_k = gw_k T_k - (sum_{i>k} gw_i w_i) / f_k
 //   dL/dsigma_k = dL/dalpha_k * delta_k exp(-delta_k relu(sigma_k)) * [sigma_k > 0];   dL/drgb_k = gC w_k
 // and through the sigmoid of the colour head: d(rgb_pre) = d(rgb) * rgb (1 - rgb).
-// Outputs in the training layout: d_rgb (P, 32) columns 0..2 (3..31 zeroed); d_sigma into column 256 of
-// g1 (P, 288) (257..287 zeroed).
-template <int K>
+// Outputs in the GEMM path's training layout: d_rgb (P, 32) columns 0..2 (3..31 zeroed); d_sigma into column 256 of
+// g1 (P, 288) (257..287 zeroed).  COMPACT (chain path): one float4 per point, d4[p] = (d_rgb_pre 0..2, d_sigma) -- 16 bytes
+// instead of 256 written per point, and one 16-byte read per point for the backward chain instead of two strided ones.
+template <int K, bool COMPACT>
 __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restrict__ rgb4, const float* __restrict__ sigma,
                                                             const float* __restrict__ z, const float* __restrict__ g_comp,
                                                             int64_t R, int N, int white,
@@ -249,6 +250,10 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
     const float dr0 = gc0 * w[i] * c0[i] * (1.0f - c0[i]);
     const float dr1 = gc1 * w[i] * c1[i] * (1.0f - c1[i]);
     const float dr2 = gc2 * w[i] * c2[i] * (1.0f - c2[i]);
+    if (COMPACT) {
+      reinterpret_cast<float4*>(d_rgb)[p] = make_float4(dr0, dr1, dr2, d_sigma);
+      continue;
+    }
     float4* dr = reinterpret_cast<float4*>(d_rgb + p * kRgbPad);
     dr[0] = make_float4(dr0, dr1, dr2, 0.0f);
 #pragma unroll
@@ -477,6 +482,7 @@ constexpr int64_t kSplitHalves = split_offset(11) + 2 * (int64_t)kSplitRows[11] 
 struct Work {   // per-pass buffers, sized for P_max = chunk * (Nc + Ni) sample points; all row-major
   float *x5, *h[9], *gs, *cc, *rgb, *sig;
   float *g0, *g1, *drgb, *col_tiles;
+  float* d4;        // chain path: (P, 4) = d(rgb_pre) 0..2, d(sigma) of every sample point (composite_bwd_kernel COMPACT)
   float *z_c, *z_f, *w_c, *comp, *g_comp, *partial, *scratch_out;
   double *block_sums, *carry;
   WeightPack pack[2];
@@ -512,8 +518,9 @@ int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base, int mod
   k.gs = take_if(gemm_path, P * kGs);
   k.cc = take_if(gemm_path, P * kDirOut);
   k.rgb = take(P * 4);   k.sig = take(P);
-  k.g0 = take_if(gemm_path, P * kGs);   k.g1 = take(P * kGs);     // the chain path keeps d_sigma in column 256 of g1
-  k.drgb = take(P * kRgbPad);
+  k.g0 = take_if(gemm_path, P * kGs);   k.g1 = take_if(gemm_path, P * kGs);
+  k.drgb = take_if(gemm_path, P * kRgbPad);
+  k.d4 = take_if(chain_path, P * 4);
   k.col_tiles = take((P / 128 + 1) * kW + 2 * 64 * kW + 64);   // per-tile column sums + 64 slices of doubles
   k.z_c = take(chunk * nc);   k.z_f = take(chunk * nf);   k.w_c = take(chunk * nc);
   k.comp = take(chunk * 3);   k.g_comp = take(chunk * 3);
@@ -726,8 +733,8 @@ int64_t n_groups_of(int64_t P) { return ((P + 127) / 128) * 4; }
 char* panel_of(char* set, int64_t P, int panel) { return set + panel_offset_bytes(n_groups_of(P), panel); }
 
 // weight and bias gradients from the panels: zpan = the forward activations, dpan = the input gradients at each point's
-// power-of-two scale (k.pscale), both fp16 (nsr_f16x3_core.h); d_rgb_pre in k.drgb (P, 32), d_sigma in column 256 of k.g1
-// (P, 288).  The 12 panel x panel products of the network are ONE launch (wgrad_jobs_kernel, nsr_wgrad_f16.hip): ~256
+// power-of-two scale (k.pscale), both fp16 (nsr_f16x3_core.h); d_rgb_pre and d_sigma in k.d4 (P, 4).  The 12 panel x panel
+// products of the network are ONE launch (wgrad_jobs_kernel, nsr_wgrad_f16.hip): ~256
 // workgroups share the products' point groups by bytes, a 256 x 256 product ends up with ~21 partial tiles instead of the
 // 256 a launch of its own needed to fill the chip -- 12 x fewer partial sums to write, and for finish_jobs_kernel to read
 // back.
@@ -774,10 +781,10 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
   const int64_t per = (P / 32 + sp - 1) / sp;
   // rgb head: d_rgb_pre^T relu(zcc), a stream over the panel
   part = big_slot();
-  hipLaunchKernelGGL((panel_wsums_kernel<128, 3>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 9), P, k.drgb, kRgbPad, per, part);
+  hipLaunchKernelGGL((panel_wsums_kernel<128, 3>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 9), P, k.d4, 4, per, part);
   NSR_CHECK_LAUNCH();
   sum_rows(g[kRgbW], 3 * 128, part);
-  NSR_TRY(colsum(st, k.drgb, kRgbPad, P, 0, 3, g[kRgbB], acc, k.partial));
+  NSR_TRY(colsum(st, k.d4, 4, P, 0, 3, g[kRgbB], acc, k.partial));
   // dir_encoding: dzc^T [g | de]
   if ((pj = product(9, 8, true)) < 0) return NSR_ERR_LAUNCH;
   note(pj, place(g[kDirW], 283, 0, 128, 256, nullptr, kW, 0));
@@ -789,10 +796,10 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
   note(pj, place(g[kFinalW], 256, 0, 256, 256, nullptr, kW, 0));
   note(pj, ~sum_rows(g[kFinalB], kW, nullptr));
   part = big_slot();
-  hipLaunchKernelGGL((panel_wsums_kernel<256, 1>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 7), P, k.g1 + kSigmaCol, kGs, per, part);
+  hipLaunchKernelGGL((panel_wsums_kernel<256, 1>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 7), P, k.d4 + 3, 4, per, part);
   NSR_CHECK_LAUNCH();
   sum_rows(g[kSigmaW], 256, part);
-  NSR_TRY(colsum(st, k.g1, kGs, P, 256, 1, g[kSigmaB], acc, k.partial));
+  NSR_TRY(colsum(st, k.d4, 4, P, 3, 1, g[kSigmaB], acc, k.partial));
   // trunk layers 8..1: dz_L^T (input of layer L)
   for (int L = 8; L >= 1; --L) {
     float* gw = g[2 * (L - 1)];
@@ -847,11 +854,14 @@ bool chain_selected(int precision) { return precision == NSR_F16X3; }
 bool train_precision_ok(int precision) { return precision == NSR_FP32 || precision == NSR_F16X3 || precision == NSR_F16X3_GEMM; }
 int gemm_precision(int precision) { return precision == NSR_F16X3_GEMM ? NSR_F16X3 : precision; }   // what the GEMM path's helpers expect
 
-int composite_bwd(hipStream_t st, const Work& k, const float* z, int64_t R, int N, int white) {
+int composite_bwd(hipStream_t st, const Work& k, const float* z, int64_t R, int N, int white, bool compact) {
   const dim3 block(256), grid((unsigned)((R + 3) / 4));
   const int K = (N + 63) / 64;
-#define NSR_LAUNCH_CB(KK) \
-  hipLaunchKernelGGL(composite_bwd_kernel<KK>, grid, block, 0, st, k.rgb, k.sig, z, k.g_comp, R, N, white, k.drgb, k.g1)
+#define NSR_LAUNCH_CB(KK)                                                                                                          \
+  do {                                                                                                                             \
+    if (compact) hipLaunchKernelGGL((composite_bwd_kernel<KK, true>), grid, block, 0, st, k.rgb, k.sig, z, k.g_comp, R, N, white, k.d4, nullptr); \
+    else hipLaunchKernelGGL((composite_bwd_kernel<KK, false>), grid, block, 0, st, k.rgb, k.sig, z, k.g_comp, R, N, white, k.drgb, k.g1);        \
+  } while (0)
   switch (K) {
     case 1: NSR_LAUNCH_CB(1); break;
     case 2: NSR_LAUNCH_CB(2); break;
@@ -974,9 +984,9 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
       hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, k.block_sums, nblk, mse_scale, lambda, losses, net,
                          k.carry);
       NSR_CHECK_LAUNCH();
-      NSR_TRY(composite_bwd(st, k, z, rc, N, white_bkgd));
+      NSR_TRY(composite_bwd(st, k, z, rc, N, white_bkgd, chain));
       if (chain) {
-        NSR_TRY(nsr_chain_bwd(k.stream_b[net], k.sgn, k.dpan, k.drgb, kRgbPad, k.g1 + kSigmaCol, kGs, P, k.gmax, k.pscale, stream));
+        NSR_TRY(nsr_chain_bwd(k.stream_b[net], k.sgn, k.dpan, k.d4, 4, k.d4 + 3, 4, P, k.gmax, k.pscale, stream));
         NSR_TRY(chain_weight_grads(st, k, P, g, acc));
       } else {
         NSR_TRY(net_backward(st, w, k.pack[net], k, P, g, acc));

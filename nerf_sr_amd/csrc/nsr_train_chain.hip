@@ -143,9 +143,10 @@ __device__ __forceinline__ void stage_factors(Scale& cur, const Scale& prev) {
 struct BwdTmp {
   unsigned hi[2];
 };
-// mask: the block's sign word (register r in bit 15 - r, set = the ReLU zeroed it): v_bfe_i32 spreads the bit over a
-// register, v_bfi_b32 keeps the accumulator where it is clear
-template <int P, bool MASK, bool CONV>
+// mask: the sign word of the block's pair (nsr_f16x3_core.h: register r in bit HB + 15 - r, HB = 16 for the even block of the
+// pair, 0 for the odd one; set = the ReLU zeroed it): v_bfe_i32 spreads the bit over a register, v_bfi_b32 keeps the
+// accumulator where it is clear
+template <int P, bool MASK, bool CONV, int HB>
 __device__ __forceinline__ void bsplit_a(Acc& p, unsigned mz, Scale& sc, BwdTmp& t) {
   unsigned& hi = t.hi[P & 1];
   unsigned t0, t1;
@@ -158,7 +159,7 @@ __device__ __forceinline__ void bsplit_a(Acc& p, unsigned mz, Scale& sc, BwdTmp&
         "v_cvt_pk_f16_f32 %2, %0, %1\n\t"
         "v_max3_f32 %3, |%0|, |%1|, %3"
         : "+v"(p.m[2 * P]), "+v"(p.m[2 * P + 1]), "=&v"(hi), "+v"(sc.mx), "=&v"(t0), "=&v"(t1)
-        : "v"(mz), "n"(15 - 2 * P), "n"(14 - 2 * P));
+        : "v"(mz), "n"(HB + 15 - 2 * P), "n"(HB + 14 - 2 * P));
   else
     asm volatile(
         "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
@@ -196,12 +197,12 @@ __device__ __forceinline__ void bsplit_b(Acc& p, const Scale& sc, BwdTmp& t, u32
   if (P < 8) bput<(P < 8 ? P : 0)>(cur, h0, h1);
   if (P > 0) bput<Q>(lo, l0, l1);
 }
-template <bool MASK, bool CONV>
+template <bool MASK, bool CONV, int HB>
 __device__ __forceinline__ void bwd_half(int hs, Acc& p, unsigned mz, Scale& sc, BwdTmp& t, u32x4& h0, u32x4& l0,
                                          u32x4& h1, u32x4& l1) {
   switch (hs) {
 #define NSR_HS(P)                                                         \
-    case 2 * P: bsplit_a<P, MASK, CONV>(p, mz, sc, t); break;             \
+    case 2 * P: bsplit_a<P, MASK, CONV, HB>(p, mz, sc, t); break;         \
     case 2 * P + 1: bsplit_b<P, CONV>(p, sc, t, h0, l0, h1, l1); break;
     NSR_HS(0) NSR_HS(1) NSR_HS(2) NSR_HS(3) NSR_HS(4) NSR_HS(5) NSR_HS(6) NSR_HS(7)
 #undef NSR_HS
@@ -209,16 +210,19 @@ __device__ __forceinline__ void bwd_half(int hs, Acc& p, unsigned mz, Scale& sc,
     default: break;
   }
 }
-// the forward kernel's schedule: 17 half-steps in k-steps 0..13 (k-steps 0, 1, 2 take two)
-template <bool MASK, bool CONV>
-__device__ __forceinline__ void bwd_step(int s, Acc& p, unsigned mz, Scale& sc, BwdTmp& t, u32x4& h0, u32x4& l0,
-                                         u32x4& h1, u32x4& l1) {
-  if (s < 3) {
-    bwd_half<MASK, CONV>(2 * s, p, mz, sc, t, h0, l0, h1, l1);
-    bwd_half<MASK, CONV>(2 * s + 1, p, mz, sc, t, h0, l0, h1, l1);
-  } else if (s < 14) {
-    bwd_half<MASK, CONV>(s + 3, p, mz, sc, t, h0, l0, h1, l1);
+// Schedule over the gaps of a 16-step chunk (block_mma3, round 5; rounds 2-4 ran this kernel on the k-step-granular
+// block_mma, whose fillers all queue behind the k-step's first MFMA): half-step i (0..15) in gap 1 + (i & 1) of k-step
+// i >> 1, the last one (two instructions) in gap 0 of k-step 8 -- the forward kernel's pending_gap.  Everything is done
+// before the publish point's DMA gaps (k-steps 8..13) and long before the operands of k-steps 14, 15 are used.
+template <bool MASK, bool CONV, int HB>
+__device__ __forceinline__ void bwd_gap(int s, int g, Acc& p, unsigned mz, Scale& sc, BwdTmp& t, u32x4& h0, u32x4& l0,
+                                        u32x4& h1, u32x4& l1) {
+  if (g == 0) {
+    if (s == 8) bwd_half<MASK, CONV, HB>(16, p, mz, sc, t, h0, l0, h1, l1);
+    return;
   }
+  const int i = 2 * s + g - 1;
+  if (i < 16) bwd_half<MASK, CONV, HB>(i, p, mz, sc, t, h0, l0, h1, l1);
 }
 // Stores of the pending block: its two units in k-steps 14 and 15 (the hi registers are final after half-step 15 =
 // k-step 12), i.e. BEHIND the chunk's last DMA piece (k-step 13).  Vector-memory operations complete in issue order, so
@@ -242,9 +246,10 @@ __device__ __forceinline__ void bwd_store_step(int s, const u32x4& h0, const u32
   if (s == 15) bwd_unit_store<1>(h1, blk, voff1);
 }
 
-// Mask load: the sign word this lane needs to mask block X is fetched during block X - 1, k-step 14 -- a whole block
-// before its first use (the re-split of X runs in the shadow of block X + 1) and as the YOUNGEST vector-memory operation
-// of its block, behind its DMA and stores.  A plain load: the compiler's own vmcnt bookkeeping guards its use; the asm
+// Mask load: the sign word this lane needs to mask blocks X, X + 1 (X even: the two share a dword) is fetched during block
+// X - 1, k-step 14 -- a whole block before its first use (the re-split of X runs in the shadow of block X + 1) and as the
+// YOUNGEST vector-memory operation of its block, behind its DMA and stores.  Two words are alive at a time (mz[pair & 1]):
+// the one of the pending block's pair and the one just fetched.  A plain load: the compiler's own vmcnt bookkeeping guards its use; the asm
 // DMA / stores it cannot see only make its waits stricter, and by then they are a block old.
 __device__ __forceinline__ void mask_load_step(int s, unsigned& mz, const unsigned* blk, int lane) {
   if (s == 14) mz = blk[lane];
@@ -299,32 +304,40 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
       stage_factors(cur, prev);
       store_pscale(cx, panel, cur.cinv * (1.0f / cur.phi));   // phi is a power of two >= 2^-14: exact
     }
-    // masks of the block AFTER this one (loaded here), of the PENDING block (loaded two blocks ago, same buffer parity)
-    const bool load_next = (nb < 7) ? MASK : NEXT_MASK;
+    // mask word of the pair that starts with the block AFTER this one (loaded here if that block is even: nb odd), and of the
+    // PENDING block's pair.  Pair q of a layer lives in mz[q & 1]; every layer has four pairs, so the previous layer's last
+    // pair (block 7 pending during this layer's block 0) is mz[1] and never collides with this layer's pair 0
+    const bool load_next = (nb & 1) && ((nb < 7) ? MASK : NEXT_MASK);
     const unsigned* next_blk =
         !load_next ? nullptr
                    : (nb < 7 ? sign_block(const_cast<unsigned*>(cx.sgn), cx.dp.group, panel, nb + 1)
                              : sign_block(const_cast<unsigned*>(cx.sgn), cx.dp.group, next_panel, 0));
-    const unsigned mz_pend = mz[(nb + 1) & 1];
-    unsigned& mz_next = mz[(nb + 1) & 1];   // block nb + 1; free again once the pending block (nb - 1) is done (k-step 13)
+    const int pb = (nb == 0) ? 7 : nb - 1;            // the pending block's index in its layer
+    const unsigned mz_pend = mz[(pb >> 1) & 1];
+    unsigned& mz_next = mz[((nb + 1) >> 1) & 1];      // pair of block nb + 1 (nb == 7: pair 0 of the next layer); its previous
+                                                      // tenant (two pairs back) was last used a block ago
     // younger than the DMA this chunk's publish point waits for: what the block before issued in its k-steps 14, 15,
-    // behind its last DMA piece (k-step 13): the 16 stores of ITS pending block and the mask load for THIS block
-    const int kYoung = ((FIRST && nb <= 1) ? 0 : 2) + ((MASK && !(FIRST && nb == 0)) ? 1 : 0);
+    // behind its last DMA piece (k-step 13): the 2 stores of ITS pending block and, if THIS block opens a pair, the mask load
+    // for it (never over-counted: a surplus would leave a DMA piece in flight)
+    const int kYoung = ((FIRST && nb <= 1) ? 0 : 2) + ((MASK && !(nb & 1) && !(FIRST && nb == 0)) ? 1 : 0);
     auto mma = [&](auto young) {
-    block_mma<16, kBar, decltype(young)::value>(
+    block_mma3<16, kBar, decltype(young)::value>(
         acc, pre, a_addr, ld, c2, [&](int s, int part) -> u32x4 { return part ? bl[s] : bh[s]; },
-        [&](int s) {
+        [&](int s, int g) {
           if (nb == 0) {
-            // block 7 of the layer before -> k-steps 14, 15 of THIS layer's input
-            bwd_step<PREV_MASK, true>(s, pend, mz_pend, prev, tmp, bh[14], bl[14], bh[15], bl[15]);
-            if (prev_panel >= 0) bwd_store_step(s, bh[14], bh[15], panel_block(cx.dp, prev_panel, 7), cx.voff0, cx.voff1);
+            // block 7 of the layer before (the odd block of its pair) -> k-steps 14, 15 of THIS layer's input
+            bwd_gap<PREV_MASK, true, 0>(s, g, pend, mz_pend, prev, tmp, bh[14], bl[14], bh[15], bl[15]);
+            if (prev_panel >= 0 && g == 2) bwd_store_step(s, bh[14], bh[15], panel_block(cx.dp, prev_panel, 7), cx.voff0, cx.voff1);
           } else {
-            bwd_step<MASK, true>(s, pend, mz_pend, cur, tmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1]);
-            bwd_store_step(s, oh[2 * nb - 2], oh[2 * nb - 1], panel_block(cx.dp, panel, nb - 1), cx.voff0, cx.voff1);
+            if (pb & 1) bwd_gap<MASK, true, 0>(s, g, pend, mz_pend, cur, tmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1]);
+            else bwd_gap<MASK, true, 16>(s, g, pend, mz_pend, cur, tmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1]);
+            if (g == 2) bwd_store_step(s, oh[2 * nb - 2], oh[2 * nb - 1], panel_block(cx.dp, panel, nb - 1), cx.voff0, cx.voff1);
           }
-          if (load_next) mask_load_step(s, mz_next, next_blk, cx.lane);
+          if (load_next && g == 1) mask_load_step(s, mz_next, next_blk, cx.lane);
         },
-        [&](int k) { prefetch_frag(nxt, k, ld.slot_next + ld.lane_off); });
+        [&](int k, int g) {
+          if (g == 0) prefetch_frag(nxt, k, ld.slot_next + ld.lane_off);
+        });
     };
     if (kYoung == 3) mma(std::integral_constant<int, 3>{});
     else if (kYoung == 2) mma(std::integral_constant<int, 2>{});
@@ -388,9 +401,9 @@ chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ 
   // ---- prologue: the colour head's input gradient on the VALU (K = 3), masked by dir_encoding's ReLU
   const float g0 = d_rgb[pc * d_rgb_stride + 0], g1 = d_rgb[pc * d_rgb_stride + 1], g2 = d_rgb[pc * d_rgb_stride + 2];
   const float gs = d_sigma[pc * d_sigma_stride];
-  unsigned zc[4];   // sign words of dir_encoding's four output blocks
+  unsigned zc[2];   // sign words of dir_encoding's four output blocks (two per dword)
 #pragma unroll
-  for (int b = 0; b < 4; ++b) zc[b] = sign_block(const_cast<unsigned*>(sgn), cx.dp.group, 9, b)[lane];
+  for (int b = 0; b < 2; ++b) zc[b] = sign_block(const_cast<unsigned*>(sgn), cx.dp.group, 9, 2 * b)[lane];
   __syncthreads();   // aux visible
   float dz[64];
   float mxin = fabsf(gs);
@@ -399,7 +412,7 @@ chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ 
     const int feat = act_feature(t, h);
     const f32x4 w4 = *reinterpret_cast<const f32x4*>(ring + kAux0 + 4 * feat);
     float v = __fmaf_rn(w4[2], g2, __fmaf_rn(w4[1], g1, __fmul_rn(w4[0], g0)));
-    v = ((zc[t >> 4] >> (15 - (t & 15))) & 1u) ? 0.0f : v;
+    v = ((zc[t >> 5] >> ((((t >> 4) & 1) ? 0 : 16) + 15 - (t & 15))) & 1u) ? 0.0f : v;
     dz[t] = v;
     mxin = fmaxf(mxin, fabsf(v));
   }
@@ -476,7 +489,7 @@ chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ 
     // give the matrix pipe its write-back latency (18 wait states for a 16-pass MFMA) before the asm below reads them
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
-    for (int hs = 0; hs < 17; ++hs) bwd_half<true, true>(hs, pend, mz[1], prev, tmp, bh[0], bl[0], bh[1], bl[1]);
+    for (int hs = 0; hs < 17; ++hs) bwd_half<true, true, 0>(hs, pend, mz[1], prev, tmp, bh[0], bl[0], bh[1], bl[1]);
     publish_max(cx, 0, prev.mx * prev.cinv);
     const char* blk = panel_block(cx.dp, 0, 7);
     unit_store<0>(bh[0], blk, cx.voff0);

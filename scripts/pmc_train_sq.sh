@@ -23,3 +23,20 @@ for n, c in acc.items():
 json.dump(out, open("$R/gpurun_out/train_traffic/SQ.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:2500])
 PY
+
+# second pass: instruction mix and LDS bank conflicts (the weight-gradient kernel's transposing reads)
+rm -rf /tmp/tsq2
+(cd /tmp && rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_WAVES --kernel-trace --output-format csv -d /tmp/tsq2 -o run -- python $R/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline > /tmp/tsq2.log 2>&1)
+python - <<PY
+import csv, collections, glob, json
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+for f in glob.glob("/tmp/tsq2/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0].split("::")[-1].strip()[:40]
+        acc[n][r["Counter_Name"]] += float(r["Counter_Value"]) / 3.0
+out = {n: {k: int(v) for k, v in c.items()} for n, c in acc.items() if c.get("SQ_INSTS_MFMA", 0) > 1e4}
+for n, c in out.items():
+    c["bank_conflict_cycles_per_lds_inst"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0) / max(c.get("SQ_INSTS_LDS", 1), 1), 3)
+json.dump(out, open("$R/gpurun_out/train_traffic/SQ_insts.json", "w"), indent=1)
+print(json.dumps(out, indent=1)[:2500])
+PY
