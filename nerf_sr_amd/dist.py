@@ -35,13 +35,14 @@ def _world(group=None) -> Tuple[int, int]:
     return 0, 1
 
 
-def all_gather_pixels(local: torch.Tensor, n_items: int, group=None) -> torch.Tensor:
+def all_gather_pixels(local: torch.Tensor, n_items: int, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Gather per-rank pixel blocks (n_local, c) into the full (n_items, c) tensor on every rank.
 
     ONE fixed-size ``all_gather_into_tensor`` (RCCL over xGMI under the ``nccl`` backend): the payload is LR pixels
     only -- 16 B per pixel, 95 KB per rank for config #4 -- so the exchange is latency-bound (tens of microseconds
     whatever algorithm RCCL picks on the point-to-point links); what matters is that it is a single collective with
-    no host round trip and no copy after it (see ``shard_bounds``)."""
+    no host round trip and no copy after it (see ``shard_bounds``).  ``out``: an optional (world * cap, ...) receive buffer
+    on ``local``'s device, re-used from step to step (a per-frame loop then allocates nothing)."""
     rank, world = _world(group)
     if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return local
@@ -60,7 +61,9 @@ def all_gather_pixels(local: torch.Tensor, n_items: int, group=None) -> torch.Te
         recv_h = torch.empty((world * cap, *c), dtype=local.dtype)
         dist.all_gather_into_tensor(recv_h, send.cpu().contiguous(), group=group)
         return recv_h[:n_items].to(local.device)
-    recv = torch.empty((world * cap, *c), dtype=local.dtype, device=local.device)
+    if out is not None and (tuple(out.shape) != (world * cap, *c) or out.dtype != local.dtype or out.device != local.device):
+        raise ValueError(f"out must be a ({world * cap}, ...) buffer of the payload's dtype on its device")
+    recv = out if out is not None else torch.empty((world * cap, *c), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
     return recv[:n_items]
 
@@ -122,7 +125,12 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         if backend is None:
             backend = os.environ.get("NSR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {}
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            if backend == "nccl":
+                # bind the communicator to this rank's device at creation (no lazy guess from the first collective's tensor;
+                # RCCL otherwise warns that the device is unknown until then)
+                kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local, world

@@ -152,3 +152,44 @@ def test_gloo_hr_gather_assembles_the_frame(world, img_wh, s):
         n_lr = 47628
         assert res[0][2] == -(-n_lr // world) * 16 * 12          # = 762,048 x 12 / N up to the block rounding
         assert abs(res[0][2] - 762048 * 12 / world) <= 16 * 12
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a torchrun environment starts two ranks itself (bench.self_launch: one process per
+    rank through torch.distributed.run on a free local port; the reference spawns its ranks too, train.py:154-156).  On this
+    GPU-less box every rank gets as far as the rendezvous (gloo) and the world-size check, then stops at "needs a GPU": the
+    launcher, the rendezvous and the argument forwarding are covered here, the render itself by the -m gpu twin
+    (tests/test_gpu_frames.py::test_bench_two_ranks_on_one_gpu_gloo)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered end to end by the -m gpu twin on a GPU box")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, cwd=repo, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
+    assert res.stderr.count("bench.py needs a GPU") >= 2, res.stderr[-1500:]          # both ranks got there
+    assert "inconsistent torchrun environment" not in res.stderr
+    # and the command it builds
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    real = subprocess.call
+    subprocess.call = fake_call
+    try:
+        old = sys.argv
+        sys.argv = ["bench.py", "--gpus", "4", "--steps", "3"]
+        assert bench.self_launch(4) == 0
+    finally:
+        subprocess.call = real
+        sys.argv = old
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -298,23 +298,20 @@ def test_config5_full_size_end_to_end(ops):
 
 # ------------------------------------------------------------------------------------------------- bench.py, N > 1
 def test_bench_two_ranks_on_one_gpu_gloo():
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), on THIS box: both
-    ranks share the one GPU and exchange over gloo (NSR_DIST_BACKEND; RCCL refuses two ranks per device).  Checks the
-    N > 1 code path end to end: the SAME workload and metric string as N = 1 (config #2's frame cut in two LR-pixel
-    blocks), config #4 cut the same way as the `config4` sub-object, one all-gather per step whose result is verified
+    """`python bench.py --gpus 2`, started PLAINLY (no torchrun: bench.py launches its own ranks, one process per rank through
+    torch.distributed.run on a free port -- round 5), on THIS box: both ranks share the one GPU and exchange over gloo
+    (NSR_DIST_BACKEND; RCCL refuses two ranks per device).  Checks the N > 1 code path end to end: the SAME workload and
+    metric string as N = 1 (config #2's frame cut in two LR-pixel blocks), config #4 cut the same way as the `config4`
+    sub-object with the HR frame as its collective's payload (12 B per ray), one all-gather per step whose result is verified
     identical on both ranks, max-over-ranks timing, one JSON line from rank 0 with the contract's fields."""
     import json
     import os
-    import socket
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, NSR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(NSR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
     res = subprocess.run(cmd, env=env, cwd=repo, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -340,6 +337,8 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     c4 = d["config4"]
     assert "config #4" in c4["workload"] and c4["rays_per_step"] == 762048 and c4["metric"] == "rays/sec (64+128 samples, 4x SS)"
     assert c4["result_identical_on_all_ranks"] is True and abs(c4["value"] - 762048 / (c4["ms_per_step"] * 1e-3)) <= 1e-6 * c4["value"]
+    assert c4["bytes_per_rank"] == 762048 * 12 // 2 and c4["hr_frame_assembled"] is True      # the HR frame, 12 B per ray
+    assert d["non_mlp_ms_per_step"] > 0.0 and c4["non_mlp_ms_per_step"] > 0.0
     assert d["numerics_status"] == [0, 0]
     src = d["roofline"]["pmc_source"]
     assert set(src) == {"file", "csrc_sha256", "this_build_sha256", "matches_this_build"}
