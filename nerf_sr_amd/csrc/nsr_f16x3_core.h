@@ -322,7 +322,8 @@ __device__ __forceinline__ void block_mma(Acc& acc, const Pre& pre, unsigned a_a
 // and the chunk's DMA pieces go one per gap (gaps 1 and 2 of k-steps BAR..BAR+5, each with its own M0 write).
 // DMA = false: the publish point stays, but no chunk is fetched behind it (the last two chunks of a one-tile workgroup:
 // there is no next tile to fetch L1 for).
-template <int NSTEP, int BAR, int YOUNGER = 0, bool DMA = true, class BOf, class Hook, class Next>
+// MMA = false (ablation builds only, -DNSR_ABL_NO_DENSITY_MMA): the block runs without its MFMAs -- what they cost.
+template <int NSTEP, int BAR, int YOUNGER = 0, bool DMA = true, bool MMA = true, class BOf, class Hook, class Next>
 __device__ __forceinline__ void block_mma3(Acc& acc, const Pre& pre, unsigned a_addr, Loader& ld, const ChunkRef& c2,
                                            BOf&& b_of, Hook&& hook, Next&& next, bool strict = false) {
   static_assert(NSTEP >= kPF, "sequence shorter than the prefetch depth");
@@ -344,7 +345,7 @@ __device__ __forceinline__ void block_mma3(Acc& acc, const Pre& pre, unsigned a_
     if (s == BAR) loader_publish<YOUNGER, (DMA && BAR < 3)>(ld, c2, strict);
     const u32x4 bh = b_of(s, 0), bl = b_of(s, 1);
     // ---- gap 0.  a_lo first: it is the younger of the step's two fragment loads, so ONE lgkmcnt wait serves all three
-    acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(al[s]), as_h8(bh), acc.m, 0, 0, 0);
+    if (MMA) acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(al[s]), as_h8(bh), acc.m, 0, 0, 0);
     if (s + kPF < NSTEP) {
       ah[s + kPF] = a_pieces[(2 * (s + kPF)) * 64];
       al[s + kPF] = a_pieces[(2 * (s + kPF) + 1) * 64];
@@ -354,12 +355,12 @@ __device__ __forceinline__ void block_mma3(Acc& acc, const Pre& pre, unsigned a_
     hook(s, 0);
     __builtin_amdgcn_sched_barrier(0);
     // ---- gap 1
-    acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bl), acc.m, 0, 0, 0);
+    if (MMA) acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bl), acc.m, 0, 0, 0);
     hook(s, 1);
     if (DMA && BAR >= 0 && s >= BAR && s < BAR + 6) loader_issue(ld, 2 * (s - BAR));
     __builtin_amdgcn_sched_barrier(0);
     // ---- gap 2
-    acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bh), acc.m, 0, 0, 0);
+    if (MMA) acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bh), acc.m, 0, 0, 0);
     hook(s, 2);
     if (s + kPF >= NSTEP) next(s + kPF - NSTEP, 2);
     if (DMA && BAR >= 0 && s >= BAR && s < BAR + 6) loader_issue(ld, 2 * (s - BAR) + 1);

@@ -504,7 +504,7 @@ __device__ __forceinline__ h8 stream_h8(const u32x4& v) { return __builtin_bit_c
 //
 // Patch layout: an entry = one pixel = 64 B = four 16-B pieces (hi channels 0-7, hi 8-15, lo 0-7, lo 8-15); piece p of
 // entry e sits in slot p ^ ((e >> 2) & 3), so the 16 lanes a ds_read_b128 serves together (16 consecutive entries, or 8
-// images x 2 pixels at an image pitch = 1 mod 4) fall on 16 distinct 16-B bank groups.  Padding pixels are fetched
+// images x 2 pixels at an image pitch = 2 mod 4) fall on 16 distinct 16-B bank groups.  Padding pixels are fetched
 // clamped and zeroed in the fragments (every DMA is issued whatever the lane: the publish points count them).
 //
 // Per k-step (tap t of chunk cc), per wave: [patch pieces of chunk cc + 1: taps 0..7, first half of the blocks] | publish =
@@ -525,7 +525,10 @@ struct HaloGeo {
   static constexpr int TW = GROUPED ? 8 : 16, TH = 128 * BM / NI / TW;      // plain: 16 x 16 / 16 x 32; grouped: 8 x 4 / 8 x 8
   static constexpr int RW = S == 1 ? TW + 2 : 2 * TW + 1;                  // region width, heights (entries)
   static constexpr int RH0 = S == 1 ? TH + 2 : TH, RH1 = S == 1 ? TH + 2 : TH + 1;
-  static constexpr int pad1(int x) { return GROUPED ? x + (5 - x % 4) % 4 : x; }      // grouped: image pitch = 1 mod 4
+  // grouped: image pitch = 2 mod 4.  (Round 4 used 1 mod 4 and measured 1.6 conflict cycles per LDS instruction on the grouped
+  // kernels; scripts/halo_lds_model.py: with 8 images x 2 pixels per 16-lane pass every A-fragment read was a 2-way conflict
+  // at that pitch and is conflict-free at this one, same swizzle.)
+  static constexpr int pad1(int x) { return GROUPED ? x + (6 - x % 4) % 4 : x; }
   static constexpr int IMG0 = pad1(RW * RH0), IMG1 = pad1(RW * RH1);
   static constexpr int ENT0 = NI * IMG0, ENT1 = NI * IMG1;
   static constexpr int PP0 = ((ENT0 * 64 + 1023) / 1024 + 3) / 4, PP1 = ((ENT1 * 64 + 1023) / 1024 + 3) / 4;   // pieces per wave
@@ -846,12 +849,17 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   if (a.Ah && a.Ch && a.Bs && a.conv.cin > 0 && (a.conv.stride == 1 || a.conv.stride == 2) && (a.conv.cin % 16) == 0 && (g.N % 128) == 0 &&
       g.n_valid == g.N && !g.mask && !g.col_sums && g.act == kActRelu && g.acc_scale != 0.0f && g.acc_scale != 1.0f &&
       (a.group == 8 || a.group <= 1) && g.K == 9 * a.conv.cin && (reinterpret_cast<uintptr_t>(a.Bs) & 15) == 0) {
-    const bool grouped = a.group == 8, s2 = a.conv.stride == 2;      // stride 2: from 256 input channels (measured: the 128-channel layer is faster staged)
+    // stride 2: every such layer of the network, the 128-channel one included (round 4 left it on the staged tile: measured
+    // slower here BEFORE the fragment-ordered weight copy existed; -DNSR_HALO_S2_MIN_CIN=256 restores that for A/B runs)
+#ifndef NSR_HALO_S2_MIN_CIN
+#define NSR_HALO_S2_MIN_CIN 128
+#endif
+    const bool grouped = a.group == 8, s2 = a.conv.stride == 2;
     const int64_t per_img = (int64_t)a.conv.Ho * a.conv.Wo;
     const int64_t in_rows = (g.M / per_img) * a.conv.Hs * a.conv.Ws;      // images x source pixels
     const bool geometry = s2 ? (!a.conv.up && a.conv.Hs == 2 * a.conv.Ho && a.conv.Ws == 2 * a.conv.Wo)
                              : (a.conv.up ? (a.conv.Ho == 2 * a.conv.Hs && a.conv.Wo == 2 * a.conv.Ws) : (a.conv.Ho == a.conv.Hs && a.conv.Wo == a.conv.Ws));
-    const bool common = (g.M % (per_img * (grouped ? 8 : 1))) == 0 && geometry && (!s2 || a.conv.cin >= 256) && (a.a_plane + in_rows * g.lda) * 2 < ((int64_t)1 << 32);
+    const bool common = (g.M % (per_img * (grouped ? 8 : 1))) == 0 && geometry && (!s2 || a.conv.cin >= NSR_HALO_S2_MIN_CIN) && (a.a_plane + in_rows * g.lda) * 2 < ((int64_t)1 << 32);
     // Shapes (rows x columns of a workgroup): 256 x 256 where N allows it, else 512 x 128 (stride 1) -- the whole register
     // file as the accumulator; 256 x 128 (half of it) where that wastes fewer CU-rounds: a 16 x 16 decoder layer is 338 of the
     // big tiles, two rounds of 256 CUs with the second a third full, against three rounds of half-size tiles.

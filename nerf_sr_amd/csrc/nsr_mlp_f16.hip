@@ -997,7 +997,12 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     Resplit ptmp;
     const unsigned next_bias = 36u * 1024u;       // dir_encoding chunks: 36 weight pieces, then the bias
     Pre nxt;
-    block_mma3<16, kBar, (TRAIN ? kTrainYoung : 0)>(
+#ifdef NSR_ABL_NO_DENSITY_MMA   // ablation (profiles/r5_headline_experiments.json): the density block without its 48 MFMAs
+    constexpr bool kDensityMma = false;
+#else
+    constexpr bool kDensityMma = true;
+#endif
+    block_mma3<16, kBar, (TRAIN ? kTrainYoung : 0), true, kDensityMma>(
         cur, pre, ld.slot_cur + ld.lane_off, ld, SIGMA_ONLY ? first_ref(1, wave) : dir_ref(1, wave),
         [&](int s, int part) -> u32x4 { return part ? ol[s] : oh[s]; },
         [&](int s, int g) {

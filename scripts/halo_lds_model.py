@@ -21,7 +21,7 @@ def geo(BN, BM, GROUPED, S):
     RW = TW + 2 if S == 1 else 2 * TW + 1
     RH0 = TH + 2 if S == 1 else TH
     RH1 = TH + 2 if S == 1 else TH + 1
-    pad1 = (lambda x: x + (5 - x % 4) % 4) if GROUPED else (lambda x: x)
+    pad1 = (lambda x: x + (6 - x % 4) % 4) if GROUPED else (lambda x: x)   # round 5: pitch = 2 mod 4 (round 4: 1 mod 4)
     return dict(NI=NI, TW=TW, TH=TH, RW=RW, IMG0=pad1(RW * RH0), IMG1=pad1(RW * RH1), S=S, BM=BM, GROUPED=GROUPED)
 
 

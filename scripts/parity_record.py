@@ -1,0 +1,116 @@
+"""Per-round parity record of the build as committed (GPU box): the per-ray contract of DESIGN section 4 --
+|dRGB| of the fine colours <= max(1e-4, 2 x the oracle's own fp32-vs-fp64 gap on that ray) -- at frame scale, on
+
+  * `N` consecutive rays from the middle of one frame of EACH BASELINE geometry (#2 504x378 2x, #3 400x400 2x Blender,
+    #4 1008x756 4x, #5 800x800 4x Blender), synthetic "smooth" field (the protocol of tests/test_gpu_frames.py), and
+  * `N_TRAINED` rays of configs #2 / #3 on density fields TRAINED on the analytic scenes of tests/trained_field.py with
+    this repository's own HIP training step (the protocol of tests/test_gpu_trained.py),
+
+for both contract-grade precisions.  Per block: max / p99.9 / median of |dRGB| against the fp32 oracle, rays over 1e-4, rays
+whose bound is the second term ("second-term rays": 2 x gap > 1e-4), violations of the contract, and the strict-rule count
+(rays over 1e-4 whose oracle gap is <= 1e-4: what the round-2 form of the rule would have flagged).  The tests assert these
+quantities on 16,384 rays per block; their printed statistics are lost in `pytest -q`, this file keeps them per round.
+
+usage: python scripts/parity_record.py out.json [N=65536] [N_TRAINED=16384] [train_steps=4000]
+The oracle runs the way bench.py's CPU baseline does: many evaluations side by side over disjoint ray chunks."""
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from nerf_sr_amd import build as nsr_build, cameras, ops  # noqa: E402
+from nerf_sr_amd.weights import make_state_dict  # noqa: E402
+from oracle import nerf_oracle as oc  # noqa: E402
+from tests import trained_field as tf  # noqa: E402
+
+OUT = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/parity_record.json"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+N_TRAINED = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
+STEPS = int(sys.argv[4]) if len(sys.argv) > 4 else 4000
+CONFIGS = {2: ((504, 378), 2, True, False), 3: ((400, 400), 2, False, True), 4: ((1008, 756), 4, True, False),
+           5: ((800, 800), 4, False, True)}
+HOST = os.cpu_count() or 1
+WORKERS, THREADS = max(1, min(64, HOST // 4)), 2
+
+
+def oracle_pair(sd_c, sd_f, rays_cpu, white):
+    """fp32 and fp64 oracle evaluations of the rays, each as WORKERS evaluations side by side over contiguous chunks."""
+    def run(dtype):
+        sc, sf = oc.to_torch_sd(sd_c, dtype), oc.to_torch_sd(sd_f, dtype)
+        chunks = [c for c in rays_cpu.to(dtype).chunk(WORKERS) if c.shape[0]]
+
+        def one(r):
+            torch.set_num_threads(THREADS)
+            with torch.no_grad():
+                return oc.forward_rays(sc, sf, r, 64, 64, white)
+        with ThreadPoolExecutor(len(chunks)) as ex:
+            parts = list(ex.map(one, chunks))
+        return {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
+    return run(torch.float32), run(torch.float64)
+
+
+def block_stats(sd_c, sd_f, blk, white):
+    t0 = time.time()
+    ref, ref64 = oracle_pair(sd_c, sd_f, blk.cpu(), white)
+    entry = {"rays": int(blk.shape[0]), "oracle_seconds": round(time.time() - t0, 1)}
+    gap = (ref["fine_comp_rgbs"].double() - ref64["fine_comp_rgbs"]).abs().max(-1)[0]
+    for prec in ("f16x3", "fp32"):
+        nc, nf = ops.VanillaMLP(precision=prec).load_state_dict(sd_c), ops.VanillaMLP(precision=prec).load_state_dict(sd_f)
+        hip = ops.forward_rays(nc, nf, blk.cuda(), 64, 64, white)
+        torch.cuda.synchronize()
+        st = tf.parity_stats(hip, ref, ref64)
+        d = (hip["fine_comp_rgbs"].cpu().double() - ref["fine_comp_rgbs"].double()).abs().max(-1)[0]
+        entry[prec] = {
+            "max": st["hip_vs_oracle32"]["max"], "p999": st["hip_vs_oracle32"]["p999"], "median": st["hip_vs_oracle32"]["median"],
+            "rays_over_1e-4": st["hip_vs_oracle32"]["over_1e-4"],
+            "second_term_rays": st["exempt_rays"],                        # bound = 2 x oracle gap (> 1e-4)
+            "violations": st["violations"], "hard_violations": st["hard_violations"],
+            "strict_rule_count": int(((d > 1e-4) & (gap <= 1e-4)).sum()),   # over 1e-4 although the oracle's own gap is <= 1e-4
+            "worst_rays": st["worst_rays"][:2],
+            "coarse_max": st["coarse_max"], "vs_fp64_oracle_max": st["hip_vs_oracle64"]["max"],
+            "psnr_build_vs_oracle_db": oc.psnr(hip["fine_comp_rgbs"].cpu(), ref["fine_comp_rgbs"]),
+            "status_flags": [nc.status(), nf.status()],
+        }
+    entry["oracle_fp32_vs_fp64"] = {"max": float(gap.max()), "p999": float(torch.quantile(gap, 0.999)), "median": float(gap.median()),
+                                    "rays_over_1e-4": int((gap > 1e-4).sum())}
+    entry["fine_weight_peak_median"] = float(ref["fine_weights"].max(-1)[0].median())
+    return entry
+
+
+rep = {"csrc_sha256": nsr_build.source_hash(), "contract": "|dRGB| <= max(1e-4, 2 x oracle fp32-vs-fp64 gap) per ray (DESIGN 4)",
+       "oracle": f"oracle/nerf_oracle.py, {WORKERS} evaluations x {THREADS} ATen threads side by side, fp32 and fp64",
+       "geometries": {}, "trained": {}}
+sd_c, sd_f = make_state_dict(99), make_state_dict(100)
+for cid, (wh, s, ndc, white) in CONFIGS.items():
+    if ndc:
+        c2w, f, nf = cameras.spiral_pose(0.4), cameras.llff_focal(wh[0]), (0.0, 1.0)
+    else:
+        c2w, f, nf = cameras.spheric_pose(40.0, -30.0, 4.0), cameras.blender_focal(wh[0]), (2.0, 6.0)
+    rays = ops.subpixel_rays(c2w, wh, f, s, ndc, *nf).view(-1, 8)
+    lo = (rays.shape[0] // 2) - (rays.shape[0] // 2) % (s * s)
+    e = block_stats(sd_c, sd_f, rays[lo:lo + N].contiguous(), white)
+    e.update(img_wh=wh, downscale=s, field="smooth synthetic field, make_state_dict(99 / 100)")
+    rep["geometries"][str(cid)] = e
+    print("config", cid, {p: (e[p]["max"], e[p]["rays_over_1e-4"], e[p]["second_term_rays"], e[p]["violations"], e[p]["strict_rule_count"])
+                          for p in ("f16x3", "fp32")}, flush=True)
+    json.dump(rep, open(OUT, "w"), indent=1)
+for family in ("llff", "blender"):
+    t0 = time.time()
+    res = tf.train_field(family, steps=STEPS)
+    torch.cuda.synchronize()
+    wh, s, ndc, white, nf, _ = tf.FAMILIES[family]
+    c2w, focal = tf.eval_pose(family)
+    rays = ops.subpixel_rays(c2w, wh, focal, s, ndc, *nf).view(-1, 8)
+    lo = (rays.shape[0] // 2) - (rays.shape[0] // 2) % (s * s)
+    e = block_stats(res["sd_coarse"], res["sd_fine"], rays[lo:lo + N_TRAINED].contiguous(), white)
+    e.update(train_steps=STEPS, train_seconds=round(time.time() - t0 - e["oracle_seconds"], 1), history=res["history"][-2:],
+             field=f"trained on the analytic {family} scene (tests/trained_field.py), pose not trained on")
+    rep["trained"][family] = e
+    print("trained", family, {p: (e[p]["max"], e[p]["rays_over_1e-4"], e[p]["second_term_rays"], e[p]["violations"], e[p]["strict_rule_count"])
+                              for p in ("f16x3", "fp32")}, flush=True)
+    json.dump(rep, open(OUT, "w"), indent=1)
+print("wrote", OUT)
