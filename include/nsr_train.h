@@ -73,6 +73,30 @@ int nsr_train_loss_and_grads(const float* const* w_coarse, const float* const* w
                              int precision, int64_t ray_chunk, float* const* outs, float* lr_coarse, float* lr_fine, float* losses,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* The optional variance losses of comp_low_res_output / calculate_losses (nerf_downX_model.py:332-336, 349-353, 374-378;
+ * options --use_var_loss / --use_depth_var_loss, :107-112):
+ *   loss_tot += lambda_coarse_var * sum_{LR pixels, channels} var_{s2 sub-rays}(coarse rgb) + lambda_fine_var * (fine rgb)
+ *   loss_tot += lambda_coarse_depth_var * sum_{LR pixels} var_{s2 sub-rays}(coarse depth / far) + lambda_fine_depth_var * (fine)
+ * with torch.var's default (unbiased: divisor s2 - 1) and `far` = the reference's self.far (:284: the far bound of the batch's
+ * first ray).  A lambda of 0 switches its term off.  s2 must be >= 2 when any lambda is non-zero (the variance of one sub-ray
+ * is 0 / 0: the reference would train on NaN) -- NSR_ERR_INVALID_ARG otherwise. */
+typedef struct nsr_train_var_losses {
+  float lambda_coarse_var, lambda_fine_var;
+  float lambda_coarse_depth_var, lambda_fine_depth_var;
+  float far;
+} nsr_train_var_losses;
+/* nsr_train_loss_and_grads with those terms in the loss and in the gradients.  var_losses (may be NULL): DEVICE float[4] =
+ * { lambda_coarse_var * var_c, lambda_fine_var * var_f, lambda_coarse_depth_var * dvar_c, lambda_fine_depth_var * dvar_f },
+ * the reference's loss_out_{coarse,fine}_var / loss_{coarse,fine}_depth_var times their lambdas.  Every other argument as above. */
+int nsr_train_loss_and_grads_var(const float* const* w_coarse, const float* const* w_fine, float* const* g_coarse,
+                                 float* const* g_fine, const float* rays, int ray_stride, int64_t R, int s2,
+                                 const float* target_lr, int n_coarse, int n_importance, int white_bkgd, int lindisp,
+                                 const float* u_coarse, const float* u_fine, const float* noise_coarse,
+                                 const float* noise_fine, float noise_std, float lambda_coarse, float lambda_fine,
+                                 int precision, int64_t ray_chunk, float* const* outs, float* lr_coarse, float* lr_fine, float* losses,
+                                 void* workspace, size_t workspace_bytes, void* stream, const nsr_train_var_losses* var,
+                                 float* var_losses);
+
 /* Numerics status of the training step (the reference drops into pdb on NaN colours, nerf_downX_model.py:273-274; a
  * replacement reports instead).  The FIRST 64 BYTES of the workspace are a sticky status block: with NSR_F16X3 every
  * nsr_train_loss_and_grads ORs NSR_FLAG_WEIGHT_RANGE (a weight of the iteration's re-pack is non-finite or |w| >= 1023.75:

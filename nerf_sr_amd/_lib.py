@@ -62,6 +62,11 @@ SIGNATURES = {
                                          c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_int, c_int64,
                                          POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nsr_train_loss_and_grads_var": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                             c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_int, c_int64,
+                                             POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
+                                             c_void_p, c_void_p]),
     "nsr_train_status_reset": (c_int, [c_void_p, c_void_p]),
     "nsr_train_status": (c_int, [c_void_p, c_int, POINTER(c_uint), c_void_p]),
     "nsr_adam_step": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int,

@@ -122,13 +122,20 @@ __global__ void sigma_noise_kernel(const float* __restrict__ sigma, int sigma_st
 
 // A1 + MSE: one thread per LR pixel.  lr = mean over the s2 sub-rays; loss partial per block; gC = dL/d(comp rgb)
 // of every sub-ray = 2 lambda (lr - target) / (3 N_lr_total) / s2.
+// Optional variance losses of the same function (comp_low_res_output, models/nerf_downX_model.py:332-336, 349-353; added to
+// loss_tot at :374-378): lambda_var * SUM over the LR pixels and channels of torch.var (unbiased: / (s2 - 1)) of the s2 sub-ray
+// colours, and lambda_dvar * SUM over the LR pixels of torch.var of the s2 sub-ray depths / far.  Their gradients join gC
+// (2 lambda_var (x_k - mean) / (s2 - 1)) and form a per-ray depth gradient g_depth (2 lambda_dvar (d_k / far - mean) /
+// ((s2 - 1) far)) that the compositing backward adds through depth = sum_k w_k z_k.
+// block_sums: [0, nblk) squared errors, [nblk, 2 nblk) colour variances, [2 nblk, 3 nblk) depth variances.
 __global__ void __launch_bounds__(256) lr_loss_kernel(const float* __restrict__ comp, const float* __restrict__ target,
                                                       int64_t n_lr, int s2, double scale, float lambda,
                                                       float* __restrict__ lr_out, float* __restrict__ g_comp,
-                                                      double* __restrict__ block_sums) {
-  __shared__ double red[256];
+                                                      double* __restrict__ block_sums, float lambda_var, float lambda_dvar,
+                                                      float far, const float* __restrict__ depth, float* __restrict__ g_depth) {
+  __shared__ double red[3][256];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  double sq = 0.0;
+  double sq = 0.0, var_rgb = 0.0, var_d = 0.0;
   if (i < n_lr) {
     for (int c = 0; c < 3; ++c) {
       float acc = 0.0f;
@@ -138,39 +145,80 @@ __global__ void __launch_bounds__(256) lr_loss_kernel(const float* __restrict__ 
       const float d = __fsub_rn(lr, target[i * 3 + c]);
       sq += (double)d * (double)d;
       const float gc = (float)(2.0 * (double)lambda * (double)d * scale / (double)s2);
-      for (int k = 0; k < s2; ++k) g_comp[(i * s2 + k) * 3 + c] = gc;
+      if (lambda_var != 0.0f) {       // wave-uniform
+        double ss = 0.0;
+        for (int k = 0; k < s2; ++k) {
+          const double e = (double)comp[(i * s2 + k) * 3 + c] - (double)lr;
+          ss += e * e;
+          g_comp[(i * s2 + k) * 3 + c] = gc + (float)(2.0 * (double)lambda_var * e / (double)(s2 - 1));
+        }
+        var_rgb += ss / (double)(s2 - 1);
+      } else {
+        for (int k = 0; k < s2; ++k) g_comp[(i * s2 + k) * 3 + c] = gc;
+      }
+    }
+    if (g_depth) {
+      if (lambda_dvar != 0.0f) {
+        double m = 0.0;
+        for (int k = 0; k < s2; ++k) m += (double)__fdiv_rn(depth[i * s2 + k], far);
+        m /= (double)s2;
+        double ss = 0.0;
+        for (int k = 0; k < s2; ++k) {
+          const double e = (double)__fdiv_rn(depth[i * s2 + k], far) - m;
+          ss += e * e;
+          g_depth[i * s2 + k] = (float)(2.0 * (double)lambda_dvar * e / ((double)(s2 - 1) * (double)far));
+        }
+        var_d = ss / (double)(s2 - 1);
+      } else {
+        for (int k = 0; k < s2; ++k) g_depth[i * s2 + k] = 0.0f;
+      }
     }
   }
-  red[threadIdx.x] = sq;
+  red[0][threadIdx.x] = sq;
+  red[1][threadIdx.x] = var_rgb;
+  red[2][threadIdx.x] = var_d;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    if ((int)threadIdx.x < o)
+      for (int q = 0; q < 3; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = red[0];
+  if (threadIdx.x < 3) block_sums[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = red[threadIdx.x][0];
 }
-// losses[slot] += lambda * scale * sum(block_sums)   (single thread block: deterministic order)
+// losses[slot] = lambda * scale * (sum of squared errors over the passes so far)   (single thread block: deterministic order);
+// var_losses (optional): [slot] = lambda_var * sum of the colour variances, [2 + slot] = lambda_dvar * sum of the depth variances
 __global__ void __launch_bounds__(256) loss_finish_kernel(const double* __restrict__ block_sums, int n, double scale,
                                                           float lambda, float* __restrict__ losses, int slot,
-                                                          double* __restrict__ carry) {
-  __shared__ double red[256];
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) s += block_sums[i];
-  red[threadIdx.x] = s;
+                                                          double* __restrict__ carry, float lambda_var, float lambda_dvar,
+                                                          float* __restrict__ var_losses) {
+  __shared__ double red[3][256];
+  for (int q = 0; q < 3; ++q) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += block_sums[(int64_t)q * n + i];
+    red[q][threadIdx.x] = s;
+  }
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    if ((int)threadIdx.x < o)
+      for (int q = 0; q < 3; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + o];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    carry[slot] += red[0];                                       // sum of squared errors over the passes so far
+    carry[slot] += red[0][0];                                       // sum of squared errors over the passes so far
     losses[slot] = (float)((double)lambda * carry[slot] * scale);   // scale = 1 / (3 N_lr)
+    carry[2 + slot] += red[1][0];
+    carry[4 + slot] += red[2][0];
+    if (var_losses) {
+      var_losses[slot] = (float)((double)lambda_var * carry[2 + slot]);
+      var_losses[2 + slot] = (float)((double)lambda_dvar * carry[4 + slot]);
+    }
   }
 }
 
 // Backward of V1 (models/rendering.py:75-111) w.r.t. the point colours and densities, given dL/d(comp rgb).
 //   w_k = alpha_k T_k, T_k = prod_{j<k} f_j, f_j = 1 - alpha_j + 1e-10, alpha_k = 1 - exp(-delta_k relu(sigma_k))
-//   gw_k = gC . rgb_k (- sum(gC) with a white background: comp += 1 - sum_k w_k)
+//   gw_k = gC . rgb_k (- sum(gC) with a white background: comp += 1 - sum_k w_k) (+ g_depth z_k: depth = sum_k w_k z_k, when a
+//   depth-variance loss is on)
 //   dL/dalpha_k = gw_k T_k - (sum_{i>k} gw_i w_i) / f_k
 //   dL/dsigma_k = dL/dalpha_k * delta_k exp(-delta_k relu(sigma_k)) * [sigma_k > 0];   dL/drgb_k = gC w_k
 // and through the sigmoid of the colour head: d(rgb_pre) = d(rgb) * rgb (1 - rgb).
@@ -181,12 +229,14 @@ template <int K, bool COMPACT>
 __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restrict__ rgb4, const float* __restrict__ sigma,
                                                             const float* __restrict__ z, const float* __restrict__ g_comp,
                                                             int64_t R, int N, int white,
-                                                            float* __restrict__ d_rgb, float* __restrict__ g1) {
+                                                            float* __restrict__ d_rgb, float* __restrict__ g1,
+                                                            const float* __restrict__ g_depth) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r >= R) return;
   const int64_t base = r * N;
   const float gc0 = g_comp[r * 3 + 0], gc1 = g_comp[r * 3 + 1], gc2 = g_comp[r * 3 + 2];
+  const float gd = g_depth ? g_depth[r] : 0.0f;
   float zk[K], sg[K], c0[K], c1[K], c2[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) {
@@ -233,6 +283,7 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
     T[i] = (k == 0) ? 1.0f : (float)t_d;
     w[i] = __fmul_rn(alpha[i], T[i]);
     gw[i] = gc0 * c0[i] + gc1 * c1[i] + gc2 * c2[i] - white_term;
+    if (g_depth) gw[i] += gd * zk[i];
     if (k < N) acc += (double)gw[i] * (double)w[i];
     pre[i] = acc;
   }
@@ -485,6 +536,7 @@ struct Work {   // per-pass buffers, sized for P_max = chunk * (Nc + Ni) sample 
   float* d4;        // chain path: (P, 4) = d(rgb_pre) 0..2, d(sigma) of every sample point (composite_bwd_kernel COMPACT)
   float *z_c, *z_f, *w_c, *comp, *g_comp, *partial, *scratch_out;
   double *block_sums, *carry;
+  float* g_depth;   // per ray: d(loss) / d(depth) of the depth-variance loss (zeros when it is off)
   WeightPack pack[2];
   // chain path (NSR_F16X3): activation panels of the forward pass, gradient panels of the backward chain (2 bytes per
   // value, nsr_f16x3_core.h), the two weight streams per network, per-slice row sums of the weight-gradient products
@@ -529,8 +581,9 @@ int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base, int mod
   // chain path: every second pass of a network waits for one launch; sized by the split-K factor of the larger pass
   const int64_t sp_max = (P + 511) / 512 < 1 ? 1 : ((P + 511) / 512 > kMaxSplits ? kMaxSplits : (P + 511) / 512);
   k.slots = take_if(chain_path, kChainSlots * sp_max * 256 * 256);
-  k.block_sums = reinterpret_cast<double*>(take(2 * (chunk / 256 + 2)));
-  k.carry = reinterpret_cast<double*>(take(8));
+  k.block_sums = reinterpret_cast<double*>(take(2 * 3 * (chunk / 256 + 2)));
+  k.carry = reinterpret_cast<double*>(take(16));
+  k.g_depth = take(chunk);
   for (int n = 0; n < 2; ++n) {
     WeightPack& q = k.pack[n];
     q.w1p = take(256 * 64);   q.w5p = take(256 * 320);   q.w9p = take(288 * 256);   q.wdirp = take(128 * 288);
@@ -854,13 +907,13 @@ bool chain_selected(int precision) { return precision == NSR_F16X3; }
 bool train_precision_ok(int precision) { return precision == NSR_FP32 || precision == NSR_F16X3 || precision == NSR_F16X3_GEMM; }
 int gemm_precision(int precision) { return precision == NSR_F16X3_GEMM ? NSR_F16X3 : precision; }   // what the GEMM path's helpers expect
 
-int composite_bwd(hipStream_t st, const Work& k, const float* z, int64_t R, int N, int white, bool compact) {
+int composite_bwd(hipStream_t st, const Work& k, const float* z, int64_t R, int N, int white, bool compact, const float* g_depth) {
   const dim3 block(256), grid((unsigned)((R + 3) / 4));
   const int K = (N + 63) / 64;
 #define NSR_LAUNCH_CB(KK)                                                                                                          \
   do {                                                                                                                             \
-    if (compact) hipLaunchKernelGGL((composite_bwd_kernel<KK, true>), grid, block, 0, st, k.rgb, k.sig, z, k.g_comp, R, N, white, k.d4, nullptr); \
-    else hipLaunchKernelGGL((composite_bwd_kernel<KK, false>), grid, block, 0, st, k.rgb, k.sig, z, k.g_comp, R, N, white, k.drgb, k.g1);        \
+    if (compact) hipLaunchKernelGGL((composite_bwd_kernel<KK, true>), grid, block, 0, st, k.rgb, k.sig, z, k.g_comp, R, N, white, k.d4, nullptr, g_depth); \
+    else hipLaunchKernelGGL((composite_bwd_kernel<KK, false>), grid, block, 0, st, k.rgb, k.sig, z, k.g_comp, R, N, white, k.drgb, k.g1, g_depth);        \
   } while (0)
   switch (K) {
     case 1: NSR_LAUNCH_CB(1); break;
@@ -887,16 +940,22 @@ extern "C" size_t nsr_train_workspace_bytes(int64_t ray_chunk, int n_coarse, int
   return (size_t)work_floats(ray_chunk, n_coarse, n_importance, nullptr, nullptr) * sizeof(float);
 }
 
-extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const float* const* w_fine, float* const* g_coarse,
-                                        float* const* g_fine, const float* rays, int ray_stride, int64_t R, int s2,
-                                        const float* target_lr, int n_coarse, int n_importance, int white_bkgd,
-                                        int lindisp, const float* u_coarse, const float* u_fine,
-                                        const float* noise_coarse, const float* noise_fine, float noise_std,
-                                        float lambda_coarse, float lambda_fine, int precision, int64_t ray_chunk, float* const* outs,
-                                        float* lr_coarse, float* lr_fine, float* losses, void* workspace,
-                                        size_t workspace_bytes, void* stream) {
+namespace {
+int train_impl(const float* const* w_coarse, const float* const* w_fine, float* const* g_coarse,
+               float* const* g_fine, const float* rays, int ray_stride, int64_t R, int s2,
+               const float* target_lr, int n_coarse, int n_importance, int white_bkgd,
+               int lindisp, const float* u_coarse, const float* u_fine,
+               const float* noise_coarse, const float* noise_fine, float noise_std,
+               float lambda_coarse, float lambda_fine, int precision, int64_t ray_chunk, float* const* outs,
+               float* lr_coarse, float* lr_fine, float* losses, void* workspace,
+               size_t workspace_bytes, void* stream, const nsr_train_var_losses* var, float* var_losses) {
   if (!w_coarse || !w_fine || !g_coarse || !g_fine || !outs || R < 0 || s2 <= 0 || !nsr_ray_stride_ok(ray_stride))
     return NSR_ERR_INVALID_ARG;
+  const bool rgb_var = var && (var->lambda_coarse_var != 0.0f || var->lambda_fine_var != 0.0f);
+  const bool depth_var = var && (var->lambda_coarse_depth_var != 0.0f || var->lambda_fine_depth_var != 0.0f);
+  // torch.var over ONE sub-ray is 0 / 0 (the reference would train on NaN); a depth variance needs the divisor
+  if ((rgb_var || depth_var) && s2 < 2) return NSR_ERR_INVALID_ARG;
+  if (depth_var && !(var->far > 0.0f)) return NSR_ERR_INVALID_ARG;
   if (n_coarse < 2 || n_importance < 1 || n_coarse + n_importance > 256) return NSR_ERR_UNSUPPORTED;
   if (!train_precision_ok(precision)) return NSR_ERR_UNSUPPORTED;
   if (R % s2 != 0) return NSR_ERR_INVALID_ARG;
@@ -937,7 +996,7 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
     NSR_TRY(prepare_weights(st, w_coarse, k.pack[0], gemm_precision(precision)));
     NSR_TRY(prepare_weights(st, w_fine, k.pack[1], gemm_precision(precision)));
   }
-  if (hipMemsetAsync(k.carry, 0, 4 * sizeof(double), st) != hipSuccess) return NSR_ERR_LAUNCH;
+  if (hipMemsetAsync(k.carry, 0, 8 * sizeof(double), st) != hipSuccess) return NSR_ERR_LAUNCH;
 
   for (int64_t r0 = 0; r0 < R; r0 += ray_chunk) {
     const int64_t rc = (R - r0 < ray_chunk) ? R - r0 : ray_chunk;
@@ -971,20 +1030,23 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
                          noise_std, P, k.sig);
       NSR_CHECK_LAUNCH();
       float* comp = outs[4 * net + 0] + r0 * 3;
-      float* depth = outs[4 * net + 1] ? outs[4 * net + 1] + r0 : nullptr;
+      float* depth = outs[4 * net + 1] ? outs[4 * net + 1] + r0 : (depth_var ? k.scratch_out : nullptr);   // the depth-variance loss reads it
       float* opac = outs[4 * net + 2] ? outs[4 * net + 2] + r0 : nullptr;
       float* wts = outs[4 * net + 3] ? outs[4 * net + 3] + r0 * N : (net ? nullptr : k.w_c);
       NSR_TRY(nsr_composite(k.rgb, 4, k.sig, 1, z, rc, N, white_bkgd, comp, depth, opac, wts, stream));
       // s^2 mean, loss, dL/d(comp)
       const float lambda = net ? lambda_fine : lambda_coarse;
       const int nblk = (int)((n_lr + 255) / 256);
+      const float l_var = var ? (net ? var->lambda_fine_var : var->lambda_coarse_var) : 0.0f;
+      const float l_dvar = var ? (net ? var->lambda_fine_depth_var : var->lambda_coarse_depth_var) : 0.0f;
       hipLaunchKernelGGL(lr_loss_kernel, dim3(nblk), dim3(256), 0, st, comp, target_lr + lr0 * 3, n_lr, s2, mse_scale,
-                         lambda, (net ? lr_fine : lr_coarse) + lr0 * 3, k.g_comp, k.block_sums);
+                         lambda, (net ? lr_fine : lr_coarse) + lr0 * 3, k.g_comp, k.block_sums, l_var, l_dvar,
+                         var ? var->far : 1.0f, depth_var ? depth : nullptr, depth_var ? k.g_depth : nullptr);
       NSR_CHECK_LAUNCH();
       hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, k.block_sums, nblk, mse_scale, lambda, losses, net,
-                         k.carry);
+                         k.carry, l_var, l_dvar, var_losses);
       NSR_CHECK_LAUNCH();
-      NSR_TRY(composite_bwd(st, k, z, rc, N, white_bkgd, chain));
+      NSR_TRY(composite_bwd(st, k, z, rc, N, white_bkgd, chain, depth_var ? k.g_depth : nullptr));
       if (chain) {
         NSR_TRY(nsr_chain_bwd(k.stream_b[net], k.sgn, k.dpan, k.d4, 4, k.d4 + 3, 4, P, k.gmax, k.pscale, stream));
         NSR_TRY(chain_weight_grads(st, k, P, g, acc));
@@ -994,6 +1056,34 @@ extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const floa
     }
   }
   return NSR_OK;
+}
+}  // namespace
+
+extern "C" int nsr_train_loss_and_grads(const float* const* w_coarse, const float* const* w_fine, float* const* g_coarse,
+                                        float* const* g_fine, const float* rays, int ray_stride, int64_t R, int s2,
+                                        const float* target_lr, int n_coarse, int n_importance, int white_bkgd,
+                                        int lindisp, const float* u_coarse, const float* u_fine,
+                                        const float* noise_coarse, const float* noise_fine, float noise_std,
+                                        float lambda_coarse, float lambda_fine, int precision, int64_t ray_chunk, float* const* outs,
+                                        float* lr_coarse, float* lr_fine, float* losses, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  return train_impl(w_coarse, w_fine, g_coarse, g_fine, rays, ray_stride, R, s2, target_lr, n_coarse, n_importance, white_bkgd, lindisp,
+                    u_coarse, u_fine, noise_coarse, noise_fine, noise_std, lambda_coarse, lambda_fine, precision, ray_chunk, outs,
+                    lr_coarse, lr_fine, losses, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int nsr_train_loss_and_grads_var(const float* const* w_coarse, const float* const* w_fine, float* const* g_coarse,
+                                            float* const* g_fine, const float* rays, int ray_stride, int64_t R, int s2,
+                                            const float* target_lr, int n_coarse, int n_importance, int white_bkgd,
+                                            int lindisp, const float* u_coarse, const float* u_fine,
+                                            const float* noise_coarse, const float* noise_fine, float noise_std,
+                                            float lambda_coarse, float lambda_fine, int precision, int64_t ray_chunk, float* const* outs,
+                                            float* lr_coarse, float* lr_fine, float* losses, void* workspace,
+                                            size_t workspace_bytes, void* stream, const nsr_train_var_losses* var, float* var_losses) {
+  if (!var) return NSR_ERR_INVALID_ARG;
+  return train_impl(w_coarse, w_fine, g_coarse, g_fine, rays, ray_stride, R, s2, target_lr, n_coarse, n_importance, white_bkgd, lindisp,
+                    u_coarse, u_fine, noise_coarse, noise_fine, noise_std, lambda_coarse, lambda_fine, precision, ray_chunk, outs,
+                    lr_coarse, lr_fine, losses, workspace, workspace_bytes, stream, var, var_losses);
 }
 
 extern "C" int nsr_train_status_reset(void* workspace, void* stream) {

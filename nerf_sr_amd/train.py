@@ -74,7 +74,9 @@ class Trainer:
                  lindisp: bool = False, downscale: int = 2, randomized: bool = True, noise_std: float = 0.0,
                  lr: float = 5e-4, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
                  lambda_coarse_mse: float = 1.0, lambda_fine_mse: float = 1.0, ray_chunk: int = 4096,
-                 precision: str = "f16x3", device="cuda", gamma_correct: bool = False):
+                 precision: str = "f16x3", device="cuda", gamma_correct: bool = False,
+                 use_var_loss: bool = False, lambda_coarse_var: float = 0.01, lambda_fine_var: float = 0.01,
+                 use_depth_var_loss: bool = False, lambda_coarse_depth_var: float = 0.01, lambda_fine_depth_var: float = 0.01):
         if gamma_correct:
             # render_rays applies rgb ** (1 / 2.2) per sample under --gamma_correct (models/nerf_downX_model.py:271-276) in
             # training too; the training kernels have no such branch, and ignoring the option would train another model
@@ -104,6 +106,12 @@ class Trainer:
         self.randomized, self.noise_std = bool(randomized), float(noise_std)
         self.lr, self.beta1, self.beta2, self.eps = float(lr), float(beta1), float(beta2), float(eps)
         self.lambda_coarse, self.lambda_fine = float(lambda_coarse_mse), float(lambda_fine_mse)
+        # the optional variance losses of comp_low_res_output (models/nerf_downX_model.py:107-112, 332-336, 349-353, 374-378);
+        # 0 = off, like the reference's flags.  [coarse rgb, fine rgb, coarse depth, fine depth]
+        self.lambda_var = [float(lambda_coarse_var) if use_var_loss else 0.0, float(lambda_fine_var) if use_var_loss else 0.0,
+                           float(lambda_coarse_depth_var) if use_depth_var_loss else 0.0,
+                           float(lambda_fine_depth_var) if use_depth_var_loss else 0.0]
+        self.var_losses = torch.zeros(4, dtype=torch.float32, device=self.device)
         self.ray_chunk = int(ray_chunk) - int(ray_chunk) % self.s2
         self.step = 0
         self._ws = None
@@ -165,14 +173,23 @@ class Trainer:
         outs = (c_void_p * 8)(*[c_void_p(o[k].data_ptr()) for k in OUT_KEYS])
         wc, wf = _ptr_array(list(self.params[0].values())), _ptr_array(list(self.params[1].values()))
         gc, gf = _ptr_array(list(self.grads[0].values())), _ptr_array(list(self.grads[1].values()))
-        _lib.check(lib.nsr_train_loss_and_grads(
-            wc, wf, gc, gf, _p(rays), stride, R, self.s2, _p(self.data_rgbs), nc, self.N_importance,
-            int(self.white_bkgd), int(self.lindisp), _p(draws.get("u_coarse")), _p(draws.get("u_fine")),
-            _p(draws.get("noise_coarse")), _p(draws.get("noise_fine")), self.noise_std,
-            self.lambda_coarse * gs, self.lambda_fine * gs, self._prec, chunk, outs, _p(lr_c), _p(lr_f), _p(self.losses),
-            _p(self._ws), self._ws.numel(), _stream()), "nsr_train_loss_and_grads")
+        common = (wc, wf, gc, gf, _p(rays), stride, R, self.s2, _p(self.data_rgbs), nc, self.N_importance,
+                  int(self.white_bkgd), int(self.lindisp), _p(draws.get("u_coarse")), _p(draws.get("u_fine")),
+                  _p(draws.get("noise_coarse")), _p(draws.get("noise_fine")), self.noise_std,
+                  self.lambda_coarse * gs, self.lambda_fine * gs, self._prec, chunk, outs, _p(lr_c), _p(lr_f), _p(self.losses),
+                  _p(self._ws), self._ws.numel(), _stream())
+        if any(self.lambda_var):
+            import ctypes
+            # self.far of the reference: the far bound of the batch's first ray (nerf_downX_model.py:284); one host read per step
+            far = float(rays[0, 7].item())
+            var = (ctypes.c_float * 5)(*[l * gs for l in self.lambda_var], far)       # struct nsr_train_var_losses
+            _lib.check(lib.nsr_train_loss_and_grads_var(*common, ctypes.cast(var, c_void_p), _p(self.var_losses)),
+                       "nsr_train_loss_and_grads_var")
+        else:
+            _lib.check(lib.nsr_train_loss_and_grads(*common), "nsr_train_loss_and_grads")
         if gs != 1.0:
             self.losses.mul_(1.0 / gs)          # report this rank's own losses, not the 1 / world share
+            self.var_losses.mul_(1.0 / gs)
         o["lr_coarse"], o["lr_fine"] = lr_c, lr_f
         self.out = o
         return self.losses, self.grads

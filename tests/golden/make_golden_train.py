@@ -34,7 +34,7 @@ def sample_idx(numel: int, cap: int = 512):
     return np.arange(0, numel, stride)[:cap]
 
 
-def build_train_model(white_bkgd, seed_c, seed_f, downscale, randomized, noise_std, dataset_mode):
+def build_train_model(white_bkgd, seed_c, seed_f, downscale, randomized, noise_std, dataset_mode, extra_argv=()):
     from options.train_options import TrainOptions
     from models import create_model
     tmp = tempfile.mkdtemp(prefix="nsr_golden_train_")
@@ -43,6 +43,7 @@ def build_train_model(white_bkgd, seed_c, seed_f, downscale, randomized, noise_s
             "--downscale", str(downscale), "--N_coarse", "64", "--N_importance", "64"]
     if white_bkgd:
         argv.append("--white_bkgd")
+    argv += list(extra_argv)
     old = sys.argv
     sys.argv = argv
     try:
@@ -84,9 +85,9 @@ class RecordDraws:
         torch.rand_like, torch.rand, torch.randn_like = self.orig
 
 
-def one_case(tag, white, ndc, near_far, s, n_lr, randomized, noise_std, seed):
+def one_case(tag, white, ndc, near_far, s, n_lr, randomized, noise_std, seed, extra_argv=()):
     torch.manual_seed(seed)
-    model, opt = build_train_model(white, 99, 100, s, randomized, noise_std, "llff_downX" if ndc else "blender_downX")
+    model, opt = build_train_model(white, 99, 100, s, randomized, noise_std, "llff_downX" if ndc else "blender_downX", extra_argv)
     import models.utils as ru
     import einops
     # rays of a small HR grid, regrouped LR-pixel-major exactly as the datasets do
@@ -106,6 +107,16 @@ def one_case(tag, white, ndc, near_far, s, n_lr, randomized, noise_std, seed):
     target = torch.rand(n_lr, 3)
     w0_c = {k: v.detach().clone() for k, v in model.netCoarse.state_dict().items()}
     model.set_input({"rays": rays.clone(), "rgbs": target.clone()})
+    if getattr(opt, "use_depth_var_loss", False):
+        # environment shim, not a change of arithmetic: forward_rays stores self.far as a 0-d NUMPY array (:284) and :351 divides
+        # a tensor that requires grad by it -- fine on the reference's pinned torch 1.8.1, a RuntimeError on torch 2.x
+        # ("Can't call numpy() on Tensor that requires grad").  Hand the same value over as a Python float.
+        inner = model.comp_low_res_output
+
+        def comp_low_res_output_with_float_far():
+            model.far = float(model.far)
+            return inner()
+        model.comp_low_res_output = comp_low_res_output_with_float_far
     with RecordDraws() as rec:
         model.optimize_parameters()
     draws = rec.draws
@@ -134,6 +145,15 @@ def one_case(tag, white, ndc, near_far, s, n_lr, randomized, noise_std, seed):
     out["loss_coarse_mse"] = float(model.loss_coarse_mse)
     out["loss_fine_mse"] = float(model.loss_fine_mse)
     out["loss_tot"] = float(model.loss_tot)
+    if opt.use_var_loss or opt.use_depth_var_loss:      # the optional variance losses (nerf_downX_model.py:332-336, 349-353, 374-378)
+        out["lambda_var"] = np.array([opt.lambda_coarse_var if opt.use_var_loss else 0.0, opt.lambda_fine_var if opt.use_var_loss else 0.0,
+                                      opt.lambda_coarse_depth_var if opt.use_depth_var_loss else 0.0,
+                                      opt.lambda_fine_depth_var if opt.use_depth_var_loss else 0.0], np.float64)
+        out["var_losses_raw"] = np.array([float(model.loss_out_coarse_var) if opt.use_var_loss else 0.0,
+                                          float(model.loss_out_fine_var) if opt.use_var_loss else 0.0,
+                                          float(model.loss_coarse_depth_var) if opt.use_depth_var_loss else 0.0,
+                                          float(model.loss_fine_depth_var) if opt.use_depth_var_loss else 0.0], np.float64)
+        out["far"] = float(model.far)
     for net, name in ((model.netCoarse, "coarse"), (model.netFine, "fine")):
         mod = net.module if hasattr(net, "module") else net
         for k, p in mod.named_parameters():
@@ -157,6 +177,11 @@ def main():
     one_case("llff_det", False, True, (0.0, 1.0), 2, 24, False, 0.0, 1)
     one_case("llff_rand", False, True, (0.0, 1.0), 2, 24, True, 1.0, 2)
     one_case("blender_rand", True, False, (2.0, 6.0), 2, 24, True, 0.0, 3)
+    # --use_var_loss --use_depth_var_loss at weights that make the terms matter next to the MSEs (the defaults, 0.01, on a
+    # 24-pixel batch are 1e-3 of the gradient)
+    one_case("blender_var", True, False, (2.0, 6.0), 2, 24, True, 0.0, 4,
+             ("--use_var_loss", "--lambda_coarse_var", "0.05", "--lambda_fine_var", "0.08",
+              "--use_depth_var_loss", "--lambda_coarse_depth_var", "0.3", "--lambda_fine_depth_var", "0.2"))
 
 
 if __name__ == "__main__":

@@ -345,6 +345,48 @@ def test_fp16_weight_gradient_operands_drift_like_fp32_over_200_adam_steps(tr):
     assert new["last40_mean_rel_diff"] < 2.0 * yard["last40_mean_rel_diff"] + 2e-3, (new, yard)
 
 
+def test_variance_losses_vs_reference_fixture_and_oracle(golden_dir, tr):
+    """A1's optional losses (--use_var_loss / --use_depth_var_loss, models/nerf_downX_model.py:332-336, 349-353, 374-378): the
+    per-LR-pixel unbiased variances of the s^2 sub-ray colours and of the sub-ray depths / far, summed, join loss_tot and
+    its gradients (the depth term through depth = sum_k w_k z_k in the compositing backward).  Against the fixture made by the
+    reference's own calculate_losses + backward and the fp64 oracle, on all three implementations of the step."""
+    g = np.load(os.path.join(golden_dir, "train_blender_var.npz"))
+    lam = g["lambda_var"].tolist()
+    sd_c, sd_f = make_state_dict(int(g["seed_coarse"])), make_state_dict(int(g["seed_fine"]))
+    _, gc64, gf64 = to.loss_and_grads(sd_c, sd_f, g["rays"], g["target_lr"], int(g["s2"]), 64, 64, bool(g["white_bkgd"]),
+                                      float(g["lambda_coarse"]), float(g["lambda_fine"]), dtype=torch.float64, lambda_var=lam,
+                                      **train_draws(g))
+    _, gc_plain, _ = to.loss_and_grads(sd_c, sd_f, g["rays"], g["target_lr"], int(g["s2"]), 64, 64, bool(g["white_bkgd"]),
+                                       float(g["lambda_coarse"]), float(g["lambda_fine"]), dtype=torch.float64, **train_draws(g))
+    k0 = "xyz_encoding_8.0.weight"       # the terms matter: without them this gradient is somewhere else entirely
+    assert float((gc64[k0] - gc_plain[k0]).norm() / gc64[k0].norm()) > 0.05
+    for prec in ("f16x3", "fp32", "f16x3_gemm"):
+        t, _, _ = _trainer(tr, g, precision=prec, use_var_loss=True, lambda_coarse_var=lam[0], lambda_fine_var=lam[1],
+                           use_depth_var_loss=True, lambda_coarse_depth_var=lam[2], lambda_fine_depth_var=lam[3])
+        t.loss_and_grads(_draws(g))
+        losses, var_losses = t.losses.cpu().numpy(), t.var_losses.cpu().numpy()
+        assert abs(losses[0] - float(g["loss_coarse_mse"])) < 1e-6 and abs(losses[1] - float(g["loss_fine_mse"])) < 2e-6
+        want = g["lambda_var"] * g["var_losses_raw"]
+        np.testing.assert_allclose(var_losses[:2], want[:2], rtol=2e-5, atol=1e-8)          # colours: coarse exact, fine behind S2
+        np.testing.assert_allclose(var_losses[2:], want[2:], rtol=2e-4, atol=1e-8)          # depths carry the resampler's conditioning
+        assert abs(float(losses.sum() + var_losses.sum()) - float(g["loss_tot"])) < 2e-5
+        for n, (name, ref) in enumerate((("coarse", gc64), ("fine", gf64))):
+            num = den = 0.0
+            for k in STATE_DICT_SPEC:
+                got = t.grads[n][k].cpu().double()
+                err, nrm = float((got - ref[k]).norm()), float(ref[k].norm())
+                num, den = num + err ** 2, den + nrm ** 2
+                assert err <= 2e-3 * nrm + 1e-9, (prec, name, k, err / nrm)
+                ref_norm = float(g[f"gnorm_{name}.{k}"])                  # the reference's own autograd
+                assert abs(float(got.norm()) - ref_norm) <= 2e-3 * ref_norm + 1e-9, (prec, name, k)
+            assert (num / den) ** 0.5 < 2e-3, (prec, name, (num / den) ** 0.5)
+    # one sub-ray per LR pixel has no variance (the reference would train on NaN): rejected before anything is enqueued
+    t1 = tr.Trainer(sd_c, sd_f, downscale=1, use_var_loss=True)
+    t1.set_input(torch.from_numpy(g["rays"]).cuda(), torch.rand(g["rays"].shape[0], 3).cuda())
+    with pytest.raises(Exception):
+        t1.loss_and_grads(_draws(g))
+
+
 def test_training_step_status_word(tr):
     """The training step has a numerics status word of its own (include/nsr_train.h): weights that leave what the
     split-fp16 stream carries are flagged by the per-iteration re-pack, a poisoned ray by the forward kernel, and

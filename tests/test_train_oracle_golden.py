@@ -12,7 +12,7 @@ from oracle import nerf_oracle as oc
 from oracle import train_oracle as tr
 from tests.util import sample_idx, train_draws
 
-CASES = ["llff_det", "llff_rand", "blender_rand"]
+CASES = ["llff_det", "llff_rand", "blender_rand", "blender_var"]     # blender_var: --use_var_loss --use_depth_var_loss
 
 
 @pytest.fixture(scope="module", params=CASES)
@@ -21,7 +21,7 @@ def case(request, golden_dir):
     sd_c, sd_f = make_state_dict(int(g["seed_coarse"])), make_state_dict(int(g["seed_fine"]))
     res, gc, gf = tr.loss_and_grads(sd_c, sd_f, g["rays"], g["target_lr"], int(g["s2"]), 64, 64,
                                     bool(g["white_bkgd"]), float(g["lambda_coarse"]), float(g["lambda_fine"]),
-                                    **train_draws(g))
+                                    lambda_var=(g["lambda_var"].tolist() if "lambda_var" in g else None), **train_draws(g))
     return g, sd_c, res, gc, gf
 
 
@@ -33,6 +33,10 @@ def test_forward_and_losses(case):
         np.testing.assert_allclose(res[k].numpy(), g[k_ref], rtol=0, atol=2e-6, err_msg=k)
     for k in ("loss_coarse_mse", "loss_fine_mse", "loss_tot"):
         assert abs(res[k] - float(g[k])) <= 1e-6 * max(1.0, abs(float(g[k]))), k
+    if "lambda_var" in g:      # the reference's loss_out_*_var / loss_*_depth_var (nerf_downX_model.py:332-336, 349-353)
+        want = g["lambda_var"] * g["var_losses_raw"]
+        np.testing.assert_allclose(np.array(res["var_losses"]), want, rtol=2e-6, atol=1e-9)
+        assert float(g["loss_tot"]) > float(g["loss_coarse_mse"]) + float(g["loss_fine_mse"]) + 0.5 * float(want.sum())
 
 
 def test_gradients(case):
