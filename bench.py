@@ -429,6 +429,10 @@ def main():
     ap.add_argument("--train-rays", type=int, default=2048, help="rays per GPU per training step (multiple of 4)")
     ap.add_argument("--train-precision", default="f16x3", choices=["f16x3", "fp32", "f16x3_gemm"],
                     help="training step: forward products on the split-fp16 MFMA (default, fp32-grade) or everything on the fp32 MFMA")
+    ap.add_argument("--n-importance", type=int, default=64,
+                    help="importance samples per ray: 64 (every script of the reference: 64 coarse + 128 fine network evaluations "
+                         "per ray, the metric's '64+128') or 128 (the other reading: 64 + 192; the fine pass then takes the "
+                         "network-then-compositor route, sample counts other than 64 / 128 are not composited in the MLP launch)")
     ap.add_argument("--config", type=int, default=0, choices=[0] + sorted(RENDER_CONFIGS),
                     help="BASELINE.json render configuration; default: #2 (the one the metric is quoted on) at every N, with "
                          "#4 (the 1008x756 frame BASELINE shards over 8 GPUs) timed after it as the `config4` sub-object")
@@ -443,6 +447,13 @@ def main():
                     help="config #5 only: after the timed render steps run depth -> warp -> refinement network on the "
                          "rendered frame and report that pass separately (`refine` object; not part of `value`)")
     args = ap.parse_args()
+    global N_IMPORTANCE, FLOP_PER_RAY
+    if args.n_importance != N_IMPORTANCE:
+        if args.n_importance < 1 or N_COARSE + args.n_importance > 256:
+            raise SystemExit("--n-importance must keep 64 + n <= 256 samples per ray")
+        N_IMPORTANCE = args.n_importance
+        FLOP_PER_RAY = FLOP_PER_POINT * (N_COARSE + N_COARSE + N_IMPORTANCE)
+        args.no_extras = True      # the sub-objects are defined on the reference's own sample counts
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
     if args.mode == "train":
@@ -556,7 +567,7 @@ def main():
         elif weak:
             how = f"; {world}-frame batch, one frame per rank, one all-gather of LR pixels per step"
         return (f"BASELINE config #{r['cfg_id']}: {cfg['name']} {wh[0]}x{wh[1]} <- {wh[0] // s}x{wh[1] // s}, {s}x supersampling, "
-                f"64 coarse + 128 fine samples/ray, {r['rays_per_frame']:,} rays per frame" + how)
+                f"{N_COARSE} coarse + {N_COARSE + N_IMPORTANCE} fine samples/ray, {r['rays_per_frame']:,} rays per frame" + how)
 
     # The headline workload is the SAME at every N: config #2's frame (the one BASELINE's metric is quoted on), cut into N
     # LR-pixel blocks.  Config #4 (the frame BASELINE shards over 8 GPUs) is timed the same way in the same process and
@@ -603,7 +614,7 @@ def main():
         except Exception:
             rccl = None
         res = {
-            "metric": f"rays/sec (64+128 samples, {DOWNSCALE}x SS)", "value": value, "unit": "rays/s",
+            "metric": f"rays/sec ({N_COARSE}+{N_COARSE + N_IMPORTANCE} samples, {DOWNSCALE}x SS)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
@@ -619,7 +630,7 @@ def main():
             # host-side enqueue): the overhead strong scaling has to keep small as the per-rank share shrinks
             "non_mlp_ms_per_step": r["ms_per_step"] - r["fine_ms"] - r["coarse_ms"],
             "achieved_tflops_whole_path": value * FLOP_PER_RAY / 1e12,
-            "roofline": {"bound": "mfma", "kernel": f"mlp kernel, fine pass ({my_rays:,} rays x 128 samples, rank 0)",
+            "roofline": {"bound": "mfma", "kernel": f"mlp kernel, fine pass ({my_rays:,} rays x {N_COARSE + N_IMPORTANCE} samples, rank 0)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": pmc.get("hbm_bytes_per_launch"),
                          "traffic_unit": f"HBM bytes/launch (PMC constants of the build named in pmc_source, {PMC_FILE}); algorithmic = "
@@ -644,7 +655,7 @@ def main():
         }
         if c4 is not None:
             f4 = c4["my_rays"] * (N_COARSE + N_IMPORTANCE) * FLOP_PER_POINT
-            res["config4"] = {"metric": "rays/sec (64+128 samples, 4x SS)", "value": c4["value"], "unit": "rays/s",
+            res["config4"] = {"metric": f"rays/sec ({N_COARSE}+{N_COARSE + N_IMPORTANCE} samples, 4x SS)", "value": c4["value"], "unit": "rays/s",
                               "ms_per_step": c4["ms_per_step"], "steps": c4["steps"], "warmup": c4["warmup"],
                               "scaling": "strong", "workload": workload(c4), "rays_per_step": c4["rays_per_step"],
                               "fine_launch_ms": c4["fine_ms"], "coarse_launch_ms": c4["coarse_ms"],

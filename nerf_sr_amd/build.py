@@ -105,6 +105,89 @@ def build(force: bool = False, verbose: bool = True, variant: str = "", defines=
     return LIB
 
 
+# ---- ISA contract of the hand-written inline asm (tests/test_isa_contract.py; ADVICE r4: run it for every variant) ----------
+# 1. M0 stays under the asm's control: LDS-DMA pieces 4q+1..4q+3 reuse the M0 their group's first piece wrote, so no other
+#    instruction of those kernels may write M0.
+# 2. A VMEM instruction issued from inline asm never takes its SGPR base straight from the compiler: hipcc restores spilled
+#    SGPRs with v_readlane, a VMEM read of a VALU-written SGPR needs five wait states, and the hazard pass cannot see through
+#    inline asm: every global_load_lds / global_store inside an asm block must read a pair written by an s_mov_b64 inside the
+#    SAME block.
+ISA_UNITS = ["nsr_mlp_f16.hip", "nsr_train_chain.hip", "nsr_gemm_f16.hip", "nsr_wgrad_f16.hip"]
+ISA_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-S",
+             "--cuda-device-only"]
+
+
+def isa_contract(text: str):
+    """(violations, n_m0_writes, n_asm_vmem) of one `hipcc -S` listing."""
+    import re
+    bad, n_m0, n_vmem = [], 0, 0
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        for line in body.split("\n"):
+            code = line.split(";")[0]
+            if re.search(r"\bm0\b", code):
+                n_m0 += 1
+                if not re.match(r"\s*s_mov_b32 m0, \w+\s*$", code):
+                    bad.append(f"{name}: unexpected use of M0: {code.strip()}")
+        for blk in re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", body, re.S):
+            copies = set(re.findall(r"s_mov_b64 (s\[\d+:\d+\])", blk))
+            for v in re.finditer(r"(?:global_load_lds_dword(?:x4)? v\d+, (s\[\d+:\d+\])|global_store_dword(?:x4)? v\d+, v(?:\d+|\[\d+:\d+\]), (s\[\d+:\d+\]))", blk):
+                base = v.group(1) or v.group(2)
+                n_vmem += 1
+                if base not in copies:
+                    bad.append(f"{name}: VMEM in inline asm reads {base} without an in-statement s_mov_b64")
+    return bad, n_m0, n_vmem
+
+
+def compile_listing(unit: str, defines=(), out_dir=None) -> str:
+    """`hipcc -S --cuda-device-only` of one translation unit (cached by source hash + flags in the temp directory)."""
+    import hashlib
+    import tempfile
+    key = hashlib.sha256((source_hash() + unit + " ".join(defines)).encode()).hexdigest()[:20]
+    out = os.path.join(out_dir or tempfile.gettempdir(), f"nsr_isa_{key}_{unit}.s")
+    if not os.path.exists(out):
+        subprocess.check_call([_hipcc(), *ISA_FLAGS, *defines, os.path.join(CSRC, unit), "-o", out + ".tmp"], stderr=subprocess.DEVNULL)
+        os.replace(out + ".tmp", out)
+    with open(out) as f:
+        return f.read()
+
+
+# ---- documented build variants (development aids: never defined in the product build).  One entry per switch GROUP: the
+# defines, the translation units they touch, what they are for.  tests/test_variants.py compiles every one of them on the CPU
+# box (and runs the ISA contract on the listing), so a variant cannot rot silently.
+VARIANTS = {
+    "persistent": (["-DNSR_PERSISTENT"], ["nsr_mlp_f16.hip"],
+                   "ray kernels loop over tiles, one workgroup per CU, weight ring streaming across tiles (DESIGN 3.1 round 4: complete, bit-identical, not faster)"),
+    "enc_overlap": (["-DNSR_PERSISTENT", "-DNSR_ENC_OVERLAP"], ["nsr_mlp_f16.hip"],
+                    "persistent + the next tile's encoding in the matrix shadow (150 pinned pieces)"),
+    "timeline": (["-DNSR_ABL_TIMELINE"], ["nsr_mlp_f16.hip", "nsr_train_chain.hip"],
+                 "s_memtime stamps at the phase boundaries of every tile (scripts/timeline.py)"),
+    "abl_chain": (["-DNSR_ABL_NO_AMAX", "-DNSR_ABL_NO_DENSITY_MMA", "-DNSR_ABL_FWD_NO_STORE", "-DNSR_ABL_BWD_NO_STORE"],
+                  ["nsr_mlp_f16.hip", "nsr_train_chain.hip"],
+                  "what the range tracking / the density block's MFMAs / the training panel stores cost (profiles/r5_headline_experiments.json)"),
+    "abl_ring": (["-DNSR_ABL_NO_DMA", "-DNSR_ABL_NO_BARRIER", "-DNSR_ABL_NO_DRAIN", "-DNSR_ABL_NO_CONVERT"], ["nsr_mlp_f16.hip"],
+                 "round 1's measurement ladder of the weight ring (profiles/r1_f16x3_pmc.txt)"),
+    "abl_fenced_barrier": (["-DNSR_ABL_FENCED_BARRIER", "-DNSR_ABL_NO_TILE_LAUNDER"], ["nsr_mlp_f16.hip"],
+                           "round 4's publish-point A/B (__syncthreads instead of s_barrier)"),
+    "dev_switches": (["-DNSR_DEV_SWITCHES"], ["nsr_gemm_f16.hip", "nsr_refine.hip"],
+                     "environment-read A/B switches of the refinement GEMMs (NSR_GEMM_TILE / _TK / _FULLN, NSR_REFINE_SEPARATE_MAX)"),
+    "abl_halo": (["-DNSR_ABL_HALO_NO_PATCH", "-DNSR_ABL_HALO_NO_BDMA", "-DNSR_ABL_HALO_NO_BARRIER", "-DNSR_ABL_HALO_NO_EPILOGUE"],
+                 ["nsr_gemm_f16.hip"], "ablations of conv_halo_kernel (profiles/r4_refine_halo.txt)"),
+    "gemm_alt": (["-DNSR_GEMM_NO_HALO", "-DNSR_GEMM_NO_XCD", "-DNSR_GEMM_NO_WROWS", "-DNSR_GEMM_K32_ONLY=1", "-DNSR_HALO_S2_MIN_CIN=256",
+                  "-DNSR_ABL_RELU_FMAX"], ["nsr_gemm_f16.hip"], "staged-kernel-only build and the other GEMM A/B partners"),
+}
+
+
+def check_variant(name: str):
+    """Compile the variant's translation units to ISA listings and run the ISA contract on them; returns the violations."""
+    defines, units, _ = VARIANTS[name]
+    bad = []
+    for u in units:
+        v, _, _ = isa_contract(compile_listing(u, defines))
+        bad += [f"{name}/{u}: {x}" for x in v]
+    return bad
+
+
 if __name__ == "__main__":
     if "--variant" in sys.argv:
         i = sys.argv.index("--variant")
