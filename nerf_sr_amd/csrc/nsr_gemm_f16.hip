@@ -221,7 +221,10 @@ __device__ __forceinline__ void epilogue_planes(const GemmF16Args& a, f32x16 (&a
   const int nw = n0 + 32 * BN * wn;
   // every refinement layer but the last: ReLU, scaled accumulator, whole column blocks, rows in eights -> the lean epilogue
   // (wave-uniform choice; the general one stays for the rest and is a tenth as fast per element)
-  if (g.act == kActRelu && g.acc_scale != 0.0f && g.acc_scale != 1.0f && all_on && nw + 32 * BN <= g.n_valid && (g.M % 8) == 0) {
+  // (and its 32-bit store offsets must reach seven rows / group members on: 16 x per x ldc bytes)
+  const int64_t span = 16 * (int64_t)(a.group == 8 ? a.conv.Ho * a.conv.Wo : 1) * g.ldc;
+  if (g.act == kActRelu && g.acc_scale != 0.0f && g.acc_scale != 1.0f && all_on && nw + 32 * BN <= g.n_valid && (g.M % 8) == 0 &&
+      span < ((int64_t)1 << 32)) {
     const int64_t mrow0 = m0 + 32 * BM * wm;
     const unsigned per = (unsigned)(a.conv.Ho * a.conv.Wo);
     auto accf = [&](int bi, int bj) -> const f32x16& { return acc[bi][bj]; };
@@ -859,7 +862,12 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
     const int64_t in_rows = (g.M / per_img) * a.conv.Hs * a.conv.Ws;      // images x source pixels
     const bool geometry = s2 ? (!a.conv.up && a.conv.Hs == 2 * a.conv.Ho && a.conv.Ws == 2 * a.conv.Wo)
                              : (a.conv.up ? (a.conv.Ho == 2 * a.conv.Hs && a.conv.Wo == 2 * a.conv.Ws) : (a.conv.Ho == a.conv.Hs && a.conv.Wo == a.conv.Ws));
-    const bool common = (g.M % (per_img * (grouped ? 8 : 1))) == 0 && geometry && (!s2 || a.conv.cin >= NSR_HALO_S2_MIN_CIN) && (a.a_plane + in_rows * g.lda) * 2 < ((int64_t)1 << 32);
+    // 32-bit byte offsets: into the input planes (patch pieces) and, in the lean epilogue, from a row's base to the lane's
+    // store (up to seven rows / group members on: 16 x per x ldc bytes bounds it); a batch cannot change either verdict on a
+    // layer of the refinement network, whose entry points cut it first (nsr_refine.hip, sets_per_pass)
+    const bool range32 = (a.a_plane + in_rows * g.lda) * 2 < ((int64_t)1 << 32) &&
+                         16 * (grouped ? per_img : 1) * g.ldc < ((int64_t)1 << 32);
+    const bool common = (g.M % (per_img * (grouped ? 8 : 1))) == 0 && geometry && (!s2 || a.conv.cin >= NSR_HALO_S2_MIN_CIN) && range32;
     // Shapes (rows x columns of a workgroup): 256 x 256 where N allows it, else 512 x 128 (stride 1) -- the whole register
     // file as the accumulator; 256 x 128 (half of it) where that wastes fewer CU-rounds: a 16 x 16 decoder layer is 338 of the
     // big tiles, two rounds of 256 CUs with the second a third full, against three rounds of half-size tiles.

@@ -472,13 +472,44 @@ extern "C" size_t nsr_refine_workspace_bytes_for(int precision, int B, int R, in
   return (size_t)work_floats(B, R, H, W, nullptr, nullptr, precision == NSR_F16X3) * sizeof(float);
 }
 
+namespace {
+// Patch sets per internal pass.  conv_halo_kernel addresses its input planes with 32-bit byte offsets (nsr_gemm_f16.hip), and
+// whether a layer runs there or on the staged tiles must be a matter of its SHAPE only (the two sum K in different orders: a
+// patch set has to give the same bits whatever batch it arrives in).  The largest input any layer sees is the 128-channel
+// full-resolution activation of the reference encoder, (hi, lo) planes of B R H W x 128 halves each: a batch is cut so that
+// (2 x that) x 2 bytes stays below 2^32 -- 255 patch sets of the reference's 64 x 64 / 8-reference shape (the
+// default tile batch of refine.py, 256, sat exactly ON the limit and dropped that layer to the staged kernel) -- and so that
+// the widest concatenated decoder input (384 channels at full resolution) does too.
+int sets_per_pass(int R, int H, int W) {
+  const int64_t px0 = (int64_t)H * W, lim = ((int64_t)1 << 32) - 1;
+  const int64_t by_refs = lim / (2 * 2 * 128 * px0 * (R > 1 ? R : 1)), by_cat = lim / (2 * 2 * 384 * px0);
+  const int64_t cap = by_refs < by_cat ? by_refs : by_cat;
+  return cap < 1 ? 1 : (cap > (1 << 20) ? (1 << 20) : (int)cap);
+}
+int forward_batched(const void* packed_v, int prec, int v, const float* x_synth, const float* x_candi, int B, int R, int H, int W,
+                    float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (B < 0 || R <= 0 || H <= 0 || W <= 0) return NSR_ERR_INVALID_ARG;
+  if (prec != NSR_FP32 && prec != NSR_F16X3) return NSR_ERR_UNSUPPORTED;
+  if (B > 0 && workspace_bytes < nsr_refine_workspace_bytes_for(prec, B, R, H, W)) return NSR_ERR_WORKSPACE;   // the documented size, whatever the cut
+  const int cap = prec == NSR_F16X3 ? sets_per_pass(R, H, W) : B;
+  const int64_t img = (int64_t)3 * H * W;
+  for (int b0 = 0; b0 < B || b0 == 0; b0 += cap) {
+    const int nb = B - b0 < cap ? B - b0 : cap;
+    const int rc = forward(packed_v, prec, v, x_synth ? x_synth + b0 * img : nullptr, x_candi ? x_candi + (int64_t)b0 * R * img : nullptr,
+                           nb, R, H, W, out ? out + b0 * img : nullptr, workspace, workspace_bytes, stream);
+    if (rc != NSR_OK || B == 0) return rc;
+  }
+  return NSR_OK;
+}
+}  // namespace
+
 extern "C" int nsr_refine_forward(const void* packed_v, int prec, const float* x_synth, const float* x_candi, int B, int R, int H,
                                   int W, float* out, void* workspace, size_t workspace_bytes, void* stream) {
-  return forward(packed_v, prec, 0, x_synth, x_candi, B, R, H, W, out, workspace, workspace_bytes, stream);
+  return forward_batched(packed_v, prec, 0, x_synth, x_candi, B, R, H, W, out, workspace, workspace_bytes, stream);
 }
 extern "C" int nsr_refine_forward_noref(const void* packed_v, int prec, const float* x_synth, int B, int H, int W, float* out,
                                         void* workspace, size_t workspace_bytes, void* stream) {
-  return forward(packed_v, prec, 1, x_synth, nullptr, B, 1, H, W, out, workspace, workspace_bytes, stream);
+  return forward_batched(packed_v, prec, 1, x_synth, nullptr, B, 1, H, W, out, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

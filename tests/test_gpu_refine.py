@@ -82,6 +82,21 @@ def test_refine_other_patch_shapes_vs_oracle(net, hw):
     assert torch.equal(y2[0], y[0]) and torch.equal(y2[1], y[0])
 
 
+def test_same_bits_per_patch_set_at_the_default_tile_batch(net):
+    """refine.py's default tile batch, 256 patch sets of the reference's shape (2,048 reference patches): the 128-channel
+    full-resolution input planes of the reference encoder then span exactly 2^32 bytes, the limit of the LDS-patch kernel's
+    32-bit offsets -- round 4 silently dropped that layer to the staged kernel (another K order: other bits) at this batch
+    size only.  The entry point now cuts the batch below the limit, so a patch set gives the bits it gives alone."""
+    gen = torch.Generator().manual_seed(21)
+    x = (torch.rand(4, 3, 64, 64, generator=gen) * 2 - 1).cuda()
+    c = (torch.rand(4, 8, 3, 64, 64, generator=gen) * 2 - 1).cuda()
+    alone = net(x, c)
+    big = net(x.repeat(64, 1, 1, 1), c.repeat(64, 1, 1, 1, 1))          # 256 patch sets: sets 0..3 repeated
+    assert big.shape[0] == 256
+    for i in (0, 1, 2, 3, 127, 252, 253, 254, 255):
+        assert torch.equal(big[i], alone[i % 4]), i
+
+
 @pytest.mark.parametrize("prec", ["f16x3", "fp32"])
 def test_not_use_ref_vs_reference_fixture_and_oracle(prec, golden_dir):
     """--not_use_ref (Model_VNPCAT_Decoder_NoPooling, networks.py:866-945): fixture from the reference's own module, and
