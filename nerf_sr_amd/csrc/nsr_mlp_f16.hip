@@ -48,10 +48,7 @@ __global__ void __launch_bounds__(256) pack_f16x3_kernel(PackPtrsH w, unsigned* 
   unsigned v = 0u;
   if (idx < stream_words) {
     const int piece = idx >> 8, word = idx & 255;
-    int q = 0;
-    for (int i = 1; i < kChunks; ++i)
-      if (piece >= chunk_info(i).piece0) q = i;
-    const Chunk c = chunk_info(q);
+    const Chunk c = chunk_info(chunk_of_piece(piece));
     const int local = piece - c.piece0;
     const int npieces = chunk_pieces(c.steps, c.nnb);
     if (local == npieces - 1) {

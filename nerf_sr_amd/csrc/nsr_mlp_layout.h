@@ -162,6 +162,16 @@ NSR_HD Chunk chunk_info(int q) {
   return c;
 }
 constexpr int kPiecesTotal = 2275 + 37 * 4;             // 2423 pieces of 1 KiB
+// chunk that holds stream piece `piece` (the inverse of chunk_info(q).piece0; the pack kernel runs it once per word --
+// round 5: as a linear search over the 71 chunks it was most of that kernel's 25 us, twice per training step)
+NSR_HD int chunk_of_piece(int piece) {
+  if (piece < 66) return piece / 33;
+  if (piece < 858) return 2 + (piece - 66) / 33;
+  if (piece < 1186) return 26 + (piece - 858) / 41;
+  if (piece < 2242) return 34 + (piece - 1186) / 33;
+  if (piece < 2275) return 66;
+  return 67 + (piece - 2275) / 37;
+}
 // aux (fp32): rgb_w 384 | rgb_b 3
 constexpr int kAuxRgbW = 0, kAuxRgbB = 384, kAuxFloats = 448;
 

@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
                                                             const float* __restrict__ z, const float* __restrict__ g_comp,
                                                             int64_t R, int N, int white,
                                                             float* __restrict__ d_rgb, float* __restrict__ g1,
-                                                            const float* __restrict__ g_depth) {
+                                                            const float* __restrict__ g_depth, float* __restrict__ bias_part) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r >= R) return;
@@ -290,6 +290,8 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
   const double lane_incl = wave_scan_add_d(acc, lane);
   const double total = __shfl(lane_incl, 63, 64);
   const double lane_excl = lane_incl - acc;
+  float bs0 = 0.0f, bs1 = 0.0f, bs2 = 0.0f, bs3 = 0.0f;     // COMPACT: this ray's sums of the four values = its share of the
+                                                            // colour head's and the density head's bias gradients
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     const int k = lane * K + i;
@@ -303,6 +305,7 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
     const float dr2 = gc2 * w[i] * c2[i] * (1.0f - c2[i]);
     if (COMPACT) {
       reinterpret_cast<float4*>(d_rgb)[p] = make_float4(dr0, dr1, dr2, d_sigma);
+      bs0 += dr0; bs1 += dr1; bs2 += dr2; bs3 += d_sigma;
       continue;
     }
     float4* dr = reinterpret_cast<float4*>(d_rgb + p * kRgbPad);
@@ -313,6 +316,10 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
     gp[0] = d_sigma;
 #pragma unroll
     for (int j = 1; j < 32; ++j) gp[j] = 0.0f;
+  }
+  if (COMPACT && bias_part) {      // one float4 per ray; finish_jobs_kernel (kind 2) sums the rays in double
+    bs0 = wave_sum(bs0); bs1 = wave_sum(bs1); bs2 = wave_sum(bs2); bs3 = wave_sum(bs3);
+    if (lane == 0) reinterpret_cast<float4*>(bias_part)[r] = make_float4(bs0, bs1, bs2, bs3);
   }
 }
 
@@ -450,6 +457,8 @@ __device__ __forceinline__ int enc_panel_row(int enc_rows, int j) {
 // All second passes of one network's weight / bias gradients in ONE launch (chain path): blockIdx.y = job.
 //   kind 0: dst[i * dst_ld + dc0 + j] (+)= scale * sum_z partial[z * stride + i * p_ld + col(j)]   (reduce_place_kernel)
 //   kind 1: dst[i] (+)= sum_z partial[z * rows + i]                                                 (rowsum_finish_kernel)
+//   kind 2: dst[i] (+)= sum_z partial[z * stride + i], i < rows <= 4, `splits` up to thousands (one partial per ray: the
+//           bias gradients of the two heads, composite_bwd_kernel): one wavefront per element, lanes stride over z
 // Twenty-odd launches of a few microseconds of work each (one wave of latency-bound workgroups) became the tail of
 // the step once the GEMMs before them had shrunk; together they keep the memory system busy.
 struct FinishJob {
@@ -467,6 +476,15 @@ struct FinishJobs {
 __global__ void __launch_bounds__(256) finish_jobs_kernel(FinishJobs jobs) {
   const FinishJob& q = jobs.j[blockIdx.y];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q.kind == 2) {
+    const int e = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (blockIdx.x != 0 || e >= q.rows) return;       // wave-uniform
+    double s = 0.0;
+    for (int z = lane; z < q.splits; z += 64) s += (double)q.partial[(int64_t)z * q.stride + e];
+    s = wave_sum_d(s);
+    if (lane == 0) q.dst[e] = (q.accumulate ? q.dst[e] : 0.0f) + (float)s;
+    return;
+  }
   if (idx >= q.rows * q.cols) return;
   const float* src;
   int64_t stride;
@@ -534,6 +552,7 @@ struct Work {   // per-pass buffers, sized for P_max = chunk * (Nc + Ni) sample 
   float *x5, *h[9], *gs, *cc, *rgb, *sig;
   float *g0, *g1, *drgb, *col_tiles;
   float* d4;        // chain path: (P, 4) = d(rgb_pre) 0..2, d(sigma) of every sample point (composite_bwd_kernel COMPACT)
+  float* bias_part; // chain path: (rays, 4) per-ray sums of d4: the bias gradients of the colour and density heads before their finish
   float *z_c, *z_f, *w_c, *comp, *g_comp, *partial, *scratch_out;
   double *block_sums, *carry;
   float* g_depth;   // per ray: d(loss) / d(depth) of the depth-variance loss (zeros when it is off)
@@ -573,6 +592,7 @@ int64_t work_floats(int64_t chunk, int nc, int ni, Work* w, float* base, int mod
   k.g0 = take_if(gemm_path, P * kGs);   k.g1 = take_if(gemm_path, P * kGs);
   k.drgb = take_if(gemm_path, P * kRgbPad);
   k.d4 = take_if(chain_path, P * 4);
+  k.bias_part = take_if(chain_path, chunk * 4);
   k.col_tiles = take((P / 128 + 1) * kW + 2 * 64 * kW + 64);   // per-tile column sums + 64 slices of doubles
   k.z_c = take(chunk * nc);   k.z_f = take(chunk * nf);   k.w_c = take(chunk * nc);
   k.comp = take(chunk * 3);   k.g_comp = take(chunk * 3);
@@ -791,7 +811,7 @@ char* panel_of(char* set, int64_t P, int panel) { return set + panel_offset_byte
 // workgroups share the products' point groups by bytes, a 256 x 256 product ends up with ~21 partial tiles instead of the
 // 256 a launch of its own needed to fill the chip -- 12 x fewer partial sums to write, and for finish_jobs_kernel to read
 // back.
-int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g, int acc) {
+int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, int64_t n_rays, float* const* g, int acc) {
   const int sp = n_splits(P);
   const int64_t sp_max = sp;   // the workspace's slots are sized for the largest pass (work_floats): at least this one's
   FinishJobs jobs{};
@@ -837,7 +857,11 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
   hipLaunchKernelGGL((panel_wsums_kernel<128, 3>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 9), P, k.d4, 4, per, part);
   NSR_CHECK_LAUNCH();
   sum_rows(g[kRgbW], 3 * 128, part);
-  NSR_TRY(colsum(st, k.d4, 4, P, 0, 3, g[kRgbB], acc, k.partial));
+  auto sum_rays = [&](float* dst, int rows, const float* partial) {     // kind 2: the per-ray partials of composite_bwd_kernel
+    FinishJob& q = jobs.j[jobs.n++];
+    q.kind = 2; q.dst = dst; q.rows = rows; q.cols = 1; q.partial = partial; q.stride = 4; q.splits = (int)n_rays; q.accumulate = acc; q.scale = 1.0f;
+  };
+  sum_rays(g[kRgbB], 3, k.bias_part);
   // dir_encoding: dzc^T [g | de]
   if ((pj = product(9, 8, true)) < 0) return NSR_ERR_LAUNCH;
   note(pj, place(g[kDirW], 283, 0, 128, 256, nullptr, kW, 0));
@@ -852,7 +876,7 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, float* const* g
   hipLaunchKernelGGL((panel_wsums_kernel<256, 1>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 7), P, k.d4 + 3, 4, per, part);
   NSR_CHECK_LAUNCH();
   sum_rows(g[kSigmaW], 256, part);
-  NSR_TRY(colsum(st, k.d4, 4, P, 3, 1, g[kSigmaB], acc, k.partial));
+  sum_rays(g[kSigmaB], 1, k.bias_part + 3);
   // trunk layers 8..1: dz_L^T (input of layer L)
   for (int L = 8; L >= 1; --L) {
     float* gw = g[2 * (L - 1)];
@@ -912,8 +936,8 @@ int composite_bwd(hipStream_t st, const Work& k, const float* z, int64_t R, int 
   const int K = (N + 63) / 64;
 #define NSR_LAUNCH_CB(KK)                                                                                                          \
   do {                                                                                                                             \
-    if (compact) hipLaunchKernelGGL((composite_bwd_kernel<KK, true>), grid, block, 0, st, k.rgb, k.sig, z, k.g_comp, R, N, white, k.d4, nullptr, g_depth); \
-    else hipLaunchKernelGGL((composite_bwd_kernel<KK, false>), grid, block, 0, st, k.rgb, k.sig, z, k.g_comp, R, N, white, k.drgb, k.g1, g_depth);        \
+    if (compact) hipLaunchKernelGGL((composite_bwd_kernel<KK, true>), grid, block, 0, st, k.rgb, k.sig, z, k.g_comp, R, N, white, k.d4, nullptr, g_depth, k.bias_part); \
+    else hipLaunchKernelGGL((composite_bwd_kernel<KK, false>), grid, block, 0, st, k.rgb, k.sig, z, k.g_comp, R, N, white, k.drgb, k.g1, g_depth, nullptr);   \
   } while (0)
   switch (K) {
     case 1: NSR_LAUNCH_CB(1); break;
@@ -1049,7 +1073,7 @@ int train_impl(const float* const* w_coarse, const float* const* w_fine, float* 
       NSR_TRY(composite_bwd(st, k, z, rc, N, white_bkgd, chain, depth_var ? k.g_depth : nullptr));
       if (chain) {
         NSR_TRY(nsr_chain_bwd(k.stream_b[net], k.sgn, k.dpan, k.d4, 4, k.d4 + 3, 4, P, k.gmax, k.pscale, stream));
-        NSR_TRY(chain_weight_grads(st, k, P, g, acc));
+        NSR_TRY(chain_weight_grads(st, k, P, rc, g, acc));
       } else {
         NSR_TRY(net_backward(st, w, k.pack[net], k, P, g, acc));
       }
