@@ -238,7 +238,11 @@ __device__ __forceinline__ void bwd_unit_store(const u32x4& v, const char* blk, 
   if (voff != 0xffffffffu) return;
 #endif
   u32x4* dst = reinterpret_cast<u32x4*>(const_cast<char*>(blk) + U * 1024 + voff);
+#ifdef NSR_ABL_BWD_DEFAULT_STORE   // A/B: the default cache policy instead of non-temporal
+  *dst = v;
+#else
   __builtin_nontemporal_store(v, dst);
+#endif
 }
 __device__ __forceinline__ void bwd_store_step(int s, const u32x4& h0, const u32x4& h1, const char* blk, unsigned voff0,
                                                unsigned voff1) {
@@ -246,13 +250,27 @@ __device__ __forceinline__ void bwd_store_step(int s, const u32x4& h0, const u32
   if (s == 15) bwd_unit_store<1>(h1, blk, voff1);
 }
 
-// Mask load: the sign word this lane needs to mask blocks X, X + 1 (X even: the two share a dword) is fetched during block
-// X - 1, k-step 14 -- a whole block before its first use (the re-split of X runs in the shadow of block X + 1) and as the
-// YOUNGEST vector-memory operation of its block, behind its DMA and stores.  Two words are alive at a time (mz[pair & 1]):
-// the one of the pending block's pair and the one just fetched.  A plain load: the compiler's own vmcnt bookkeeping guards its use; the asm
-// DMA / stores it cannot see only make its waits stricter, and by then they are a block old.
-__device__ __forceinline__ void mask_load_step(int s, unsigned& mz, const unsigned* blk, int lane) {
-  if (s == 14) mz = blk[lane];
+// Mask fetch: the sign word this lane needs to mask blocks X, X + 1 (X even: the two share a dword) travels by LDS-DMA into a
+// 256-byte area of the wave's own (round 5), issued in k-step 6 of block X - 1 -- BEFORE that chunk's weight pieces (k-steps
+// 8..13; M0 is written by every group's first piece, so the detour leaves no stale M0 behind), hence older than everything
+// the next publish point (block X, k-step 8) waits for: by then it has landed.  The register copy is a plain ds_read in
+// k-step 14 of block X, a whole block before its first use (the re-split of X runs in the shadow of block X + 1).  Two words
+// are alive at a time (mz[pair & 1]).  (Rounds 2-4 used a plain global load here: hipcc's vmcnt for it can only count the
+// operations it sees, i.e. not the asm DMA pieces issued behind the load, so its wait at the first use may also cover the
+// chunk's youngest DMA pieces and stores.  Measured, interleaved on one box: 676.8 -> 671.7 us per pass -- the wait was rarely
+// exposed; what the DMA form buys is that the publish points' vmcnt accounting has no compiler-visible load left in it.)
+__device__ __forceinline__ void mask_dma(const unsigned* blk, unsigned lane4, unsigned lds_dst) {
+  unsigned long long tmp;
+  asm volatile(
+      "s_mov_b32 m0, %3\n\t"
+      "s_mov_b64 %0, %2\n\t"
+      "global_load_lds_dword %1, %0"
+      : "=&s"(tmp)
+      : "v"(lane4), "s"(blk), "s"(lds_dst)
+      : "memory");
+}
+__device__ __forceinline__ unsigned mask_read(unsigned lds_addr_lane) {
+  return *(const __attribute__((address_space(3))) unsigned*)(size_t)lds_addr_lane;
 }
 
 struct BwdCtx {
@@ -260,6 +278,8 @@ struct BwdCtx {
   PanelRef dp;           // gradient panels
   unsigned voff0, voff1; // this lane's slot in unit 0 / 1 of a block (unit_voff)
   int lane;
+  unsigned lane4;     // lane * 4
+  unsigned lmask;     // LDS byte address of this wave's 256-byte mask area (mask_dma / mask_read)
   unsigned* lmax;     // LDS, 16 words: per gradient panel, float bits of the largest magnitude this workgroup wrote
   float* pscale;      // (10 panels, padded points): stored value x pscale = true gradient
   int64_t pidx;       // this lane's point slot (group * 32 + m); lanes of the upper half do not write
@@ -314,12 +334,10 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
                              : sign_block(const_cast<unsigned*>(cx.sgn), cx.dp.group, next_panel, 0));
     const int pb = (nb == 0) ? 7 : nb - 1;            // the pending block's index in its layer
     const unsigned mz_pend = mz[(pb >> 1) & 1];
-    unsigned& mz_next = mz[((nb + 1) >> 1) & 1];      // pair of block nb + 1 (nb == 7: pair 0 of the next layer); its previous
-                                                      // tenant (two pairs back) was last used a block ago
     // younger than the DMA this chunk's publish point waits for: what the block before issued in its k-steps 14, 15,
-    // behind its last DMA piece (k-step 13): the 2 stores of ITS pending block and, if THIS block opens a pair, the mask load
-    // for it (never over-counted: a surplus would leave a DMA piece in flight)
-    const int kYoung = ((FIRST && nb <= 1) ? 0 : 2) + ((MASK && !(nb & 1) && !(FIRST && nb == 0)) ? 1 : 0);
+    // behind its last DMA piece (k-step 13): the 2 stores of ITS pending block (never over-counted: a surplus would leave a
+    // DMA piece in flight; the mask DMA goes out BEFORE a chunk's pieces)
+    const int kYoung = (FIRST && nb <= 1) ? 0 : 2;
     auto mma = [&](auto young) {
     block_mma3<16, kBar, decltype(young)::value>(
         acc, pre, a_addr, ld, c2, [&](int s, int part) -> u32x4 { return part ? bl[s] : bh[s]; },
@@ -333,15 +351,14 @@ __device__ __forceinline__ void bwd_layer(int lam, int prev_panel, int panel, in
             else bwd_gap<MASK, true, 16>(s, g, pend, mz_pend, cur, tmp, oh[2 * nb - 2], ol[2 * nb - 2], oh[2 * nb - 1], ol[2 * nb - 1]);
             if (g == 2) bwd_store_step(s, oh[2 * nb - 2], oh[2 * nb - 1], panel_block(cx.dp, panel, nb - 1), cx.voff0, cx.voff1);
           }
-          if (load_next && g == 1) mask_load_step(s, mz_next, next_blk, cx.lane);
+          if (load_next && g == 1 && s == 6) mask_dma(next_blk, cx.lane4, cx.lmask);         // the pair that opens with block nb + 1
+          if (MASK && !(nb & 1) && g == 1 && s == 14) mz[(nb >> 1) & 1] = mask_read(cx.lmask + cx.lane4);   // this block opens a pair
         },
         [&](int k, int g) {
           if (g == 0) prefetch_frag(nxt, k, ld.slot_next + ld.lane_off);
         });
     };
-    if (kYoung == 3) mma(std::integral_constant<int, 3>{});
-    else if (kYoung == 2) mma(std::integral_constant<int, 2>{});
-    else if (kYoung == 1) mma(std::integral_constant<int, 1>{});
+    if (kYoung == 2) mma(std::integral_constant<int, 2>{});
     else mma(std::integral_constant<int, 0>{});
     if (ADD) {   // plain C++ on purpose: the compiler inserts the MFMA -> VALU wait states
 #pragma unroll
@@ -359,7 +376,7 @@ chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ 
                  const float* __restrict__ d_rgb, int d_rgb_stride, const float* __restrict__ d_sigma, int d_sigma_stride,
                  int64_t P, unsigned* __restrict__ gmax, float* __restrict__ pscale) {
   constexpr int kAux0 = 3 * kSlotFloats;
-  __shared__ __attribute__((aligned(16))) float ring[kAux0 + kBwdAuxFloats + 16];
+  __shared__ __attribute__((aligned(16))) float ring[kAux0 + kBwdAuxFloats + 16 + 4 * 64];
   unsigned* lmax = reinterpret_cast<unsigned*>(ring + kAux0 + kBwdAuxFloats);
   if (threadIdx.x < 16) lmax[threadIdx.x] = 0u;
   const int lane = threadIdx.x & 63;
@@ -393,6 +410,8 @@ chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ 
   cx.voff0 = unit_voff(m, h, 0);
   cx.voff1 = unit_voff(m, h, 1);
   cx.lane = lane;
+  cx.lane4 = (unsigned)lane * 4u;
+  cx.lmask = lds_addr(ring + kAux0 + kBwdAuxFloats + 16) + (unsigned)wave * 256u;
   cx.lmax = lmax;
   cx.pscale = pscale;
   cx.pidx = cx.dp.group * 32 + m;
