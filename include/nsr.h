@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define NSR_VERSION 110 /* 0.1.1: numerics status word, gamma epilogue, checked weight packing */
+#define NSR_VERSION 120 /* 0.1.2: colour-head option word (gamma, color_activation none), renderer option word (softplus density) */
 
 typedef enum nsr_status {
   NSR_OK = 0,
@@ -110,10 +110,25 @@ int nsr_pack_weights_async(const float* const* w, void* packed_dev, int precisio
 #define NSR_FLAG_OUTPUT_NONFINITE 8u
 int nsr_weights_status(const void* packed_dev, int precision, int clear, unsigned* flags_out, void* stream);
 
-/* --gamma_correct (models/nerf_downX_model.py:271-276): render_rays returns pow(rgb, 1 / 2.2) per sample.  An option of
- * the packed network (stream-ordered write into the blob's tail, read by every later launch; cleared by re-packing):
- * enable != 0 makes the colour head of every entry point that evaluates this blob apply it. */
+/* Colour-head options of a packed network (stream-ordered write into the blob's tail, read by every later launch of every
+ * entry point that evaluates this blob; cleared by re-packing).  `options` = the whole word, an OR of
+ *   NSR_OPT_GAMMA       --gamma_correct (models/nerf_downX_model.py:271-276): render_rays returns pow(rgb, 1 / 2.2) per sample
+ *   NSR_OPT_COLOR_NONE  --color_activation none (models/networks.py:173-180): the rgb head ends in nn.Identity, not nn.Sigmoid
+ * NSR_ERR_INVALID_ARG for any other bit.  nsr_weights_set_gamma(enable) = nsr_weights_set_options(enable ? NSR_OPT_GAMMA : 0).
+ * Inference only: the training step (nsr_train.h) evaluates its own copy of the weights with the default head. */
+#define NSR_OPT_GAMMA 1u
+#define NSR_OPT_COLOR_NONE 2u
+int nsr_weights_set_options(void* packed_dev, int precision, unsigned options, void* stream);
 int nsr_weights_set_gamma(void* packed_dev, int precision, int enable, void* stream);
+
+/* The `white_bkgd` argument of the compositing entry points below (nsr_composite, nsr_render_rays_composited,
+ * nsr_forward_rays*) is a word of renderer options, like the reference's VolumetricRenderer(opt) + white_bkgd pair
+ * (models/rendering.py:66-111): 0 / 1 keep their meaning;
+ *   NSR_WHITE_BKGD      comp_rgb += 1 - opacity
+ *   NSR_SIGMA_SOFTPLUS  --sigma_activation softplus (models/rendering.py:69-73): log(1 + exp(sigma - 1)) instead of relu(sigma)
+ * The training entry points accept NSR_WHITE_BKGD only (NSR_ERR_UNSUPPORTED otherwise). */
+#define NSR_WHITE_BKGD 1
+#define NSR_SIGMA_SOFTPLUS 2
 
 /* ---- R1-R4: sub-pixel ray generation ---------------------------------------
  * Replaces get_ray_directions + get_rays (+ get_ndc_rays) + the einops regroup

@@ -19,6 +19,8 @@ NSR_ERR_RANGE = -5
 # numerics status word of a packed network (include/nsr.h)
 FLAGS = {1: "WEIGHT_RANGE", 2: "INPUT_RANGE", 4: "ACTIVATION_RANGE", 8: "OUTPUT_NONFINITE"}
 NSR_F16X3_GEMM = 18   # include/nsr_train.h: training entry points only
+NSR_OPT_GAMMA, NSR_OPT_COLOR_NONE = 1, 2     # include/nsr.h: colour-head option word (nsr_weights_set_options)
+NSR_WHITE_BKGD, NSR_SIGMA_SOFTPLUS = 1, 2    # include/nsr.h: renderer option word (the `white_bkgd` argument)
 PRECISIONS = {"fp32": NSR_FP32, "bf16": NSR_BF16, "f16x3": NSR_F16X3, "f16": NSR_F16}
 TRAIN_PRECISIONS = {"fp32": NSR_FP32, "f16x3": NSR_F16X3, "f16x3_gemm": NSR_F16X3_GEMM}
 
@@ -31,6 +33,7 @@ SIGNATURES = {
     "nsr_pack_weights_async": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p]),
     "nsr_weights_status": (c_int, [c_void_p, c_int, c_int, POINTER(c_uint), c_void_p]),
     "nsr_weights_set_gamma": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "nsr_weights_set_options": (c_int, [c_void_p, c_int, ctypes.c_uint, c_void_p]),
     "nsr_gen_rays": (c_int, [POINTER(c_float), c_int, c_int, c_double, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
     "nsr_gen_rays_range": (c_int, [POINTER(c_float), c_int, c_int, c_double, c_int, c_int, c_float, c_float, c_int64, c_int64,
                                    c_void_p, c_void_p]),

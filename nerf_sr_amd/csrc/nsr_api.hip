@@ -77,7 +77,8 @@ extern "C" int nsr_forward_rays_profiled(const void* packed_coarse, const void* 
   auto mark = [&](int i) {
     if (events && events[i]) (void)hipEventRecord(static_cast<hipEvent_t>(events[i]), st);
   };
-  if (!packed_coarse || !outs || R < 0 || n_coarse <= 0 || n_importance < 0) return NSR_ERR_INVALID_ARG;
+  if (!packed_coarse || !outs || R < 0 || n_coarse <= 0 || n_importance < 0 || (white_bkgd & ~(NSR_WHITE_BKGD | NSR_SIGMA_SOFTPLUS)) != 0)
+    return NSR_ERR_INVALID_ARG;
   if (n_importance > 0 && !packed_fine) return NSR_ERR_INVALID_ARG;
   if (workspace_bytes < nsr_forward_rays_workspace_bytes_for(precision, R, n_coarse, n_importance)) return NSR_ERR_WORKSPACE;
   if (R == 0) return NSR_OK;

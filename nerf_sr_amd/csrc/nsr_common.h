@@ -27,9 +27,10 @@ static inline const char* nsr_dev_env(const char*) { return nullptr; }
 
 // ---- tail of every packed weight blob (include/nsr.h "numerics status word"): 16 bytes behind the 16-byte-aligned
 // payload of the precision's own layout: word 0 = sticky NSR_FLAG_* status, word 1 = colour-head options
-// (bit 0: --gamma_correct, models/nerf_downX_model.py:271-276), words 2, 3 reserved.
+// (bit 0: --gamma_correct, models/nerf_downX_model.py:271-276; bit 1: --color_activation none, models/networks.py:173-176),
+// words 2, 3 reserved.
 constexpr size_t kBlobTailBytes = 16;
-constexpr unsigned kOptGamma = 1u;
+constexpr unsigned kOptGamma = 1u, kOptColorNone = 2u;   // = NSR_OPT_* of include/nsr.h
 static inline size_t nsr_blob_tail_offset(size_t payload_bytes) { return (payload_bytes + 15) & ~(size_t)15; }
 NSR_INTERNAL size_t nsr_payload_bytes(int precision);   // nsr_mlp.hip
 static inline unsigned* nsr_blob_tail(const void* packed_dev, int precision) {
@@ -45,8 +46,11 @@ struct NsrTail {
 __device__ __forceinline__ void nsr_raise(const NsrTail& t, unsigned flags) {
   if (flags != 0u && t.w) atomicOr(t.w, flags);
 }
-__device__ __forceinline__ bool nsr_opt_gamma(const NsrTail& t) {
-  return t.w && (__builtin_nontemporal_load(t.w + 1) & kOptGamma) != 0u;
+__device__ __forceinline__ unsigned nsr_opts(const NsrTail& t) { return t.w ? __builtin_nontemporal_load(t.w + 1) : 0u; }
+// the colour head's activation on the pre-activation s: nn.Sigmoid, or nn.Identity under --color_activation none
+// (models/networks.py:173-180), then --gamma_correct's pow (nerf_downX_model.py:271-276; nsr_gamma below)
+__device__ __forceinline__ float nsr_colour_activation(float s, unsigned opts) {
+  return (opts & kOptColorNone) ? s : 1.0f / (1.0f + expf(-s));
 }
 // torch.max over the reference patches propagates NaN (models/networks.py:980-983); fmaxf drops it
 __device__ __forceinline__ float nsr_max_nan(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
@@ -65,6 +69,8 @@ __device__ __forceinline__ float nsr_max_relu(float a, float b) {
   return __builtin_bit_cast(float, __builtin_elementwise_max(ua, ub));      // v_max_u32
 }
 __device__ __forceinline__ bool nsr_finite(float x) { return fabsf(x) <= 3.402823466e38f; }   // false for inf and NaN
+// sigma_activation == 'softplus' (models/rendering.py:72): log(1 + exp(x - 1)), fp32 operation by operation
+__device__ __forceinline__ float nsr_softplus_density(float x) { return logf(__fadd_rn(1.0f, expf(__fsub_rn(x, 1.0f)))); }
 // --gamma_correct: out_rgbs = pow(out_rgbs, 1 / 2.2) on the per-sample colours (nerf_downX_model.py:271-276)
 __device__ __forceinline__ float nsr_gamma(float c) { return powf(c, 1.0f / 2.2f); }
 

@@ -6,6 +6,7 @@
 #pragma once
 #include "nsr_common.h"
 
+// `white`: the entry points' `white_bkgd` word (include/nsr.h): bit 0 = white background, bit 1 = sigma_activation 'softplus'.
 // K samples per lane, lane l owns samples l*K .. l*K+K-1 of the ray whose sample k lives at rgb[k * rgb_stride + c],
 // sigma[k * sigma_stride], z[k] (pointers already offset to the ray); r = the ray's index in the output arrays.
 template <int K>
@@ -34,7 +35,7 @@ __device__ __forceinline__ void composite_ray(const float* rgb, int rgb_stride, 
     const int k = lane * K + i;
     const float zn = (i + 1 < K) ? zk[(i + 1 < K) ? i + 1 : i] : z_next_lane;
     const float delta = (k >= N - 1) ? 1e10f : __fsub_rn(zn, zk[i]);
-    const float s = fmaxf(sg[i], 0.0f);
+    const float s = (white & NSR_SIGMA_SOFTPLUS) ? nsr_softplus_density(sg[i]) : fmaxf(sg[i], 0.0f);
     float a = __fsub_rn(1.0f, expf(__fmul_rn(-delta, s)));
     if (k >= N) a = 0.0f;
     alpha[i] = a;
@@ -66,7 +67,7 @@ __device__ __forceinline__ void composite_ray(const float* rgb, int rgb_stride, 
   acc_r = wave_sum(acc_r); acc_g = wave_sum(acc_g); acc_b = wave_sum(acc_b);
   acc_d = wave_sum(acc_d); acc_o = wave_sum(acc_o);
   if (lane == 0) {
-    if (white) {
+    if (white & NSR_WHITE_BKGD) {
       const float bg = __fsub_rn(1.0f, acc_o);
       acc_r = __fadd_rn(acc_r, bg); acc_g = __fadd_rn(acc_g, bg); acc_b = __fadd_rn(acc_b, bg);
     }

@@ -190,13 +190,17 @@ extern "C" int nsr_pack_weights(const float* const* w, void* packed_dev, int pre
   return (flags & NSR_FLAG_WEIGHT_RANGE) ? NSR_ERR_RANGE : NSR_OK;
 }
 
-extern "C" int nsr_weights_set_gamma(void* packed_dev, int precision, int enable, void* stream) {
-  if (!packed_dev) return NSR_ERR_INVALID_ARG;
+extern "C" int nsr_weights_set_options(void* packed_dev, int precision, unsigned options, void* stream) {
+  static_assert(kOptGamma == NSR_OPT_GAMMA && kOptColorNone == NSR_OPT_COLOR_NONE, "option bits of include/nsr.h");
+  if (!packed_dev || (options & ~(NSR_OPT_GAMMA | NSR_OPT_COLOR_NONE)) != 0u) return NSR_ERR_INVALID_ARG;
   if (!precision_built(precision)) return NSR_ERR_UNSUPPORTED;
   unsigned* tail = nsr_blob_tail(packed_dev, precision);
-  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(tail + 1), enable ? (int)kOptGamma : 0, 1, nsr_stream(stream)) != hipSuccess)
+  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(tail + 1), (int)options, 1, nsr_stream(stream)) != hipSuccess)
     return NSR_ERR_LAUNCH;
   return NSR_OK;
+}
+extern "C" int nsr_weights_set_gamma(void* packed_dev, int precision, int enable, void* stream) {
+  return nsr_weights_set_options(packed_dev, precision, enable ? NSR_OPT_GAMMA : 0u, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -449,16 +453,17 @@ mlp_fp32_kernel(const float* __restrict__ packed, const float* __restrict__ x, c
 #pragma unroll
     for (int r = 0; r < 16; ++r) cfe[16 * nb + r] = relu_nan(acc4[nb][r]);
 
-  // ---- rgb head: 128 -> 3, sigmoid
+  // ---- rgb head: 128 -> 3, sigmoid (or none: the network's option word)
+  const unsigned opts = nsr_opts(tail);
   float rgb[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     float s = half_dot<4>(cfe, aux + kAuxRgbW + 128 * k, h);
     s += __shfl_xor(s, 32, 64);
     s += aux[kAuxRgbB + k];
-    rgb[k] = 1.0f / (1.0f + expf(-s));
+    rgb[k] = nsr_colour_activation(s, opts);
   }
-  if (nsr_opt_gamma(tail)) {
+  if (opts & kOptGamma) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) rgb[k] = nsr_gamma(rgb[k]);
   }
@@ -518,7 +523,8 @@ extern "C" NSR_INTERNAL int nsr_f16x3_render_composite(const void* packed, const
 extern "C" int nsr_render_rays_composited(const void* packed_dev, int precision, const float* rays, int ray_stride, const float* z,
                                           int64_t R, int n_samples, int white_bkgd, float* raw, float* comp_rgb, float* depth,
                                           float* opacity, float* weights, void* stream) {
-  if (!packed_dev || R < 0 || n_samples <= 0 || !nsr_ray_stride_ok(ray_stride)) return NSR_ERR_INVALID_ARG;
+  if (!packed_dev || R < 0 || n_samples <= 0 || !nsr_ray_stride_ok(ray_stride) || (white_bkgd & ~(NSR_WHITE_BKGD | NSR_SIGMA_SOFTPLUS)) != 0)
+    return NSR_ERR_INVALID_ARG;
   if (!precision_built(precision)) return NSR_ERR_UNSUPPORTED;
   if ((precision != NSR_FP32 && precision != NSR_F16X3) || (n_samples != 64 && n_samples != 128)) return NSR_ERR_UNSUPPORTED;
   if (R == 0) return NSR_OK;

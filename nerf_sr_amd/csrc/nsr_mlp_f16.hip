@@ -720,7 +720,7 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
 
   const int64_t n_tiles = (P + 127) / 128;
   const int samples = (NS > 0) ? NS : N;
-  const bool gamma = !TRAIN && nsr_opt_gamma(tail);
+  const unsigned opts = TRAIN ? 0u : nsr_opts(tail);      // colour-head options of the packed network (nsr_common.h)
   // (the inference instantiations never use them; their voff0 is the expression rounds 2-4 had here, which keeps the register
   // allocation -- and with it the whole ISA of those kernels -- bit-identical to the measured round-4 build)
   const unsigned voff0 = TRAIN ? unit_voff(m, h, 0) : 4u * (unsigned)(m + 128 * h), voff1 = TRAIN ? unit_voff(m, h, 1) : 0u;   // panel stores: this lane's slot in either unit of a block
@@ -1103,9 +1103,9 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
     float s = rgb[k];
     s += __shfl_xor(s, 32, 64);
     s += aux[hx::kAuxRgbB + k];
-    rgb[k] = 1.0f / (1.0f + expf(-s));
+    rgb[k] = nsr_colour_activation(s, opts);
   }
-  if (gamma) {
+  if (opts & kOptGamma) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) rgb[k] = nsr_gamma(rgb[k]);
   }

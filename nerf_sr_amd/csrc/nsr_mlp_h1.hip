@@ -518,14 +518,15 @@ mlp_h1_kernel(const float* __restrict__ packed, const float* __restrict__ x, con
   }
 #pragma unroll
   for (int q = 0; q < 16; ++q) rgb_q(q, pend, aux + kAuxRgbW + 64, h, rgb);   // blocks 2, 3
+  const unsigned opts = nsr_opts(tail);
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     float s = rgb[k];
     s += __shfl_xor(s, 32, 64);
     s += aux[kAuxRgbB + k];
-    rgb[k] = 1.0f / (1.0f + expf(-s));
+    rgb[k] = nsr_colour_activation(s, opts);
   }
-  if (nsr_opt_gamma(tail)) {
+  if (opts & kOptGamma) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) rgb[k] = nsr_gamma(rgb[k]);
   }

@@ -34,7 +34,8 @@ __global__ void __launch_bounds__(256) composite_kernel(const float* __restrict_
 extern "C" int nsr_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z,
                              int64_t R, int n_samples, int white_bkgd, float* comp_rgb, float* depth,
                              float* opacity, float* weights, void* stream) {
-  if (R < 0 || n_samples <= 0 || rgb_stride < 3 || sigma_stride < 1) return NSR_ERR_INVALID_ARG;
+  if (R < 0 || n_samples <= 0 || rgb_stride < 3 || sigma_stride < 1 || (white_bkgd & ~(NSR_WHITE_BKGD | NSR_SIGMA_SOFTPLUS)) != 0)
+    return NSR_ERR_INVALID_ARG;
   if (n_samples > NSR_MAX_SAMPLES) return NSR_ERR_UNSUPPORTED;
   if (R == 0) return NSR_OK;
   if (!rgb || !sigma || !z) return NSR_ERR_INVALID_ARG;

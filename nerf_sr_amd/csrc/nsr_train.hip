@@ -998,6 +998,7 @@ int train_impl(const float* const* w_coarse, const float* const* w_fine, float* 
   if (!rays || !target_lr || !outs[0] || !outs[4] || !lr_coarse || !lr_fine || !losses || !workspace)
     return NSR_ERR_INVALID_ARG;
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return NSR_ERR_INVALID_ARG;
+  if ((white_bkgd & ~NSR_WHITE_BKGD) != 0) return NSR_ERR_UNSUPPORTED;   // the backward pass differentiates relu(sigma) only (include/nsr.h)
   if (workspace_bytes < nsr_train_workspace_bytes_for(precision, ray_chunk, n_coarse, n_importance)) return NSR_ERR_WORKSPACE;
   const bool noisy = noise_std > 0.0f;
   hipStream_t st = nsr_stream(stream);

@@ -22,8 +22,9 @@ def default_options(**kw) -> SimpleNamespace:
     opt = SimpleNamespace(
         N_coarse=64, N_importance=64, lindisp=False, white_bkgd=False, randomized=True, noise_std=0.0,
         deg_pos=10, deg_dir=4, dim_pos=3, dim_dir=3, dim_rgb=3, downscale=2, img_wh=(504, 378),
-        D=8, W=256, skips=[4], no_dir=False,        # models/networks.py:124-128; anything else raises (ops.check_mlp_options)
-        sigma_activation="relu", color_activation="sigmoid", gamma_correct=False,
+        D=8, W=256, skips=[4],                      # models/networks.py:124-128; anything else raises (ops.check_mlp_options)
+        no_dir=False, color_activation="sigmoid",   # :128, :160-180 ('none'; True): options of VanillaMLP
+        sigma_activation="relu", gamma_correct=False,   # models/rendering.py:69-73 ('softplus'); nerf_downX_model.py:271-276
         ray_chunk=4096, point_chunk=262144, precision="fp32",
         check_numerics=True,    # forward() raises on NaN / out-of-range values (the reference: pdb, nerf_downX_model.py:273-274)
     )
@@ -57,10 +58,7 @@ class NeRFDownXModel:
         ``{epoch}_net_Coarse.pth`` / ``{epoch}_net_Fine.pth`` (models/base_model.py:181-219)."""
         self.netCoarse.load_state_dict(sd_coarse)
         self.netFine.load_state_dict(sd_fine)
-        if getattr(self.opt, "gamma_correct", False):    # render_rays returns rgb ** (1 / 2.2) (:271-276)
-            self.netCoarse.set_gamma_correct(True)
-            self.netFine.set_gamma_correct(True)
-        return self
+        return self        # (the colour-head options of `opt` -- gamma_correct, color_activation -- are applied by VanillaMLP)
 
     # -- mode toggles (nerf_downX_model.py:250-258) ------------------------------
     def train(self):
@@ -93,7 +91,8 @@ class NeRFDownXModel:
         if not self.randomized:
             self._outs = ops.forward_rays(self.netCoarse, self.netFine if opt.N_importance > 0 else None, rays,
                                           opt.N_coarse, opt.N_importance, opt.white_bkgd, opt.lindisp,
-                                          check=bool(getattr(opt, "check_numerics", True)))
+                                          check=bool(getattr(opt, "check_numerics", True)),
+                                          sigma_activation=self.renderer.sigma_activation)
             return self._outs
         # randomized (training-mode) forward: same kernels, stage by stage, jitter drawn with torch.rand
         o, d, near, far = rays[:, 0:3], rays[:, 3:6], rays[:, 6:7], rays[:, 7:8]
@@ -178,7 +177,8 @@ class NeRFDownXModel:
         rays = ops.subpixel_rays(c2w, opt.img_wh, focal, s, ndc, near, far, self.device, lr_range=(lo, hi)).view(-1, 8)
         fine = opt.N_importance > 0
         out = ops.forward_rays(self.netCoarse, self.netFine if fine else None, rays, opt.N_coarse, opt.N_importance,
-                               opt.white_bkgd, opt.lindisp, workspace=workspace, outs=outs, want_weights=want_weights)
+                               opt.white_bkgd, opt.lindisp, workspace=workspace, outs=outs, want_weights=want_weights,
+                               sigma_activation=self.renderer.sigma_activation)
         tag = "fine" if fine else "coarse"
         cap = (lo, hi) if lr_range is not None else nsr_dist.shard_bounds(n_lr, world)[0]   # the block the payload is sized by
         if gather == "hr":

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .weights import STATE_DICT_SPEC, check_state_dict, IN_CH
+from .weights import STATE_DICT_SPEC, check_state_dict, pad_no_dir, DIR_W, IN_CH
 
 __all__ = [
     "subpixel_rays", "PositionalEncoding", "sample_along_rays", "resample_along_rays", "cast_rays",
@@ -165,15 +165,16 @@ def resample_along_rays(ori, dir, z_vals, weights, num_samples: int, randomized:
 
 # ----------------------------------------------------------------------------- M1
 # the one architecture the HIP kernels are built for: the values every script of the reference uses
-_MLP_FIXED = {"D": 8, "W": 256, "skips": [4], "no_dir": False, "color_activation": "sigmoid", "deg_pos": 10, "deg_dir": 4,
-              "dim_pos": 3, "dim_dir": 3, "dim_rgb": 3, "stop_grad": False}
+_MLP_FIXED = {"D": 8, "W": 256, "skips": [4], "deg_pos": 10, "deg_dir": 4, "dim_pos": 3, "dim_dir": 3, "dim_rgb": 3,
+              "stop_grad": False}
+_MLP_CHOICES = {"color_activation": ("sigmoid", "none"), "no_dir": (False, True)}     # built since round 5 (inference)
 
 
 def check_mlp_options(opt) -> None:
-    """Reject every VanillaMLP option value the kernels do not implement (models/networks.py:124-128 ``--D --W --skips
-    --no_dir``, :160-173 ``no_dir`` / ``color_activation``; models/embedding.py degrees) instead of silently computing
-    the default architecture: a replacement that ignores ``color_activation='none'`` would return sigmoid colours
-    without a word.  Options that are absent from ``opt`` count as the reference's defaults."""
+    """Reject every VanillaMLP option value the kernels do not implement (models/networks.py:124-128 ``--D --W --skips``;
+    models/embedding.py degrees; ``stop_grad``, a training-only switch) instead of silently computing the default
+    architecture.  ``no_dir`` and ``color_activation`` (:160-180) are options of ``VanillaMLP`` since round 5.
+    Options that are absent from ``opt`` count as the reference's defaults."""
     if opt is None:
         return
     bad = []
@@ -184,9 +185,12 @@ def check_mlp_options(opt) -> None:
         got = list(got) if isinstance(got, (list, tuple)) else got
         if got != want:
             bad.append(f"{name}={got!r} (built: {want!r})")
+    for name, choices in _MLP_CHOICES.items():
+        if hasattr(opt, name) and getattr(opt, name) not in choices:
+            bad.append(f"{name}={getattr(opt, name)!r} (built: {list(choices)!r})")
     if bad:
         raise ValueError("VanillaMLP option(s) outside the built path (the MFMA kernels are laid out for the 8 x 256 network with "
-                         "a skip at layer 5, the view-direction branch and a sigmoid colour head, models/networks.py:131-180): "
+                         "a skip at layer 5, models/networks.py:131-180): "
                          + ", ".join(bad))
 
 
@@ -214,15 +218,23 @@ class VanillaMLP:
         self._sd = None
         self._gamma = False
         self._want_gamma = bool(getattr(opt, "gamma_correct", False)) if opt is not None else False
+        # --color_activation none (models/networks.py:173-180): the rgb head ends in nn.Identity; --no_dir (:160-169):
+        # dir_encoding sees xyz_encoding_final alone (weights.pad_no_dir)
+        self.color_activation = getattr(opt, "color_activation", "sigmoid") if opt is not None else "sigmoid"
+        self.no_dir = bool(getattr(opt, "no_dir", False)) if opt is not None else False
+
+    def _options_word(self) -> int:
+        return (_lib.NSR_OPT_GAMMA if self._want_gamma else 0) | (_lib.NSR_OPT_COLOR_NONE if self.color_activation == "none" else 0)
 
     def load_state_dict(self, sd: Dict[str, "np.ndarray | torch.Tensor"]):
-        check_state_dict(sd)
-        dev = {}
+        check_state_dict(sd, self.no_dir)
+        dev, packed_from = {}, {}
         for k in STATE_DICT_SPEC:
             v = sd[k]
             v = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v.detach()
             dev[k] = v.to(device=self.device, dtype=torch.float32).contiguous()
-        ptrs = (c_void_p * len(dev))(*[c_void_p(t.data_ptr()) for t in dev.values()])
+            packed_from[k] = pad_no_dir(dev[k]).contiguous() if (self.no_dir and k == DIR_W) else dev[k]
+        ptrs = (c_void_p * len(dev))(*[c_void_p(t.data_ptr()) for t in packed_from.values()])
         rc = _lib.load().nsr_pack_weights(ptrs, _p(self.packed), self._prec, _stream())
         if rc == _lib.NSR_ERR_RANGE:
             # the blob HAS been overwritten with the out-of-range network (include/nsr.h): this object no longer holds a
@@ -237,18 +249,22 @@ class VanillaMLP:
         _lib.check(rc, "nsr_pack_weights")
         self._sd = dev     # keep the fp32 originals alive (state_dict() round trip)
         self._gamma = False
-        if self._want_gamma:       # packing clears the blob's option word: the requested colour-head option is re-applied
-            self.set_gamma_correct(True)
+        if self._options_word():   # packing clears the blob's option word: the requested colour-head options are re-applied
+            self._write_options()
         return self
+
+    def _write_options(self):
+        _lib.check(_lib.load().nsr_weights_set_options(_p(self.packed), self._prec, self._options_word(), _stream()),
+                   "nsr_weights_set_options")
+        self._gamma = self._want_gamma
 
     def set_gamma_correct(self, enable: bool = True):
         """``--gamma_correct`` (models/nerf_downX_model.py:271-276): the colour head returns ``rgb ** (1 / 2.2)``.
         An option of the PACKED network: call it after ``load_state_dict`` (re-packing clears it)."""
         if self._sd is None:
             raise RuntimeError("VanillaMLP.set_gamma_correct called before load_state_dict")
-        _lib.check(_lib.load().nsr_weights_set_gamma(_p(self.packed), self._prec, int(bool(enable)), _stream()),
-                   "nsr_weights_set_gamma")
-        self._gamma = self._want_gamma = bool(enable)       # remembered: every later load_state_dict re-applies it
+        self._want_gamma = bool(enable)       # remembered: every later load_state_dict re-applies it
+        self._write_options()
         return self
 
     def status(self, clear: bool = False) -> int:
@@ -292,14 +308,20 @@ class VanillaMLP:
 
 
 # ----------------------------------------------------------------------------- V1
+def renderer_flags(white_bkgd: bool, sigma_activation: str = "relu") -> int:
+    """The renderer option word of the compositing entry points (include/nsr.h): white background | softplus density."""
+    if sigma_activation not in ("relu", "softplus"):
+        raise ValueError(f"sigma_activation={sigma_activation!r}: 'relu' or 'softplus' (models/rendering.py:69-73)")
+    return (_lib.NSR_WHITE_BKGD if white_bkgd else 0) | (_lib.NSR_SIGMA_SOFTPLUS if sigma_activation == "softplus" else 0)
+
+
 class VolumetricRenderer:
-    """Alpha compositing; mirrors models/rendering.py:66-111 (sigma_activation = relu)."""
+    """Alpha compositing; mirrors models/rendering.py:66-111 (``opt.sigma_activation``: 'relu' or 'softplus' =
+    ``log(1 + exp(sigma - 1))``, :69-73)."""
 
     def __init__(self, opt=None):
-        act = getattr(opt, "sigma_activation", "relu") if opt is not None else "relu"
-        if act != "relu":
-            raise ValueError(f"sigma_activation={act!r}: the built path implements 'relu' only (models/rendering.py:69-73; no "
-                             "script of the reference uses 'softplus')")
+        self.sigma_activation = getattr(opt, "sigma_activation", "relu") if opt is not None else "relu"
+        renderer_flags(False, self.sigma_activation)     # validates
 
     def forward(self, rgb, sigma, z_vals, white_bkgd: bool):
         rgb, sigma, z_vals = _f32(rgb, "rgb"), _f32(sigma, "sigma"), _f32(z_vals, "z_vals")
@@ -311,7 +333,7 @@ class VolumetricRenderer:
         depth = torch.empty(R, dtype=torch.float32, device=dev)
         opac = torch.empty(R, dtype=torch.float32, device=dev)
         w = torch.empty(R, N, dtype=torch.float32, device=dev)
-        _lib.check(_lib.load().nsr_composite(_p(rgb), 3, _p(sigma), 1, _p(z_vals), R, N, int(bool(white_bkgd)),
+        _lib.check(_lib.load().nsr_composite(_p(rgb), 3, _p(sigma), 1, _p(z_vals), R, N, renderer_flags(white_bkgd, self.sigma_activation),
                                              _p(comp), _p(depth), _p(opac), _p(w), _stream()), "nsr_composite")
         return comp, depth, opac, w
 
@@ -333,7 +355,7 @@ def render_rays(model: VanillaMLP, rays: torch.Tensor, z_vals: torch.Tensor):
 
 
 def render_rays_composited(model: VanillaMLP, rays: torch.Tensor, z_vals: torch.Tensor, white_bkgd: bool,
-                           want_raw: bool = False):
+                           want_raw: bool = False, sigma_activation: str = "relu"):
     """``render_rays`` + ``VolumetricRenderer.forward`` in one launch (models/nerf_downX_model.py:289-291): 64 or 128
     samples per ray, fp32 / f16x3.  Returns ``(comp_rgb (R,3), depth (R), opacity (R), weights (R,N))`` and, if
     ``want_raw``, the (R, N, 4) network output as a fifth element.  Bit-identical to the two-call route."""
@@ -346,7 +368,7 @@ def render_rays_composited(model: VanillaMLP, rays: torch.Tensor, z_vals: torch.
     w = torch.empty(R, N, dtype=torch.float32, device=dev)
     raw = torch.empty(R, N, 4, dtype=torch.float32, device=dev) if want_raw else None
     _lib.check(_lib.load().nsr_render_rays_composited(_p(model.packed), model._prec, _p(rays), _ray_stride(rays), _p(z_vals), R, N,
-                                                      int(bool(white_bkgd)), _p(raw), _p(comp), _p(depth), _p(opac), _p(w),
+                                                      renderer_flags(white_bkgd, sigma_activation), _p(raw), _p(comp), _p(depth), _p(opac), _p(w),
                                                       _stream()), "nsr_render_rays_composited")
     return (comp, depth, opac, w, raw) if want_raw else (comp, depth, opac, w)
 
@@ -358,7 +380,8 @@ OUT_KEYS = ("coarse_comp_rgbs", "coarse_depth", "coarse_opacity", "coarse_weight
 def forward_rays(coarse: VanillaMLP, fine: Optional[VanillaMLP], rays: torch.Tensor, N_coarse: int = 64,
                  N_importance: int = 64, white_bkgd: bool = False, lindisp: bool = False,
                  workspace: Optional[torch.Tensor] = None, outs: Optional[Dict[str, torch.Tensor]] = None,
-                 want_weights: bool = True, events=None, check: bool = False) -> Dict[str, torch.Tensor]:
+                 want_weights: bool = True, events=None, check: bool = False,
+                 sigma_activation: str = "relu") -> Dict[str, torch.Tensor]:
     """Eval-mode forward_rays for the WHOLE batch in one enqueue sequence
     (models/nerf_downX_model.py:280-324; with 11-wide rays: the vanilla model's models/nerf_model.py:207-242):
     returns the reference's 8-entry dict.
@@ -395,7 +418,8 @@ def forward_rays(coarse: VanillaMLP, fine: Optional[VanillaMLP], rays: torch.Ten
     ptrs = (c_void_p * 8)(*[_p(outs.get(k)) for k in OUT_KEYS])
     ev = (c_void_p * 4)(*events) if events is not None else None
     _lib.check(lib.nsr_forward_rays_profiled(_p(coarse.packed), _p(fine.packed) if fine is not None else c_void_p(0),
-                                             coarse._prec, _p(rays), stride, R, N_coarse, N_importance, int(bool(white_bkgd)),
+                                             coarse._prec, _p(rays), stride, R, N_coarse, N_importance,
+                                             renderer_flags(white_bkgd, sigma_activation),
                                              int(bool(lindisp)), ptrs, _p(workspace), workspace.numel(), _stream(), ev),
                "nsr_forward_rays")
     if check:

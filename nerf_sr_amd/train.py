@@ -21,7 +21,7 @@ import torch
 
 from . import _lib
 from .ops import _f32, _p, _ray_stride, _stream
-from .weights import STATE_DICT_SPEC, check_state_dict
+from .weights import STATE_DICT_SPEC, check_state_dict, pad_no_dir, DIR_W
 
 OUT_KEYS = ("coarse_comp_rgbs", "coarse_depth", "coarse_opacity", "coarse_weights",
             "fine_comp_rgbs", "fine_depth", "fine_opacity", "fine_weights")
@@ -44,13 +44,14 @@ def _flat_like(params: Dict[str, torch.Tensor]):
     return flat, views
 
 
-def _to_dev(sd, device) -> Dict[str, torch.Tensor]:
-    check_state_dict(sd)
+def _to_dev(sd, device, no_dir: bool = False) -> Dict[str, torch.Tensor]:
+    check_state_dict(sd, no_dir)
     out = {}
     for k in STATE_DICT_SPEC:
         v = sd[k]
         v = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v.detach()
-        out[k] = v.to(device=device, dtype=torch.float32).contiguous().clone()
+        v = v.to(device=device, dtype=torch.float32)
+        out[k] = (pad_no_dir(v) if (no_dir and k == DIR_W) else v).contiguous().clone()
     return out
 
 
@@ -76,7 +77,8 @@ class Trainer:
                  lambda_coarse_mse: float = 1.0, lambda_fine_mse: float = 1.0, ray_chunk: int = 4096,
                  precision: str = "f16x3", device="cuda", gamma_correct: bool = False,
                  use_var_loss: bool = False, lambda_coarse_var: float = 0.01, lambda_fine_var: float = 0.01,
-                 use_depth_var_loss: bool = False, lambda_coarse_depth_var: float = 0.01, lambda_fine_depth_var: float = 0.01):
+                 use_depth_var_loss: bool = False, lambda_coarse_depth_var: float = 0.01, lambda_fine_depth_var: float = 0.01,
+                 no_dir: bool = False):
         if gamma_correct:
             # render_rays applies rgb ** (1 / 2.2) per sample under --gamma_correct (models/nerf_downX_model.py:271-276) in
             # training too; the training kernels have no such branch, and ignoring the option would train another model
@@ -88,7 +90,11 @@ class Trainer:
                              "per product) or 'f16x3_gemm' (layer by layer, forward products split-fp16, gradients fp32)")
         self.precision, self._prec = precision, _lib.TRAIN_PRECISIONS[precision]
         self.device = torch.device(device)
-        self.params = [_to_dev(sd_coarse, self.device), _to_dev(sd_fine, self.device)]
+        # --no_dir (models/networks.py:160-169): the networks are trained as the full layout with 27 zero columns in
+        # dir_encoding's weight (weights.pad_no_dir) whose gradients are dropped every step, so Adam never moves them
+        # (m = v = 0 -> update 0): the function, its gradients and the trajectory are the narrow network's
+        self.no_dir = bool(no_dir)
+        self.params = [_to_dev(sd_coarse, self.device, self.no_dir), _to_dev(sd_fine, self.device, self.no_dir)]
         flat = [_flat_like(p) for p in self.params]
         self.flat_grads, self.grads = [f for f, _ in flat], [v for _, v in flat]
         self.exp_avg = [_flat_like(p)[1] for p in self.params]
@@ -187,6 +193,9 @@ class Trainer:
                        "nsr_train_loss_and_grads_var")
         else:
             _lib.check(lib.nsr_train_loss_and_grads(*common), "nsr_train_loss_and_grads")
+        if self.no_dir:
+            for g in self.grads:
+                g[DIR_W][:, 256:].zero_()
         if gs != 1.0:
             self.losses.mul_(1.0 / gs)          # report this rank's own losses, not the 1 / world share
             self.var_losses.mul_(1.0 / gs)
@@ -267,4 +276,4 @@ class Trainer:
         return self.lr
 
     def state_dicts(self):
-        return [{k: v.clone() for k, v in p.items()} for p in self.params]
+        return [{k: (v[:, :256] if (self.no_dir and k == DIR_W) else v).clone() for k, v in p.items()} for p in self.params]

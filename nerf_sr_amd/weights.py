@@ -120,12 +120,28 @@ def make_state_dict(seed: int = 99, field: str = "smooth", bias_scale: float = 0
     return sd
 
 
-def check_state_dict(sd) -> None:
-    """Raise ``ValueError`` unless ``sd`` has exactly the 24 keys/shapes of the path."""
+DIR_W = "dir_encoding.0.weight"          # (128, 256 + 27); (128, 256) in a --no_dir network (models/networks.py:160-169)
+
+
+def check_state_dict(sd, no_dir: bool = False) -> None:
+    """Raise ``ValueError`` unless ``sd`` has exactly the 24 keys/shapes of the path (``no_dir``: of the ``--no_dir``
+    variant, whose ``dir_encoding`` layer sees ``xyz_encoding_final`` alone)."""
     missing = [k for k in STATE_DICT_SPEC if k not in sd]
     if missing:
         raise ValueError(f"state_dict is missing keys: {missing}")
     for k, shape in STATE_DICT_SPEC.items():
         got = tuple(sd[k].shape)
-        if got != tuple(shape):
-            raise ValueError(f"state_dict[{k!r}] has shape {got}, expected {tuple(shape)}")
+        want = (shape[0], shape[1] - 27) if (no_dir and k == DIR_W) else tuple(shape)
+        if got != want:
+            raise ValueError(f"state_dict[{k!r}] has shape {got}, expected {want}" + (" (no_dir network)" if no_dir else ""))
+
+
+def pad_no_dir(w):
+    """``--no_dir`` (models/networks.py:160-169, 213-216): ``dir_encoding`` is Linear(256, 128) on ``xyz_encoding_final``
+    alone.  The kernels are laid out for the (128, 283) layer over ``cat([final, dir_pe])``: the same function with 27
+    ZERO columns behind the 256 -- every product with them is an exact 0, so the outputs are those of the narrow layer
+    bit for bit in any accumulation order.  Works on numpy arrays and torch tensors."""
+    if isinstance(w, np.ndarray):
+        return np.concatenate([w, np.zeros((w.shape[0], 27), dtype=w.dtype)], 1)
+    import torch
+    return torch.cat([w, torch.zeros(w.shape[0], 27, dtype=w.dtype, device=w.device)], 1)

@@ -221,12 +221,16 @@ def resample_conditioning(z, weights, n_imp: int, u: torch.Tensor = None):
 # M1: the NeRF MLP
 # ----------------------------------------------------------------------------
 
-def mlp_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, sigma_only: bool = False) -> torch.Tensor:
+def mlp_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, sigma_only: bool = False,
+                color_activation: str = "sigmoid") -> torch.Tensor:
     """``VanillaMLP.forward`` on embedded rows x (B, 90) -> (B, 4) = [rgb, sigma_raw].
 
     Restates ``models/networks.py:182-226`` with D=8, W=256, skips=[4]: the skip
     layer sees ``cat([pe, h])`` (input first); sigma is the raw Linear output (the
-    ReLU is applied by the renderer); colour goes through sigmoid.
+    ReLU is applied by the renderer); colour goes through sigmoid, or through nothing
+    with ``color_activation='none'`` (``:173-180``).  A ``--no_dir`` network
+    (``:160-169, 213-216``: ``dir_encoding.0.weight`` of shape (128, 256)) feeds
+    ``xyz_encoding_final`` alone to ``dir_encoding``.
     ``sd`` is the 24-key state_dict (torch tensors).
     """
     lin = torch.nn.functional.linear
@@ -240,13 +244,18 @@ def mlp_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, sigma_only: bool =
     if sigma_only:
         return sigma
     g = lin(h, sd["xyz_encoding_final.weight"], sd["xyz_encoding_final.bias"])
-    c = torch.relu(lin(torch.cat([g, de], -1), sd["dir_encoding.0.weight"], sd["dir_encoding.0.bias"]))
-    rgb = torch.sigmoid(lin(c, sd["rgb.0.weight"], sd["rgb.0.bias"]))
+    no_dir = sd["dir_encoding.0.weight"].shape[1] == g.shape[1]
+    c = torch.relu(lin(g if no_dir else torch.cat([g, de], -1), sd["dir_encoding.0.weight"], sd["dir_encoding.0.bias"]))
+    rgb = lin(c, sd["rgb.0.weight"], sd["rgb.0.bias"])
+    if color_activation == "sigmoid":
+        rgb = torch.sigmoid(rgb)
+    elif color_activation != "none":
+        raise ValueError(color_activation)
     return torch.cat([rgb, sigma], -1)
 
 
 def render_points(sd, xyz: torch.Tensor, dir_embedded: torch.Tensor, point_chunk: int = 262144,
-                  gamma_correct: bool = False):
+                  gamma_correct: bool = False, color_activation: str = "sigmoid"):
     """(R, N, 3) points + (R, 27) dir embedding -> rgb (R, N, 3), sigma (R, N).
 
     Restates ``models/nerf_downX_model.py:260-278`` (render_rays): PE of the points,
@@ -257,7 +266,7 @@ def render_points(sd, xyz: torch.Tensor, dir_embedded: torch.Tensor, point_chunk
     R, N = xyz.shape[:2]
     pts = xyz.reshape(-1, 3)
     x = torch.cat([posenc(pts, 10), dir_embedded.repeat_interleave(N, dim=0)], -1)
-    outs = [mlp_forward(sd, x[i:i + point_chunk]) for i in range(0, x.shape[0], point_chunk)]
+    outs = [mlp_forward(sd, x[i:i + point_chunk], color_activation=color_activation) for i in range(0, x.shape[0], point_chunk)]
     out = torch.cat(outs, 0).view(R, N, 4)
     rgb = out[..., :3]
     if gamma_correct:
@@ -269,16 +278,22 @@ def render_points(sd, xyz: torch.Tensor, dir_embedded: torch.Tensor, point_chunk
 # V1: volumetric compositing
 # ----------------------------------------------------------------------------
 
-def composite(rgb: torch.Tensor, sigma: torch.Tensor, z: torch.Tensor, white_bkgd: bool):
+def composite(rgb: torch.Tensor, sigma: torch.Tensor, z: torch.Tensor, white_bkgd: bool, sigma_activation: str = "relu"):
     """sigma -> alpha -> transmittance -> weights -> (rgb, depth, opacity, weights).
 
     Restates ``models/rendering.py:75-111`` (VolumetricRenderer.forward): last
     delta is 1e10, ``T_k = prod_{j<k}(1 - alpha_j + 1e-10)``, deltas are not scaled
-    by |d|, relu on sigma.
+    by |d|, relu on sigma -- or, ``sigma_activation='softplus'`` (``:69-73``), ``log(1 + exp(sigma - 1))``.
     """
     delta = z[:, 1:] - z[:, :-1]
     delta = torch.cat([delta, 1e10 * torch.ones_like(delta[:, :1])], -1)
-    alpha = 1 - torch.exp(-delta * torch.relu(sigma))
+    if sigma_activation == "relu":
+        dens = torch.relu(sigma)
+    elif sigma_activation == "softplus":
+        dens = torch.log(1 + torch.exp(sigma - 1))
+    else:
+        raise ValueError(sigma_activation)
+    alpha = 1 - torch.exp(-delta * dens)
     trans = torch.cat([torch.ones_like(alpha[:, :1]), torch.cumprod(1 - alpha[:, :-1] + 1e-10, -1)], -1)
     w = alpha * trans
     comp = (w[..., None] * rgb).sum(-2)
@@ -294,7 +309,8 @@ def composite(rgb: torch.Tensor, sigma: torch.Tensor, z: torch.Tensor, white_bkg
 # ----------------------------------------------------------------------------
 
 def forward_rays(sd_coarse, sd_fine, rays: torch.Tensor, n_coarse: int = 64, n_importance: int = 64,
-                 white_bkgd: bool = False, lindisp: bool = False, ray_chunk: int = 4096, gamma_correct: bool = False):
+                 white_bkgd: bool = False, lindisp: bool = False, ray_chunk: int = 4096, gamma_correct: bool = False,
+                 sigma_activation: str = "relu", color_activation: str = "sigmoid"):
     """Eval-mode ``forward_rays`` over (R, 8) rays -> dict of the 8 reference outputs.
 
     Restates ``models/nerf_downX_model.py:280-313`` chunked as ``:316-324``
@@ -308,14 +324,14 @@ def forward_rays(sd_coarse, sd_fine, rays: torch.Tensor, n_coarse: int = 64, n_i
         o, d, near, far = r[:, 0:3], r[:, 3:6], r[:, 6:7], r[:, 7:8]
         de = posenc(r[:, 8:11] if r.shape[1] == 11 else d, 4)
         z, xyz = sample_coarse(o, d, near, far, n_coarse, lindisp)
-        rgb, sig = render_points(sd_coarse, xyz, de, gamma_correct=gamma_correct)
-        c_rgb, c_depth, c_op, c_w = composite(rgb, sig, z, white_bkgd)
+        rgb, sig = render_points(sd_coarse, xyz, de, gamma_correct=gamma_correct, color_activation=color_activation)
+        c_rgb, c_depth, c_op, c_w = composite(rgb, sig, z, white_bkgd, sigma_activation)
         res = {"coarse_comp_rgbs": c_rgb, "coarse_depth": c_depth, "coarse_opacity": c_op,
                "coarse_weights": c_w}
         if n_importance > 0:
             z2, xyz2 = resample_fine(o, d, z, c_w, n_importance)
-            rgb2, sig2 = render_points(sd_fine, xyz2, de, gamma_correct=gamma_correct)
-            f_rgb, f_depth, f_op, f_w = composite(rgb2, sig2, z2, white_bkgd)
+            rgb2, sig2 = render_points(sd_fine, xyz2, de, gamma_correct=gamma_correct, color_activation=color_activation)
+            f_rgb, f_depth, f_op, f_w = composite(rgb2, sig2, z2, white_bkgd, sigma_activation)
             res.update({"fine_comp_rgbs": f_rgb, "fine_depth": f_depth, "fine_opacity": f_op,
                         "fine_weights": f_w})
         outs.append(res)

@@ -37,7 +37,7 @@ def test_header_symbols_exported_and_bound(lib):
 
 
 def test_version_and_status_strings(lib):
-    assert lib.nsr_version() == 110
+    assert lib.nsr_version() == 120
     assert lib.nsr_status_string(0) == b"ok"
     for code in (-1, -2, -3, -4, -5, -99):
         assert len(lib.nsr_status_string(code)) > 0
@@ -86,6 +86,8 @@ def test_invalid_arguments_are_rejected_before_any_launch(lib):
     assert lib.nsr_weights_status(one, 2, 0, None, null) == -1
     assert lib.nsr_weights_status(one, 9, 0, ctypes.byref(flags), null) == -2
     assert lib.nsr_weights_set_gamma(null, 2, 1, null) == -1 and lib.nsr_weights_set_gamma(one, 9, 1, null) == -2
+    assert lib.nsr_weights_set_options(null, 2, 1, null) == -1 and lib.nsr_weights_set_options(one, 2, 4, null) == -1    # unknown option bit
+    assert lib.nsr_weights_set_options(one, 9, 3, null) == -2
     p24 = (c_void_p * 24)(*[one] * 24)
     for pack in (lib.nsr_pack_weights, lib.nsr_pack_weights_async):
         assert pack(p24, null, 2, null) == -1 and pack(p24, c_void_p(24), 2, null) == -1      # null / misaligned blob

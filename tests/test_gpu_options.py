@@ -1,0 +1,167 @@
+"""The three option values of the path that no script of the reference turns on, through the C ABI, against fixtures made
+by the reference's own ``forward`` with the option set (tests/golden/make_golden_options.py) and against the oracle:
+
+  --no_dir                      models/networks.py:128, 160-169, 213-216   dir_encoding sees xyz_encoding_final alone
+  --color_activation none       models/networks.py:173-180                 the rgb head ends in nn.Identity
+  --sigma_activation softplus   models/rendering.py:69-73                  density = log(1 + exp(sigma - 1))
+
+``color_activation`` is a bit of the packed network's option word (``nsr_weights_set_options``), ``softplus`` a bit of the
+compositing entry points' ``white_bkgd`` word (include/nsr.h), ``no_dir`` is host-side: the narrow layer is packed as the
+full layer with 27 zero columns.  Rounds 3-4 refused all three loudly (tests/test_options.py).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from nerf_sr_amd.weights import make_state_dict, DIR_W, STATE_DICT_SPEC
+from oracle import nerf_oracle as oc
+from oracle import train_oracle as to
+from tests.util import train_draws
+
+pytestmark = pytest.mark.gpu
+
+CASES = {"no_dir": {"no_dir": True}, "color_none": {"color_activation": "none"}, "softplus": {"sigma_activation": "softplus"}}
+OUT_KEYS = ("coarse_comp_rgbs", "coarse_depth", "coarse_opacity", "coarse_weights",
+            "fine_comp_rgbs", "fine_depth", "fine_opacity", "fine_weights")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected (-m gpu) but no GPU is visible")
+    from nerf_sr_amd import ops as _ops
+    return _ops
+
+
+def _narrow(sd):
+    sd = dict(sd)
+    sd[DIR_W] = sd[DIR_W][:, :256].copy()
+    return sd
+
+
+def _networks(p, case):
+    sds = [make_state_dict(int(p["seed_coarse"])), make_state_dict(int(p["seed_fine"]))]
+    return [_narrow(sd) for sd in sds] if case == "no_dir" else sds
+
+
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
+@pytest.mark.parametrize("tag,white", [("llff", False), ("blender", True)])
+@pytest.mark.parametrize("case", list(CASES))
+def test_option_matches_the_reference(ops, golden_dir, case, tag, white, prec):
+    from nerf_sr_amd.model import NeRFDownXModel, default_options
+    g = np.load(os.path.join(golden_dir, "options.npz"))
+    p = np.load(os.path.join(golden_dir, f"path_{tag}.npz"))
+    n = int(g["n_rays"])
+    r = torch.from_numpy(p["rays"])[:n].cuda()
+    sd_c, sd_f = _networks(p, case)
+    m = NeRFDownXModel(default_options(white_bkgd=white, precision=prec, **CASES[case])).load_networks(sd_c, sd_f).eval()
+    m.set_input({"rays": r[None]})
+    m.forward()                                   # the fused route: one enqueue sequence, compositing inside the MLP launches
+    fused = {k: getattr(m, f"out_{k}").cpu() for k in OUT_KEYS}
+    # colours without the sigmoid are not confined to [0, 1]: the fixture's reach |rgb| ~ 4, the tolerance scales with them
+    tol = 1e-4 * max(1.0, float(np.abs(g[f"{case}_{tag}_fine_comp_rgbs"]).max()))
+    for k in ("coarse_comp_rgbs", "fine_comp_rgbs", "coarse_opacity", "fine_opacity"):
+        assert float((fused[k] - torch.from_numpy(g[f"{case}_{tag}_{k}"])).abs().max()) <= tol, k
+    assert float((fused["coarse_weights"] - torch.from_numpy(g[f"{case}_{tag}_coarse_weights"])).abs().max()) <= 1e-5
+    assert float((fused["coarse_depth"] - torch.from_numpy(g[f"{case}_{tag}_coarse_depth"])).abs().max()) <= 1e-4
+    # the oracle with the same option (pinned to the same fixture on the CPU, tests/test_oracle_golden.py)
+    kw = {k: v for k, v in CASES[case].items() if k != "no_dir"}
+    ref = oc.forward_rays(oc.to_torch_sd(sd_c), oc.to_torch_sd(sd_f), r.cpu(), 64, 64, white, **kw)
+    assert float((fused["fine_comp_rgbs"] - ref["fine_comp_rgbs"]).abs().max()) <= tol
+    # per-sample values through the unfused render_rays route + the stand-alone compositor: same bits as the fused launch
+    z, _ = ops.sample_along_rays(r[:, 0:3], r[:, 3:6], r[:, 6:7], r[:, 7:8], 64, False, False)
+    rgb, sig = ops.render_rays(m.netCoarse, r, z)
+    assert float((rgb[:16].cpu() - torch.from_numpy(g[f"{case}_{tag}_coarse_point_rgb"])).abs().max()) <= (2e-5 if case != "color_none" else 1e-4)
+    assert float((sig[:16].cpu() - torch.from_numpy(g[f"{case}_{tag}_coarse_point_sigma"])).abs().max()) <= 1e-3
+    comp, depth, opac, w = m.renderer(rgb.contiguous(), sig.contiguous(), z, white)
+    assert torch.equal(comp.cpu(), fused["coarse_comp_rgbs"]) and torch.equal(w.cpu(), fused["coarse_weights"])
+    # ... and the option does something
+    plain = NeRFDownXModel(default_options(white_bkgd=white, precision=prec)).load_networks(
+        make_state_dict(int(p["seed_coarse"])), make_state_dict(int(p["seed_fine"]))).eval()
+    plain.set_input({"rays": r[None]})
+    plain.forward()
+    assert float((plain.out_fine_comp_rgbs.cpu() - fused["fine_comp_rgbs"]).abs().max()) > 1e-3
+    assert m.netCoarse.status() == 0 and m.netFine.status() == 0
+
+
+def test_colour_head_options_combine_and_survive_repacking(ops, golden_dir):
+    """gamma_correct and color_activation are bits of ONE option word: setting one must not clear the other, and
+    load_state_dict (which re-packs and clears the word) re-applies both."""
+    from types import SimpleNamespace
+    p = np.load(os.path.join(golden_dir, "path_llff.npz"))
+    x = torch.from_numpy(p["mlp_in_512"]).cuda()
+    sd = make_state_dict(int(p["seed_coarse"]))
+    ref = oc.mlp_forward(oc.to_torch_sd(sd), x.cpu(), color_activation="none")
+    net = ops.VanillaMLP(SimpleNamespace(color_activation="none"), precision="fp32").load_state_dict(sd)
+    assert float((net(x).cpu() - ref).abs().max()) <= 2e-5
+    net.set_gamma_correct(True)        # pow(rgb, 1 / 2.2) of the raw head output: NaN for negative values, like torch.pow
+    got = net(x).cpu()
+    want = torch.pow(ref[:, :3], 1 / 2.2)
+    ok = torch.isfinite(want)
+    assert bool((torch.isfinite(got[:, :3]) == ok).all()) and float((got[:, :3][ok] - want[ok]).abs().max()) <= 1e-4
+    net.set_gamma_correct(False)
+    assert float((net(x).cpu() - ref).abs().max()) <= 2e-5          # 'none' survived both writes
+    net.load_state_dict(make_state_dict(7))
+    assert float((net(x).cpu() - oc.mlp_forward(oc.to_torch_sd(make_state_dict(7)), x.cpu(), color_activation="none")).abs().max()) <= 2e-5
+    net.status(clear=True)
+
+
+def test_narrow_network_round_trips(ops):
+    sd = _narrow(make_state_dict(11))
+    from types import SimpleNamespace
+    net = ops.VanillaMLP(SimpleNamespace(no_dir=True), precision="f16x3").load_state_dict(sd)
+    back = net.state_dict()
+    assert tuple(back[DIR_W].shape) == (128, 256) and np.array_equal(back[DIR_W].cpu().numpy(), sd[DIR_W])
+    with pytest.raises(ValueError, match="no_dir"):
+        net.load_state_dict(make_state_dict(11))            # a full network into a no_dir object
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "fp32"])
+def test_training_a_no_dir_network(golden_dir, prec):
+    """The training step on a --no_dir pair: losses and gradients against the training oracle run on the NARROW networks
+    (autograd through oracle/nerf_oracle.py, whose no_dir forward is pinned to the reference's fixture); the padded columns
+    get no gradient, so Adam never moves them and the exported state_dict is the narrow one."""
+    from nerf_sr_amd import train as tr
+    g = np.load(os.path.join(golden_dir, "train_llff_rand.npz"))
+    sd_c, sd_f = _narrow(make_state_dict(int(g["seed_coarse"]))), _narrow(make_state_dict(int(g["seed_fine"])))
+    t = tr.Trainer(sd_c, sd_f, white_bkgd=bool(g["white_bkgd"]), downscale=int(round(int(g["s2"]) ** 0.5)),
+                   randomized=bool(g["randomized"]), noise_std=float(g["noise_std"]), lr=float(g["lr"]), beta1=float(g["beta1"]),
+                   lambda_coarse_mse=float(g["lambda_coarse"]), lambda_fine_mse=float(g["lambda_fine"]), precision=prec, no_dir=True)
+    t.set_input(torch.from_numpy(g["rays"]).cuda(), torch.from_numpy(g["target_lr"]).cuda())
+    draws = {k: v for k, v in train_draws(g).items() if k != "noise_std"}
+    t.loss_and_grads(draws)
+    res, gc, gf = to.loss_and_grads(sd_c, sd_f, g["rays"], g["target_lr"], int(g["s2"]), 64, 64, bool(g["white_bkgd"]),
+                                    float(g["lambda_coarse"]), float(g["lambda_fine"]), dtype=torch.float64, **train_draws(g))
+    losses = t.losses.cpu().numpy()
+    assert abs(losses[0] - res["loss_coarse_mse"]) < 1e-6 and abs(losses[1] - res["loss_fine_mse"]) < 2e-6
+    for n, ref in enumerate((gc, gf)):
+        for k in STATE_DICT_SPEC:
+            got = t.grads[n][k].cpu().double()
+            if k == DIR_W:
+                assert not bool(got[:, 256:].any())
+                got = got[:, :256]
+            err, nrm = float((got - ref[k]).norm()), float(ref[k].norm())
+            assert err <= 2e-3 * nrm + 1e-9, (n, k, err / nrm)
+    for _ in range(3):
+        t.optimize_parameters(draws)
+    for n in range(2):
+        assert not bool(t.params[n][DIR_W][:, 256:].any())
+    out = t.state_dicts()
+    assert tuple(out[0][DIR_W].shape) == (128, 256) and not torch.equal(out[0][DIR_W].cpu(), torch.from_numpy(sd_c[DIR_W]))
+    assert t.status() == 0
+
+
+def test_training_refuses_the_other_two(golden_dir):
+    """The backward pass differentiates relu(sigma) and the sigmoid head only: the C entry point returns NSR_ERR_UNSUPPORTED
+    for a renderer word with the softplus bit, and Trainer has no argument through which either could be asked for."""
+    import inspect
+    from nerf_sr_amd import train as tr, _lib
+    assert not {"sigma_activation", "color_activation"} & set(inspect.signature(tr.Trainer.__init__).parameters)
+    g = np.load(os.path.join(golden_dir, "train_llff_det.npz"))
+    t = tr.Trainer(make_state_dict(1), make_state_dict(2), randomized=False)
+    t.set_input(torch.from_numpy(g["rays"]).cuda(), torch.from_numpy(g["target_lr"]).cuda())
+    t.white_bkgd = _lib.NSR_SIGMA_SOFTPLUS       # int(self.white_bkgd) is what reaches the C ABI
+    with pytest.raises(_lib.NsrError):
+        t.loss_and_grads({})

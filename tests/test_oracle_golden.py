@@ -150,3 +150,31 @@ def test_gamma_correct_forward(golden_dir):
         rgb, sig = oc.render_points(sd_c, xyz, oc.posenc(d, 4), gamma_correct=True)
         _close(rgb[:16], g[f"{tag}_coarse_point_rgb"])
         _close(sig[:16], g[f"{tag}_coarse_point_sigma"], 1e-5)
+
+
+@pytest.mark.parametrize("case", ["no_dir", "color_none", "softplus"])
+def test_option_values_no_script_uses(golden_dir, case):
+    """--no_dir (models/networks.py:160-169, 213-216), --color_activation none (:173-180), --sigma_activation softplus
+    (models/rendering.py:69-73): fixtures made by the reference's own forward with the option set
+    (tests/golden/make_golden_options.py)."""
+    g = np.load(os.path.join(golden_dir, "options.npz"))
+    kw = {"color_none": {"color_activation": "none"}, "softplus": {"sigma_activation": "softplus"}, "no_dir": {}}[case]
+    for tag, white in (("llff", False), ("blender", True)):
+        p = np.load(os.path.join(golden_dir, f"path_{tag}.npz"))
+        sds = [make_state_dict(int(p["seed_coarse"])), make_state_dict(int(p["seed_fine"]))]
+        if case == "no_dir":
+            for sd in sds:
+                sd["dir_encoding.0.weight"] = sd["dir_encoding.0.weight"][:, :256].copy()
+        sd_c, sd_f = oc.to_torch_sd(sds[0]), oc.to_torch_sd(sds[1])
+        rays = _t(p["rays"])[:int(g["n_rays"])]
+        out = oc.forward_rays(sd_c, sd_f, rays, 64, 64, white, **kw)
+        for k, v in out.items():
+            _close(v, g[f"{case}_{tag}_{k}"], 1e-5 if "depth" in k else ATOL)
+        plain = oc.forward_rays(oc.to_torch_sd(make_state_dict(int(p["seed_coarse"]))), oc.to_torch_sd(make_state_dict(int(p["seed_fine"]))),
+                                rays, 64, 64, white)
+        assert float((plain["fine_comp_rgbs"] - out["fine_comp_rgbs"]).abs().max()) > 1e-3      # the option does something
+        o, d, near, far = rays[:, 0:3], rays[:, 3:6], rays[:, 6:7], rays[:, 7:8]
+        z, xyz = oc.sample_coarse(o, d, near, far, 64)
+        rgb, sig = oc.render_points(sd_c, xyz, oc.posenc(d, 4), color_activation=kw.get("color_activation", "sigmoid"))
+        _close(rgb[:16], g[f"{case}_{tag}_coarse_point_rgb"], 1e-5 if case == "color_none" else ATOL)
+        _close(sig[:16], g[f"{case}_{tag}_coarse_point_sigma"], 1e-5)
