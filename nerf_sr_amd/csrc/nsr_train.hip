@@ -215,13 +215,30 @@ __global__ void __launch_bounds__(256) loss_finish_kernel(const double* __restri
   }
 }
 
+// --gamma_correct while training: the per-sample colours of a pass (rgb4: (P, 4), columns 0..2) become pow(rgb, 1 / 2.2)
+__global__ void __launch_bounds__(256) gamma_points_kernel(float* __restrict__ rgb4, int64_t P) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float4 v = reinterpret_cast<float4*>(rgb4)[p];
+  v.x = nsr_gamma(v.x); v.y = nsr_gamma(v.y); v.z = nsr_gamma(v.z);
+  reinterpret_cast<float4*>(rgb4)[p] = v;
+}
+// g d(colour) / d(pre-activation) of the colour head from the colour y it produced: the slope is y (1 - y) for the sigmoid
+// and y (1 - y^2.2) / 2.2 for the gamma-corrected sigmoid y = s^(1 / 2.2).  (The plain form keeps rounds 2-4's operation
+// order, (g y) (1 - y): training trajectories are compared bit for bit across builds.)
+__device__ __forceinline__ float colour_head_bwd(float g, float y, bool gamma) {
+  return gamma ? g * y * (1.0f - powf(y, 2.2f)) * (1.0f / 2.2f) : g * y * (1.0f - y);
+}
+
 // Backward of V1 (models/rendering.py:75-111) w.r.t. the point colours and densities, given dL/d(comp rgb).
 //   w_k = alpha_k T_k, T_k = prod_{j<k} f_j, f_j = 1 - alpha_j + 1e-10, alpha_k = 1 - exp(-delta_k relu(sigma_k))
 //   gw_k = gC . rgb_k (- sum(gC) with a white background: comp += 1 - sum_k w_k) (+ g_depth z_k: depth = sum_k w_k z_k, when a
 //   depth-variance loss is on)
 //   dL/dalpha_k = gw_k T_k - (sum_{i>k} gw_i w_i) / f_k
 //   dL/dsigma_k = dL/dalpha_k * delta_k exp(-delta_k relu(sigma_k)) * [sigma_k > 0];   dL/drgb_k = gC w_k
-// and through the sigmoid of the colour head: d(rgb_pre) = d(rgb) * rgb (1 - rgb).
+// and through the sigmoid of the colour head: d(rgb_pre) = d(rgb) * rgb (1 - rgb); under --gamma_correct the colours held
+// are y = s^(1/2.2), s = sigmoid(pre), and dy/d(pre) = s^(1/2.2 - 1) s (1 - s) / 2.2 = y (1 - y^2.2) / 2.2.
+// `white`: the training entry points' option word (NSR_WHITE_BKGD | NSR_TRAIN_GAMMA_CORRECT).
 // Outputs in the GEMM path's training layout: d_rgb (P, 32) columns 0..2 (3..31 zeroed); d_sigma into column 256 of
 // g1 (P, 288) (257..287 zeroed).  COMPACT (chain path): one float4 per point, d4[p] = (d_rgb_pre 0..2, d_sigma) -- 16 bytes
 // instead of 256 written per point, and one 16-byte read per point for the backward chain instead of two strided ones.
@@ -275,7 +292,8 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
   float T[K], w[K], gw[K];
   double pre[K];
   double acc = 0.0;
-  const float white_term = white ? __fadd_rn(__fadd_rn(gc0, gc1), gc2) : 0.0f;
+  const float white_term = (white & NSR_WHITE_BKGD) ? __fadd_rn(__fadd_rn(gc0, gc1), gc2) : 0.0f;
+  const bool gamma = (white & NSR_TRAIN_GAMMA_CORRECT) != 0;
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     const int k = lane * K + i;
@@ -300,9 +318,9 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
     const double suffix = total - (lane_excl + pre[i]);             // sum_{i' > k} gw w
     const float d_alpha = (float)((double)gw[i] * (double)T[i] - suffix / (double)ff[i]);
     const float d_sigma = (sg[i] > 0.0f) ? d_alpha * dl[i] * ex[i] : 0.0f;
-    const float dr0 = gc0 * w[i] * c0[i] * (1.0f - c0[i]);
-    const float dr1 = gc1 * w[i] * c1[i] * (1.0f - c1[i]);
-    const float dr2 = gc2 * w[i] * c2[i] * (1.0f - c2[i]);
+    const float dr0 = colour_head_bwd(gc0 * w[i], c0[i], gamma);
+    const float dr1 = colour_head_bwd(gc1 * w[i], c1[i], gamma);
+    const float dr2 = colour_head_bwd(gc2 * w[i], c2[i], gamma);
     if (COMPACT) {
       reinterpret_cast<float4*>(d_rgb)[p] = make_float4(dr0, dr1, dr2, d_sigma);
       bs0 += dr0; bs1 += dr1; bs2 += dr2; bs3 += d_sigma;
@@ -998,7 +1016,10 @@ int train_impl(const float* const* w_coarse, const float* const* w_fine, float* 
   if (!rays || !target_lr || !outs[0] || !outs[4] || !lr_coarse || !lr_fine || !losses || !workspace)
     return NSR_ERR_INVALID_ARG;
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return NSR_ERR_INVALID_ARG;
-  if ((white_bkgd & ~NSR_WHITE_BKGD) != 0) return NSR_ERR_UNSUPPORTED;   // the backward pass differentiates relu(sigma) only (include/nsr.h)
+  // the backward pass differentiates relu(sigma) only (include/nsr.h: NSR_SIGMA_SOFTPLUS is refused); NSR_TRAIN_GAMMA_CORRECT is the
+  // training entry points' own bit (include/nsr_train.h)
+  if ((white_bkgd & ~(NSR_WHITE_BKGD | NSR_TRAIN_GAMMA_CORRECT)) != 0) return NSR_ERR_UNSUPPORTED;
+  const int gamma = (white_bkgd & NSR_TRAIN_GAMMA_CORRECT) != 0;
   if (workspace_bytes < nsr_train_workspace_bytes_for(precision, ray_chunk, n_coarse, n_importance)) return NSR_ERR_WORKSPACE;
   const bool noisy = noise_std > 0.0f;
   hipStream_t st = nsr_stream(stream);
@@ -1058,7 +1079,11 @@ int train_impl(const float* const* w_coarse, const float* const* w_fine, float* 
       float* depth = outs[4 * net + 1] ? outs[4 * net + 1] + r0 : (depth_var ? k.scratch_out : nullptr);   // the depth-variance loss reads it
       float* opac = outs[4 * net + 2] ? outs[4 * net + 2] + r0 : nullptr;
       float* wts = outs[4 * net + 3] ? outs[4 * net + 3] + r0 * N : (net ? nullptr : k.w_c);
-      NSR_TRY(nsr_composite(k.rgb, 4, k.sig, 1, z, rc, N, white_bkgd, comp, depth, opac, wts, stream));
+      if (gamma) {   // render_rays: out_rgbs = pow(out_rgbs, 1 / 2.2) per sample, in training too (nerf_downX_model.py:271-276)
+        hipLaunchKernelGGL(gamma_points_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, k.rgb, P);
+        NSR_CHECK_LAUNCH();
+      }
+      NSR_TRY(nsr_composite(k.rgb, 4, k.sig, 1, z, rc, N, white_bkgd & NSR_WHITE_BKGD, comp, depth, opac, wts, stream));
       // s^2 mean, loss, dL/d(comp)
       const float lambda = net ? lambda_fine : lambda_coarse;
       const int nblk = (int)((n_lr + 255) / 256);

@@ -79,11 +79,9 @@ class Trainer:
                  use_var_loss: bool = False, lambda_coarse_var: float = 0.01, lambda_fine_var: float = 0.01,
                  use_depth_var_loss: bool = False, lambda_coarse_depth_var: float = 0.01, lambda_fine_depth_var: float = 0.01,
                  no_dir: bool = False):
-        if gamma_correct:
-            # render_rays applies rgb ** (1 / 2.2) per sample under --gamma_correct (models/nerf_downX_model.py:271-276) in
-            # training too; the training kernels have no such branch, and ignoring the option would train another model
-            raise ValueError("training with gamma_correct=True is not built (the HIP training step has no gamma branch); "
-                             "the render path supports it (VanillaMLP.set_gamma_correct)")
+        # render_rays applies rgb ** (1 / 2.2) per sample under --gamma_correct (models/nerf_downX_model.py:271-276) in training
+        # too: NSR_TRAIN_GAMMA_CORRECT of the step's option word (include/nsr_train.h)
+        self.gamma_correct = bool(gamma_correct)
         if precision not in _lib.TRAIN_PRECISIONS:
             raise ValueError("precision must be 'fp32' (every product on the fp32 MFMA, layer by layer), 'f16x3' (the chain "
                              "kernels: forward and input gradients on the split-fp16 MFMA, weight gradients on one fp16 MFMA "
@@ -180,7 +178,8 @@ class Trainer:
         wc, wf = _ptr_array(list(self.params[0].values())), _ptr_array(list(self.params[1].values()))
         gc, gf = _ptr_array(list(self.grads[0].values())), _ptr_array(list(self.grads[1].values()))
         common = (wc, wf, gc, gf, _p(rays), stride, R, self.s2, _p(self.data_rgbs), nc, self.N_importance,
-                  int(self.white_bkgd), int(self.lindisp), _p(draws.get("u_coarse")), _p(draws.get("u_fine")),
+                  int(self.white_bkgd) | (_lib.NSR_TRAIN_GAMMA_CORRECT if self.gamma_correct else 0), int(self.lindisp),
+                  _p(draws.get("u_coarse")), _p(draws.get("u_fine")),
                   _p(draws.get("noise_coarse")), _p(draws.get("noise_fine")), self.noise_std,
                   self.lambda_coarse * gs, self.lambda_fine * gs, self._prec, chunk, outs, _p(lr_c), _p(lr_f), _p(self.losses),
                   _p(self._ws), self._ws.numel(), _stream())

@@ -174,6 +174,10 @@ def one_case(tag, white, ndc, near_far, s, n_lr, randomized, noise_std, seed, ex
 def main():
     mg.install_shim()
     torch.set_grad_enabled(True)
+    if len(sys.argv) > 1 and sys.argv[1] == "gamma":      # only the round-5 addition (the others regenerate bit for bit)
+        # --gamma_correct in training (render_rays, nerf_downX_model.py:271-276)
+        one_case("llff_gamma", False, True, (0.0, 1.0), 2, 24, True, 1.0, 5, ("--gamma_correct",))
+        return
     one_case("llff_det", False, True, (0.0, 1.0), 2, 24, False, 0.0, 1)
     one_case("llff_rand", False, True, (0.0, 1.0), 2, 24, True, 1.0, 2)
     one_case("blender_rand", True, False, (2.0, 6.0), 2, 24, True, 0.0, 3)
@@ -182,6 +186,7 @@ def main():
     one_case("blender_var", True, False, (2.0, 6.0), 2, 24, True, 0.0, 4,
              ("--use_var_loss", "--lambda_coarse_var", "0.05", "--lambda_fine_var", "0.08",
               "--use_depth_var_loss", "--lambda_coarse_depth_var", "0.3", "--lambda_fine_depth_var", "0.2"))
+    one_case("llff_gamma", False, True, (0.0, 1.0), 2, 24, True, 1.0, 5, ("--gamma_correct",))
 
 
 if __name__ == "__main__":

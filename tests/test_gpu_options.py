@@ -165,3 +165,44 @@ def test_training_refuses_the_other_two(golden_dir):
     t.white_bkgd = _lib.NSR_SIGMA_SOFTPLUS       # int(self.white_bkgd) is what reaches the C ABI
     with pytest.raises(_lib.NsrError):
         t.loss_and_grads({})
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "fp32", "f16x3_gemm"])
+def test_training_with_gamma_correct(golden_dir, prec):
+    """--gamma_correct while training (render_rays, models/nerf_downX_model.py:271-276): one optimize_parameters of the
+    reference with the option on (tests/golden/train_llff_gamma.npz) -- losses, forward outputs, every gradient tensor
+    against the reference's digests and the fp64 oracle, all three implementations of the step."""
+    from nerf_sr_amd import train as tr
+    from tests.util import sample_idx
+    g = np.load(os.path.join(golden_dir, "train_llff_gamma.npz"))
+    sd_c, sd_f = make_state_dict(int(g["seed_coarse"])), make_state_dict(int(g["seed_fine"]))
+    t = tr.Trainer(sd_c, sd_f, white_bkgd=bool(g["white_bkgd"]), downscale=int(round(int(g["s2"]) ** 0.5)),
+                   randomized=bool(g["randomized"]), noise_std=float(g["noise_std"]), lr=float(g["lr"]), beta1=float(g["beta1"]),
+                   lambda_coarse_mse=float(g["lambda_coarse"]), lambda_fine_mse=float(g["lambda_fine"]), precision=prec,
+                   gamma_correct=True)
+    t.set_input(torch.from_numpy(g["rays"]).cuda(), torch.from_numpy(g["target_lr"]).cuda())
+    draws = {k: v for k, v in train_draws(g).items() if k != "noise_std"}
+    t.loss_and_grads(draws)
+    losses = t.losses.cpu().numpy()
+    assert abs(losses[0] - float(g["loss_coarse_mse"])) < 1e-6 and abs(losses[1] - float(g["loss_fine_mse"])) < 2e-6
+    np.testing.assert_allclose(t.out["coarse_comp_rgbs"].cpu().numpy(), g["hr_coarse"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(t.out["lr_fine"].cpu().numpy(), g["lr_fine"], rtol=0, atol=1e-4)
+    _, gc, gf = to.loss_and_grads(sd_c, sd_f, g["rays"], g["target_lr"], int(g["s2"]), 64, 64, bool(g["white_bkgd"]),
+                                  float(g["lambda_coarse"]), float(g["lambda_fine"]), dtype=torch.float64, gamma_correct=True,
+                                  **train_draws(g))
+    for n, (name, ref) in enumerate((("coarse", gc), ("fine", gf))):
+        for k in STATE_DICT_SPEC:
+            got = t.grads[n][k].cpu().double()
+            err, nrm = float((got - ref[k]).norm()), float(ref[k].norm())
+            assert err <= 2e-3 * nrm + 1e-9, (name, k, err / nrm)
+            ref_norm = float(g[f"gnorm_{name}.{k}"])
+            assert abs(float(got.norm()) - ref_norm) <= 2e-3 * ref_norm + 1e-9, (name, k)
+            sub = got.reshape(-1).numpy()[sample_idx(got.numel())]
+            want_sub = g[f"grad_{name}.{k}"].astype(np.float64)
+            assert np.linalg.norm(sub - want_sub) <= 4e-3 * np.linalg.norm(want_sub) + 1e-9, (name, k)
+    # the option changes the step (same inputs without it)
+    t0 = tr.Trainer(sd_c, sd_f, white_bkgd=bool(g["white_bkgd"]), randomized=True, noise_std=float(g["noise_std"]), precision=prec)
+    t0.set_input(torch.from_numpy(g["rays"]).cuda(), torch.from_numpy(g["target_lr"]).cuda())
+    t0.loss_and_grads(draws)
+    assert abs(float(t0.losses[0]) - float(losses[0])) > 1e-3
+    assert t.status() == 0

@@ -65,10 +65,16 @@ def test_no_dir_state_dict_shapes():
     assert padded.shape == (128, 283) and np.array_equal(padded[:, :256], narrow[DIR_W]) and not padded[:, 256:].any()
 
 
-def test_training_rejects_gamma_correct():
-    """render_rays applies rgb ** (1 / 2.2) in training too (models/nerf_downX_model.py:271-276); the HIP training step has
-    no such branch, so the option must raise instead of training another model."""
-    from nerf_sr_amd import train
-    from nerf_sr_amd.weights import make_state_dict
-    with pytest.raises(ValueError, match="gamma_correct"):
-        train.Trainer(make_state_dict(1), make_state_dict(2), gamma_correct=True, device="cuda")
+def test_training_option_word():
+    """render_rays applies rgb ** (1 / 2.2) in training too (models/nerf_downX_model.py:271-276): rounds 3-4 refused the
+    option (the step had no such branch); since round 5 it is NSR_TRAIN_GAMMA_CORRECT of the step's option word
+    (include/nsr_train.h; parity in tests/test_gpu_options.py against the reference's own --gamma_correct iteration)."""
+    import re
+    from nerf_sr_amd import _lib
+    here = __import__("os").path.dirname(__import__("os").path.abspath(__file__))
+    hdr = open(__import__("os").path.join(here, "..", "include", "nsr_train.h")).read()
+    assert int(re.search(r"#define NSR_TRAIN_GAMMA_CORRECT (\d+)", hdr).group(1)) == _lib.NSR_TRAIN_GAMMA_CORRECT == 4
+    top = open(__import__("os").path.join(here, "..", "include", "nsr.h")).read()
+    assert int(re.search(r"#define NSR_WHITE_BKGD (\d+)", top).group(1)) == _lib.NSR_WHITE_BKGD
+    assert int(re.search(r"#define NSR_SIGMA_SOFTPLUS (\d+)", top).group(1)) == _lib.NSR_SIGMA_SOFTPLUS
+    assert int(re.search(r"#define NSR_OPT_COLOR_NONE (\d+)u", top).group(1)) == _lib.NSR_OPT_COLOR_NONE

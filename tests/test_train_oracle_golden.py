@@ -12,7 +12,7 @@ from oracle import nerf_oracle as oc
 from oracle import train_oracle as tr
 from tests.util import sample_idx, train_draws
 
-CASES = ["llff_det", "llff_rand", "blender_rand", "blender_var"]     # blender_var: --use_var_loss --use_depth_var_loss
+CASES = ["llff_det", "llff_rand", "blender_rand", "blender_var", "llff_gamma"]     # blender_var: --use_var_loss --use_depth_var_loss; llff_gamma: --gamma_correct
 
 
 @pytest.fixture(scope="module", params=CASES)
@@ -21,7 +21,8 @@ def case(request, golden_dir):
     sd_c, sd_f = make_state_dict(int(g["seed_coarse"])), make_state_dict(int(g["seed_fine"]))
     res, gc, gf = tr.loss_and_grads(sd_c, sd_f, g["rays"], g["target_lr"], int(g["s2"]), 64, 64,
                                     bool(g["white_bkgd"]), float(g["lambda_coarse"]), float(g["lambda_fine"]),
-                                    lambda_var=(g["lambda_var"].tolist() if "lambda_var" in g else None), **train_draws(g))
+                                    lambda_var=(g["lambda_var"].tolist() if "lambda_var" in g else None),
+                                    gamma_correct=request.param.endswith("gamma"), **train_draws(g))
     return g, sd_c, res, gc, gf
 
 
