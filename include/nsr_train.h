@@ -62,15 +62,18 @@ size_t nsr_train_workspace_bytes_for(int precision, int64_t ray_chunk, int n_coa
  * GEMM contracts over the points in K tiles of 32); otherwise NSR_ERR_UNSUPPORTED is returned before anything
  * is enqueued (outputs and gradients untouched).  All of the reference's scripts (64 + 64 samples) satisfy it
  * for any ray count.
- * white_bkgd: a word of options like the render path's (include/nsr.h): NSR_WHITE_BKGD, and NSR_TRAIN_GAMMA_CORRECT =
- * --gamma_correct while training (render_rays returns pow(rgb, 1 / 2.2) per sample, nerf_downX_model.py:271-276; the
- * colours are corrected between the network and the compositor and the backward pass carries the slope
- * y (1 - y^2.2) / 2.2 of the corrected sigmoid).  NSR_SIGMA_SOFTPLUS is refused (NSR_ERR_UNSUPPORTED): the backward
- * kernels differentiate relu(sigma) only.
+ * white_bkgd: a word of options like the render path's (include/nsr.h): NSR_WHITE_BKGD and NSR_SIGMA_SOFTPLUS as there
+ * (the backward pass carries sigmoid(sigma - 1) instead of [sigma > 0]), and the colour head's two, which the render
+ * path keeps in the packed network: NSR_TRAIN_GAMMA_CORRECT = --gamma_correct while training (render_rays returns
+ * pow(rgb, 1 / 2.2) per sample, nerf_downX_model.py:271-276; the colours are corrected between the network and the
+ * compositor and the backward pass carries the slope y (1 - y^2.2) / 2.2 of the corrected sigmoid);
+ * NSR_TRAIN_COLOR_NONE = --color_activation none (models/networks.py:173-180; slope 1).  The two together are
+ * NSR_ERR_UNSUPPORTED (the power of an unbounded head is NaN for every negative value); any other bit NSR_ERR_INVALID_ARG.
  * outs: the 8 forward outputs in nsr_forward_rays order (entries may be NULL except the two comp_rgbs).
  * lr_coarse / lr_fine: (R / s2, 3) s2-means (comp_low_res_output, :326-348); losses: DEVICE float[2] =
  * { lambda_coarse * mse_coarse, lambda_fine * mse_fine }. */
 #define NSR_TRAIN_GAMMA_CORRECT 4
+#define NSR_TRAIN_COLOR_NONE 8
 int nsr_train_loss_and_grads(const float* const* w_coarse, const float* const* w_fine, float* const* g_coarse,
                              float* const* g_fine, const float* rays, int ray_stride, int64_t R, int s2,
                              const float* target_lr, int n_coarse, int n_importance, int white_bkgd, int lindisp,

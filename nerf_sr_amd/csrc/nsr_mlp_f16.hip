@@ -720,7 +720,9 @@ mlp_f16x3_kernel(const float* __restrict__ packed, const float* __restrict__ x, 
 
   const int64_t n_tiles = (P + 127) / 128;
   const int samples = (NS > 0) ? NS : N;
-  const unsigned opts = TRAIN ? 0u : nsr_opts(tail);      // colour-head options of the packed network (nsr_common.h)
+  // colour-head options of the packed network (nsr_common.h); TRAIN: word 1 of the step's status block, of which the kernel
+  // honours the activation only (the step applies --gamma_correct itself, between this launch and the compositor)
+  const unsigned opts = nsr_opts(tail) & (TRAIN ? kOptColorNone : ~0u);
   // (the inference instantiations never use them; their voff0 is the expression rounds 2-4 had here, which keeps the register
   // allocation -- and with it the whole ISA of those kernels -- bit-identical to the measured round-4 build)
   const unsigned voff0 = TRAIN ? unit_voff(m, h, 0) : 4u * (unsigned)(m + 128 * h), voff1 = TRAIN ? unit_voff(m, h, 1) : 0u;   // panel stores: this lane's slot in either unit of a block

@@ -226,8 +226,10 @@ __global__ void __launch_bounds__(256) gamma_points_kernel(float* __restrict__ r
 // g d(colour) / d(pre-activation) of the colour head from the colour y it produced: the slope is y (1 - y) for the sigmoid
 // and y (1 - y^2.2) / 2.2 for the gamma-corrected sigmoid y = s^(1 / 2.2).  (The plain form keeps rounds 2-4's operation
 // order, (g y) (1 - y): training trajectories are compared bit for bit across builds.)
-__device__ __forceinline__ float colour_head_bwd(float g, float y, bool gamma) {
-  return gamma ? g * y * (1.0f - powf(y, 2.2f)) * (1.0f / 2.2f) : g * y * (1.0f - y);
+// head: 0 = sigmoid, 1 = gamma-corrected sigmoid, 2 = none (--color_activation none: slope 1)
+__device__ __forceinline__ float colour_head_bwd(float g, float y, int head) {
+  if (head == 2) return g;
+  return head == 1 ? g * y * (1.0f - powf(y, 2.2f)) * (1.0f / 2.2f) : g * y * (1.0f - y);
 }
 
 // Backward of V1 (models/rendering.py:75-111) w.r.t. the point colours and densities, given dL/d(comp rgb).
@@ -238,7 +240,8 @@ __device__ __forceinline__ float colour_head_bwd(float g, float y, bool gamma) {
 //   dL/dsigma_k = dL/dalpha_k * delta_k exp(-delta_k relu(sigma_k)) * [sigma_k > 0];   dL/drgb_k = gC w_k
 // and through the sigmoid of the colour head: d(rgb_pre) = d(rgb) * rgb (1 - rgb); under --gamma_correct the colours held
 // are y = s^(1/2.2), s = sigmoid(pre), and dy/d(pre) = s^(1/2.2 - 1) s (1 - s) / 2.2 = y (1 - y^2.2) / 2.2.
-// `white`: the training entry points' option word (NSR_WHITE_BKGD | NSR_TRAIN_GAMMA_CORRECT).
+// `white`: the training entry points' option word (include/nsr_train.h).  NSR_SIGMA_SOFTPLUS: density log(1 + exp(sigma - 1)),
+// whose slope sigmoid(sigma - 1) replaces [sigma > 0]; NSR_TRAIN_COLOR_NONE: no colour activation, slope 1.
 // Outputs in the GEMM path's training layout: d_rgb (P, 32) columns 0..2 (3..31 zeroed); d_sigma into column 256 of
 // g1 (P, 288) (257..287 zeroed).  COMPACT (chain path): one float4 per point, d4[p] = (d_rgb_pre 0..2, d_sigma) -- 16 bytes
 // instead of 256 written per point, and one 16-byte read per point for the backward chain instead of two strided ones.
@@ -254,6 +257,8 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
   const int64_t base = r * N;
   const float gc0 = g_comp[r * 3 + 0], gc1 = g_comp[r * 3 + 1], gc2 = g_comp[r * 3 + 2];
   const float gd = g_depth ? g_depth[r] : 0.0f;
+  const int head = (white & NSR_TRAIN_GAMMA_CORRECT) ? 1 : ((white & NSR_TRAIN_COLOR_NONE) ? 2 : 0);
+  const bool softplus = (white & NSR_SIGMA_SOFTPLUS) != 0;
   float zk[K], sg[K], c0[K], c1[K], c2[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) {
@@ -274,7 +279,7 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
     const int k = lane * K + i;
     const float zn = (i + 1 < K) ? zk[(i + 1 < K) ? i + 1 : i] : z_next_lane;
     const float delta = (k >= N - 1) ? 1e10f : __fsub_rn(zn, zk[i]);
-    const float e = expf(__fmul_rn(-delta, fmaxf(sg[i], 0.0f)));
+    const float e = expf(__fmul_rn(-delta, softplus ? nsr_softplus_density(sg[i]) : fmaxf(sg[i], 0.0f)));
     float a = __fsub_rn(1.0f, e);
     if (k >= N) a = 0.0f;
     alpha[i] = a;
@@ -293,7 +298,7 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
   double pre[K];
   double acc = 0.0;
   const float white_term = (white & NSR_WHITE_BKGD) ? __fadd_rn(__fadd_rn(gc0, gc1), gc2) : 0.0f;
-  const bool gamma = (white & NSR_TRAIN_GAMMA_CORRECT) != 0;
+
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     const int k = lane * K + i;
@@ -317,10 +322,12 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
     const int64_t p = base + k;
     const double suffix = total - (lane_excl + pre[i]);             // sum_{i' > k} gw w
     const float d_alpha = (float)((double)gw[i] * (double)T[i] - suffix / (double)ff[i]);
-    const float d_sigma = (sg[i] > 0.0f) ? d_alpha * dl[i] * ex[i] : 0.0f;
-    const float dr0 = colour_head_bwd(gc0 * w[i], c0[i], gamma);
-    const float dr1 = colour_head_bwd(gc1 * w[i], c1[i], gamma);
-    const float dr2 = colour_head_bwd(gc2 * w[i], c2[i], gamma);
+    float d_sigma;
+    if (softplus) d_sigma = d_alpha * dl[i] * ex[i] * (1.0f / (1.0f + expf(1.0f - sg[i])));      // d log(1 + e^(x - 1)) / dx = sigmoid(x - 1)
+    else d_sigma = (sg[i] > 0.0f) ? d_alpha * dl[i] * ex[i] : 0.0f;
+    const float dr0 = colour_head_bwd(gc0 * w[i], c0[i], head);
+    const float dr1 = colour_head_bwd(gc1 * w[i], c1[i], head);
+    const float dr2 = colour_head_bwd(gc2 * w[i], c2[i], head);
     if (COMPACT) {
       reinterpret_cast<float4*>(d_rgb)[p] = make_float4(dr0, dr1, dr2, d_sigma);
       bs0 += dr0; bs1 += dr1; bs2 += dr2; bs3 += d_sigma;
@@ -749,7 +756,7 @@ int colsum(hipStream_t st, const float* src, int64_t ld, int64_t P, int col0, in
 }
 
 // M1 forward with everything kept for the backward pass
-int net_forward(hipStream_t st, const float* const* w, const WeightPack& q, const Work& k, int64_t P, int precision) {
+int net_forward(hipStream_t st, const float* const* w, const WeightPack& q, const Work& k, int64_t P, int precision, int color_none) {
   const unsigned short* sp = precision == NSR_F16X3 ? q.split : nullptr;
   NSR_TRY(lin_fwd(st, k.x5, kX5, kPe, q.w1p, 64, w[1], kActRelu, k.h[1], kW, P, kW, kW, sp, 0));
   NSR_TRY(lin_fwd(st, k.h[1], kW, kW, w[2], 256, w[3], kActRelu, k.h[2], kW, P, kW, kW, sp, 1));
@@ -765,7 +772,7 @@ int net_forward(hipStream_t st, const float* const* w, const WeightPack& q, cons
   NSR_TRY(lin_fwd(st, k.h[8], kW, kW, q.w9p, 256, q.b9p, kActNone, k.gs, kGs, P, kW, kW, sp, 8));
   NSR_TRY(lin_fwd(st, k.h[8], kW, kW, q.w9p + 256 * 256, 256, q.b9p + 256, kActNone, k.gs + kSigmaCol, kGs, P, 32, 1, sp, 9));
   NSR_TRY(lin_fwd(st, k.gs, kGs, kGs, q.wdirp, 288, w[kDirB], kActRelu, k.cc, kDirOut, P, kDirOut, kDirOut, sp, 10));
-  NSR_TRY(lin_fwd(st, k.cc, kDirOut, kDirOut, q.wrgbp, 128, q.brgbp, kActSigmoid, k.rgb, 4, P, kRgbPad, 3, sp, 11));
+  NSR_TRY(lin_fwd(st, k.cc, kDirOut, kDirOut, q.wrgbp, 128, q.brgbp, color_none ? kActNone : kActSigmoid, k.rgb, 4, P, kRgbPad, 3, sp, 11));
   return NSR_OK;
 }
 
@@ -1016,10 +1023,11 @@ int train_impl(const float* const* w_coarse, const float* const* w_fine, float* 
   if (!rays || !target_lr || !outs[0] || !outs[4] || !lr_coarse || !lr_fine || !losses || !workspace)
     return NSR_ERR_INVALID_ARG;
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return NSR_ERR_INVALID_ARG;
-  // the backward pass differentiates relu(sigma) only (include/nsr.h: NSR_SIGMA_SOFTPLUS is refused); NSR_TRAIN_GAMMA_CORRECT is the
-  // training entry points' own bit (include/nsr_train.h)
-  if ((white_bkgd & ~(NSR_WHITE_BKGD | NSR_TRAIN_GAMMA_CORRECT)) != 0) return NSR_ERR_UNSUPPORTED;
-  const int gamma = (white_bkgd & NSR_TRAIN_GAMMA_CORRECT) != 0;
+  // the step's option word (include/nsr_train.h): the renderer's two bits + the colour head's two
+  constexpr int kTrainOpts = NSR_WHITE_BKGD | NSR_SIGMA_SOFTPLUS | NSR_TRAIN_GAMMA_CORRECT | NSR_TRAIN_COLOR_NONE;
+  if ((white_bkgd & ~kTrainOpts) != 0) return NSR_ERR_INVALID_ARG;
+  const int gamma = (white_bkgd & NSR_TRAIN_GAMMA_CORRECT) != 0, color_none = (white_bkgd & NSR_TRAIN_COLOR_NONE) != 0;
+  if (gamma && color_none) return NSR_ERR_UNSUPPORTED;   // pow(x, 1 / 2.2) of an unbounded head: NaN for every negative value
   if (workspace_bytes < nsr_train_workspace_bytes_for(precision, ray_chunk, n_coarse, n_importance)) return NSR_ERR_WORKSPACE;
   const bool noisy = noise_std > 0.0f;
   hipStream_t st = nsr_stream(stream);
@@ -1043,6 +1051,10 @@ int train_impl(const float* const* w_coarse, const float* const* w_fine, float* 
     NSR_TRY(prepare_weights(st, w_fine, k.pack[1], gemm_precision(precision)));
   }
   if (hipMemsetAsync(k.carry, 0, 8 * sizeof(double), st) != hipSuccess) return NSR_ERR_LAUNCH;
+  // word 1 of the status block = the colour-head option word the TRAIN instantiation of the forward kernel reads (the
+  // blob tail's layout, nsr_common.h); written every call, so a workspace that was never reset cannot switch an option on
+  if (chain && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(k.status + 1), color_none ? (int)kOptColorNone : 0, 1, st) != hipSuccess)
+    return NSR_ERR_LAUNCH;
 
   for (int64_t r0 = 0; r0 < R; r0 += ray_chunk) {
     const int64_t rc = (R - r0 < ray_chunk) ? R - r0 : ray_chunk;
@@ -1069,7 +1081,7 @@ int train_impl(const float* const* w_coarse, const float* const* w_fine, float* 
         NSR_CHECK_LAUNCH();
       }
       if (chain) NSR_TRY(nsr_f16x3_train_forward(k.stream_f[net], rays_c, ray_stride, z, rc, N, k.rgb, k.zpan, k.sgn, k.status, stream));
-      else NSR_TRY(net_forward(st, w, k.pack[net], k, P, gemm_precision(precision)));
+      else NSR_TRY(net_forward(st, w, k.pack[net], k, P, gemm_precision(precision), color_none));
       const float* noise = net ? noise_fine : noise_coarse;
       hipLaunchKernelGGL(sigma_noise_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st,
                          chain ? k.rgb + 3 : k.gs + kSigmaCol, chain ? 4 : kGs, (noisy && noise) ? noise + r0 * N : nullptr,
@@ -1083,7 +1095,7 @@ int train_impl(const float* const* w_coarse, const float* const* w_fine, float* 
         hipLaunchKernelGGL(gamma_points_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, k.rgb, P);
         NSR_CHECK_LAUNCH();
       }
-      NSR_TRY(nsr_composite(k.rgb, 4, k.sig, 1, z, rc, N, white_bkgd & NSR_WHITE_BKGD, comp, depth, opac, wts, stream));
+      NSR_TRY(nsr_composite(k.rgb, 4, k.sig, 1, z, rc, N, white_bkgd & (NSR_WHITE_BKGD | NSR_SIGMA_SOFTPLUS), comp, depth, opac, wts, stream));
       // s^2 mean, loss, dL/d(comp)
       const float lambda = net ? lambda_fine : lambda_coarse;
       const int nblk = (int)((n_lr + 255) / 256);

@@ -171,12 +171,19 @@ def one_case(tag, white, ndc, near_far, s, n_lr, randomized, noise_std, seed, ex
     print(tag, "loss", out["loss_tot"], "->", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def option_cases():
+    # --gamma_correct in training (render_rays, nerf_downX_model.py:271-276); --sigma_activation softplus
+    # (models/rendering.py:69-73); --color_activation none (models/networks.py:173-180)
+    one_case("llff_gamma", False, True, (0.0, 1.0), 2, 24, True, 1.0, 5, ("--gamma_correct",))
+    one_case("blender_softplus", True, False, (2.0, 6.0), 2, 24, True, 0.0, 6, ("--sigma_activation", "softplus"))
+    one_case("llff_colornone", False, True, (0.0, 1.0), 2, 24, True, 1.0, 7, ("--color_activation", "none"))
+
+
 def main():
     mg.install_shim()
     torch.set_grad_enabled(True)
-    if len(sys.argv) > 1 and sys.argv[1] == "gamma":      # only the round-5 addition (the others regenerate bit for bit)
-        # --gamma_correct in training (render_rays, nerf_downX_model.py:271-276)
-        one_case("llff_gamma", False, True, (0.0, 1.0), 2, 24, True, 1.0, 5, ("--gamma_correct",))
+    if len(sys.argv) > 1 and sys.argv[1] == "options":      # only the round-5 additions (the others regenerate bit for bit)
+        option_cases()
         return
     one_case("llff_det", False, True, (0.0, 1.0), 2, 24, False, 0.0, 1)
     one_case("llff_rand", False, True, (0.0, 1.0), 2, 24, True, 1.0, 2)
@@ -186,7 +193,7 @@ def main():
     one_case("blender_var", True, False, (2.0, 6.0), 2, 24, True, 0.0, 4,
              ("--use_var_loss", "--lambda_coarse_var", "0.05", "--lambda_fine_var", "0.08",
               "--use_depth_var_loss", "--lambda_coarse_depth_var", "0.3", "--lambda_fine_depth_var", "0.2"))
-    one_case("llff_gamma", False, True, (0.0, 1.0), 2, 24, True, 1.0, 5, ("--gamma_correct",))
+    option_cases()
 
 
 if __name__ == "__main__":

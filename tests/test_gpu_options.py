@@ -7,7 +7,8 @@ by the reference's own ``forward`` with the option set (tests/golden/make_golden
 
 ``color_activation`` is a bit of the packed network's option word (``nsr_weights_set_options``), ``softplus`` a bit of the
 compositing entry points' ``white_bkgd`` word (include/nsr.h), ``no_dir`` is host-side: the narrow layer is packed as the
-full layer with 27 zero columns.  Rounds 3-4 refused all three loudly (tests/test_options.py).
+full layer with 27 zero columns.  Rounds 3-4 refused all three loudly (tests/test_options.py).  The training step takes
+them too (and --gamma_correct), as bits of its own option word (include/nsr_train.h).
 """
 import os
 
@@ -153,53 +154,62 @@ def test_training_a_no_dir_network(golden_dir, prec):
     assert t.status() == 0
 
 
-def test_training_refuses_the_other_two(golden_dir):
-    """The backward pass differentiates relu(sigma) and the sigmoid head only: the C entry point returns NSR_ERR_UNSUPPORTED
-    for a renderer word with the softplus bit, and Trainer has no argument through which either could be asked for."""
-    import inspect
+def test_training_option_word_is_checked(golden_dir):
+    """Unknown bits of the step's option word are NSR_ERR_INVALID_ARG; --gamma_correct with --color_activation none (the
+    power of an unbounded head: NaN for every negative value) is refused by the host mirror and by the C entry point."""
     from nerf_sr_amd import train as tr, _lib
-    assert not {"sigma_activation", "color_activation"} & set(inspect.signature(tr.Trainer.__init__).parameters)
+    with pytest.raises(ValueError, match="gamma_correct"):
+        tr.Trainer(make_state_dict(1), make_state_dict(2), gamma_correct=True, color_activation="none")
+    with pytest.raises(ValueError):
+        tr.Trainer(make_state_dict(1), make_state_dict(2), sigma_activation="elu")
     g = np.load(os.path.join(golden_dir, "train_llff_det.npz"))
     t = tr.Trainer(make_state_dict(1), make_state_dict(2), randomized=False)
     t.set_input(torch.from_numpy(g["rays"]).cuda(), torch.from_numpy(g["target_lr"]).cuda())
-    t.white_bkgd = _lib.NSR_SIGMA_SOFTPLUS       # int(self.white_bkgd) is what reaches the C ABI
-    with pytest.raises(_lib.NsrError):
-        t.loss_and_grads({})
+    for word, code in ((16, "-1"), (_lib.NSR_TRAIN_GAMMA_CORRECT | _lib.NSR_TRAIN_COLOR_NONE, "-2")):
+        t.white_bkgd = word                      # int(self.white_bkgd) is what reaches the C ABI
+        with pytest.raises(_lib.NsrError, match=f"nsr_status {code}"):
+            t.loss_and_grads({})
+
+
+TRAIN_OPTIONS = {"llff_gamma": {"gamma_correct": True}, "blender_softplus": {"sigma_activation": "softplus"},
+                 "llff_colornone": {"color_activation": "none"}}
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "fp32", "f16x3_gemm"])
-def test_training_with_gamma_correct(golden_dir, prec):
-    """--gamma_correct while training (render_rays, models/nerf_downX_model.py:271-276): one optimize_parameters of the
-    reference with the option on (tests/golden/train_llff_gamma.npz) -- losses, forward outputs, every gradient tensor
-    against the reference's digests and the fp64 oracle, all three implementations of the step."""
+@pytest.mark.parametrize("name", list(TRAIN_OPTIONS))
+def test_training_with_the_option(golden_dir, name, prec):
+    """--gamma_correct (render_rays, models/nerf_downX_model.py:271-276), --sigma_activation softplus
+    (models/rendering.py:69-73) and --color_activation none (models/networks.py:173-180) in the TRAINING step: one
+    optimize_parameters of the reference with the option on (tests/golden/train_<name>.npz) -- losses, forward outputs, every
+    gradient tensor against the reference's digests and the fp64 oracle, all three implementations of the step."""
     from nerf_sr_amd import train as tr
     from tests.util import sample_idx
-    g = np.load(os.path.join(golden_dir, "train_llff_gamma.npz"))
+    opts = TRAIN_OPTIONS[name]
+    g = np.load(os.path.join(golden_dir, f"train_{name}.npz"))
     sd_c, sd_f = make_state_dict(int(g["seed_coarse"])), make_state_dict(int(g["seed_fine"]))
     t = tr.Trainer(sd_c, sd_f, white_bkgd=bool(g["white_bkgd"]), downscale=int(round(int(g["s2"]) ** 0.5)),
                    randomized=bool(g["randomized"]), noise_std=float(g["noise_std"]), lr=float(g["lr"]), beta1=float(g["beta1"]),
-                   lambda_coarse_mse=float(g["lambda_coarse"]), lambda_fine_mse=float(g["lambda_fine"]), precision=prec,
-                   gamma_correct=True)
+                   lambda_coarse_mse=float(g["lambda_coarse"]), lambda_fine_mse=float(g["lambda_fine"]), precision=prec, **opts)
     t.set_input(torch.from_numpy(g["rays"]).cuda(), torch.from_numpy(g["target_lr"]).cuda())
     draws = {k: v for k, v in train_draws(g).items() if k != "noise_std"}
     t.loss_and_grads(draws)
     losses = t.losses.cpu().numpy()
-    assert abs(losses[0] - float(g["loss_coarse_mse"])) < 1e-6 and abs(losses[1] - float(g["loss_fine_mse"])) < 2e-6
-    np.testing.assert_allclose(t.out["coarse_comp_rgbs"].cpu().numpy(), g["hr_coarse"], rtol=0, atol=2e-6)
-    np.testing.assert_allclose(t.out["lr_fine"].cpu().numpy(), g["lr_fine"], rtol=0, atol=1e-4)
+    scale = max(1.0, float(np.abs(g["hr_fine"]).max()))          # colours without the sigmoid are not confined to [0, 1]
+    assert abs(losses[0] - float(g["loss_coarse_mse"])) < 1e-6 * scale * scale and abs(losses[1] - float(g["loss_fine_mse"])) < 2e-6 * scale * scale
+    np.testing.assert_allclose(t.out["coarse_comp_rgbs"].cpu().numpy(), g["hr_coarse"], rtol=0, atol=2e-6 * scale)
+    np.testing.assert_allclose(t.out["lr_fine"].cpu().numpy(), g["lr_fine"], rtol=0, atol=1e-4 * scale)
     _, gc, gf = to.loss_and_grads(sd_c, sd_f, g["rays"], g["target_lr"], int(g["s2"]), 64, 64, bool(g["white_bkgd"]),
-                                  float(g["lambda_coarse"]), float(g["lambda_fine"]), dtype=torch.float64, gamma_correct=True,
-                                  **train_draws(g))
-    for n, (name, ref) in enumerate((("coarse", gc), ("fine", gf))):
+                                  float(g["lambda_coarse"]), float(g["lambda_fine"]), dtype=torch.float64, **opts, **train_draws(g))
+    for n, (net, ref) in enumerate((("coarse", gc), ("fine", gf))):
         for k in STATE_DICT_SPEC:
             got = t.grads[n][k].cpu().double()
             err, nrm = float((got - ref[k]).norm()), float(ref[k].norm())
-            assert err <= 2e-3 * nrm + 1e-9, (name, k, err / nrm)
-            ref_norm = float(g[f"gnorm_{name}.{k}"])
-            assert abs(float(got.norm()) - ref_norm) <= 2e-3 * ref_norm + 1e-9, (name, k)
+            assert err <= 2e-3 * nrm + 1e-9, (net, k, err / nrm)
+            ref_norm = float(g[f"gnorm_{net}.{k}"])
+            assert abs(float(got.norm()) - ref_norm) <= 2e-3 * ref_norm + 1e-9, (net, k)
             sub = got.reshape(-1).numpy()[sample_idx(got.numel())]
-            want_sub = g[f"grad_{name}.{k}"].astype(np.float64)
-            assert np.linalg.norm(sub - want_sub) <= 4e-3 * np.linalg.norm(want_sub) + 1e-9, (name, k)
+            want_sub = g[f"grad_{net}.{k}"].astype(np.float64)
+            assert np.linalg.norm(sub - want_sub) <= 4e-3 * np.linalg.norm(want_sub) + 1e-9, (net, k)
     # the option changes the step (same inputs without it)
     t0 = tr.Trainer(sd_c, sd_f, white_bkgd=bool(g["white_bkgd"]), randomized=True, noise_std=float(g["noise_std"]), precision=prec)
     t0.set_input(torch.from_numpy(g["rays"]).cuda(), torch.from_numpy(g["target_lr"]).cuda())

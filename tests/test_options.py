@@ -74,6 +74,7 @@ def test_training_option_word():
     here = __import__("os").path.dirname(__import__("os").path.abspath(__file__))
     hdr = open(__import__("os").path.join(here, "..", "include", "nsr_train.h")).read()
     assert int(re.search(r"#define NSR_TRAIN_GAMMA_CORRECT (\d+)", hdr).group(1)) == _lib.NSR_TRAIN_GAMMA_CORRECT == 4
+    assert int(re.search(r"#define NSR_TRAIN_COLOR_NONE (\d+)", hdr).group(1)) == _lib.NSR_TRAIN_COLOR_NONE == 8
     top = open(__import__("os").path.join(here, "..", "include", "nsr.h")).read()
     assert int(re.search(r"#define NSR_WHITE_BKGD (\d+)", top).group(1)) == _lib.NSR_WHITE_BKGD
     assert int(re.search(r"#define NSR_SIGMA_SOFTPLUS (\d+)", top).group(1)) == _lib.NSR_SIGMA_SOFTPLUS

@@ -12,7 +12,10 @@ from oracle import nerf_oracle as oc
 from oracle import train_oracle as tr
 from tests.util import sample_idx, train_draws
 
-CASES = ["llff_det", "llff_rand", "blender_rand", "blender_var", "llff_gamma"]     # blender_var: --use_var_loss --use_depth_var_loss; llff_gamma: --gamma_correct
+CASES = ["llff_det", "llff_rand", "blender_rand", "blender_var", "llff_gamma", "blender_softplus", "llff_colornone"]
+# blender_var: --use_var_loss --use_depth_var_loss; the last three: --gamma_correct, --sigma_activation softplus, --color_activation none
+OPTIONS = {"llff_gamma": {"gamma_correct": True}, "blender_softplus": {"sigma_activation": "softplus"},
+           "llff_colornone": {"color_activation": "none"}}
 
 
 @pytest.fixture(scope="module", params=CASES)
@@ -22,7 +25,7 @@ def case(request, golden_dir):
     res, gc, gf = tr.loss_and_grads(sd_c, sd_f, g["rays"], g["target_lr"], int(g["s2"]), 64, 64,
                                     bool(g["white_bkgd"]), float(g["lambda_coarse"]), float(g["lambda_fine"]),
                                     lambda_var=(g["lambda_var"].tolist() if "lambda_var" in g else None),
-                                    gamma_correct=request.param.endswith("gamma"), **train_draws(g))
+                                    **OPTIONS.get(request.param, {}), **train_draws(g))
     return g, sd_c, res, gc, gf
 
 
