@@ -67,13 +67,16 @@ size_t nsr_train_workspace_bytes_for(int precision, int64_t ray_chunk, int n_coa
  * path keeps in the packed network: NSR_TRAIN_GAMMA_CORRECT = --gamma_correct while training (render_rays returns
  * pow(rgb, 1 / 2.2) per sample, nerf_downX_model.py:271-276; the colours are corrected between the network and the
  * compositor and the backward pass carries the slope y (1 - y^2.2) / 2.2 of the corrected sigmoid);
- * NSR_TRAIN_COLOR_NONE = --color_activation none (models/networks.py:173-180; slope 1).  The two together are
+ * NSR_TRAIN_COLOR_NONE = --color_activation none (models/networks.py:173-180; slope 1); NSR_TRAIN_STOP_GRAD =
+ * --stop_grad true (models/networks.py:218-219: the colour branch's input is detached -- xyz_encoding_final gets zero
+ * gradients, the trunk the density head's alone).  Gamma and none together are
  * NSR_ERR_UNSUPPORTED (the power of an unbounded head is NaN for every negative value); any other bit NSR_ERR_INVALID_ARG.
  * outs: the 8 forward outputs in nsr_forward_rays order (entries may be NULL except the two comp_rgbs).
  * lr_coarse / lr_fine: (R / s2, 3) s2-means (comp_low_res_output, :326-348); losses: DEVICE float[2] =
  * { lambda_coarse * mse_coarse, lambda_fine * mse_fine }. */
 #define NSR_TRAIN_GAMMA_CORRECT 4
 #define NSR_TRAIN_COLOR_NONE 8
+#define NSR_TRAIN_STOP_GRAD 16
 int nsr_train_loss_and_grads(const float* const* w_coarse, const float* const* w_fine, float* const* g_coarse,
                              float* const* g_fine, const float* rays, int ray_stride, int64_t R, int s2,
                              const float* target_lr, int n_coarse, int n_importance, int white_bkgd, int lindisp,

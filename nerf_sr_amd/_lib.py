@@ -21,7 +21,7 @@ FLAGS = {1: "WEIGHT_RANGE", 2: "INPUT_RANGE", 4: "ACTIVATION_RANGE", 8: "OUTPUT_
 NSR_F16X3_GEMM = 18   # include/nsr_train.h: training entry points only
 NSR_OPT_GAMMA, NSR_OPT_COLOR_NONE = 1, 2     # include/nsr.h: colour-head option word (nsr_weights_set_options)
 NSR_WHITE_BKGD, NSR_SIGMA_SOFTPLUS = 1, 2    # include/nsr.h: renderer option word (the `white_bkgd` argument)
-NSR_TRAIN_GAMMA_CORRECT, NSR_TRAIN_COLOR_NONE = 4, 8    # include/nsr_train.h: the training entry points' own bits of that word
+NSR_TRAIN_GAMMA_CORRECT, NSR_TRAIN_COLOR_NONE, NSR_TRAIN_STOP_GRAD = 4, 8, 16    # include/nsr_train.h: the training entry points' own bits of that word
 PRECISIONS = {"fp32": NSR_FP32, "bf16": NSR_BF16, "f16x3": NSR_F16X3, "f16": NSR_F16}
 TRAIN_PRECISIONS = {"fp32": NSR_FP32, "f16x3": NSR_F16X3, "f16x3_gemm": NSR_F16X3_GEMM}
 

@@ -778,7 +778,7 @@ int net_forward(hipStream_t st, const float* const* w, const WeightPack& q, cons
 
 // backward of M1: d_rgb_pre in k.drgb (P, 32), d_sigma in column 256 of k.g1 (P, 288)
 int net_backward(hipStream_t st, const float* const* w, const WeightPack& q, const Work& k, int64_t P, float* const* g,
-                 int acc) {
+                 int acc, int stop_grad) {
   const int sp = n_splits(P);
   float* part = k.partial;
   // rgb head
@@ -791,7 +791,12 @@ int net_backward(hipStream_t st, const float* const* w, const WeightPack& q, con
   NSR_TRY(reduce_place(st, g[kDirW], 283, 0, 128, 256, part, sp, kGs, 0, 0, acc));
   NSR_TRY(reduce_place(st, g[kDirW], 283, 256, 128, 27, part, sp, kGs, 0, kDeCol, acc));
   // d g (its column sums are xyz_encoding_final's bias gradient); column 256 keeps d sigma
-  NSR_TRY(lin_dgrad(st, k, k.g0, kDirOut, kDirOut, q.wdirp, 288, nullptr, 0, k.g1, kGs, P, kW, g[kFinalB], acc));
+  if (stop_grad) {   // --stop_grad (models/networks.py:218-219): dir_encoding's input is detached, d g = 0
+    if (hipMemset2DAsync(k.g1, (size_t)kGs * sizeof(float), 0, (size_t)kW * sizeof(float), (size_t)P, st) != hipSuccess) return NSR_ERR_LAUNCH;
+    if (!acc && hipMemsetAsync(g[kFinalB], 0, (size_t)kW * sizeof(float), st) != hipSuccess) return NSR_ERR_LAUNCH;
+  } else {
+    NSR_TRY(lin_dgrad(st, k, k.g0, kDirOut, kDirOut, q.wdirp, 288, nullptr, 0, k.g1, kGs, P, kW, g[kFinalB], acc));
+  }
   // xyz_encoding_final + sigma (288-row layer over h8)
   NSR_TRY(lin_wgrad(st, k.g1, kGs, kW, k.h[8], kW, kW, P, part, sp));                 // rows 0..255: xyz_encoding_final
   NSR_TRY(reduce_place(st, g[kFinalW], 256, 0, 256, 256, part, sp, kW, 0, 0, acc));
@@ -1024,9 +1029,10 @@ int train_impl(const float* const* w_coarse, const float* const* w_fine, float* 
     return NSR_ERR_INVALID_ARG;
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return NSR_ERR_INVALID_ARG;
   // the step's option word (include/nsr_train.h): the renderer's two bits + the colour head's two
-  constexpr int kTrainOpts = NSR_WHITE_BKGD | NSR_SIGMA_SOFTPLUS | NSR_TRAIN_GAMMA_CORRECT | NSR_TRAIN_COLOR_NONE;
+  constexpr int kTrainOpts = NSR_WHITE_BKGD | NSR_SIGMA_SOFTPLUS | NSR_TRAIN_GAMMA_CORRECT | NSR_TRAIN_COLOR_NONE | NSR_TRAIN_STOP_GRAD;
   if ((white_bkgd & ~kTrainOpts) != 0) return NSR_ERR_INVALID_ARG;
   const int gamma = (white_bkgd & NSR_TRAIN_GAMMA_CORRECT) != 0, color_none = (white_bkgd & NSR_TRAIN_COLOR_NONE) != 0;
+  const int stop_grad = (white_bkgd & NSR_TRAIN_STOP_GRAD) != 0;
   if (gamma && color_none) return NSR_ERR_UNSUPPORTED;   // pow(x, 1 / 2.2) of an unbounded head: NaN for every negative value
   if (workspace_bytes < nsr_train_workspace_bytes_for(precision, ray_chunk, n_coarse, n_importance)) return NSR_ERR_WORKSPACE;
   const bool noisy = noise_std > 0.0f;
@@ -1044,7 +1050,7 @@ int train_impl(const float* const* w_coarse, const float* const* w_fine, float* 
       // (|w| >= 1023.75, or NaN) raises NSR_FLAG_WEIGHT_RANGE in the step's status word, like nsr_pack_weights does
       NSR_TRY(nsr_check_weights_range(net ? w_fine : w_coarse, precision, k.status, stream));
       NSR_TRY(nsr_f16x3_pack(net ? w_fine : w_coarse, k.stream_f[net], stream));
-      NSR_TRY(nsr_chain_bwd_pack(net ? w_fine : w_coarse, k.stream_b[net], stream));
+      NSR_TRY(nsr_chain_bwd_pack(net ? w_fine : w_coarse, k.stream_b[net], stop_grad, stream));
     }
   } else {
     NSR_TRY(prepare_weights(st, w_coarse, k.pack[0], gemm_precision(precision)));
@@ -1113,7 +1119,7 @@ int train_impl(const float* const* w_coarse, const float* const* w_fine, float* 
         NSR_TRY(nsr_chain_bwd(k.stream_b[net], k.sgn, k.dpan, k.d4, 4, k.d4 + 3, 4, P, k.gmax, k.pscale, stream));
         NSR_TRY(chain_weight_grads(st, k, P, rc, g, acc));
       } else {
-        NSR_TRY(net_backward(st, w, k.pack[net], k, P, g, acc));
+        NSR_TRY(net_backward(st, w, k.pack[net], k, P, g, acc, stop_grad));
       }
     }
   }

@@ -18,7 +18,7 @@ extern "C" NSR_INTERNAL int nsr_f16x3_pack(const float* const* w, void* packed_d
 // gmax[10] (device): float bits of the largest TRUE magnitude of each gradient panel (zeroed, then atomicMax);
 // pscale (10, ceil(P / 128) * 128): per panel and point the power of two that turns the stored fp16 values into true gradients
 extern "C" NSR_INTERNAL size_t nsr_chain_bwd_packed_bytes(void);
-extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* packed_dev, void* stream);
+extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* packed_dev, int stop_grad, void* stream);
 extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const unsigned* sgn, void* dpan, const float* d_rgb, int d_rgb_stride,
                                           const float* d_sigma, int d_sigma_stride, int64_t P, unsigned* gmax,
                                           float* pscale, void* stream);

@@ -50,7 +50,10 @@ struct BwdPackPtrs {
 // one thread per 32-bit word.  Piece (layer lam, block nb, k-step s, part): lane (i, h), halves j = 0..7 hold
 // 64 W[k = act_feature(8 s + j, h)][column 32 nb + i] of the layer's nn.Linear weight (out, in) -- its transpose as the
 // MFMA A operand.
-__global__ void __launch_bounds__(256) pack_bwd_kernel(BwdPackPtrs w, unsigned* __restrict__ out) {
+// stop_grad (--stop_grad, models/networks.py:218-219: dir_encoding's input is detached): the g columns of dir_encoding's weight
+// are packed as zeros, so the gradient that leaves the colour branch for xyz_encoding_final is an exact 0 at every point --
+// xyz_encoding_final's weights and bias get zero gradients, the trunk sees the density head's gradient alone.
+__global__ void __launch_bounds__(256) pack_bwd_kernel(BwdPackPtrs w, unsigned* __restrict__ out, int stop_grad) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int stream_words = kBwdPieces * 256;
   if (idx >= stream_words + kBwdAuxFloats) return;
@@ -69,7 +72,7 @@ __global__ void __launch_bounds__(256) pack_bwd_kernel(BwdPackPtrs w, unsigned* 
       float x = 0.0f;
       if (lam == 0) {                                   // dir_encoding.weight (128, 283): columns 0..255 = g
         const int k = act_feature(8 * s + j, h);
-        if (k < 128) x = w.p[18][k * 283 + n];
+        if (k < 128 && !stop_grad) x = w.p[18][k * 283 + n];
       } else if (lam == 1) {                            // xyz_encoding_final.weight (256, 256)
         x = w.p[16][act_feature(8 * s + j, h) * 256 + n];
       } else {                                          // trunk layer l = 10 - lam (8..2), tensor 2 (l - 1)
@@ -523,7 +526,7 @@ chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ 
 
 extern "C" NSR_INTERNAL size_t nsr_chain_bwd_packed_bytes(void) { return 4 * (size_t)(kBwdPieces * 256 + kBwdAuxFloats); }
 
-extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* packed_dev, void* stream) {
+extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* packed_dev, int stop_grad, void* stream) {
   BwdPackPtrs pp;
   for (int i = 0; i < NSR_N_STATE_TENSORS; ++i) {
     if (!w[i]) return NSR_ERR_INVALID_ARG;
@@ -531,7 +534,7 @@ extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* pack
   }
   const int total = kBwdPieces * 256 + kBwdAuxFloats;
   hipLaunchKernelGGL(pack_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, nsr_stream(stream), pp,
-                     static_cast<unsigned*>(packed_dev));
+                     static_cast<unsigned*>(packed_dev), stop_grad);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }

@@ -165,15 +165,16 @@ def resample_along_rays(ori, dir, z_vals, weights, num_samples: int, randomized:
 
 # ----------------------------------------------------------------------------- M1
 # the one architecture the HIP kernels are built for: the values every script of the reference uses
-_MLP_FIXED = {"D": 8, "W": 256, "skips": [4], "deg_pos": 10, "deg_dir": 4, "dim_pos": 3, "dim_dir": 3, "dim_rgb": 3,
-              "stop_grad": False}
-_MLP_CHOICES = {"color_activation": ("sigmoid", "none"), "no_dir": (False, True)}     # built since round 5 (inference)
+_MLP_FIXED = {"D": 8, "W": 256, "skips": [4], "deg_pos": 10, "deg_dir": 4, "dim_pos": 3, "dim_dir": 3, "dim_rgb": 3}
+# built since round 5; stop_grad (a detach: models/networks.py:218-219) changes nothing in a forward pass and is an option of
+# train.Trainer
+_MLP_CHOICES = {"color_activation": ("sigmoid", "none"), "no_dir": (False, True), "stop_grad": (False, True)}
 
 
 def check_mlp_options(opt) -> None:
     """Reject every VanillaMLP option value the kernels do not implement (models/networks.py:124-128 ``--D --W --skips``;
-    models/embedding.py degrees; ``stop_grad``, a training-only switch) instead of silently computing the default
-    architecture.  ``no_dir`` and ``color_activation`` (:160-180) are options of ``VanillaMLP`` since round 5.
+    models/embedding.py degrees) instead of silently computing the default architecture.  ``no_dir`` and
+    ``color_activation`` (:160-180) are options of ``VanillaMLP`` since round 5, ``stop_grad`` of ``train.Trainer``.
     Options that are absent from ``opt`` count as the reference's defaults."""
     if opt is None:
         return

@@ -78,7 +78,7 @@ class Trainer:
                  precision: str = "f16x3", device="cuda", gamma_correct: bool = False,
                  use_var_loss: bool = False, lambda_coarse_var: float = 0.01, lambda_fine_var: float = 0.01,
                  use_depth_var_loss: bool = False, lambda_coarse_depth_var: float = 0.01, lambda_fine_depth_var: float = 0.01,
-                 no_dir: bool = False, sigma_activation: str = "relu", color_activation: str = "sigmoid"):
+                 no_dir: bool = False, sigma_activation: str = "relu", color_activation: str = "sigmoid", stop_grad: bool = False):
         # render_rays applies rgb ** (1 / 2.2) per sample under --gamma_correct (models/nerf_downX_model.py:271-276) in training
         # too: NSR_TRAIN_GAMMA_CORRECT of the step's option word (include/nsr_train.h)
         self.gamma_correct = bool(gamma_correct)
@@ -88,6 +88,7 @@ class Trainer:
         if gamma_correct and color_activation == "none":
             raise ValueError("gamma_correct with color_activation='none': pow(rgb, 1 / 2.2) of an unbounded head is NaN for every negative value")
         self.sigma_activation, self.color_activation = sigma_activation, color_activation
+        self.stop_grad = bool(stop_grad)       # --stop_grad (models/networks.py:127, 218-219): the colour branch's input is detached
         if precision not in _lib.TRAIN_PRECISIONS:
             raise ValueError("precision must be 'fp32' (every product on the fp32 MFMA, layer by layer), 'f16x3' (the chain "
                              "kernels: forward and input gradients on the split-fp16 MFMA, weight gradients on one fp16 MFMA "
@@ -186,7 +187,8 @@ class Trainer:
         common = (wc, wf, gc, gf, _p(rays), stride, R, self.s2, _p(self.data_rgbs), nc, self.N_importance,
                   int(self.white_bkgd) | (_lib.NSR_TRAIN_GAMMA_CORRECT if self.gamma_correct else 0)
                   | (_lib.NSR_SIGMA_SOFTPLUS if self.sigma_activation == "softplus" else 0)
-                  | (_lib.NSR_TRAIN_COLOR_NONE if self.color_activation == "none" else 0), int(self.lindisp),
+                  | (_lib.NSR_TRAIN_COLOR_NONE if self.color_activation == "none" else 0)
+                  | (_lib.NSR_TRAIN_STOP_GRAD if self.stop_grad else 0), int(self.lindisp),
                   _p(draws.get("u_coarse")), _p(draws.get("u_fine")),
                   _p(draws.get("noise_coarse")), _p(draws.get("noise_fine")), self.noise_std,
                   self.lambda_coarse * gs, self.lambda_fine * gs, self._prec, chunk, outs, _p(lr_c), _p(lr_f), _p(self.losses),

@@ -222,7 +222,7 @@ def resample_conditioning(z, weights, n_imp: int, u: torch.Tensor = None):
 # ----------------------------------------------------------------------------
 
 def mlp_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, sigma_only: bool = False,
-                color_activation: str = "sigmoid") -> torch.Tensor:
+                color_activation: str = "sigmoid", stop_grad: bool = False) -> torch.Tensor:
     """``VanillaMLP.forward`` on embedded rows x (B, 90) -> (B, 4) = [rgb, sigma_raw].
 
     Restates ``models/networks.py:182-226`` with D=8, W=256, skips=[4]: the skip
@@ -230,7 +230,8 @@ def mlp_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, sigma_only: bool =
     ReLU is applied by the renderer); colour goes through sigmoid, or through nothing
     with ``color_activation='none'`` (``:173-180``).  A ``--no_dir`` network
     (``:160-169, 213-216``: ``dir_encoding.0.weight`` of shape (128, 256)) feeds
-    ``xyz_encoding_final`` alone to ``dir_encoding``.
+    ``xyz_encoding_final`` alone to ``dir_encoding``.  ``stop_grad`` (``:218-219``): the input of ``dir_encoding`` is detached
+    (matters under autograd only: oracle/train_oracle.py).
     ``sd`` is the 24-key state_dict (torch tensors).
     """
     lin = torch.nn.functional.linear
@@ -245,7 +246,8 @@ def mlp_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, sigma_only: bool =
         return sigma
     g = lin(h, sd["xyz_encoding_final.weight"], sd["xyz_encoding_final.bias"])
     no_dir = sd["dir_encoding.0.weight"].shape[1] == g.shape[1]
-    c = torch.relu(lin(g if no_dir else torch.cat([g, de], -1), sd["dir_encoding.0.weight"], sd["dir_encoding.0.bias"]))
+    dir_in = g if no_dir else torch.cat([g, de], -1)
+    c = torch.relu(lin(dir_in.detach() if stop_grad else dir_in, sd["dir_encoding.0.weight"], sd["dir_encoding.0.bias"]))
     rgb = lin(c, sd["rgb.0.weight"], sd["rgb.0.bias"])
     if color_activation == "sigmoid":
         rgb = torch.sigmoid(rgb)
@@ -255,7 +257,7 @@ def mlp_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, sigma_only: bool =
 
 
 def render_points(sd, xyz: torch.Tensor, dir_embedded: torch.Tensor, point_chunk: int = 262144,
-                  gamma_correct: bool = False, color_activation: str = "sigmoid"):
+                  gamma_correct: bool = False, color_activation: str = "sigmoid", stop_grad: bool = False):
     """(R, N, 3) points + (R, 27) dir embedding -> rgb (R, N, 3), sigma (R, N).
 
     Restates ``models/nerf_downX_model.py:260-278`` (render_rays): PE of the points,
@@ -266,7 +268,8 @@ def render_points(sd, xyz: torch.Tensor, dir_embedded: torch.Tensor, point_chunk
     R, N = xyz.shape[:2]
     pts = xyz.reshape(-1, 3)
     x = torch.cat([posenc(pts, 10), dir_embedded.repeat_interleave(N, dim=0)], -1)
-    outs = [mlp_forward(sd, x[i:i + point_chunk], color_activation=color_activation) for i in range(0, x.shape[0], point_chunk)]
+    outs = [mlp_forward(sd, x[i:i + point_chunk], color_activation=color_activation, stop_grad=stop_grad)
+            for i in range(0, x.shape[0], point_chunk)]
     out = torch.cat(outs, 0).view(R, N, 4)
     rgb = out[..., :3]
     if gamma_correct:

@@ -157,7 +157,8 @@ def one_case(tag, white, ndc, near_far, s, n_lr, randomized, noise_std, seed, ex
     for net, name in ((model.netCoarse, "coarse"), (model.netFine, "fine")):
         mod = net.module if hasattr(net, "module") else net
         for k, p in mod.named_parameters():
-            g = p.grad.detach()
+            # --stop_grad leaves xyz_encoding_final without a gradient (None: torch.optim.Adam skips the tensor); stored as zeros
+            g = p.grad.detach() if p.grad is not None else torch.zeros_like(p)
             out[f"gnorm_{name}.{k}"] = float(g.double().norm())
             out[f"gsum_{name}.{k}"] = float(g.double().sum())
             out[f"grad_{name}.{k}"] = mg.np32(g).reshape(-1)[sample_idx(g.numel())]
@@ -177,6 +178,8 @@ def option_cases():
     one_case("llff_gamma", False, True, (0.0, 1.0), 2, 24, True, 1.0, 5, ("--gamma_correct",))
     one_case("blender_softplus", True, False, (2.0, 6.0), 2, 24, True, 0.0, 6, ("--sigma_activation", "softplus"))
     one_case("llff_colornone", False, True, (0.0, 1.0), 2, 24, True, 1.0, 7, ("--color_activation", "none"))
+    # --stop_grad true (models/networks.py:127, 218-219)
+    one_case("blender_stopgrad", True, False, (2.0, 6.0), 2, 24, True, 0.0, 8, ("--stop_grad", "true"))
 
 
 def main():

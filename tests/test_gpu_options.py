@@ -165,21 +165,22 @@ def test_training_option_word_is_checked(golden_dir):
     g = np.load(os.path.join(golden_dir, "train_llff_det.npz"))
     t = tr.Trainer(make_state_dict(1), make_state_dict(2), randomized=False)
     t.set_input(torch.from_numpy(g["rays"]).cuda(), torch.from_numpy(g["target_lr"]).cuda())
-    for word, code in ((16, "-1"), (_lib.NSR_TRAIN_GAMMA_CORRECT | _lib.NSR_TRAIN_COLOR_NONE, "-2")):
+    for word, code in ((32, "-1"), (_lib.NSR_TRAIN_GAMMA_CORRECT | _lib.NSR_TRAIN_COLOR_NONE, "-2")):
         t.white_bkgd = word                      # int(self.white_bkgd) is what reaches the C ABI
         with pytest.raises(_lib.NsrError, match=f"nsr_status {code}"):
             t.loss_and_grads({})
 
 
 TRAIN_OPTIONS = {"llff_gamma": {"gamma_correct": True}, "blender_softplus": {"sigma_activation": "softplus"},
-                 "llff_colornone": {"color_activation": "none"}}
+                 "llff_colornone": {"color_activation": "none"}, "blender_stopgrad": {"stop_grad": True}}
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "fp32", "f16x3_gemm"])
 @pytest.mark.parametrize("name", list(TRAIN_OPTIONS))
 def test_training_with_the_option(golden_dir, name, prec):
     """--gamma_correct (render_rays, models/nerf_downX_model.py:271-276), --sigma_activation softplus
-    (models/rendering.py:69-73) and --color_activation none (models/networks.py:173-180) in the TRAINING step: one
+    (models/rendering.py:69-73), --color_activation none (models/networks.py:173-180) and --stop_grad true (:218-219: zero
+    gradients for xyz_encoding_final, exactly) in the TRAINING step: one
     optimize_parameters of the reference with the option on (tests/golden/train_<name>.npz) -- losses, forward outputs, every
     gradient tensor against the reference's digests and the fp64 oracle, all three implementations of the step."""
     from nerf_sr_amd import train as tr
@@ -214,5 +215,12 @@ def test_training_with_the_option(golden_dir, name, prec):
     t0 = tr.Trainer(sd_c, sd_f, white_bkgd=bool(g["white_bkgd"]), randomized=True, noise_std=float(g["noise_std"]), precision=prec)
     t0.set_input(torch.from_numpy(g["rays"]).cuda(), torch.from_numpy(g["target_lr"]).cuda())
     t0.loss_and_grads(draws)
-    assert abs(float(t0.losses[0]) - float(losses[0])) > 1e-3
+    if name == "blender_stopgrad":      # a detach: same forward, other gradients -- xyz_encoding_final's exactly zero
+        assert abs(float(t0.losses[0]) - float(losses[0])) < 1e-6
+        for n in range(2):
+            assert not bool(t.grads[n]["xyz_encoding_final.weight"].any()) and not bool(t.grads[n]["xyz_encoding_final.bias"].any())
+            assert float((t.grads[n]["xyz_encoding_8.0.weight"] - t0.grads[n]["xyz_encoding_8.0.weight"]).norm()) > \
+                0.05 * float(t0.grads[n]["xyz_encoding_8.0.weight"].norm())
+    else:
+        assert abs(float(t0.losses[0]) - float(losses[0])) > 1e-3
     assert t.status() == 0

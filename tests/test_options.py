@@ -13,7 +13,7 @@ from nerf_sr_amd.model import NeRFDownXModel, default_options
 
 @pytest.mark.parametrize("kw", [
     {"color_activation": "tanh"}, {"no_dir": 2}, {"D": 6}, {"W": 128}, {"skips": [4, 6]}, {"skips": []},
-    {"deg_pos": 8}, {"deg_dir": 2}, {"dim_rgb": 4}, {"stop_grad": True},
+    {"deg_pos": 8}, {"deg_dir": 2}, {"dim_rgb": 4}, {"stop_grad": "yes"},
 ])
 def test_unbuilt_mlp_options_raise(kw):
     with pytest.raises(ValueError, match="outside the built path"):
@@ -75,6 +75,7 @@ def test_training_option_word():
     hdr = open(__import__("os").path.join(here, "..", "include", "nsr_train.h")).read()
     assert int(re.search(r"#define NSR_TRAIN_GAMMA_CORRECT (\d+)", hdr).group(1)) == _lib.NSR_TRAIN_GAMMA_CORRECT == 4
     assert int(re.search(r"#define NSR_TRAIN_COLOR_NONE (\d+)", hdr).group(1)) == _lib.NSR_TRAIN_COLOR_NONE == 8
+    assert int(re.search(r"#define NSR_TRAIN_STOP_GRAD (\d+)", hdr).group(1)) == _lib.NSR_TRAIN_STOP_GRAD == 16
     top = open(__import__("os").path.join(here, "..", "include", "nsr.h")).read()
     assert int(re.search(r"#define NSR_WHITE_BKGD (\d+)", top).group(1)) == _lib.NSR_WHITE_BKGD
     assert int(re.search(r"#define NSR_SIGMA_SOFTPLUS (\d+)", top).group(1)) == _lib.NSR_SIGMA_SOFTPLUS

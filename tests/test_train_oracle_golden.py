@@ -12,10 +12,11 @@ from oracle import nerf_oracle as oc
 from oracle import train_oracle as tr
 from tests.util import sample_idx, train_draws
 
-CASES = ["llff_det", "llff_rand", "blender_rand", "blender_var", "llff_gamma", "blender_softplus", "llff_colornone"]
-# blender_var: --use_var_loss --use_depth_var_loss; the last three: --gamma_correct, --sigma_activation softplus, --color_activation none
+CASES = ["llff_det", "llff_rand", "blender_rand", "blender_var", "llff_gamma", "blender_softplus", "llff_colornone", "blender_stopgrad"]
+# blender_var: --use_var_loss --use_depth_var_loss; the last four: --gamma_correct, --sigma_activation softplus,
+# --color_activation none, --stop_grad true
 OPTIONS = {"llff_gamma": {"gamma_correct": True}, "blender_softplus": {"sigma_activation": "softplus"},
-           "llff_colornone": {"color_activation": "none"}}
+           "llff_colornone": {"color_activation": "none"}, "blender_stopgrad": {"stop_grad": True}}
 
 
 @pytest.fixture(scope="module", params=CASES)
