@@ -18,6 +18,7 @@ NSR_FP32, NSR_BF16, NSR_F16X3, NSR_F16 = 0, 1, 2, 3
 NSR_ERR_RANGE = -5
 # numerics status word of a packed network (include/nsr.h)
 FLAGS = {1: "WEIGHT_RANGE", 2: "INPUT_RANGE", 4: "ACTIVATION_RANGE", 8: "OUTPUT_NONFINITE"}
+NSR_FLAG_OUTPUT_NONFINITE = 8
 NSR_F16X3_GEMM = 18   # include/nsr_train.h: training entry points only
 NSR_OPT_GAMMA, NSR_OPT_COLOR_NONE = 1, 2     # include/nsr.h: colour-head option word (nsr_weights_set_options)
 NSR_WHITE_BKGD, NSR_SIGMA_SOFTPLUS = 1, 2    # include/nsr.h: renderer option word (the `white_bkgd` argument)

@@ -14,7 +14,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
-from .ops import VanillaMLP, VolumetricRenderer, PositionalEncoding
+from .ops import VanillaMLP, GenericMLP, VolumetricRenderer, PositionalEncoding
 
 
 def default_options(**kw) -> SimpleNamespace:
@@ -22,7 +22,7 @@ def default_options(**kw) -> SimpleNamespace:
     opt = SimpleNamespace(
         N_coarse=64, N_importance=64, lindisp=False, white_bkgd=False, randomized=True, noise_std=0.0,
         deg_pos=10, deg_dir=4, dim_pos=3, dim_dir=3, dim_rgb=3, downscale=2, img_wh=(504, 378),
-        D=8, W=256, skips=[4],                      # models/networks.py:124-128; anything else raises (ops.check_mlp_options)
+        D=8, W=256, skips=[4],                      # models/networks.py:124-128; other values run layer by layer (ops.GenericMLP)
         no_dir=False, color_activation="sigmoid",   # :128, :160-180 ('none'; True): options of VanillaMLP
         sigma_activation="relu", gamma_correct=False,   # models/rendering.py:69-73 ('softplus'); nerf_downX_model.py:271-276
         ray_chunk=4096, point_chunk=262144, precision="fp32",
@@ -39,13 +39,15 @@ class NeRFDownXModel:
 
     def __init__(self, opt: Optional[SimpleNamespace] = None, device="cuda"):
         self.opt = opt or default_options()
-        ops.check_mlp_options(self.opt)
+        ops.check_mlp_options(self.opt, fused=False)
         if int(self.opt.N_coarse) < 2 or int(self.opt.N_importance) < 0:
             raise ValueError("N_coarse must be >= 2 and N_importance >= 0")
         self.renderer = VolumetricRenderer(self.opt)      # validates sigma_activation before any device is touched
         self.device = torch.device(device)
-        self.netCoarse = VanillaMLP(self.opt, precision=self.opt.precision, device=self.device)
-        self.netFine = VanillaMLP(self.opt, precision=self.opt.precision, device=self.device)
+        # the fused kernels for the architecture every script of the reference uses, nn.Linear by nn.Linear for any other
+        self.netCoarse = ops.make_mlp(self.opt, precision=self.opt.precision, device=self.device)
+        self.netFine = ops.make_mlp(self.opt, precision=self.opt.precision, device=self.device)
+        self.fused = isinstance(self.netCoarse, VanillaMLP)
         self.models = {"coarse": self.netCoarse, "fine": self.netFine}
         self.embeddings = {"pos": PositionalEncoding(3, self.opt.deg_pos), "dir": PositionalEncoding(3, self.opt.deg_dir)}
         self.randomized = False
@@ -88,24 +90,30 @@ class NeRFDownXModel:
     # -- D3 ------------------------------------------------------------------------
     def forward_rays(self, rays: torch.Tensor) -> Dict[str, torch.Tensor]:
         opt = self.opt
-        if not self.randomized:
+        if not self.randomized and self.fused:
             self._outs = ops.forward_rays(self.netCoarse, self.netFine if opt.N_importance > 0 else None, rays,
                                           opt.N_coarse, opt.N_importance, opt.white_bkgd, opt.lindisp,
                                           check=bool(getattr(opt, "check_numerics", True)),
                                           sigma_activation=self.renderer.sigma_activation)
             return self._outs
-        # randomized (training-mode) forward: same kernels, stage by stage, jitter drawn with torch.rand
+        # randomized (training-mode) forward, and every forward of a GenericMLP pair: same kernels, stage by stage, jitter
+        # drawn with torch.rand
         o, d, near, far = rays[:, 0:3], rays[:, 3:6], rays[:, 6:7], rays[:, 7:8]
-        z, _ = ops.sample_along_rays(o, d, near, far, opt.N_coarse, True, opt.lindisp)
-        rgb, sig = ops.render_rays(self.netCoarse, rays, z)
-        if opt.noise_std > 0:
+        rnd = self.randomized
+        z, xyz = ops.sample_along_rays(o, d, near, far, opt.N_coarse, rnd, opt.lindisp)
+        if not self.fused:
+            dir_emb = self.embeddings["dir"]((rays[:, 8:11] if rays.shape[1] == 11 else d).contiguous())
+        rgb, sig = ops.render_rays(self.netCoarse, rays, z) if self.fused else self.render_rays(self.netCoarse, xyz, dir_emb)
+        rgb, sig = rgb.contiguous(), sig.contiguous()
+        if rnd and opt.noise_std > 0:          # add_gaussian_noise (models/utils.py:199-212): only when randomized
             sig = sig + torch.randn_like(sig) * opt.noise_std
         c = self.renderer(rgb, sig, z, opt.white_bkgd)
         out = dict(zip(ops.OUT_KEYS[:4], c))
         if opt.N_importance > 0:
-            z2, _ = ops.resample_along_rays(o, d, z, c[3], opt.N_importance, True)
-            rgb2, sig2 = ops.render_rays(self.netFine, rays, z2)
-            if opt.noise_std > 0:
+            z2, xyz2 = ops.resample_along_rays(o, d, z, c[3], opt.N_importance, rnd)
+            rgb2, sig2 = ops.render_rays(self.netFine, rays, z2) if self.fused else self.render_rays(self.netFine, xyz2, dir_emb)
+            rgb2, sig2 = rgb2.contiguous(), sig2.contiguous()
+            if rnd and opt.noise_std > 0:
                 sig2 = sig2 + torch.randn_like(sig2) * opt.noise_std
             out.update(zip(ops.OUT_KEYS[4:], self.renderer(rgb2, sig2, z2, opt.white_bkgd)))
         if getattr(opt, "check_numerics", True):
@@ -176,9 +184,16 @@ class NeRFDownXModel:
         lo, hi = lr_range if lr_range is not None else nsr_dist.shard_bounds(n_lr, world)[rank]
         rays = ops.subpixel_rays(c2w, opt.img_wh, focal, s, ndc, near, far, self.device, lr_range=(lo, hi)).view(-1, 8)
         fine = opt.N_importance > 0
-        out = ops.forward_rays(self.netCoarse, self.netFine if fine else None, rays, opt.N_coarse, opt.N_importance,
-                               opt.white_bkgd, opt.lindisp, workspace=workspace, outs=outs, want_weights=want_weights,
-                               sigma_activation=self.renderer.sigma_activation)
+        if self.fused:
+            out = ops.forward_rays(self.netCoarse, self.netFine if fine else None, rays, opt.N_coarse, opt.N_importance,
+                                   opt.white_bkgd, opt.lindisp, workspace=workspace, outs=outs, want_weights=want_weights,
+                                   sigma_activation=self.renderer.sigma_activation)
+        else:               # a GenericMLP pair: the eval-mode staged route
+            was, self.randomized = self.randomized, False
+            try:
+                out = self.forward_rays(rays)
+            finally:
+                self.randomized = was
         tag = "fine" if fine else "coarse"
         cap = (lo, hi) if lr_range is not None else nsr_dist.shard_bounds(n_lr, world)[0]   # the block the payload is sized by
         if gather == "hr":

@@ -15,7 +15,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from .weights import STATE_DICT_SPEC, check_state_dict, pad_no_dir, DIR_W, IN_CH
+from .weights import (STATE_DICT_SPEC, check_state_dict, pad_no_dir, DIR_W, IN_CH, arch_of, arch_spec, is_default_arch,
+                      check_state_dict_arch)
 
 __all__ = [
     "subpixel_rays", "PositionalEncoding", "sample_along_rays", "resample_along_rays", "cast_rays",
@@ -166,20 +167,23 @@ def resample_along_rays(ori, dir, z_vals, weights, num_samples: int, randomized:
 # ----------------------------------------------------------------------------- M1
 # the one architecture the HIP kernels are built for: the values every script of the reference uses
 _MLP_FIXED = {"D": 8, "W": 256, "skips": [4], "deg_pos": 10, "deg_dir": 4, "dim_pos": 3, "dim_dir": 3, "dim_rgb": 3}
+_GENERIC_FIXED = {"dim_pos": 3, "dim_dir": 3, "dim_rgb": 3}     # what the ray kernels and the compositor cannot vary either
+#                                                                   (GenericMLP on its own takes any dim_rgb)
 # built since round 5; stop_grad (a detach: models/networks.py:218-219) changes nothing in a forward pass and is an option of
 # train.Trainer
 _MLP_CHOICES = {"color_activation": ("sigmoid", "none"), "no_dir": (False, True), "stop_grad": (False, True)}
 
 
-def check_mlp_options(opt) -> None:
+def check_mlp_options(opt, fused: bool = True) -> None:
     """Reject every VanillaMLP option value the kernels do not implement (models/networks.py:124-128 ``--D --W --skips``;
     models/embedding.py degrees) instead of silently computing the default architecture.  ``no_dir`` and
     ``color_activation`` (:160-180) are options of ``VanillaMLP`` since round 5, ``stop_grad`` of ``train.Trainer``.
-    Options that are absent from ``opt`` count as the reference's defaults."""
+    Options that are absent from ``opt`` count as the reference's defaults.  ``fused=False``: the check of ``make_mlp`` /
+    ``NeRFDownXModel``, which serve other ``--D --W --skips`` / degrees / ``dim_rgb`` layer by layer (``GenericMLP``)."""
     if opt is None:
         return
     bad = []
-    for name, want in _MLP_FIXED.items():
+    for name, want in (_MLP_FIXED if fused else _GENERIC_FIXED).items():
         if not hasattr(opt, name):
             continue
         got = getattr(opt, name)
@@ -306,6 +310,150 @@ class VanillaMLP:
         return out
 
     __call__ = forward
+
+
+class GenericMLP:
+    """``VanillaMLP`` (models/networks.py:121-226) for the architecture flags the fused kernels are not laid out for:
+    ``--D --W --skips`` (:124-126), ``--deg_pos --deg_dir --dim_rgb`` (models/nerf_model.py:53-57), with ``--no_dir`` and
+    ``--color_activation none`` as there.  Every ``nn.Linear`` (+ activation) is one launch of the training step's fp32-MFMA
+    GEMM (``nsr_linear``, include/nsr_train.h) over zero-padded operands -- K and N rounded up to multiples of 32 with
+    zero weight columns / rows, whose products are exact zeros -- writing straight into the next layer's input buffer, so
+    ``cat([input_xyz, h])`` of a skip layer and ``cat([final, dir])`` are column ranges of one buffer, never copies of
+    activations.  Same interface as ``VanillaMLP`` (``forward(x, sigma_only)``, ``state_dict``, ``check``); inference only
+    (the training step is built for the default architecture)."""
+
+    POINT_CHUNK = 262144          # rows per pass (the reference's point_chunk, options/base_options.py:70): bounds the buffers
+
+    def __init__(self, opt=None, device="cuda", **arch):
+        self.arch = {**arch_of(opt), **arch}
+        self.spec = arch_spec(**self.arch)                  # validates
+        self.color_activation = getattr(opt, "color_activation", "sigmoid") if opt is not None else "sigmoid"
+        if self.color_activation not in ("sigmoid", "none"):
+            raise ValueError(f"color_activation={self.color_activation!r}: 'sigmoid' or 'none' (models/networks.py:173-180)")
+        if opt is not None and getattr(opt, "gamma_correct", False):
+            raise ValueError("gamma_correct is built into the fused kernels' colour head only (default architecture)")
+        self.device = torch.device(device)
+        _check_device(self.device, "GenericMLP device")
+        a = self.arch
+        self.in_xyz, self.in_dir = 3 + 6 * a["deg_pos"], 3 + 6 * a["deg_dir"]
+        r32 = lambda n: (n + 31) // 32 * 32
+        self.Kx, self.Wp, self.Hp, self.Dp, self.Rp = r32(self.in_xyz), r32(a["W"]), r32(a["W"] // 2), r32(self.in_dir), r32(a["dim_rgb"])
+        self.precision = "fp32"
+        self._sd = None
+        self._bad = None
+
+    # -- weights ------------------------------------------------------------------------------------------------------
+    def _padded(self, w, rows, col_map, cols):
+        """(rows, cols) zero matrix with w's column ranges placed by col_map = [(src0, n, dst0), ...]."""
+        out = torch.zeros(rows, cols, dtype=torch.float32, device=self.device)
+        for s0, n, d0 in col_map:
+            out[: w.shape[0], d0:d0 + n] = w[:, s0:s0 + n]
+        return out
+
+    def _padded_bias(self, b, n):
+        out = torch.zeros(n, dtype=torch.float32, device=self.device)
+        out[: b.shape[0]] = b
+        return out
+
+    def load_state_dict(self, sd):
+        check_state_dict_arch(sd, **self.arch)
+        a, dev = self.arch, {}
+        for k in self.spec:
+            v = sd[k]
+            v = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v.detach()
+            dev[k] = v.to(device=self.device, dtype=torch.float32).contiguous()
+        W, ix, Kx, Wp = a["W"], self.in_xyz, self.Kx, self.Wp
+        self._layers = []                       # (weight, bias, first input column, K): the trunk, inputs = slots [pe | h]
+        for i in range(a["D"]):
+            w, b = dev[f"xyz_encoding_{i + 1}.0.weight"], self._padded_bias(dev[f"xyz_encoding_{i + 1}.0.bias"], Wp)
+            if i == 0:
+                self._layers.append((self._padded(w, Wp, [(0, ix, 0)], Kx), b, 0, Kx))
+            elif i in a["skips"]:               # cat([input_xyz, h]): pe at columns 0.., h at columns Kx..
+                self._layers.append((self._padded(w, Wp, [(0, ix, 0), (ix, W, Kx)], Kx + Wp), b, 0, Kx + Wp))
+            else:
+                self._layers.append((self._padded(w, Wp, [(0, W, 0)], Wp), b, Kx, Wp))
+        self._sigma = (self._padded(dev["sigma.weight"], 32, [(0, W, 0)], Wp), self._padded_bias(dev["sigma.bias"], 32))
+        self._final = (self._padded(dev["xyz_encoding_final.weight"], Wp, [(0, W, 0)], Wp), self._padded_bias(dev["xyz_encoding_final.bias"], Wp))
+        dmap = [(0, W, 0)] + ([] if a["no_dir"] else [(W, self.in_dir, Wp)])
+        self._dir = (self._padded(dev["dir_encoding.0.weight"], self.Hp, dmap, Wp + (0 if a["no_dir"] else self.Dp)),
+                     self._padded_bias(dev["dir_encoding.0.bias"], self.Hp))
+        self._rgb = (self._padded(dev["rgb.0.weight"], self.Rp, [(0, W // 2, 0)], self.Hp), self._padded_bias(dev["rgb.0.bias"], self.Rp))
+        self._sd = dev
+        self._bad = torch.zeros((), dtype=torch.bool, device=self.device)
+        return self
+
+    def state_dict(self):
+        if self._sd is None:
+            raise RuntimeError("no weights loaded")
+        return {k: v.clone() for k, v in self._sd.items()}
+
+    # -- numerics status: the reference drops into pdb on NaN colours (models/nerf_downX_model.py:273-274) ---------------------------
+    def status(self, clear: bool = False) -> int:
+        flags = _lib.NSR_FLAG_OUTPUT_NONFINITE if (self._bad is not None and bool(self._bad)) else 0
+        if clear and self._bad is not None:
+            self._bad.zero_()
+        return flags
+
+    def check(self, what: str = "network"):
+        flags = self.status(clear=True)
+        if flags:
+            raise _lib.NsrNumericsError(f"{what} (layer-by-layer fp32): non-finite network output", flags)
+        return self
+
+    # -- forward ------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _gemm(x, col0, ldx, K, w, b, act, y, ycol0, ldy, P):
+        lib, esz = _lib.load(), 4
+        _lib.check(lib.nsr_linear(c_void_p(x.data_ptr() + col0 * esz), ldx, _p(w), w.shape[1], _p(b), act,
+                                  c_void_p(y.data_ptr() + ycol0 * esz), ldy, c_void_p(0), 0, P, K, w.shape[0], _stream()), "nsr_linear")
+
+    def forward(self, x: torch.Tensor, sigma_only: bool = False) -> torch.Tensor:
+        if self._sd is None:
+            raise RuntimeError("GenericMLP.forward called before load_state_dict")
+        x = _f32(x, "x")
+        n_in = self.in_xyz + (0 if sigma_only else self.in_dir)
+        if x.ndim != 2 or x.shape[1] < n_in:
+            raise ValueError(f"x must be (B, {n_in}), got {tuple(x.shape)}")
+        a, B = self.arch, x.shape[0]
+        out = torch.empty(B, 1 if sigma_only else a["dim_rgb"] + 1, dtype=torch.float32, device=x.device)
+        Kx, Wp, Ls = self.Kx, self.Wp, self.Kx + self.Wp
+        for r0 in range(0, B, self.POINT_CHUNK):
+            xb = x[r0:r0 + self.POINT_CHUNK]
+            P = xb.shape[0]
+            slots = [torch.zeros(P, Ls, dtype=torch.float32, device=x.device) for _ in range(2)]     # [pe | pad | h | pad] twice
+            for s in slots:
+                s[:, : self.in_xyz] = xb[:, : self.in_xyz]
+            for i, (w, b, c0, K) in enumerate(self._layers):        # layer i reads slot (i - 1) % 2, writes h of slot i % 2
+                self._gemm(slots[(i - 1) % 2], c0, Ls, K, w, b, 1, slots[i % 2], Kx, Ls, P)
+            h = slots[(a["D"] - 1) % 2]
+            small = torch.empty(P, 32, dtype=torch.float32, device=x.device)
+            self._gemm(h, Kx, Ls, Wp, self._sigma[0], self._sigma[1], 0, small, 0, 32, P)
+            if sigma_only:
+                out[r0:r0 + P, 0] = small[:, 0]
+                continue
+            Ld = Wp + (0 if a["no_dir"] else self.Dp)
+            dbuf = torch.zeros(P, Ld, dtype=torch.float32, device=x.device)                             # [final | pad | dir pe | pad]
+            self._gemm(h, Kx, Ls, Wp, self._final[0], self._final[1], 0, dbuf, 0, Ld, P)
+            if not a["no_dir"]:
+                dbuf[:, Wp:Wp + self.in_dir] = xb[:, self.in_xyz:self.in_xyz + self.in_dir]
+            c = torch.empty(P, self.Hp, dtype=torch.float32, device=x.device)
+            self._gemm(dbuf, 0, Ld, Ld, self._dir[0], self._dir[1], 1, c, 0, self.Hp, P)
+            rgb = torch.empty(P, self.Rp, dtype=torch.float32, device=x.device)
+            self._gemm(c, 0, self.Hp, self.Hp, self._rgb[0], self._rgb[1], 2 if self.color_activation == "sigmoid" else 0, rgb, 0, self.Rp, P)
+            out[r0:r0 + P, : a["dim_rgb"]] = rgb[:, : a["dim_rgb"]]
+            out[r0:r0 + P, a["dim_rgb"]] = small[:, 0]
+        self._bad |= ~torch.isfinite(out).all()
+        return out
+
+    __call__ = forward
+
+
+def make_mlp(opt=None, precision: str = "fp32", device="cuda"):
+    """The network class for an options object: the fused-kernel ``VanillaMLP`` for the architecture every script of the
+    reference uses, ``GenericMLP`` for other ``--D --W --skips`` / degrees / ``dim_rgb``."""
+    if is_default_arch(arch_of(opt)):
+        return VanillaMLP(opt, precision=precision, device=device)
+    return GenericMLP(opt, device=device)
 
 
 # ----------------------------------------------------------------------------- V1

@@ -145,3 +145,76 @@ def pad_no_dir(w):
         return np.concatenate([w, np.zeros((w.shape[0], 27), dtype=w.dtype)], 1)
     import torch
     return torch.cat([w, torch.zeros(w.shape[0], 27, dtype=w.dtype, device=w.device)], 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The architecture flags of VanillaMLP (models/networks.py:124-128 --D --W --skips --no_dir; models/nerf_model.py:53-57
+# --dim_rgb --deg_pos --deg_dir).  The fused kernels are laid out for the defaults above; any other value runs layer by
+# layer (ops.GenericMLP).
+# ---------------------------------------------------------------------------------------------------------------------
+def arch_of(opt=None) -> dict:
+    """The architecture values of an options object (absent ones = the reference's defaults)."""
+    g = (lambda k, d: getattr(opt, k, d)) if opt is not None else (lambda k, d: d)
+    return {"D": int(g("D", D_LAYERS)), "W": int(g("W", WIDTH)), "skips": tuple(int(s) for s in g("skips", (SKIP_LAYER,))),
+            "deg_pos": int(g("deg_pos", DEG_POS)), "deg_dir": int(g("deg_dir", DEG_DIR)), "dim_rgb": int(g("dim_rgb", 3)),
+            "no_dir": bool(g("no_dir", False))}
+
+
+def is_default_arch(arch: dict) -> bool:
+    """True when the fused kernels cover it (``no_dir`` rides them too: weights.pad_no_dir)."""
+    return all(arch[k] == v for k, v in (("D", D_LAYERS), ("W", WIDTH), ("skips", (SKIP_LAYER,)), ("deg_pos", DEG_POS),
+                                          ("deg_dir", DEG_DIR), ("dim_rgb", 3)))
+
+
+def arch_spec(D=D_LAYERS, W=WIDTH, skips=(SKIP_LAYER,), deg_pos=DEG_POS, deg_dir=DEG_DIR, dim_rgb=3, no_dir=False):
+    """key -> shape of ``VanillaMLP(opt).state_dict()`` for these flags, in the module's own order (models/networks.py:131-180)."""
+    if D < 1 or W < 2 or W % 2 or deg_pos < 0 or deg_dir < 0 or dim_rgb < 1 or any(s < 1 or s >= D for s in skips):
+        raise ValueError("D >= 1, even W >= 2, degrees >= 0, dim_rgb >= 1 and skip layers inside 1 .. D - 1 "
+                         "(a skip at layer 0 would double the input: the reference's constructor gives layer 0 the plain width)")
+    in_xyz, in_dir = 3 + 6 * deg_pos, 3 + 6 * deg_dir
+    spec = OrderedDict()
+    for i in range(D):
+        fan_in = in_xyz if i == 0 else (W + in_xyz if i in skips else W)
+        spec[f"xyz_encoding_{i + 1}.0.weight"] = (W, fan_in)
+        spec[f"xyz_encoding_{i + 1}.0.bias"] = (W,)
+    spec["xyz_encoding_final.weight"] = (W, W)
+    spec["xyz_encoding_final.bias"] = (W,)
+    spec["dir_encoding.0.weight"] = (W // 2, W + (0 if no_dir else in_dir))
+    spec["dir_encoding.0.bias"] = (W // 2,)
+    spec["sigma.weight"] = (1, W)
+    spec["sigma.bias"] = (1,)
+    spec["rgb.0.weight"] = (dim_rgb, W // 2)
+    spec["rgb.0.bias"] = (dim_rgb,)
+    return spec
+
+
+def make_state_dict_arch(seed: int, bias_scale: float = 0.05, **arch):
+    """Deterministic synthetic weights for any architecture ``arch_spec`` describes: kaiming weights, small biases, the
+    "smooth" field's density head (``sigma.weight`` x 10, ``sigma.bias`` -3) and 1/f positional-encoding columns."""
+    spec = arch_spec(**arch)
+    deg_pos = arch.get("deg_pos", DEG_POS)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = OrderedDict()
+    for key, shape in spec.items():
+        if key.endswith("weight"):
+            sd[key] = (rng.standard_normal(shape, dtype=np.float64) * np.sqrt(2.0 / shape[1])).astype(np.float32)
+        else:
+            sd[key] = (rng.standard_normal(shape, dtype=np.float64) * bias_scale).astype(np.float32)
+    in_xyz = 3 + 6 * deg_pos
+    for key, shape in spec.items():
+        if key.startswith("xyz_encoding_") and key.endswith("0.weight") and shape[1] in (in_xyz, arch.get("W", WIDTH) + in_xyz):
+            for k in range(deg_pos):
+                sd[key][:, 3 + 6 * k: 9 + 6 * k] *= np.float32(2.0 ** (-k))
+    sd["sigma.weight"] = (sd["sigma.weight"] * np.float32(10.0)).astype(np.float32)
+    sd["sigma.bias"] = np.full((1,), -3.0, dtype=np.float32)
+    return sd
+
+
+def check_state_dict_arch(sd, **arch) -> None:
+    spec = arch_spec(**arch)
+    missing = [k for k in spec if k not in sd]
+    if missing:
+        raise ValueError(f"state_dict is missing keys: {missing}")
+    for k, shape in spec.items():
+        if tuple(sd[k].shape) != tuple(shape):
+            raise ValueError(f"state_dict[{k!r}] has shape {tuple(sd[k].shape)}, expected {tuple(shape)} for {arch}")

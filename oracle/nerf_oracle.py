@@ -225,8 +225,8 @@ def mlp_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, sigma_only: bool =
                 color_activation: str = "sigmoid", stop_grad: bool = False) -> torch.Tensor:
     """``VanillaMLP.forward`` on embedded rows x (B, 90) -> (B, 4) = [rgb, sigma_raw].
 
-    Restates ``models/networks.py:182-226`` with D=8, W=256, skips=[4]: the skip
-    layer sees ``cat([pe, h])`` (input first); sigma is the raw Linear output (the
+    Restates ``models/networks.py:182-226`` (D=8, W=256, skips=[4] in every script; any other ``--D --W --skips`` is
+    read off the tensors' shapes): a skip layer sees ``cat([pe, h])`` (input first); sigma is the raw Linear output (the
     ReLU is applied by the renderer); colour goes through sigmoid, or through nothing
     with ``color_activation='none'`` (``:173-180``).  A ``--no_dir`` network
     (``:160-169, 213-216``: ``dir_encoding.0.weight`` of shape (128, 256)) feeds
@@ -235,10 +235,15 @@ def mlp_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, sigma_only: bool =
     ``sd`` is the 24-key state_dict (torch tensors).
     """
     lin = torch.nn.functional.linear
-    pe, de = x[:, :63], x[:, 63:]
+    # the architecture flags (--D --W --skips, encoding degrees: models/networks.py:124-157) are read off the tensors: the
+    # first layer's fan-in is the encoded position's width, a trunk layer whose fan-in is W + that width is a skip layer
+    n_xyz = sd["xyz_encoding_1.0.weight"].shape[1]
+    width = sd["xyz_encoding_1.0.weight"].shape[0]
+    depth = sum(1 for k in sd if k.startswith("xyz_encoding_") and k.endswith(".0.weight"))
+    pe, de = x[:, :n_xyz], x[:, n_xyz:]
     h = pe
-    for i in range(8):
-        if i == 4:
+    for i in range(depth):
+        if i > 0 and sd[f"xyz_encoding_{i + 1}.0.weight"].shape[1] == width + n_xyz:
             h = torch.cat([pe, h], -1)
         h = torch.relu(lin(h, sd[f"xyz_encoding_{i + 1}.0.weight"], sd[f"xyz_encoding_{i + 1}.0.bias"]))
     sigma = lin(h, sd["sigma.weight"], sd["sigma.bias"])
@@ -257,7 +262,7 @@ def mlp_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, sigma_only: bool =
 
 
 def render_points(sd, xyz: torch.Tensor, dir_embedded: torch.Tensor, point_chunk: int = 262144,
-                  gamma_correct: bool = False, color_activation: str = "sigmoid", stop_grad: bool = False):
+                  gamma_correct: bool = False, color_activation: str = "sigmoid", stop_grad: bool = False, deg_pos: int = 10):
     """(R, N, 3) points + (R, 27) dir embedding -> rgb (R, N, 3), sigma (R, N).
 
     Restates ``models/nerf_downX_model.py:260-278`` (render_rays): PE of the points,
@@ -267,14 +272,14 @@ def render_points(sd, xyz: torch.Tensor, dir_embedded: torch.Tensor, point_chunk
     """
     R, N = xyz.shape[:2]
     pts = xyz.reshape(-1, 3)
-    x = torch.cat([posenc(pts, 10), dir_embedded.repeat_interleave(N, dim=0)], -1)
+    x = torch.cat([posenc(pts, deg_pos), dir_embedded.repeat_interleave(N, dim=0)], -1)
     outs = [mlp_forward(sd, x[i:i + point_chunk], color_activation=color_activation, stop_grad=stop_grad)
             for i in range(0, x.shape[0], point_chunk)]
-    out = torch.cat(outs, 0).view(R, N, 4)
-    rgb = out[..., :3]
+    out = torch.cat(outs, 0).view(R, N, -1)
+    rgb = out[..., :-1]
     if gamma_correct:
         rgb = torch.pow(rgb, 1 / 2.2)
-    return rgb, out[..., 3]
+    return rgb, out[..., -1]
 
 
 # ----------------------------------------------------------------------------
@@ -313,7 +318,7 @@ def composite(rgb: torch.Tensor, sigma: torch.Tensor, z: torch.Tensor, white_bkg
 
 def forward_rays(sd_coarse, sd_fine, rays: torch.Tensor, n_coarse: int = 64, n_importance: int = 64,
                  white_bkgd: bool = False, lindisp: bool = False, ray_chunk: int = 4096, gamma_correct: bool = False,
-                 sigma_activation: str = "relu", color_activation: str = "sigmoid"):
+                 sigma_activation: str = "relu", color_activation: str = "sigmoid", deg_pos: int = 10, deg_dir: int = 4):
     """Eval-mode ``forward_rays`` over (R, 8) rays -> dict of the 8 reference outputs.
 
     Restates ``models/nerf_downX_model.py:280-313`` chunked as ``:316-324``
@@ -325,15 +330,15 @@ def forward_rays(sd_coarse, sd_fine, rays: torch.Tensor, n_coarse: int = 64, n_i
     for i in range(0, rays.shape[0], ray_chunk):
         r = rays[i:i + ray_chunk]
         o, d, near, far = r[:, 0:3], r[:, 3:6], r[:, 6:7], r[:, 7:8]
-        de = posenc(r[:, 8:11] if r.shape[1] == 11 else d, 4)
+        de = posenc(r[:, 8:11] if r.shape[1] == 11 else d, deg_dir)
         z, xyz = sample_coarse(o, d, near, far, n_coarse, lindisp)
-        rgb, sig = render_points(sd_coarse, xyz, de, gamma_correct=gamma_correct, color_activation=color_activation)
+        rgb, sig = render_points(sd_coarse, xyz, de, gamma_correct=gamma_correct, color_activation=color_activation, deg_pos=deg_pos)
         c_rgb, c_depth, c_op, c_w = composite(rgb, sig, z, white_bkgd, sigma_activation)
         res = {"coarse_comp_rgbs": c_rgb, "coarse_depth": c_depth, "coarse_opacity": c_op,
                "coarse_weights": c_w}
         if n_importance > 0:
             z2, xyz2 = resample_fine(o, d, z, c_w, n_importance)
-            rgb2, sig2 = render_points(sd_fine, xyz2, de, gamma_correct=gamma_correct, color_activation=color_activation)
+            rgb2, sig2 = render_points(sd_fine, xyz2, de, gamma_correct=gamma_correct, color_activation=color_activation, deg_pos=deg_pos)
             f_rgb, f_depth, f_op, f_w = composite(rgb2, sig2, z2, white_bkgd, sigma_activation)
             res.update({"fine_comp_rgbs": f_rgb, "fine_depth": f_depth, "fine_opacity": f_op,
                         "fine_weights": f_w})

@@ -20,8 +20,30 @@ def test_unbuilt_mlp_options_raise(kw):
         ops.check_mlp_options(SimpleNamespace(**kw))
     with pytest.raises(ValueError, match="outside the built path"):
         ops.VanillaMLP(SimpleNamespace(**kw), precision="fp32")          # before any device is touched
+    if set(kw) & {"color_activation", "no_dir", "stop_grad"}:      # not architecture: no class serves a malformed value
+        with pytest.raises(ValueError):
+            NeRFDownXModel(default_options(**kw))
+
+
+def test_architecture_flags_select_the_layer_by_layer_class():
+    """--D --W --skips / degrees / dim_rgb (round 5): refused by the fused-kernel class, served by ops.GenericMLP through
+    ops.make_mlp (host logic only here: constructing either class touches no device memory beyond the packed blob)."""
+    from nerf_sr_amd.weights import arch_of, arch_spec, is_default_arch, make_state_dict_arch, check_state_dict_arch
+    assert is_default_arch(arch_of(None)) and is_default_arch(arch_of(default_options())) and is_default_arch(arch_of(SimpleNamespace(no_dir=True)))
+    a = arch_of(SimpleNamespace(D=4, W=128, skips=[2], deg_pos=6, deg_dir=2))
+    assert not is_default_arch(a)
+    spec = arch_spec(**a)
+    assert spec["xyz_encoding_3.0.weight"] == (128, 128 + 39) and spec["dir_encoding.0.weight"] == (64, 128 + 15) and len(spec) == 16
+    sd = make_state_dict_arch(3, **a)
+    check_state_dict_arch(sd, **a)
+    with pytest.raises(ValueError):
+        check_state_dict_arch(sd, **{**a, "W": 64})
+    for bad in ({"D": 0}, {"W": 5}, {"skips": (0,)}, {"skips": (9,)}, {"dim_rgb": 0}):
+        with pytest.raises(ValueError):
+            arch_spec(**{**a, **bad})
+    ops.check_mlp_options(SimpleNamespace(D=4, W=128), fused=False)
     with pytest.raises(ValueError, match="outside the built path"):
-        NeRFDownXModel(default_options(**kw))
+        ops.check_mlp_options(SimpleNamespace(dim_pos=2), fused=False)
 
 
 def test_reference_defaults_pass():

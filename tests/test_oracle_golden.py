@@ -178,3 +178,27 @@ def test_option_values_no_script_uses(golden_dir, case):
         rgb, sig = oc.render_points(sd_c, xyz, oc.posenc(d, 4), color_activation=kw.get("color_activation", "sigmoid"))
         _close(rgb[:16], g[f"{case}_{tag}_coarse_point_rgb"], 1e-5 if case == "color_none" else ATOL)
         _close(sig[:16], g[f"{case}_{tag}_coarse_point_sigma"], 1e-5)
+
+
+ARCH_CASES = {"small": ({"D": 4, "W": 128, "skips": (2,), "deg_pos": 6, "deg_dir": 2}, "llff", False),
+              "odd": ({"D": 6, "W": 192, "skips": (1, 3), "deg_pos": 10, "deg_dir": 4}, "blender", True)}
+
+
+@pytest.mark.parametrize("case", list(ARCH_CASES))
+def test_architecture_flags(golden_dir, case):
+    """--D --W --skips --deg_pos --deg_dir (models/networks.py:124-157, models/nerf_model.py:53-57): the reference's own
+    forward for two non-default networks (tests/golden/make_golden_arch.py); the oracle reads the architecture off the
+    tensors' shapes."""
+    from nerf_sr_amd.weights import make_state_dict_arch
+    g = np.load(os.path.join(golden_dir, "arch.npz"))
+    arch, tag, white = ARCH_CASES[case]
+    p = np.load(os.path.join(golden_dir, f"path_{tag}.npz"))
+    sd_c = oc.to_torch_sd(make_state_dict_arch(int(g["seed_coarse"]), **arch))
+    sd_f = oc.to_torch_sd(make_state_dict_arch(int(g["seed_fine"]), **arch))
+    x = _t(g[f"{case}_mlp_in_256"])
+    _close(oc.mlp_forward(sd_c, x), g[f"{case}_mlp_out_256"], 1e-5)
+    _close(oc.mlp_forward(sd_c, x[:64], sigma_only=True), g[f"{case}_mlp_sigma_only_64"], 1e-5)
+    rays = _t(p["rays"])[:int(g["n_rays"])]
+    out = oc.forward_rays(sd_c, sd_f, rays, 64, 64, white, deg_pos=arch["deg_pos"], deg_dir=arch["deg_dir"])
+    for k, v in out.items():
+        _close(v, g[f"{case}_{k}"], 1e-5 if "depth" in k else ATOL)
