@@ -223,3 +223,18 @@ def test_headers_are_plain_c99_and_the_library_links_from_c(lib, tmp_path):
     ver, mlp_bytes, refine_bytes, msg = out.stdout.strip().split(" ", 3)
     assert int(ver) == lib.nsr_version() and int(mlp_bytes) == lib.nsr_packed_weights_bytes(_lib.NSR_F16X3)
     assert int(refine_bytes) == lib.nsr_refine_packed_bytes(_lib.NSR_F16X3) and "invalid argument" in msg
+
+
+def test_driver_build_entry_point_runs():
+    """`__graft_entry__.build()` is what the driver runs on the CPU box every round: it must compile (or find) the library,
+    bind every symbol and agree with include/nsr.h on the version -- a stale hard-coded version number there would fail the
+    round's build check although every other test is green."""
+    import importlib
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
+
+
+@pytest.mark.gpu
+def test_driver_smoke_entry_point_runs():
+    import importlib
+    importlib.import_module("__graft_entry__").smoke()
