@@ -45,3 +45,18 @@ if lib.nsr_dbg_ksteps(kb.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(kb.nby
     out["ksteps_of_one_trunk_chunk_cycles"] = {n: float(np.median(seg[:, :, i])) for i, n in enumerate(["k0-3", "k4-7", "k8-10", "k11-13", "k14-15"])}
 json.dump(out, open(OUT, "w"), indent=1)
 print(json.dumps(out))
+
+# per-chunk stamps (scripts/patches/fwd_train_chunks.patch): start of every trunk chunk (L2 .. L8, xyz_encoding_final: 64) + the end
+if hasattr(lib, "nsr_dbg_chunks"):
+    cb = np.zeros(4096 * 4 * 80, dtype=np.uint64)
+    lib.nsr_dbg_chunks.restype = ctypes.c_int
+    if lib.nsr_dbg_chunks(cb.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(cb.nbytes)) == 0:
+        c = cb.reshape(4096, 4, 80)[:n_wg].astype(np.int64)[steady]
+        dur = c[:, :, 1:65] - c[:, :, 0:64]
+        # the last stamp (index 64) is the kernel's end: chunk 63's figure includes sigma, dir_encoding and the tail
+        tab = [[round(float(dur[:, :, 8 * l + nb].mean())) for nb in range(8)] for l in range(8)]
+        print("chunk cycles by layer (L2 .. L8, final) and block:")
+        for row in tab:
+            print(row)
+        out["chunk_cycles_mean_by_layer_and_block"] = tab
+        json.dump(out, open(OUT, "w"), indent=1)
