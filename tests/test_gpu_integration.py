@@ -67,6 +67,15 @@ def test_integration_md_stub_runs_verbatim(golden_dir):
     out_g = ns["forward_rays"](blob_g, blob_f, rays, 64, 64, bool(g["white_bkgd"]), False)
     torch.cuda.synchronize()
     assert float((out_g["coarse_comp_rgbs"] - out["coarse_comp_rgbs"]).abs().max()) > 1e-3
+    # the two option words of round 5 through the stub, against the reference's own forward with the option on (options.npz)
+    o = np.load(os.path.join(golden_dir, "options.npz"))
+    n = int(o["n_rays"])
+    out_s = ns["forward_rays"](blob_c, blob_f, rays[:n].contiguous(), 64, 64, bool(g["white_bkgd"]), False, softplus=True)
+    blob_nc, blob_nf = (ns["pack"](_Net(make_state_dict(int(g[k]))), color_none=True) for k in ("seed_coarse", "seed_fine"))
+    out_n = ns["forward_rays"](blob_nc, blob_nf, rays[:n].contiguous(), 64, 64, bool(g["white_bkgd"]), False)
+    torch.cuda.synchronize()
+    assert np.abs(out_s["fine_comp_rgbs"].cpu().numpy() - o["softplus_llff_fine_comp_rgbs"]).max() <= 1e-4
+    assert np.abs(out_n["fine_comp_rgbs"].cpu().numpy() - o["color_none_llff_fine_comp_rgbs"]).max() <= 1e-4 * max(1.0, np.abs(o["color_none_llff_fine_comp_rgbs"]).max())
     # ... and check() of the stub raises on a poisoned input (the reference drops into pdb there)
     bad = rays.clone()
     bad[3, 0] = float("nan")
