@@ -208,6 +208,9 @@ def train_cpu_baseline(sd_c, sd_f, rays_cpu, target_cpu, s2: int, draws):
                       f"threads over disjoint LR-aligned ray chunks = {len(jobs) * threads} of {host} host threads"}
 
 
+CHAIN_PRECISIONS = ("f16x3", "f16x3_bwd3", "f16x3_bwd2", "f16x3_bwd1")   # the chain kernels (include/nsr_train.h)
+
+
 def train_bench(args, rank, local, world, steps=None, warmup=None, cpu=True, shape="downx"):
     """Training-step benchmark (not the headline).  shape "downx": scripts/train_llff_downX.sh's batch -- 512 LR pixels x 4
     sub-rays = 2,048 rays per GPU per step, 64 + 128 samples, randomized sampling, noise_std 1 -- through
@@ -264,7 +267,7 @@ def train_bench(args, rank, local, world, steps=None, warmup=None, cpu=True, sha
                        "training rays/sec (64+128 samples, 2x SS; forward + backward + Adam)"), "value": value,
             "unit": "rays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (forward products split-fp16 x3, fp32-grade)" if args.train_precision == "f16x3" else "f32",
+            "dtype": "f32 (forward products split-fp16 x3, fp32-grade)" if args.train_precision.startswith("f16x3") else "f32",
             "data": "synthetic",
             "config": {"workload": (f"BASELINE config #1: training iteration of the vanilla nerf model (scripts/train_llff.sh "
                                     f"shape): {R} 11-wide rays of a 252x189 frame per GPU per step, no supersampling, 64 coarse + "
@@ -282,7 +285,7 @@ def train_bench(args, rank, local, world, steps=None, warmup=None, cpu=True, sha
                          "note": "algorithmic flops = 3 x 593,408 MAC x 2 per sample point x 192 points per ray"},
             "losses": [float(x) for x in t.losses.tolist()],
         }
-        if args.train_precision == "f16x3":
+        if args.train_precision in CHAIN_PRECISIONS:
             # chain path: forward and input gradients run on the split-fp16 MFMA, the weight gradients on one
             # fp16 MFMA per product, and the step is bound by the 2-byte panels it moves through HBM.  Rows of 2-byte values
             # per sample point: the forward kernel writes 2,560 (ten activation panels + the two encodings), the backward
@@ -427,7 +430,7 @@ def main():
                     help="render (default): the headline metric; train: one optimize_parameters iteration per step "
                          "(SURVEY §8f N1: forward + backward + Adam, fp32) on a 2,048-ray batch per GPU")
     ap.add_argument("--train-rays", type=int, default=2048, help="rays per GPU per training step (multiple of 4)")
-    ap.add_argument("--train-precision", default="f16x3", choices=["f16x3", "fp32", "f16x3_gemm"],
+    ap.add_argument("--train-precision", default="f16x3", choices=["f16x3", "fp32", "f16x3_gemm", "f16x3_bwd3", "f16x3_bwd2", "f16x3_bwd1"],
                     help="training step: forward products on the split-fp16 MFMA (default, fp32-grade) or everything on the fp32 MFMA")
     ap.add_argument("--n-importance", type=int, default=64,
                     help="importance samples per ray: 64 (every script of the reference: 64 coarse + 128 fine network evaluations "

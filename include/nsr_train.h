@@ -30,6 +30,18 @@ extern "C" {
 
 /* A third `precision` value, valid for the training entry points only (nsr_precision in nsr.h holds the others). */
 #define NSR_F16X3_GEMM 18
+/* The chain path with the arithmetic of its BACKWARD chain (the input gradients dz_{l-1} = W_l^T dz_l) named explicitly
+ * (round 6; forward pass and weight gradients as under NSR_F16X3 in all three):
+ *   NSR_F16X3_BWD3: W_hi g_hi + W_hi g_lo + W_lo g_hi, three MFMAs per product, fp32-grade (rounds 2-5's arithmetic);
+ *   NSR_F16X3_BWD2: W_hi g_hi + W_lo g_hi: the gradient entering a layer is its fp16 `hi` alone (11 bits, scaled per point by a
+ *                   power of two), the weights keep their 22 bits;
+ *   NSR_F16X3_BWD1: W_hi g_hi: one MFMA per product, both operands rounded to 11 bits.
+ * NSR_F16X3 selects the cheapest of them whose gradients stay inside the bounds of tests/test_gpu_train.py (every gradient
+ * tensor within 2e-3 of its norm of the fp64 oracle, 5e-4 on the heads, a 200-step Adam trajectory no further from the fp32
+ * run than another fp32-grade implementation is): NSR_F16X3_BWD1 as of NSR_VERSION 130 (measured: DESIGN.md 7.1). */
+#define NSR_F16X3_BWD3 19
+#define NSR_F16X3_BWD2 20
+#define NSR_F16X3_BWD1 21
 
 /* Workspace for one pass over `ray_chunk` rays (activations of one network, gradient buffers, padded weight copies,
  * split-K partials; for NSR_F16X3 the activation / gradient panels, ~24 KB per sample point in all).  0 on invalid

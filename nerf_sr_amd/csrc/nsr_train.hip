@@ -957,8 +957,15 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, int64_t n_rays,
 }
 
 // which implementation a precision value selects (include/nsr_train.h): the chain kernels or the layer-by-layer GEMMs
-bool chain_selected(int precision) { return precision == NSR_F16X3; }
-bool train_precision_ok(int precision) { return precision == NSR_FP32 || precision == NSR_F16X3 || precision == NSR_F16X3_GEMM; }
+bool chain_selected(int precision) {
+  return precision == NSR_F16X3 || precision == NSR_F16X3_BWD3 || precision == NSR_F16X3_BWD2 || precision == NSR_F16X3_BWD1;
+}
+// MFMAs per product of the backward chain (include/nsr_train.h; NSR_F16X3 = the default, kDefaultBwdTerms)
+constexpr int kDefaultBwdTerms = 1;
+int chain_bwd_terms(int precision) {
+  return precision == NSR_F16X3_BWD3 ? 3 : (precision == NSR_F16X3_BWD2 ? 2 : (precision == NSR_F16X3_BWD1 ? 1 : kDefaultBwdTerms));
+}
+bool train_precision_ok(int precision) { return precision == NSR_FP32 || chain_selected(precision) || precision == NSR_F16X3_GEMM; }
 int gemm_precision(int precision) { return precision == NSR_F16X3_GEMM ? NSR_F16X3 : precision; }   // what the GEMM path's helpers expect
 
 int composite_bwd(hipStream_t st, const Work& k, const float* z, int64_t R, int N, int white, bool compact, const float* g_depth) {
@@ -1048,9 +1055,9 @@ int train_impl(const float* const* w_coarse, const float* const* w_fine, float* 
     for (int net = 0; net < 2; ++net) {
       // the weights are re-packed every iteration: a run whose weights drift beyond what the split-fp16 stream carries
       // (|w| >= 1023.75, or NaN) raises NSR_FLAG_WEIGHT_RANGE in the step's status word, like nsr_pack_weights does
-      NSR_TRY(nsr_check_weights_range(net ? w_fine : w_coarse, precision, k.status, stream));
+      NSR_TRY(nsr_check_weights_range(net ? w_fine : w_coarse, NSR_F16X3, k.status, stream));
       NSR_TRY(nsr_f16x3_pack(net ? w_fine : w_coarse, k.stream_f[net], stream));
-      NSR_TRY(nsr_chain_bwd_pack(net ? w_fine : w_coarse, k.stream_b[net], stop_grad, stream));
+      NSR_TRY(nsr_chain_bwd_pack(net ? w_fine : w_coarse, k.stream_b[net], stop_grad, chain_bwd_terms(precision), stream));
     }
   } else {
     NSR_TRY(prepare_weights(st, w_coarse, k.pack[0], gemm_precision(precision)));
@@ -1116,7 +1123,7 @@ int train_impl(const float* const* w_coarse, const float* const* w_fine, float* 
       NSR_CHECK_LAUNCH();
       NSR_TRY(composite_bwd(st, k, z, rc, N, white_bkgd, chain, depth_var ? k.g_depth : nullptr));
       if (chain) {
-        NSR_TRY(nsr_chain_bwd(k.stream_b[net], k.sgn, k.dpan, k.d4, 4, k.d4 + 3, 4, P, k.gmax, k.pscale, stream));
+        NSR_TRY(nsr_chain_bwd(k.stream_b[net], k.sgn, k.dpan, k.d4, 4, k.d4 + 3, 4, P, k.gmax, k.pscale, chain_bwd_terms(precision), stream));
         NSR_TRY(chain_weight_grads(st, k, P, rc, g, acc));
       } else {
         NSR_TRY(net_backward(st, w, k.pack[net], k, P, g, acc, stop_grad));

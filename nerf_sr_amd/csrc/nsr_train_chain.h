@@ -18,7 +18,9 @@ extern "C" NSR_INTERNAL int nsr_f16x3_pack(const float* const* w, void* packed_d
 // gmax[10] (device): float bits of the largest TRUE magnitude of each gradient panel (zeroed, then atomicMax);
 // pscale (10, ceil(P / 128) * 128): per panel and point the power of two that turns the stored fp16 values into true gradients
 extern "C" NSR_INTERNAL size_t nsr_chain_bwd_packed_bytes(void);
-extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* packed_dev, int stop_grad, void* stream);
+// terms (round 6): MFMAs per product of the chain -- 3 = W_hi g_hi + W_hi g_lo + W_lo g_hi (fp32-grade), 2 = W_hi g_hi + W_lo g_hi,
+// 1 = W_hi g_hi (the stream then carries the hi pieces only); pack and run must agree
+extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* packed_dev, int stop_grad, int terms, void* stream);
 extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const unsigned* sgn, void* dpan, const float* d_rgb, int d_rgb_stride,
                                           const float* d_sigma, int d_sigma_stride, int64_t P, unsigned* gmax,
-                                          float* pscale, void* stream);
+                                          float* pscale, int terms, void* stream);

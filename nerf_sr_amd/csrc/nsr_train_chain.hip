@@ -53,16 +53,18 @@ struct BwdPackPtrs {
 // stop_grad (--stop_grad, models/networks.py:218-219: dir_encoding's input is detached): the g columns of dir_encoding's weight
 // are packed as zeros, so the gradient that leaves the colour branch for xyz_encoding_final is an exact 0 at every point --
 // xyz_encoding_final's weights and bias get zero gradients, the trunk sees the density head's gradient alone.
-__global__ void __launch_bounds__(256) pack_bwd_kernel(BwdPackPtrs w, unsigned* __restrict__ out, int stop_grad) {
+// hi_only (round 6, the one-term chain): the stream carries the hi pieces alone -- 16 pieces per chunk, 128 per layer
+__global__ void __launch_bounds__(256) pack_bwd_kernel(BwdPackPtrs w, unsigned* __restrict__ out, int stop_grad, int hi_only) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int stream_words = kBwdPieces * 256;
+  const int stream_words = (hi_only ? kBwdPieces / 2 : kBwdPieces) * 256;
   if (idx >= stream_words + kBwdAuxFloats) return;
   unsigned v = 0u;
   if (idx < stream_words) {
     const int piece = idx >> 8, word = idx & 255;
-    const int lam = piece >> 8, local = piece & 255;
-    const int nb = local / kBwdChunkPieces, rem = local % kBwdChunkPieces;
-    const int s = rem >> 1, part = rem & 1;
+    const int per_layer = hi_only ? 128 : 256, per_chunk = hi_only ? kBwdChunkPieces / 2 : kBwdChunkPieces;
+    const int lam = piece / per_layer, local = piece % per_layer;
+    const int nb = local / per_chunk, rem = local % per_chunk;
+    const int s = hi_only ? rem : rem >> 1, part = hi_only ? 0 : rem & 1;
     const int lane = word >> 2, jj = word & 3;
     const int n = 32 * nb + (lane & 31), h = lane >> 5;
     float f[2];
@@ -539,31 +541,370 @@ chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ 
   if (threadIdx.x < 10) atomicMax(gmax + threadIdx.x, lmax[threadIdx.x]);
 }
 
+
+// =========================================================================================================
+// Reduced-term variants of the chain (round 6): NT = 2 or 1 MFMAs per product instead of three.
+//   NT = 2:  W_hi g_hi + W_lo g_hi   -- the weights keep their 22 bits, the incoming gradient is its fp16 `hi` alone
+//   NT = 1:  W_hi g_hi               -- both operands rounded to 11 bits; the stream carries the hi pieces only (16 KiB chunks)
+// The gradient's `hi` registers are what the chain has stored for the weight-gradient kernel since round 5, so nothing about
+// the panels, the sign words, pscale or gmax changes; what goes away is the `lo` operand set (64 registers), its two
+// v_fma_mix per register pair, and one (NT = 2) or two (NT = 1) of the three MFMAs.  Error of a gradient tensor against
+// the fp64 oracle, predicted on the CPU (scripts/study_bwd_terms.py -> profiles/r6_bwd_terms_study.txt) and measured on
+// the device (tests/test_gpu_train.py, tolerances unchanged: 2e-3 of the norm, 5e-4 on the heads): see DESIGN 7.1.
+// A workgroup is still 4 waves x 32 points; with <= 256 registers and a 48 KiB ring (NT = 1) two workgroups share a CU,
+// so one wave's re-split VALU, LDS reads and DMA issue run under the other's MFMAs.
+// =========================================================================================================
+template <int NT>
+struct HCfg {
+  static_assert(NT == 1 || NT == 2, "reduced-term chain: one or two MFMAs per product");
+  static constexpr int kChunkPieces = NT == 1 ? 16 : 32;       // 16 k-steps x hi (x lo)
+  static constexpr int kSlotB = kChunkPieces * 1024;           // one ring slot
+  static constexpr int kLayerPieces = 8 * kChunkPieces;
+  static constexpr int kPieces = kLayerPieces * kBwdLayers;
+  static constexpr int kWavesPerEu = NT == 1 ? 2 : 1;
+};
+template <int NT>
+__device__ __forceinline__ ChunkRef hseq(int q, int wave) {   // chunk q = 8 lam + nb; past the end chunk 0 again (idle slot)
+  return make_ref((q < 8 * kBwdLayers ? q : 0) * HCfg<NT>::kChunkPieces, HCfg<NT>::kChunkPieces, wave);
+}
+struct PreH {
+  u32x4 ah[kPF], al[kPF];   // al: NT = 2 only
+};
+template <int NT>
+__device__ __forceinline__ void prefetch_frag_h(PreH& pre, int k, unsigned seq_addr) {
+  const u32x4* a = lds_vec(seq_addr);
+  if (NT == 2) {
+    pre.ah[k] = a[(2 * k) * 64];
+    pre.al[k] = a[(2 * k + 1) * 64];
+  } else {
+    pre.ah[k] = a[k * 64];
+  }
+}
+// the 16 k-steps of one output block; every MFMA opens a fenced gap (block_mma3's discipline): hook(s, g) runs in gap g of
+// k-step s (g < NT), the fragment reads of k-step s + kPF (or next(k)) in gap 0, the chunk's DMA pieces one per gap from
+// the publish point on (NT = 2: 8 pieces per wave in k-steps BAR .. BAR + 3; NT = 1: 4 pieces, one per k-step)
+template <int NT, int BAR, int YOUNGER, class BOf, class Hook, class Next>
+__device__ __forceinline__ void block_mma_h(Acc& acc, const PreH& pre, unsigned a_addr, Loader& ld, const ChunkRef& c2,
+                                            BOf&& b_of, Hook&& hook, Next&& next) {
+  constexpr int NSTEP = 16;
+  const u32x4* a_pieces = lds_vec(a_addr);
+  u32x4 ah[NSTEP], al[NT == 2 ? NSTEP : 1];
+#pragma unroll
+  for (int s = 0; s < kPF; ++s) {
+    ah[s] = pre.ah[s];
+    if (NT == 2) al[s] = pre.al[s];
+  }
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    if (s == BAR - 3) loader_prepare_dma(ld, c2, ld.slot_free);
+    if (s == BAR) loader_publish<YOUNGER, false>(ld, c2);
+    const u32x4 bh = b_of(s);
+    if (NT == 2) {
+      acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(al[s]), as_h8(bh), acc.m, 0, 0, 0);
+      if (s + kPF < NSTEP) {
+        ah[s + kPF] = a_pieces[(2 * (s + kPF)) * 64];
+        al[s + kPF] = a_pieces[(2 * (s + kPF) + 1) * 64];
+      } else {
+        next(s + kPF - NSTEP);
+      }
+      hook(s, 0);
+      if (s >= BAR && s < BAR + 4) loader_issue(ld, 2 * (s - BAR));
+      __builtin_amdgcn_sched_barrier(0);
+      acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bh), acc.m, 0, 0, 0);
+      hook(s, 1);
+      if (s >= BAR && s < BAR + 4) loader_issue(ld, 2 * (s - BAR) + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bh), acc.m, 0, 0, 0);
+      if (s + kPF < NSTEP) ah[s + kPF] = a_pieces[(s + kPF) * 64];
+      else next(s + kPF - NSTEP);
+      hook(s, 0);
+      if (s >= BAR && s < BAR + 4) loader_issue(ld, s - BAR);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// re-split of a finished gradient block without a lo part, per register pair P: X = mask in place (4 VALU, only where the
+// layer has a ReLU), Y = hi = RNE_f16(x) * phi + the running maximum (3 VALU).  Sixteen parts.
+template <int P, bool MASK, int HB>
+__device__ __forceinline__ void hsplit_x(Acc& p, unsigned mz) {
+  if (!MASK) return;
+  unsigned t0, t1;
+  asm volatile(
+      "v_bfe_i32 %2, %4, %5, 1\n\t"
+      "v_bfe_i32 %3, %4, %6, 1\n\t"
+      "v_bfi_b32 %0, %2, 0, %0\n\t"
+      "v_bfi_b32 %1, %3, 0, %1"
+      : "+v"(p.m[2 * P]), "+v"(p.m[2 * P + 1]), "=&v"(t0), "=&v"(t1)
+      : "v"(mz), "n"(HB + 15 - 2 * P), "n"(HB + 14 - 2 * P));
+}
+template <int P>
+__device__ __forceinline__ void hsplit_y(const Acc& p, Scale& sc, u32x4& h0, u32x4& h1) {
+  unsigned hi;
+  asm volatile(
+      "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+      "v_max3_f32 %1, |%2|, |%3|, %1\n\t"
+      "v_pk_mul_f16 %0, %0, %4"
+      : "=&v"(hi), "+v"(sc.mx)
+      : "v"(p.m[2 * P]), "v"(p.m[2 * P + 1]), "v"(sc.phi2));
+  bput<P>(hi, h0, h1);
+}
+template <bool MASK, int HB>
+__device__ __forceinline__ void hsplit_part(int i, Acc& p, unsigned mz, Scale& sc, u32x4& h0, u32x4& h1) {
+  switch (i) {
+#define NSR_HP(P)                                            \
+    case 2 * P: hsplit_x<P, MASK, HB>(p, mz); break;         \
+    case 2 * P + 1: hsplit_y<P>(p, sc, h0, h1); break;
+    NSR_HP(0) NSR_HP(1) NSR_HP(2) NSR_HP(3) NSR_HP(4) NSR_HP(5) NSR_HP(6) NSR_HP(7)
+#undef NSR_HP
+    default: break;
+  }
+}
+// Where the parts go.  The accumulators of the pending block were written by the MFMAs of the block before and are read
+// here by inline asm, which the hazard recognizer does not look into: nothing touches them before TWO MFMAs of the new
+// block have issued (the three-term kernel starts in gap 1 of k-step 0 as well).
+//   NT = 2: part i in gap number i + 1 (k-step (i + 1) >> 1, gap (i + 1) & 1): done in k-step 8, gap 0
+//   NT = 1: register pair P (parts 2P, 2P + 1) in k-step P + 1: done in k-step 8
+// i.e. before the operands of k-steps 14, 15 are read (block 0 of a layer converts INTO its own input) and before the
+// stores of k-steps 14, 15.
+template <int NT, bool MASK, int HB>
+__device__ __forceinline__ void hsplit_gap(int s, int g, Acc& p, unsigned mz, Scale& sc, u32x4& h0, u32x4& h1) {
+  if (NT == 2) {
+    const int i = 2 * s + g - 1;
+    if (i >= 0 && i < 16) hsplit_part<MASK, HB>(i, p, mz, sc, h0, h1);
+  } else if (s >= 1 && s <= 8) {
+    hsplit_part<MASK, HB>(2 * (s - 1), p, mz, sc, h0, h1);
+    hsplit_part<MASK, HB>(2 * (s - 1) + 1, p, mz, sc, h0, h1);
+  }
+}
+
+// bwd_layer without the lo operand set (see there for the flags)
+template <int NT, bool PREV_MASK, bool MASK, bool ADD, bool LAST, bool NEXT_MASK, bool FIRST = false>
+__device__ __forceinline__ void bwd_layer_h(int lam, int prev_panel, int panel, int next_panel, u32x4 (&bh)[16], u32x4 (&oh)[16],
+                                            const float* wsig_h, float d_sigma, Loader& ld, Acc& pend, PreH& pre,
+                                            unsigned (&mz)[2], Scale& prev, const BwdCtx& cx) {
+  constexpr int LG = NT - 1;   // the last gap of a k-step
+  Scale cur{};
+  const float sig = ADD ? d_sigma / (prev.cinv * (1.0f / 64.0f) / prev.phi) : 0.0f;
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) {
+    const int q = 8 * lam + nb;
+    const ChunkRef c2 = hseq<NT>(q + 2, ld.wave);
+    Acc acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc.m[r] = 0.0f;
+    unsigned a_addr = ld.slot_cur + ld.lane_off;
+    PreH nxt;
+    if (nb == 1) {
+      if (prev_panel >= 0) publish_max(cx, prev_panel, prev.mx * prev.cinv);
+      stage_factors(cur, prev);
+      store_pscale(cx, panel, cur.cinv * (1.0f / cur.phi));
+    }
+    const bool load_next = (nb & 1) && ((nb < 7) ? MASK : NEXT_MASK);
+    const unsigned* next_blk =
+        !load_next ? nullptr
+                   : (nb < 7 ? sign_block(const_cast<unsigned*>(cx.sgn), cx.dp.group, panel, nb + 1)
+                             : sign_block(const_cast<unsigned*>(cx.sgn), cx.dp.group, next_panel, 0));
+    const int pb = (nb == 0) ? 7 : nb - 1;
+    const unsigned mz_pend = mz[(pb >> 1) & 1];
+    const int kYoung = (FIRST && nb <= 1) ? 0 : 2;
+    auto mma = [&](auto young) {
+      block_mma_h<NT, kBar, decltype(young)::value>(
+          acc, pre, a_addr, ld, c2, [&](int s) -> u32x4 { return bh[s]; },
+          [&](int s, int g) {
+            if (nb == 0) {
+              hsplit_gap<NT, PREV_MASK, 0>(s, g, pend, mz_pend, prev, bh[14], bh[15]);
+              if (prev_panel >= 0 && g == LG) bwd_store_step(s, bh[14], bh[15], panel_block(cx.dp, prev_panel, 7), cx.voff0, cx.voff1);
+            } else {
+              if (pb & 1) hsplit_gap<NT, MASK, 0>(s, g, pend, mz_pend, cur, oh[2 * nb - 2], oh[2 * nb - 1]);
+              else hsplit_gap<NT, MASK, 16>(s, g, pend, mz_pend, cur, oh[2 * nb - 2], oh[2 * nb - 1]);
+              if (g == LG) bwd_store_step(s, oh[2 * nb - 2], oh[2 * nb - 1], panel_block(cx.dp, panel, nb - 1), cx.voff0, cx.voff1);
+            }
+            if (load_next && g == LG && s == 6) mask_dma(next_blk, cx.lane4, cx.lmask);
+            if (MASK && !(nb & 1) && g == LG && s == 14) mz[(nb >> 1) & 1] = mask_read(cx.lmask + cx.lane4);
+          },
+          [&](int k) { prefetch_frag_h<NT>(nxt, k, ld.slot_next + ld.lane_off); });
+    };
+    if (kYoung == 2) mma(std::integral_constant<int, 2>{});
+    else mma(std::integral_constant<int, 0>{});
+    if (ADD) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc.m[r] = fmaf(wsig_h[32 * nb + 8 * (r >> 2) + (r & 3)], sig, acc.m[r]);
+    }
+    pend = acc;
+    pre = nxt;
+    loader_advance(ld);
+  }
+  prev = cur;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HCfg<NT>::kWavesPerEu, HCfg<NT>::kWavesPerEu)))
+chain_bwd_h_kernel(const float* __restrict__ packed, const unsigned* __restrict__ sgn, char* __restrict__ dpan,
+                   const float* __restrict__ d_rgb, int d_rgb_stride, const float* __restrict__ d_sigma, int d_sigma_stride,
+                   int64_t P, unsigned* __restrict__ gmax, float* __restrict__ pscale) {
+  using C = HCfg<NT>;
+  constexpr int kAux0 = 3 * C::kSlotB / 4;
+  __shared__ __attribute__((aligned(16))) float ring[kAux0 + kBwdAuxFloats + 16 + 4 * 64];
+  unsigned* lmax = reinterpret_cast<unsigned*>(ring + kAux0 + kBwdAuxFloats);
+  if (threadIdx.x < 16) lmax[threadIdx.x] = 0u;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  for (int i = threadIdx.x; i < kBwdAuxFloats; i += 256) ring[kAux0 + i] = packed[C::kPieces * 256 + i];
+
+  Loader ld;
+  ld.stream = packed;
+  ld.wave = wave;
+  ld.lane_off = (unsigned)lane * 16u;
+  ld.slot_cur = lds_addr(ring);
+  ld.slot_next = ld.slot_cur + C::kSlotB;
+  ld.slot_free = ld.slot_cur + 2 * C::kSlotB;
+  constexpr int kMine = C::kChunkPieces / 4;   // pieces of a chunk this wave moves
+  loader_prepare_dma(ld, hseq<NT>(0, wave), ld.slot_cur);
+#pragma unroll
+  for (int i = 0; i < kMine; ++i) loader_issue(ld, i);
+  loader_prepare_dma(ld, hseq<NT>(1, wave), ld.slot_next);
+#pragma unroll
+  for (int i = 0; i < kMine; ++i) loader_issue(ld, i);
+
+  const int64_t p = (int64_t)blockIdx.x * 128 + wave * 32 + m;
+  const int64_t pc = p < P ? p : P - 1;
+  BwdCtx cx;
+  cx.sgn = sgn;
+  cx.dp.base = dpan;
+  cx.dp.n_groups = (int64_t)gridDim.x * 4;
+  cx.dp.group = (int64_t)blockIdx.x * 4 + wave;
+  cx.dp.sgn = nullptr;
+  cx.voff0 = unit_voff(m, h, 0);
+  cx.voff1 = unit_voff(m, h, 1);
+  cx.lane = lane;
+  cx.lane4 = (unsigned)lane * 4u;
+  cx.lmask = lds_addr(ring + kAux0 + kBwdAuxFloats + 16) + (unsigned)wave * 256u;
+  cx.lmax = lmax;
+  cx.pscale = pscale;
+  cx.pidx = cx.dp.group * 32 + m;
+  cx.writer = h == 0;
+
+  // ---- prologue: as in chain_bwd_kernel (the colour head's input gradient on the VALU, K = 3), hi operands only
+  const float g0 = d_rgb[pc * d_rgb_stride + 0], g1 = d_rgb[pc * d_rgb_stride + 1], g2 = d_rgb[pc * d_rgb_stride + 2];
+  const float gs = d_sigma[pc * d_sigma_stride];
+  unsigned zc[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) zc[b] = sign_block(const_cast<unsigned*>(sgn), cx.dp.group, 9, 2 * b)[lane];
+  __syncthreads();   // aux visible
+  float dz[64];
+  float mxin = fabsf(gs);
+#pragma unroll
+  for (int t = 0; t < 64; ++t) {
+    const int feat = act_feature(t, h);
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(ring + kAux0 + 4 * feat);
+    float v = __fmaf_rn(w4[2], g2, __fmaf_rn(w4[1], g1, __fmul_rn(w4[0], g0)));
+    v = ((zc[t >> 5] >> ((((t >> 4) & 1) ? 0 : 16) + 15 - (t & 15))) & 1u) ? 0.0f : v;
+    dz[t] = v;
+    mxin = fmaxf(mxin, fabsf(v));
+  }
+  {
+    float mdz = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 64; ++t) mdz = fmaxf(mdz, fabsf(dz[t]));
+    publish_max(cx, 9, mdz);
+  }
+  mxin = fmaxf(mxin, __shfl_xor(mxin, 32, 64));
+  const float S = mxin > 0.0f ? pow2f(1 - floor_log2(mxin)) : 1.0f;
+  store_pscale(cx, 9, 1.0f / S);
+  u32x4 bh[16], oh[16];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    unsigned a[4];
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) a[pr] = pack_hl(dz[8 * s + 2 * pr] * S, dz[8 * s + 2 * pr + 1] * S, 0);
+    bh[s] = u32x4{a[0], a[1], a[2], a[3]};
+  }
+#pragma unroll
+  for (int s = 8; s < 16; ++s) bh[s] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const char* blk = panel_block(cx.dp, 9, b);
+    unit_store<0>(bh[2 * b], blk, cx.voff0);
+    unit_store<1>(bh[2 * b + 1], blk, cx.voff1);
+  }
+  const float* wsig_h = ring + kAux0 + 512 + 4 * h;
+  Scale prev;
+  prev.cinv = 1.0f / S;
+  prev.phi = 1.0f;
+  prev.phi2 = 0u;
+  prev.mx = 3.0f;
+
+  dma_drain();
+  __syncthreads();
+  PreH pre;
+#pragma unroll
+  for (int k = 0; k < kPF; ++k) prefetch_frag_h<NT>(pre, k, ld.slot_cur + ld.lane_off);
+  loader_prepare_dma(ld, hseq<NT>(2, wave), ld.slot_free);
+
+  Acc pend;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) pend.m[r] = 0.0f;
+  unsigned mz[2] = {0u, 0u};
+
+  bwd_layer_h<NT, false, false, false, false, true, true>(0, -1, 8, 7, bh, oh, wsig_h, gs, ld, pend, pre, mz, prev, cx);
+  bwd_layer_h<NT, false, true, true, false, true>(1, 8, 7, 6, oh, bh, wsig_h, gs, ld, pend, pre, mz, prev, cx);
+#pragma unroll 1
+  for (int pair = 0; pair < 3; ++pair) {
+    const int lam = 2 + 2 * pair;
+    bwd_layer_h<NT, true, true, false, false, true>(lam, 9 - lam, 8 - lam, 7 - lam, bh, oh, wsig_h, gs, ld, pend, pre, mz, prev, cx);
+    bwd_layer_h<NT, true, true, false, false, true>(lam + 1, 8 - lam, 7 - lam, 6 - lam, oh, bh, wsig_h, gs, ld, pend, pre, mz, prev, cx);
+  }
+  bwd_layer_h<NT, true, true, false, true, false>(8, 1, 0, -1, bh, oh, wsig_h, gs, ld, pend, pre, mz, prev, cx);
+  {
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA write-back before inline asm reads the accumulators
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hsplit_part<true, 0>(i, pend, mz[1], prev, bh[0], bh[1]);
+    publish_max(cx, 0, prev.mx * prev.cinv);
+    const char* blk = panel_block(cx.dp, 0, 7);
+    unit_store<0>(bh[0], blk, cx.voff0);
+    unit_store<1>(bh[1], blk, cx.voff1);
+  }
+  dma_drain();
+  __syncthreads();
+  if (threadIdx.x < 10) atomicMax(gmax + threadIdx.x, lmax[threadIdx.x]);
+}
+
 }  // namespace
 
 extern "C" NSR_INTERNAL size_t nsr_chain_bwd_packed_bytes(void) { return 4 * (size_t)(kBwdPieces * 256 + kBwdAuxFloats); }
 
-extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* packed_dev, int stop_grad, void* stream) {
+extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* packed_dev, int stop_grad, int terms, void* stream) {
+  if (terms < 1 || terms > 3) return NSR_ERR_INVALID_ARG;
   BwdPackPtrs pp;
   for (int i = 0; i < NSR_N_STATE_TENSORS; ++i) {
     if (!w[i]) return NSR_ERR_INVALID_ARG;
     pp.p[i] = w[i];
   }
-  const int total = kBwdPieces * 256 + kBwdAuxFloats;
+  const int total = (terms == 1 ? kBwdPieces / 2 : kBwdPieces) * 256 + kBwdAuxFloats;
   hipLaunchKernelGGL(pack_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, nsr_stream(stream), pp,
-                     static_cast<unsigned*>(packed_dev), stop_grad);
+                     static_cast<unsigned*>(packed_dev), stop_grad, terms == 1 ? 1 : 0);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
 
 extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const unsigned* sgn, void* dpan, const float* d_rgb, int d_rgb_stride,
                                           const float* d_sigma, int d_sigma_stride, int64_t P, unsigned* gmax,
-                                          float* pscale, void* stream) {
+                                          float* pscale, int terms, void* stream) {
+  if (terms < 1 || terms > 3) return NSR_ERR_INVALID_ARG;
   if (P <= 0) return NSR_OK;
   if (hipMemsetAsync(gmax, 0, 10 * sizeof(unsigned), nsr_stream(stream)) != hipSuccess) return NSR_ERR_LAUNCH;
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
-  hipLaunchKernelGGL(chain_bwd_kernel, grid, block, 0, nsr_stream(stream), static_cast<const float*>(packed), sgn, static_cast<char*>(dpan), d_rgb,
-                     d_rgb_stride, d_sigma, d_sigma_stride, P, gmax, pscale);
+  const float* pk = static_cast<const float*>(packed);
+  char* dp = static_cast<char*>(dpan);
+  if (terms == 3)
+    hipLaunchKernelGGL(chain_bwd_kernel, grid, block, 0, nsr_stream(stream), pk, sgn, dp, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, P, gmax, pscale);
+  else if (terms == 2)
+    hipLaunchKernelGGL(chain_bwd_h_kernel<2>, grid, block, 0, nsr_stream(stream), pk, sgn, dp, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, P, gmax, pscale);
+  else
+    hipLaunchKernelGGL(chain_bwd_h_kernel<1>, grid, block, 0, nsr_stream(stream), pk, sgn, dp, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, P, gmax, pscale);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }

@@ -91,8 +91,10 @@ class Trainer:
         self.stop_grad = bool(stop_grad)       # --stop_grad (models/networks.py:127, 218-219): the colour branch's input is detached
         if precision not in _lib.TRAIN_PRECISIONS:
             raise ValueError("precision must be 'fp32' (every product on the fp32 MFMA, layer by layer), 'f16x3' (the chain "
-                             "kernels: forward and input gradients on the split-fp16 MFMA, weight gradients on one fp16 MFMA "
-                             "per product) or 'f16x3_gemm' (layer by layer, forward products split-fp16, gradients fp32)")
+                             "kernels: forward on the split-fp16 MFMA, weight gradients on one fp16 MFMA per product, input "
+                             "gradients on the default number of MFMA terms), 'f16x3_bwd3' / 'f16x3_bwd2' / 'f16x3_bwd1' (the "
+                             "chain kernels with three / two / one MFMA per product of the input gradients, include/nsr_train.h) "
+                             "or 'f16x3_gemm' (layer by layer, forward products split-fp16, gradients fp32)")
         self.precision, self._prec = precision, _lib.TRAIN_PRECISIONS[precision]
         self.device = torch.device(device)
         # --no_dir (models/networks.py:160-169): the networks are trained as the full layout with 27 zero columns in

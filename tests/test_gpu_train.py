@@ -69,7 +69,12 @@ def test_training_gemm(tr):
 _ORACLE64 = {}
 
 
-@pytest.fixture(scope="module", params=[(c, p) for c in CASES for p in ("f16x3", "fp32")], ids=lambda cp: f"{cp[0]}-{cp[1]}")
+# every arithmetic of the step that claims the bounds below: the chain path with its default backward chain ("f16x3"), with
+# the backward chain on two and on three MFMAs per product named explicitly (round 6; include/nsr_train.h), and the all-fp32 path
+CONTRACT_PRECISIONS = ("f16x3", "f16x3_bwd2", "f16x3_bwd3", "fp32")
+
+
+@pytest.fixture(scope="module", params=[(c, p) for c in CASES for p in CONTRACT_PRECISIONS], ids=lambda cp: f"{cp[0]}-{cp[1]}")
 def case(request, golden_dir, tr):
     """Both arithmetic modes of the step: forward products on the split-fp16 MFMA (default) or everything on the fp32
     MFMA; the same tolerances hold (split-fp16 products are exact to ~2^-21)."""
