@@ -257,6 +257,27 @@ def train_bench(args, rank, local, world, steps=None, warmup=None, cpu=True, sha
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # after the timed region: did the data-parallel protocol deliver?  Every rank started from the same weights, scaled its
+    # loss by 1 / world, summed the two flat gradient buffers with ONE all-reduce each per step and ran Adam replicated
+    # (Trainer.all_reduce_grads; replaces DistributedDataParallel, models/networks.py:72-86): the weights must be
+    # bit-identical on all ranks, and differ from what a rank would have reached alone on its own batch.
+    collective = {"backend": None, "world": world, "op": None, "calls_per_step": 0, "bytes_per_call": 0,
+                  "grad_scale": 1.0, "weights_identical_on_all_ranks": None}
+    if world > 1:
+        flat = torch.cat([v.reshape(-1) for p in t.params for v in p.values()]).double()
+        cs = torch.stack([flat.sum(), -flat.sum(), flat.abs().max(), (flat * flat).sum(), -(flat * flat).sum()])
+        cs = cs.to(dev if dist.get_backend() == "nccl" else "cpu")
+        lo = cs.clone()
+        dist.all_reduce(cs, op=dist.ReduceOp.MAX)          # max(x) == -max(-x) on every checksum <=> all ranks hold the same weights
+        same = bool(cs[0] == -cs[1]) and bool(cs[3] == -cs[4]) and bool((cs == lo).all())
+        agree = torch.tensor([1 if same else 0], dtype=torch.int32, device=cs.device)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        from nerf_sr_amd.dist import _world
+        collective = {"backend": dist.get_backend(), "world": world, "op": "all_reduce(sum) of the flat gradient buffer, one per network",
+                      "calls_per_step": len(t.flat_grads), "bytes_per_call": int(t.flat_grads[0].numel() * 4),
+                      "grad_scale": float(t.grad_scale) if t.grad_scale is not None else 1.0 / _world(t.group)[1],
+                      "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None,
+                      "weights_identical_on_all_ranks": bool(agree.item() == 1), "adam_steps": int(t.step)}
     res = None
     if rank == 0:
         value = R * world * steps / dt
@@ -284,6 +305,7 @@ def train_bench(args, rank, local, world, steps=None, warmup=None, cpu=True, sha
                          "flop_per_step": flop_step,
                          "note": "algorithmic flops = 3 x 593,408 MAC x 2 per sample point x 192 points per ray"},
             "losses": [float(x) for x in t.losses.tolist()],
+            "collective": collective,
         }
         if args.train_precision in CHAIN_PRECISIONS:
             # chain path: forward and input gradients run on the split-fp16 MFMA, the weight gradients on one

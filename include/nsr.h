@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define NSR_VERSION 120 /* 0.1.2: colour-head option word (gamma, color_activation none), renderer option word (softplus density) */
+#define NSR_VERSION 130 /* 0.1.3: training precisions NSR_F16X3_BWD3 / _BWD2 / _BWD1 (nsr_train.h); NSR_F16X3 trains with the two-term backward chain; `white_bkgd` arguments renamed `render_flags` (same values) */
 
 typedef enum nsr_status {
   NSR_OK = 0,
@@ -121,12 +121,15 @@ int nsr_weights_status(const void* packed_dev, int precision, int clear, unsigne
 int nsr_weights_set_options(void* packed_dev, int precision, unsigned options, void* stream);
 int nsr_weights_set_gamma(void* packed_dev, int precision, int enable, void* stream);
 
-/* The `white_bkgd` argument of the compositing entry points below (nsr_composite, nsr_render_rays_composited,
- * nsr_forward_rays*) is a word of renderer options, like the reference's VolumetricRenderer(opt) + white_bkgd pair
- * (models/rendering.py:66-111): 0 / 1 keep their meaning;
+/* The `render_flags` argument of the compositing entry points below (nsr_composite, nsr_render_rays_composited,
+ * nsr_forward_rays*; named `white_bkgd` until NSR_VERSION 120) is a word of renderer options, like the reference's
+ * VolumetricRenderer(opt) + white_bkgd pair (models/rendering.py:66-111):
  *   NSR_WHITE_BKGD      comp_rgb += 1 - opacity
  *   NSR_SIGMA_SOFTPLUS  --sigma_activation softplus (models/rendering.py:69-73): log(1 + exp(sigma - 1)) instead of relu(sigma)
- * The training entry points accept NSR_WHITE_BKGD only (NSR_ERR_UNSUPPORTED otherwise). */
+ * It is NOT a C boolean: 0 and 1 keep the meaning they had when the argument was one (black / white background), but
+ * any other "true" value (2, -1, ...) is an option word -- 2 selects softplus density on a black background, a bit outside
+ * the defined ones returns NSR_ERR_INVALID_ARG (the break is listed in INTEGRATION.md, "Migration notes").  Pass
+ * `flag ? NSR_WHITE_BKGD : 0`.  The training entry points take the same word plus their own bits (nsr_train.h). */
 #define NSR_WHITE_BKGD 1
 #define NSR_SIGMA_SOFTPLUS 2
 
@@ -180,7 +183,7 @@ int nsr_render_rays(const void* packed_dev, int precision, const float* rays, in
  * weights (R, N): any may be NULL.  Results are bit-identical to nsr_render_rays + nsr_composite (the same device code).
  * NSR_ERR_UNSUPPORTED for other sample counts and for the NSR_F16 / NSR_BF16 fast paths (callers fall back to the pair). */
 int nsr_render_rays_composited(const void* packed_dev, int precision, const float* rays, int ray_stride, const float* z,
-                               int64_t R, int n_samples, int white_bkgd, float* raw, float* comp_rgb, float* depth,
+                               int64_t R, int n_samples, int render_flags, float* raw, float* comp_rgb, float* depth,
                                float* opacity, float* weights, void* stream);
 
 /* ---- V1: volumetric compositing ------------------------------------------------
@@ -190,7 +193,7 @@ int nsr_render_rays_composited(const void* packed_dev, int precision, const floa
  * 4/4 with sigma = rgb+3 = the interleaved (P,4) MLP output).
  * Outputs: comp_rgb (R,3), depth (R), opacity (R), weights (R,N); any may be NULL. */
 int nsr_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z,
-                  int64_t R, int n_samples, int white_bkgd, float* comp_rgb, float* depth, float* opacity,
+                  int64_t R, int n_samples, int render_flags, float* comp_rgb, float* depth, float* opacity,
                   float* weights, void* stream);
 
 /* ---- S2: hierarchical inverse-CDF resampling -----------------------------------
@@ -216,7 +219,7 @@ int nsr_resample_along_rays(const float* rays, int ray_stride, const float* z, c
 size_t nsr_forward_rays_workspace_bytes_for(int precision, int64_t R, int n_coarse, int n_importance);
 size_t nsr_forward_rays_workspace_bytes(int64_t R, int n_coarse, int n_importance);
 int nsr_forward_rays(const void* packed_coarse, const void* packed_fine, int precision, const float* rays,
-                     int ray_stride, int64_t R, int n_coarse, int n_importance, int white_bkgd, int lindisp,
+                     int ray_stride, int64_t R, int n_coarse, int n_importance, int render_flags, int lindisp,
                      float* const* outs, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Same as nsr_forward_rays, plus HIP-event instrumentation for benchmarks: `events` is a HOST
@@ -224,7 +227,7 @@ int nsr_forward_rays(const void* packed_coarse, const void* packed_fine, int pre
  * MLP launch ([0],[1]) and the fine MLP launch ([2],[3]) — the kernels that carry >99 % of the
  * path's FLOPs — so that a harness can read per-launch durations without a profiler. */
 int nsr_forward_rays_profiled(const void* packed_coarse, const void* packed_fine, int precision, const float* rays,
-                              int ray_stride, int64_t R, int n_coarse, int n_importance, int white_bkgd, int lindisp,
+                              int ray_stride, int64_t R, int n_coarse, int n_importance, int render_flags, int lindisp,
                               float* const* outs, void* workspace, size_t workspace_bytes, void* stream,
                               void* const* events);
 /* Thin wrappers over hipEventCreate / hipEventDestroy / hipEventSynchronize+hipEventElapsedTime so a

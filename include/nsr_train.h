@@ -38,7 +38,9 @@ extern "C" {
  *   NSR_F16X3_BWD1: W_hi g_hi: one MFMA per product, both operands rounded to 11 bits.
  * NSR_F16X3 selects the cheapest of them whose gradients stay inside the bounds of tests/test_gpu_train.py (every gradient
  * tensor within 2e-3 of its norm of the fp64 oracle, 5e-4 on the heads, a 200-step Adam trajectory no further from the fp32
- * run than another fp32-grade implementation is): NSR_F16X3_BWD1 as of NSR_VERSION 130 (measured: DESIGN.md 7.1). */
+ * run than another fp32-grade implementation is; the whole gradient within 2e-4 of the fp32-gradient path at 393,216 sample
+ * points): NSR_F16X3_BWD2 as of NSR_VERSION 130.  NSR_F16X3_BWD1 is a stated FAST path: it holds the per-tensor bounds (measured
+ * 6.6e-4 / 2.2e-4 on the heads) and the trajectory bound, not the whole-gradient one (3.1e-4) -- measured: DESIGN.md 7.1. */
 #define NSR_F16X3_BWD3 19
 #define NSR_F16X3_BWD2 20
 #define NSR_F16X3_BWD1 21
@@ -74,7 +76,7 @@ size_t nsr_train_workspace_bytes_for(int precision, int64_t ray_chunk, int n_coa
  * GEMM contracts over the points in K tiles of 32); otherwise NSR_ERR_UNSUPPORTED is returned before anything
  * is enqueued (outputs and gradients untouched).  All of the reference's scripts (64 + 64 samples) satisfy it
  * for any ray count.
- * white_bkgd: a word of options like the render path's (include/nsr.h): NSR_WHITE_BKGD and NSR_SIGMA_SOFTPLUS as there
+ * render_flags (`white_bkgd` until NSR_VERSION 120): a word of options like the render path's (include/nsr.h): NSR_WHITE_BKGD and NSR_SIGMA_SOFTPLUS as there
  * (the backward pass carries sigmoid(sigma - 1) instead of [sigma > 0]), and the colour head's two, which the render
  * path keeps in the packed network: NSR_TRAIN_GAMMA_CORRECT = --gamma_correct while training (render_rays returns
  * pow(rgb, 1 / 2.2) per sample, nerf_downX_model.py:271-276; the colours are corrected between the network and the
@@ -91,7 +93,7 @@ size_t nsr_train_workspace_bytes_for(int precision, int64_t ray_chunk, int n_coa
 #define NSR_TRAIN_STOP_GRAD 16
 int nsr_train_loss_and_grads(const float* const* w_coarse, const float* const* w_fine, float* const* g_coarse,
                              float* const* g_fine, const float* rays, int ray_stride, int64_t R, int s2,
-                             const float* target_lr, int n_coarse, int n_importance, int white_bkgd, int lindisp,
+                             const float* target_lr, int n_coarse, int n_importance, int render_flags, int lindisp,
                              const float* u_coarse, const float* u_fine, const float* noise_coarse,
                              const float* noise_fine, float noise_std, float lambda_coarse, float lambda_fine,
                              int precision, int64_t ray_chunk, float* const* outs, float* lr_coarse, float* lr_fine, float* losses,
@@ -114,7 +116,7 @@ typedef struct nsr_train_var_losses {
  * the reference's loss_out_{coarse,fine}_var / loss_{coarse,fine}_depth_var times their lambdas.  Every other argument as above. */
 int nsr_train_loss_and_grads_var(const float* const* w_coarse, const float* const* w_fine, float* const* g_coarse,
                                  float* const* g_fine, const float* rays, int ray_stride, int64_t R, int s2,
-                                 const float* target_lr, int n_coarse, int n_importance, int white_bkgd, int lindisp,
+                                 const float* target_lr, int n_coarse, int n_importance, int render_flags, int lindisp,
                                  const float* u_coarse, const float* u_fine, const float* noise_coarse,
                                  const float* noise_fine, float noise_std, float lambda_coarse, float lambda_fine,
                                  int precision, int64_t ray_chunk, float* const* outs, float* lr_coarse, float* lr_fine, float* losses,

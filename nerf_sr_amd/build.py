@@ -15,6 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnsr.so")
+AB_DIR = os.path.join(os.path.dirname(HERE), "ab")     # A/B variant libraries (git-ignored *.so)
 ARCH = "gfx950"
 
 UNITS = [
@@ -69,9 +70,12 @@ def source_hash() -> str:
 def build(force: bool = False, verbose: bool = True, variant: str = "", defines=()) -> str:
     """Compile every HIP unit for gfx950 and link ``nerf_sr_amd/libnsr.so``; returns its path.
 
-    ``variant`` / ``defines`` build an ablation library ``libnsr_<variant>.so`` with extra ``-D`` flags
-    (development aid; select it at run time with ``NSR_LIB_PATH``)."""
-    LIB = os.path.join(HERE, f"libnsr_{variant}.so") if variant else globals()["LIB"]
+    ``variant`` / ``defines`` build an ablation library ``<repo>/ab/libnsr_<variant>.so`` with extra ``-D`` flags
+    (development aid; select it at run time with ``NSR_LIB_PATH``; ``ab/`` travels to the GPU box, stale variant
+    libraries next to the product library do not: .gpurunignore)."""
+    if variant:
+        os.makedirs(AB_DIR, exist_ok=True)
+    LIB = os.path.join(AB_DIR, f"libnsr_{variant}.so") if variant else globals()["LIB"]
     if variant:
         force = True
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source_mtime():

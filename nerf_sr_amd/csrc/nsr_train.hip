@@ -961,7 +961,7 @@ bool chain_selected(int precision) {
   return precision == NSR_F16X3 || precision == NSR_F16X3_BWD3 || precision == NSR_F16X3_BWD2 || precision == NSR_F16X3_BWD1;
 }
 // MFMAs per product of the backward chain (include/nsr_train.h; NSR_F16X3 = the default, kDefaultBwdTerms)
-constexpr int kDefaultBwdTerms = 1;
+constexpr int kDefaultBwdTerms = 2;
 int chain_bwd_terms(int precision) {
   return precision == NSR_F16X3_BWD3 ? 3 : (precision == NSR_F16X3_BWD2 ? 2 : (precision == NSR_F16X3_BWD1 ? 1 : kDefaultBwdTerms));
 }

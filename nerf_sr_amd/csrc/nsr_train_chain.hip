@@ -554,18 +554,60 @@ chain_bwd_kernel(const float* __restrict__ packed, const unsigned* __restrict__ 
 // A workgroup is still 4 waves x 32 points; with <= 256 registers and a 48 KiB ring (NT = 1) two workgroups share a CU,
 // so one wave's re-split VALU, LDS reads and DMA issue run under the other's MFMAs.
 // =========================================================================================================
-template <int NT>
+template <int NT, int W>
 struct HCfg {
   static_assert(NT == 1 || NT == 2, "reduced-term chain: one or two MFMAs per product");
+  static_assert(W == 4 || W == 8, "waves per workgroup: one or two per SIMD");
   static constexpr int kChunkPieces = NT == 1 ? 16 : 32;       // 16 k-steps x hi (x lo)
   static constexpr int kSlotB = kChunkPieces * 1024;           // one ring slot
   static constexpr int kLayerPieces = 8 * kChunkPieces;
   static constexpr int kPieces = kLayerPieces * kBwdLayers;
-  static constexpr int kWavesPerEu = NT == 1 ? 2 : 1;
+  static constexpr int kMine = kChunkPieces / W;               // pieces of every chunk one wave moves
+  // ring depth: the chunk of sequence number q lives in slot q % kDepth and is fetched kDepth - 1 chunks ahead, during chunk
+  // q - kDepth + 1, into the slot chunk q - kDepth has just left.
+  static constexpr int kDepth = 3;
+  // Deeper rings were built and measured (NT = 1: 8 slots, NT = 2: 4): 239.7 / 358.9 us per pass against 243.9 / 359.7 with
+  // three -- the ring is not what these kernels wait for -- AND they raced: the mask words travel by LDS-DMA one block ahead
+  // of their use (mask_dma), which is older than everything a publish point waits for only while that wait leaves just the
+  // 2 youngest operations in flight.  A deeper ring must fetch the masks kDepth - 1 blocks ahead into a ring of their own.
+  static_assert(kDepth == 3, "mask_dma's landing is only covered by the publish points of a three-slot ring");
+  // vector-memory operations that are provably YOUNGER than the pieces of chunk b + 1 at the publish point of block b in
+  // the steady state (operations complete in issue order; per block: [mask fetch, 0 or 1][kMine pieces][2 stores]; the
+  // mask fetches are not counted, so the wait may cover the oldest of these stores as well -- never a piece too few):
+  // the 2 stores of the block that issued chunk b + 1, then kDepth - 3 whole blocks
+  static constexpr int kYoungSteady = 2 + (kDepth - 3) * (kMine + 2);
+  static_assert(kYoungSteady <= 60, "vmcnt is a 6-bit counter");
 };
-template <int NT>
+// the same count for block `nb` of the FIRST layer (global block b = nb): block 0 stores nothing (no pending block), and the
+// chunks 1 .. kDepth - 2 were fetched -- and waited for -- by the prologue (63 = no wait)
+template <int NT, int W>
+constexpr int hyoung_first(int nb) {
+  using C = HCfg<NT, W>;
+  const int lo = nb - C::kDepth + 2;           // the block that issued chunk nb + 1
+  if (lo < 0) return 63;
+  int n = lo == 0 ? 0 : 2;
+  for (int i = lo + 1; i < nb; ++i) n += C::kMine + (i == 0 ? 0 : 2);
+  return n;
+}
+template <int NT, int W>
+struct HOcc {
+  // waves per SIMD: W = 8 is one workgroup of two waves per SIMD sharing the ring (256 points per tile: half the L2 -> LDS
+  // weight traffic per point); W = 4 is one wave per SIMD
+  static constexpr int kWavesPerEu = W == 8 ? 2 : 1;
+};
+// the contiguous share of a chunk that wave `wave` of W moves
+template <int W>
+__device__ __forceinline__ ChunkRef make_ref_w(int piece0, int pieces, int wave) {
+  ChunkRef c;
+  c.piece0 = piece0;
+  c.pieces = pieces;
+  c.first = (wave * pieces) / W;
+  c.count = ((wave + 1) * pieces) / W - c.first;
+  return c;
+}
+template <int NT, int W>
 __device__ __forceinline__ ChunkRef hseq(int q, int wave) {   // chunk q = 8 lam + nb; past the end chunk 0 again (idle slot)
-  return make_ref((q < 8 * kBwdLayers ? q : 0) * HCfg<NT>::kChunkPieces, HCfg<NT>::kChunkPieces, wave);
+  return make_ref_w<W>((q < 8 * kBwdLayers ? q : 0) * HCfg<NT, W>::kChunkPieces, HCfg<NT, W>::kChunkPieces, wave);
 }
 struct PreH {
   u32x4 ah[kPF], al[kPF];   // al: NT = 2 only
@@ -583,10 +625,11 @@ __device__ __forceinline__ void prefetch_frag_h(PreH& pre, int k, unsigned seq_a
 // the 16 k-steps of one output block; every MFMA opens a fenced gap (block_mma3's discipline): hook(s, g) runs in gap g of
 // k-step s (g < NT), the fragment reads of k-step s + kPF (or next(k)) in gap 0, the chunk's DMA pieces one per gap from
 // the publish point on (NT = 2: 8 pieces per wave in k-steps BAR .. BAR + 3; NT = 1: 4 pieces, one per k-step)
-template <int NT, int BAR, int YOUNGER, class BOf, class Hook, class Next>
+template <int NT, int PW, int BAR, int YOUNGER, class BOf, class Hook, class Next>
 __device__ __forceinline__ void block_mma_h(Acc& acc, const PreH& pre, unsigned a_addr, Loader& ld, const ChunkRef& c2,
                                             BOf&& b_of, Hook&& hook, Next&& next) {
   constexpr int NSTEP = 16;
+  static_assert(PW <= NT * (NSTEP - BAR - 2), "the DMA pieces must be out before the stores of k-steps 14, 15");
   const u32x4* a_pieces = lds_vec(a_addr);
   u32x4 ah[NSTEP], al[NT == 2 ? NSTEP : 1];
 #pragma unroll
@@ -599,6 +642,7 @@ __device__ __forceinline__ void block_mma_h(Acc& acc, const PreH& pre, unsigned 
     if (s == BAR - 3) loader_prepare_dma(ld, c2, ld.slot_free);
     if (s == BAR) loader_publish<YOUNGER, false>(ld, c2);
     const u32x4 bh = b_of(s);
+    const int j0 = (s - BAR) * NT;     // DMA issue slot of this k-step's first gap (one piece per gap from the publish point on)
     if (NT == 2) {
       acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(al[s]), as_h8(bh), acc.m, 0, 0, 0);
       if (s + kPF < NSTEP) {
@@ -608,18 +652,18 @@ __device__ __forceinline__ void block_mma_h(Acc& acc, const PreH& pre, unsigned 
         next(s + kPF - NSTEP);
       }
       hook(s, 0);
-      if (s >= BAR && s < BAR + 4) loader_issue(ld, 2 * (s - BAR));
+      if (s >= BAR && j0 < PW) loader_issue(ld, j0);
       __builtin_amdgcn_sched_barrier(0);
       acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bh), acc.m, 0, 0, 0);
       hook(s, 1);
-      if (s >= BAR && s < BAR + 4) loader_issue(ld, 2 * (s - BAR) + 1);
+      if (s >= BAR && j0 + 1 < PW) loader_issue(ld, j0 + 1);
       __builtin_amdgcn_sched_barrier(0);
     } else {
       acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[s]), as_h8(bh), acc.m, 0, 0, 0);
       if (s + kPF < NSTEP) ah[s + kPF] = a_pieces[(s + kPF) * 64];
       else next(s + kPF - NSTEP);
       hook(s, 0);
-      if (s >= BAR && s < BAR + 4) loader_issue(ld, s - BAR);
+      if (s >= BAR && j0 < PW) loader_issue(ld, j0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -680,17 +724,25 @@ __device__ __forceinline__ void hsplit_gap(int s, int g, Acc& p, unsigned mz, Sc
 }
 
 // bwd_layer without the lo operand set (see there for the flags)
-template <int NT, bool PREV_MASK, bool MASK, bool ADD, bool LAST, bool NEXT_MASK, bool FIRST = false>
+template <int NT, int W, bool PREV_MASK, bool MASK, bool ADD, bool LAST, bool NEXT_MASK, bool FIRST = false>
 __device__ __forceinline__ void bwd_layer_h(int lam, int prev_panel, int panel, int next_panel, u32x4 (&bh)[16], u32x4 (&oh)[16],
-                                            const float* wsig_h, float d_sigma, Loader& ld, Acc& pend, PreH& pre,
+                                            const float* wsig_h, float d_sigma, Loader& ld, unsigned ring0, Acc& pend, PreH& pre,
                                             unsigned (&mz)[2], Scale& prev, const BwdCtx& cx) {
   constexpr int LG = NT - 1;   // the last gap of a k-step
+  // the slot addresses below are constants: made opaque once per layer, or LICM hoists the sixteen lane addresses of the
+  // two-layer loop body out of the loop and the allocator spills (the persistent inference build's lesson)
+  asm volatile("" : "+s"(ring0));
   Scale cur{};
   const float sig = ADD ? d_sigma / (prev.cinv * (1.0f / 64.0f) / prev.phi) : 0.0f;
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) {
     const int q = 8 * lam + nb;
-    const ChunkRef c2 = hseq<NT>(q + 2, ld.wave);
+    constexpr int D = HCfg<NT, W>::kDepth;
+    const ChunkRef c2 = hseq<NT, W>(q + D - 1, ld.wave);     // the chunk fetched during this block
+    // slots of chunks q, q + 1 and of the chunk fetched now (= the slot chunk q - 1 has left)
+    ld.slot_cur = ring0 + ((unsigned)q % D) * (unsigned)HCfg<NT, W>::kSlotB;
+    ld.slot_next = ring0 + ((unsigned)(q + 1) % D) * (unsigned)HCfg<NT, W>::kSlotB;
+    ld.slot_free = ring0 + ((unsigned)(q + D - 1) % D) * (unsigned)HCfg<NT, W>::kSlotB;
     Acc acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc.m[r] = 0.0f;
@@ -708,9 +760,8 @@ __device__ __forceinline__ void bwd_layer_h(int lam, int prev_panel, int panel, 
                              : sign_block(const_cast<unsigned*>(cx.sgn), cx.dp.group, next_panel, 0));
     const int pb = (nb == 0) ? 7 : nb - 1;
     const unsigned mz_pend = mz[(pb >> 1) & 1];
-    const int kYoung = (FIRST && nb <= 1) ? 0 : 2;
     auto mma = [&](auto young) {
-      block_mma_h<NT, kBar, decltype(young)::value>(
+      block_mma_h<NT, HCfg<NT, W>::kMine, kBar, decltype(young)::value>(
           acc, pre, a_addr, ld, c2, [&](int s) -> u32x4 { return bh[s]; },
           [&](int s, int g) {
             if (nb == 0) {
@@ -726,56 +777,70 @@ __device__ __forceinline__ void bwd_layer_h(int lam, int prev_panel, int panel, 
           },
           [&](int k) { prefetch_frag_h<NT>(nxt, k, ld.slot_next + ld.lane_off); });
     };
-    if (kYoung == 2) mma(std::integral_constant<int, 2>{});
-    else mma(std::integral_constant<int, 0>{});
+    if (FIRST) {
+      switch (nb) {   // nb is a constant after unrolling
+#define NSR_YF(B) case B: mma(std::integral_constant<int, hyoung_first<NT, W>(B)>{}); break;
+        NSR_YF(0) NSR_YF(1) NSR_YF(2) NSR_YF(3) NSR_YF(4) NSR_YF(5) NSR_YF(6) NSR_YF(7)
+#undef NSR_YF
+        default: break;
+      }
+    } else {
+      mma(std::integral_constant<int, HCfg<NT, W>::kYoungSteady>{});
+    }
     if (ADD) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc.m[r] = fmaf(wsig_h[32 * nb + 8 * (r >> 2) + (r & 3)], sig, acc.m[r]);
     }
     pend = acc;
     pre = nxt;
-    loader_advance(ld);
   }
   prev = cur;
 }
 
-template <int NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HCfg<NT>::kWavesPerEu, HCfg<NT>::kWavesPerEu)))
+template <int NT, int W>
+__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(HOcc<NT, W>::kWavesPerEu, HOcc<NT, W>::kWavesPerEu)))
 chain_bwd_h_kernel(const float* __restrict__ packed, const unsigned* __restrict__ sgn, char* __restrict__ dpan,
                    const float* __restrict__ d_rgb, int d_rgb_stride, const float* __restrict__ d_sigma, int d_sigma_stride,
                    int64_t P, unsigned* __restrict__ gmax, float* __restrict__ pscale) {
-  using C = HCfg<NT>;
-  constexpr int kAux0 = 3 * C::kSlotB / 4;
-  __shared__ __attribute__((aligned(16))) float ring[kAux0 + kBwdAuxFloats + 16 + 4 * 64];
+  using C = HCfg<NT, W>;
+  constexpr int kAux0 = C::kDepth * C::kSlotB / 4;
+  __shared__ __attribute__((aligned(16))) float ring[kAux0 + kBwdAuxFloats + 16 + W * 64];
   unsigned* lmax = reinterpret_cast<unsigned*>(ring + kAux0 + kBwdAuxFloats);
   if (threadIdx.x < 16) lmax[threadIdx.x] = 0u;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 31, h = lane >> 5;
-  for (int i = threadIdx.x; i < kBwdAuxFloats; i += 256) ring[kAux0 + i] = packed[C::kPieces * 256 + i];
+  for (int i = threadIdx.x; i < kBwdAuxFloats; i += 64 * W) ring[kAux0 + i] = packed[C::kPieces * 256 + i];
 
   Loader ld;
   ld.stream = packed;
   ld.wave = wave;
   ld.lane_off = (unsigned)lane * 16u;
-  ld.slot_cur = lds_addr(ring);
-  ld.slot_next = ld.slot_cur + C::kSlotB;
-  ld.slot_free = ld.slot_cur + 2 * C::kSlotB;
-  constexpr int kMine = C::kChunkPieces / 4;   // pieces of a chunk this wave moves
-  loader_prepare_dma(ld, hseq<NT>(0, wave), ld.slot_cur);
+  const unsigned ring0 = lds_addr(ring);
+  ld.slot_cur = ring0;
+  ld.slot_next = ring0 + C::kSlotB;
+  ld.slot_free = ring0 + (C::kDepth - 1) * C::kSlotB;
+  // chunks 0 .. kDepth - 2 stream in behind the prologue
 #pragma unroll
-  for (int i = 0; i < kMine; ++i) loader_issue(ld, i);
-  loader_prepare_dma(ld, hseq<NT>(1, wave), ld.slot_next);
+  for (int c = 0; c < C::kDepth - 1; ++c) {
+    loader_prepare_dma(ld, hseq<NT, W>(c, wave), ring0 + (unsigned)c * (unsigned)C::kSlotB);
 #pragma unroll
-  for (int i = 0; i < kMine; ++i) loader_issue(ld, i);
+    for (int i = 0; i < C::kMine; ++i) loader_issue(ld, i);
+  }
 
-  const int64_t p = (int64_t)blockIdx.x * 128 + wave * 32 + m;
+  // panels are laid out in point groups of 32 (one wave), four per 128-point tile of the FORWARD kernel: n_groups follows
+  // from P alone.  With W = 8 the last workgroup may hold up to four waves past the end: they repeat the last real group
+  // (same inputs, same results, same stores: a benign duplicate) so that every wave's DMA / store counts stay uniform.
+  const int64_t n_groups = ((P + 127) / 128) * 4;
+  int64_t group = (int64_t)blockIdx.x * W + wave;
+  group = group < n_groups ? group : n_groups - 1;
+  const int64_t p = group * 32 + m;
   const int64_t pc = p < P ? p : P - 1;
   BwdCtx cx;
   cx.sgn = sgn;
   cx.dp.base = dpan;
-  cx.dp.n_groups = (int64_t)gridDim.x * 4;
-  cx.dp.group = (int64_t)blockIdx.x * 4 + wave;
+  cx.dp.n_groups = n_groups;
+  cx.dp.group = group;
   cx.dp.sgn = nullptr;
   cx.voff0 = unit_voff(m, h, 0);
   cx.voff1 = unit_voff(m, h, 1);
@@ -842,22 +907,22 @@ chain_bwd_h_kernel(const float* __restrict__ packed, const unsigned* __restrict_
   PreH pre;
 #pragma unroll
   for (int k = 0; k < kPF; ++k) prefetch_frag_h<NT>(pre, k, ld.slot_cur + ld.lane_off);
-  loader_prepare_dma(ld, hseq<NT>(2, wave), ld.slot_free);
+  loader_prepare_dma(ld, hseq<NT, W>(C::kDepth - 1, wave), ld.slot_free);   // replaced at the first publish point; keeps the descriptor defined
 
   Acc pend;
 #pragma unroll
   for (int r = 0; r < 16; ++r) pend.m[r] = 0.0f;
   unsigned mz[2] = {0u, 0u};
 
-  bwd_layer_h<NT, false, false, false, false, true, true>(0, -1, 8, 7, bh, oh, wsig_h, gs, ld, pend, pre, mz, prev, cx);
-  bwd_layer_h<NT, false, true, true, false, true>(1, 8, 7, 6, oh, bh, wsig_h, gs, ld, pend, pre, mz, prev, cx);
+  bwd_layer_h<NT, W, false, false, false, false, true, true>(0, -1, 8, 7, bh, oh, wsig_h, gs, ld, ring0, pend, pre, mz, prev, cx);
+  bwd_layer_h<NT, W, false, true, true, false, true>(1, 8, 7, 6, oh, bh, wsig_h, gs, ld, ring0, pend, pre, mz, prev, cx);
 #pragma unroll 1
   for (int pair = 0; pair < 3; ++pair) {
     const int lam = 2 + 2 * pair;
-    bwd_layer_h<NT, true, true, false, false, true>(lam, 9 - lam, 8 - lam, 7 - lam, bh, oh, wsig_h, gs, ld, pend, pre, mz, prev, cx);
-    bwd_layer_h<NT, true, true, false, false, true>(lam + 1, 8 - lam, 7 - lam, 6 - lam, oh, bh, wsig_h, gs, ld, pend, pre, mz, prev, cx);
+    bwd_layer_h<NT, W, true, true, false, false, true>(lam, 9 - lam, 8 - lam, 7 - lam, bh, oh, wsig_h, gs, ld, ring0, pend, pre, mz, prev, cx);
+    bwd_layer_h<NT, W, true, true, false, false, true>(lam + 1, 8 - lam, 7 - lam, 6 - lam, oh, bh, wsig_h, gs, ld, ring0, pend, pre, mz, prev, cx);
   }
-  bwd_layer_h<NT, true, true, false, true, false>(8, 1, 0, -1, bh, oh, wsig_h, gs, ld, pend, pre, mz, prev, cx);
+  bwd_layer_h<NT, W, true, true, false, true, false>(8, 1, 0, -1, bh, oh, wsig_h, gs, ld, ring0, pend, pre, mz, prev, cx);
   {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA write-back before inline asm reads the accumulators
 #pragma unroll
@@ -895,16 +960,27 @@ extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const unsigned* sg
                                           float* pscale, int terms, void* stream) {
   if (terms < 1 || terms > 3) return NSR_ERR_INVALID_ARG;
   if (P <= 0) return NSR_OK;
+#ifdef NSR_BWD_WAVES   // A/B builds: 4 = one wave per SIMD for the two-term chain / two 4-wave workgroups per CU for the one-term chain
+  const int waves = NSR_BWD_WAVES;
+#else
+  const int waves = 8;
+#endif
   if (hipMemsetAsync(gmax, 0, 10 * sizeof(unsigned), nsr_stream(stream)) != hipSuccess) return NSR_ERR_LAUNCH;
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
+  const dim3 grid8((unsigned)((P + 255) / 256)), block8(512);
   const float* pk = static_cast<const float*>(packed);
   char* dp = static_cast<char*>(dpan);
+  hipStream_t st = nsr_stream(stream);
   if (terms == 3)
-    hipLaunchKernelGGL(chain_bwd_kernel, grid, block, 0, nsr_stream(stream), pk, sgn, dp, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, P, gmax, pscale);
+    hipLaunchKernelGGL(chain_bwd_kernel, grid, block, 0, st, pk, sgn, dp, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, P, gmax, pscale);
+  else if (terms == 2 && waves == 8)
+    hipLaunchKernelGGL((chain_bwd_h_kernel<2, 8>), grid8, block8, 0, st, pk, sgn, dp, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, P, gmax, pscale);
   else if (terms == 2)
-    hipLaunchKernelGGL(chain_bwd_h_kernel<2>, grid, block, 0, nsr_stream(stream), pk, sgn, dp, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, P, gmax, pscale);
+    hipLaunchKernelGGL((chain_bwd_h_kernel<2, 4>), grid, block, 0, st, pk, sgn, dp, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, P, gmax, pscale);
+  else if (waves == 8)
+    hipLaunchKernelGGL((chain_bwd_h_kernel<1, 8>), grid8, block8, 0, st, pk, sgn, dp, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, P, gmax, pscale);
   else
-    hipLaunchKernelGGL(chain_bwd_h_kernel<1>, grid, block, 0, nsr_stream(stream), pk, sgn, dp, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, P, gmax, pscale);
+    hipLaunchKernelGGL((chain_bwd_h_kernel<1, 4>), grid, block, 0, st, pk, sgn, dp, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, P, gmax, pscale);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }

@@ -197,8 +197,12 @@ class Trainer:
                   _p(self._ws), self._ws.numel(), _stream())
         if any(self.lambda_var):
             import ctypes
-            # self.far of the reference: the far bound of the batch's first ray (nerf_downX_model.py:284); one host read per step
-            far = float(rays[0, 7].item())
+            # self.far of the reference (nerf_downX_model.py:284): forward_rays overwrites it per ray_chunk, so what
+            # calculate_losses divides by is the far bound of the FIRST ray of the LAST chunk.  Only the depth-variance
+            # terms use it: read (one host sync) only when one of them is on; the colour-variance terms never need it.
+            far = 1.0
+            if any(self.lambda_var[2:]):
+                far = float(rays[((R - 1) // chunk) * chunk, 7].item())
             var = (ctypes.c_float * 5)(*[l * gs for l in self.lambda_var], far)       # struct nsr_train_var_losses
             _lib.check(lib.nsr_train_loss_and_grads_var(*common, ctypes.cast(var, c_void_p), _p(self.var_losses)),
                        "nsr_train_loss_and_grads_var")

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/refstats; mkdir -p $O; cd $R
 for v in "$@"; do
-  lib=$R/nerf_sr_amd/libnsr_$v.so; [ "$v" = "new" ] && lib=$R/nerf_sr_amd/libnsr.so
+  lib=$R/ab/libnsr_$v.so; [ "$v" = "new" ] && lib=$R/nerf_sr_amd/libnsr.so
   rm -rf /tmp/rs_$v
   (cd /tmp && NSR_LIB_PATH=$lib timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rs_$v -o run -- python $R/scripts/refine_out.py $O/$v.pt 3 > $O/$v.log 2>&1)
   tail -1 $O/$v.log
