@@ -422,6 +422,49 @@ def refine_pass(img_wh, downscale, c2w, focal, o, dev, reps: int = 3):
                                  "constant (scripts/pmc_refine.py), null unless pmc_source.matches_this_build"}}
 
 
+def arch_bench(spec: str, dev, fused_rays_per_s: float, n_rays: int = 32768, reps: int = 3) -> dict:
+    """`--arch D,W,skip+skip`: one NON-DEFAULT network architecture (models/networks.py:124-157) through the same model
+    interface.  Such a network is outside the fused kernels' layout and runs nn.Linear by nn.Linear on the fp32-MFMA GEMM
+    (ops.GenericMLP: every (P, W) activation travels through HBM) on the stage-by-stage route; this figure makes that path's
+    price visible (VERDICT r5 "next" #7).  Workload: `n_rays` consecutive rays from the middle of config #2's frame, eval
+    mode, 64 + 128 samples, the architecture's own synthetic weights."""
+    import warnings
+    from nerf_sr_amd.model import NeRFDownXModel, default_options
+    from nerf_sr_amd.weights import make_state_dict_arch
+    D, W, skips = spec.split(",")
+    arch = {"D": int(D), "W": int(W), "skips": tuple(int(x) for x in skips.split("+") if x != ""), "deg_pos": 10, "deg_dir": 4}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)        # the slow-path warning is what this figure quantifies
+        m = NeRFDownXModel(default_options(**{**arch, "skips": list(arch["skips"])}), device=dev)
+    m.load_networks(make_state_dict_arch(99, **arch), make_state_dict_arch(100, **arch)).eval()
+    frame = ops.subpixel_rays(cameras.spiral_pose(0.4), (504, 378), cameras.llff_focal(504), 2, True, device=dev).view(-1, 8)
+    r0 = (frame.shape[0] - n_rays) // 2 // 4 * 4
+    rays = frame[r0:r0 + n_rays].contiguous()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ms = []
+    with torch.no_grad():
+        for i in range(reps + 1):
+            ev[0].record()
+            out = m.forward_rays(rays)
+            ev[1].record()
+            torch.cuda.synchronize()
+            if i:
+                ms.append(ev[0].elapsed_time(ev[1]))
+    in_xyz, in_dir, Wd = 3 + 6 * arch["deg_pos"], 3 + 6 * arch["deg_dir"], arch["W"]
+    macs = sum((in_xyz if i == 0 else (Wd + in_xyz if i in arch["skips"] else Wd)) * Wd for i in range(arch["D"]))
+    macs += Wd + Wd * Wd + (Wd + in_dir) * (Wd // 2) + (Wd // 2) * 3
+    t = sum(ms) / len(ms) * 1e-3
+    rps = n_rays / t
+    tf = rps * (N_COARSE + N_COARSE + N_IMPORTANCE) * 2 * macs / 1e12
+    return {"arch": arch | {"skips": list(arch["skips"])}, "route": "ops.GenericMLP: one fp32-MFMA GEMM launch per nn.Linear, stage-by-stage forward_rays",
+            "value": rps, "unit": "rays/s", "rays": n_rays, "ms": t * 1e3, "macs_per_point": macs,
+            "achieved_tflops": tf, "frac_of_fp32_mfma_peak": tf / PEAK_TFLOPS["fp32"],
+            "finite": bool(torch.isfinite(out["fine_comp_rgbs"]).all()),
+            "fused_default_arch_rays_per_s": fused_rays_per_s,
+            "slowdown_vs_fused_default_per_ray": fused_rays_per_s / rps,
+            "slowdown_vs_fused_default_per_flop": (fused_rays_per_s * 2 * 593408) / (rps * 2 * macs)}
+
+
 def refine_pmc_busy():
     """Time-weighted matrix-pipe busy share of the refinement pass's GEMM kernels from profiles/r5_refine_pmc.json (rocprofv3
     --pmc passes, scripts/pmc_refine.py), valid for the build whose source hash it carries."""
@@ -468,6 +511,9 @@ def main():
                     help="skip the `config4` sub-object (config #4's frame sharded over the same ranks, timed after the headline)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the `train` and `config5` (+ `refine`) sub-objects of the default N = 1 line")
+    ap.add_argument("--arch", default="6,192,1+3",
+                    help="D,W,skips (skips joined by +): a NON-default network architecture timed on the layer-by-layer route "
+                         "(ops.GenericMLP) as the `arch` sub-object of the default N = 1 line; '' skips it")
     ap.add_argument("--with-refine", action="store_true",
                     help="config #5 only: after the timed render steps run depth -> warp -> refinement network on the "
                          "rendered frame and report that pass separately (`refine` object; not part of `value`)")
@@ -621,6 +667,9 @@ def main():
         c5 = guarded("config5", lambda: time_config(5, 2, 1))
         train_res = guarded("train", lambda: train_bench(args, rank, local, world, steps=20, warmup=5, cpu=True))
         c1_res = guarded("config1", lambda: train_bench(args, rank, local, world, steps=20, warmup=5, cpu=True, shape="vanilla"))
+    arch_res = None
+    if args.arch and not args.config and not args.no_extras and world == 1:
+        arch_res = guarded("arch", lambda: arch_bench(args.arch, dev, main_r["value"]))
 
     if rank == 0:
         r = main_r
@@ -702,6 +751,8 @@ def main():
             res["train"] = {k: train_res[k] for k in keys}
         if c1_res is not None:
             res["config1"] = {k: c1_res[k] for k in keys}
+        if arch_res is not None:
+            res["arch"] = arch_res
         for name, err in extras_err.items():
             top, _, sub = name.partition(".")
             if sub and isinstance(res.get(top), dict):

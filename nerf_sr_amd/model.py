@@ -85,7 +85,12 @@ class NeRFDownXModel:
         R, N = xyz.shape[:2]
         x = torch.cat([self.embeddings["pos"](xyz.reshape(-1, 3)), dir_embedded.repeat_interleave(N, dim=0)], -1)
         out = model(x, **kwargs).view(R, N, -1)
-        return out[..., :3], out[..., 3]
+        rgb = out[..., :3]
+        if isinstance(model, GenericMLP) and model.gamma_correct and not kwargs.get("sigma_only", False):
+            # models/nerf_downX_model.py:271-276: pow(rgb, 1 / 2.2) after the network (VanillaMLP's fused colour head has
+            # done it already: nsr_weights_set_gamma); the NaN trap that follows it there is the network's status word here
+            rgb = torch.pow(rgb, 1.0 / 2.2)
+        return rgb, out[..., 3]
 
     # -- D3 ------------------------------------------------------------------------
     def forward_rays(self, rays: torch.Tensor) -> Dict[str, torch.Tensor]:

@@ -330,8 +330,10 @@ class GenericMLP:
         self.color_activation = getattr(opt, "color_activation", "sigmoid") if opt is not None else "sigmoid"
         if self.color_activation not in ("sigmoid", "none"):
             raise ValueError(f"color_activation={self.color_activation!r}: 'sigmoid' or 'none' (models/networks.py:173-180)")
-        if opt is not None and getattr(opt, "gamma_correct", False):
-            raise ValueError("gamma_correct is built into the fused kernels' colour head only (default architecture)")
+        # --gamma_correct is not a property of the network in the reference either: render_rays raises the colours to 1 / 2.2
+        # after the network call (models/nerf_downX_model.py:271-276).  The fused kernels carry it as an option of their
+        # colour head; on this route NeRFDownXModel.render_rays applies it to what forward() returns.
+        self.gamma_correct = bool(getattr(opt, "gamma_correct", False)) if opt is not None else False
         self.device = torch.device(device)
         _check_device(self.device, "GenericMLP device")
         a = self.arch
@@ -453,7 +455,28 @@ def make_mlp(opt=None, precision: str = "fp32", device="cuda"):
     reference uses, ``GenericMLP`` for other ``--D --W --skips`` / degrees / ``dim_rgb``."""
     if is_default_arch(arch_of(opt)):
         return VanillaMLP(opt, precision=precision, device=device)
+    warn_generic_mlp(arch_of(opt), precision)
     return GenericMLP(opt, device=device)
+
+
+_GENERIC_WARNED = set()
+
+
+def warn_generic_mlp(arch: dict, precision: str = "fp32") -> None:
+    """One warning per architecture and process: a non-default ``--D --W --skips`` / encoding degree leaves the fused MFMA
+    kernels (whose register, LDS and weight-stream layouts ARE the 8 x 256 network with a skip at layer 5) for the
+    layer-by-layer fp32 GEMM route -- correct (tests/golden/arch.npz, made by the reference's own forward), but every
+    activation matrix travels through HBM: `bench.py --arch D,W,skips` times it (README: ~an order of magnitude slower per
+    sample point than the fused f16x3 kernel at the default size) -- and ``precision`` is ignored there (always fp32)."""
+    import warnings
+    key = (arch.get("D"), arch.get("W"), tuple(arch.get("skips", ())), arch.get("deg_pos"), arch.get("deg_dir"))
+    if key in _GENERIC_WARNED:
+        return
+    _GENERIC_WARNED.add(key)
+    note = "" if precision == "fp32" else f"; precision={precision!r} is ignored on this route (fp32 MFMA GEMMs)"
+    warnings.warn(f"NeRF-SR network D={key[0]} W={key[1]} skips={list(key[2])} deg_pos={key[3]} deg_dir={key[4]} is not the "
+                  "architecture of the fused kernels (8 x 256, skip at 4, degrees 10 / 4): running the layer-by-layer fp32 GEMM "
+                  f"path (ops.GenericMLP), several times slower per sample point{note}", RuntimeWarning, stacklevel=3)
 
 
 # ----------------------------------------------------------------------------- V1

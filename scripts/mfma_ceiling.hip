@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <vector>
+#include <string>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -121,7 +122,46 @@ static void run(const char* data_name, int data, int n_cu) {
   CHECK(hipFree(da)); CHECK(hipFree(db)); CHECK(hipFree(sink)); CHECK(hipFree(clk));
 }
 
-int main() {
+// `mfma_ceiling hold <data 0|1|2> <seconds>`: keep launching the one-wave-per-SIMD loop on that operand data for that long, so
+// that an outside sampler (rocm-smi: power, clocks -- scripts/power_clock_probe.sh) sees a steady state
+static void hold(int data, double seconds, int n_cu) {
+  const int threads = 256, blocks = n_cu, n = threads * blocks;
+  std::vector<_Float16> ha((size_t)n * 32), hb((size_t)n * 32);
+  for (size_t i = 0; i < ha.size(); ++i) {
+    const int set = (int)((i / 8) % 4);
+    float va = 0.0f, vb = 0.0f;
+    if (data >= 1) { va = 0.08f * gauss(); vb = fmaxf(gauss(), 0.0f); }
+    if (data == 2) { if (set == 1) va *= 4.8828125e-4f; if (set == 2) vb *= 4.8828125e-4f; }
+    ha[i] = (_Float16)va;
+    hb[i] = (_Float16)vb;
+  }
+  h8 *da, *db; float* sink; unsigned long long* clk;
+  CHECK(hipMalloc(&da, ha.size() * 2)); CHECK(hipMalloc(&db, hb.size() * 2));
+  CHECK(hipMalloc(&sink, (size_t)n * 4)); CHECK(hipMalloc(&clk, (size_t)blocks * 16));
+  CHECK(hipMemcpy(da, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(db, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  double total_ms = 0.0; long launches = 0;
+  while (total_ms < seconds * 1e3) {
+    CHECK(hipEventRecord(e0, 0));
+    for (int k = 0; k < 8; ++k) hipLaunchKernelGGL((mfma_loop<1, 1>), dim3(blocks), dim3(threads), 0, 0, da, db, 40000, sink, clk);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    total_ms += ms; launches += 8;
+  }
+  const double flops = (double)launches * blocks * 4 * 40000 * 24.0 * 2.0 * 32 * 32 * 16;
+  printf("hold data=%d: %.1f s, %.3f PFLOP/s issued\n", data, total_ms * 1e-3, flops / (total_ms * 1e-3) / 1e15);
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 4 && std::string(argv[1]) == "hold") {
+    hipDeviceProp_t q;
+    CHECK(hipGetDeviceProperties(&q, 0));
+    hold(atoi(argv[2]), atof(argv[3]), q.multiProcessorCount);
+    return 0;
+  }
   hipDeviceProp_t p;
   CHECK(hipGetDeviceProperties(&p, 0));
   const int n_cu = p.multiProcessorCount;

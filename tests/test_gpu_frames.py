@@ -246,8 +246,8 @@ def test_config5_composed_small_vs_oracles(ops):
     out = pipeline.render_warp_refine(model, net, c2w, ref_c2w, ref_img.cuda(), focal, False, 2.0, 6.0)
     # stage 1: the render (colours and depth) vs the oracle
     rays = oc.subpixel_ray_grid(torch.from_numpy(c2w), H, W, focal, s, False, 2.0, 6.0).reshape(-1, 8)
-    with torch.no_grad():
-        ref = oc.forward_rays(oc.to_torch_sd(sd_c), oc.to_torch_sd(sd_f), rays, 64, 64, True)
+    from tests.util import oracle_forward_parallel
+    ref = oracle_forward_parallel(sd_c, sd_f, rays, True)              # 16,384 rays over the host's cores (VERDICT r5 "next" #5)
     hr_ref = oc.unflatten_hr(ref["fine_comp_rgbs"], H, W, s)
     d_ref = oc.unflatten_hr(ref["fine_depth"].reshape(-1, 1), H, W, s)[..., 0]
     assert float((out["hr_rgb"].cpu() - hr_ref).abs().max()) <= 2e-4          # a frame of 16k rays: see test 1 for the 1e-4 bar
@@ -265,7 +265,15 @@ def test_config5_composed_small_vs_oracles(ops):
     sr = (out["hr_rgb"].cpu().permute(2, 0, 1) * 2 - 1).numpy()
     starts, refs = rt.tile(locs_want, W, H, 64, 8)
     srp, refp = rt.gather(sr, (ref_img * 2 - 1).numpy(), starts, refs, 64)
-    pred = ro.forward(sd_r, torch.from_numpy(srp), torch.from_numpy(refp), dtype=torch.float64).float().numpy()
+    # the fp64 network oracle, one tile (1 + 8 patches) per host thread team: the tiles are independent
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+
+    def one_tile(i):
+        torch.set_num_threads(max(1, (os.cpu_count() or 4) // (2 * srp.shape[0])))
+        return ro.forward(sd_r, torch.from_numpy(srp[i:i + 1]), torch.from_numpy(refp[i:i + 1]), dtype=torch.float64).float().numpy()
+    with ThreadPoolExecutor(srp.shape[0]) as ex:
+        pred = np.concatenate(list(ex.map(one_tile, range(srp.shape[0]))), 0)
     want = (rt.stitch(pred, starts, 64, W, H) + 1.0) * 0.5
     assert float(np.abs(out["refined"].cpu().numpy() - want).max()) <= 2e-5
     assert refs.min() >= -1 and (refs >= 0).any()                               # warped reference patches were used

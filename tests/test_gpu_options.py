@@ -275,5 +275,35 @@ def test_default_architecture_keeps_the_fused_kernels(ops):
     assert m.fused and isinstance(m.netCoarse, ops.VanillaMLP) and not isinstance(m.netCoarse, ops.GenericMLP)
     with pytest.raises(ValueError, match="outside the built path"):
         ops.VanillaMLP(default_options(W=128))            # the fused class itself still refuses what it is not laid out for
-    with pytest.raises(ValueError, match="gamma_correct"):
-        NeRFDownXModel(default_options(W=128, gamma_correct=True))
+
+
+def test_generic_mlp_warns_once_and_applies_gamma(ops, golden_dir):
+    """Round 6: a non-default architecture leaves the fused kernels SILENTLY no longer -- one
+    RuntimeWarning per architecture names the layer-by-layer route -- and --gamma_correct, which the reference applies in
+    render_rays for any architecture (models/nerf_downX_model.py:271-276), works there too: against the oracle with the option
+    on, and equal to pow(., 1 / 2.2) of the colours without it."""
+    import warnings
+    from nerf_sr_amd.model import NeRFDownXModel, default_options
+    from nerf_sr_amd.weights import make_state_dict_arch
+    arch = {"D": 4, "W": 128, "skips": (2,), "deg_pos": 6, "deg_dir": 2}
+    g = np.load(os.path.join(golden_dir, "arch.npz"))
+    p = np.load(os.path.join(golden_dir, "path_llff.npz"))
+    sd_c, sd_f = make_state_dict_arch(int(g["seed_coarse"]), **arch), make_state_dict_arch(int(g["seed_fine"]), **arch)
+    ops._GENERIC_WARNED.clear()
+    with pytest.warns(RuntimeWarning, match="layer-by-layer fp32 GEMM"):
+        m = NeRFDownXModel(default_options(gamma_correct=True, **{**arch, "skips": [2]})).load_networks(sd_c, sd_f).eval()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")             # the second model of the same architecture does not warn again
+        m0 = NeRFDownXModel(default_options(**{**arch, "skips": [2]})).load_networks(sd_c, sd_f).eval()
+    r = torch.from_numpy(p["rays"])[:64].cuda()
+    ref = oc.forward_rays(oc.to_torch_sd(sd_c), oc.to_torch_sd(sd_f), r.cpu(), 64, 64, False, gamma_correct=True,
+                          deg_pos=arch["deg_pos"], deg_dir=arch["deg_dir"])
+    m.set_input({"rays": r[None]})
+    m.forward()
+    for k in ("coarse_comp_rgbs", "fine_comp_rgbs"):
+        assert float((getattr(m, f"out_{k}").cpu() - ref[k]).abs().max()) <= 1e-4, k
+    z, xyz = ops.sample_along_rays(r[:, 0:3], r[:, 3:6], r[:, 6:7], r[:, 7:8], 64, False, False)
+    de = m.embeddings["dir"](r[:, 3:6].contiguous())
+    rgb_g, sig_g = m.render_rays(m.netCoarse, xyz, de)
+    rgb_0, sig_0 = m0.render_rays(m0.netCoarse, xyz, de)
+    assert torch.equal(sig_g, sig_0) and torch.equal(rgb_g, torch.pow(rgb_0, 1.0 / 2.2))

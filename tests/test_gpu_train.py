@@ -327,27 +327,42 @@ def test_chain_path_matches_gemm_path_at_bench_scale(tr):
 
 def test_fp16_weight_gradient_operands_drift_like_fp32_over_200_adam_steps(tr):
     """Round 5: the chain path contracts its weight gradients from the fp16 `hi` operands of the forward / backward chains
-    (11-bit activations and input gradients, one MFMA per product).  profiles/r4_train_fp16_wgrad_study.txt predicted, on the
-    CPU, that such a run leaves the exact trajectory exactly as fast as ANY fp32-grade run does (after 200 Adam steps: weights
-    0.15 of the distance moved, per-step losses within 1e-4 .. 9e-3, mean loss of the last 40 steps within 3e-4 .. 8e-4).
-    Here, on the device: 200 steps on the analytic scene from one start with identical batches and draws, the chain path
-    ('f16x3') against the all-fp32 GEMM path ('fp32'), with the third implementation ('f16x3_gemm': fp32 weight gradients,
-    split-fp16 forward) as the yardstick of what two fp32-grade runs do to each other."""
+    (11-bit activations and input gradients, one MFMA per product); round 6: its backward chain runs on two MFMA terms.
+    profiles/r4_train_fp16_wgrad_study.txt predicted, on the CPU, that such a run leaves the exact trajectory exactly as fast as
+    ANY fp32-grade run does (after 200 Adam steps: weights 0.15 of the distance moved, per-step losses within 1e-4 .. 9e-3, mean
+    loss of the last 40 steps within 3e-4 .. 8e-4).  Here, on the device: 200 steps on the analytic scene from one start with
+    identical batches and draws, the chain path ('f16x3') against the all-fp32 GEMM path ('fp32'), with the third
+    implementation ('f16x3_gemm': fp32 weight gradients, split-fp16 forward) as the yardstick of what two fp32-grade runs do to
+    each other.
+
+    Round 6: THREE seeds instead of one, the same bounds on the MEDIAN over the seeds.  The trajectories are chaotic after
+    ~100 steps and every statistic below moves by 2-4x from seed to seed for EVERY arithmetic, the fp32-grade yardstick
+    included (profiles/r6_train_drift_seeds.json, six seeds: max per-step loss difference 0.017 .. 0.034 for the yardstick,
+    0.016 .. 0.031 / 0.015 .. 0.059 / 0.011 .. 0.033 for the backward chain on three / two / one MFMA terms; the first-10-steps
+    figure of the YARDSTICK is 1.0e-2 on seed 0, twice the bound it was given on that seed's chain-path value): one seed's
+    value of such a statistic says nothing about an arithmetic.  No single seed may exceed twice a bound."""
     from tests.trained_field import adam_trajectory, trajectory_drift
-    runs = {p: adam_trajectory(p, steps=200) for p in ("fp32", "f16x3", "f16x3_gemm")}
-    assert all(r["status"] == 0 for r in runs.values())
-    assert all(np.isfinite(r["fine"]).all() for r in runs.values())
-    new, yard = trajectory_drift(runs["f16x3"], runs["fp32"]), trajectory_drift(runs["f16x3_gemm"], runs["fp32"])
-    print("\nchain (fp16 wgrad operands) vs fp32:", new, "\nf16x3_gemm (fp32 wgrad) vs fp32:  ", yard)
-    assert runs["f16x3"]["fine"][-1] < 0.5 * runs["f16x3"]["fine"][0]                    # it trains
-    # the study's figures with a factor of a few of margin (one trajectory, chaotic after ~100 steps) ...
-    assert new["loss_rel_diff_first10_max"] < 5e-3, new
-    assert new["loss_rel_diff_max"] < 5e-2, new
-    assert new["last40_mean_rel_diff"] < 5e-3, new
-    assert new["weights_rel_distance"] < 0.45, new
+    seeds = (0, 1, 2)
+    new, yard, runs = [], [], None
+    for sd in seeds:
+        runs = {p: adam_trajectory(p, steps=200, seed=sd) for p in ("fp32", "f16x3", "f16x3_gemm")}
+        assert all(r["status"] == 0 for r in runs.values())
+        assert all(np.isfinite(r["fine"]).all() for r in runs.values())
+        assert runs["f16x3"]["fine"][-1] < 0.5 * runs["f16x3"]["fine"][0]                    # it trains
+        new.append(trajectory_drift(runs["f16x3"], runs["fp32"]))
+        yard.append(trajectory_drift(runs["f16x3_gemm"], runs["fp32"]))
+    print("\nchain (fp16 wgrad operands, two-term backward chain) vs fp32:", new, "\nf16x3_gemm (fp32 wgrad) vs fp32:  ", yard)
+    med = lambda rows, k: float(np.median([r[k] for r in rows]))
+    worst = lambda rows, k: float(max(r[k] for r in rows))
+    # the study's figures with a factor of a few of margin: the bounds of round 5, on the median over the seeds ...
+    bounds = {"loss_rel_diff_first10_max": 5e-3, "loss_rel_diff_max": 5e-2, "last40_mean_rel_diff": 5e-3, "weights_rel_distance": 0.45}
+    for k, b in bounds.items():
+        assert med(new, k) < b, (k, new)
+        assert worst(new, k) < 2.0 * b, (k, new)
     # ... and relative to the yardstick: no further from the fp32 run than twice what another fp32-grade path is
-    assert new["weights_rel_distance"] < 2.0 * yard["weights_rel_distance"] + 0.05, (new, yard)
-    assert new["last40_mean_rel_diff"] < 2.0 * yard["last40_mean_rel_diff"] + 2e-3, (new, yard)
+    assert med(new, "weights_rel_distance") < 2.0 * med(yard, "weights_rel_distance") + 0.05, (new, yard)
+    assert med(new, "last40_mean_rel_diff") < 2.0 * med(yard, "last40_mean_rel_diff") + 2e-3, (new, yard)
+    assert med(new, "loss_rel_diff_max") < 2.0 * med(yard, "loss_rel_diff_max") + 1e-2, (new, yard)
 
 
 def test_backward_chain_term_variants(golden_dir, tr):

@@ -60,21 +60,54 @@ def train_draws(g):
 
 
 def oracle_fp32_and_fp64(sd_c, sd_f, rays, white_bkgd, n_coarse=64, n_importance=64, threads=32):
-    """The oracle's fp32 and fp64 evaluations of the same rays, run CONCURRENTLY in two Python threads with `threads` ATen
-    threads each (torch releases the GIL inside its operators; OpenMP gives each calling thread its own team).  The GPU
-    boxes have 128 hardware threads and the oracle stops scaling at ~32 (bench.py's policy), so running the two
-    evaluations side by side costs about max(fp32, fp64) instead of their sum.  The fp32 results do not depend on the
-    thread count (checked: bit-identical); the fp64 ones move by one ulp (2e-16) in the final colour sum, far below anything
-    the parity statistics resolve."""
+    """The oracle's fp32 and fp64 evaluations of the same rays, the way bench.py's `cpu_baseline` runs the oracle fastest
+    (profiles/r4_cpu_sweep.json; VERDICT r5 "next" #5): the port is bound by per-operator overhead on small matrices, so ONE
+    evaluation stops scaling at ~32 threads while MANY evaluations side by side over disjoint ray chunks keep scaling (torch
+    releases the GIL inside its operators, OpenMP gives every calling thread its own team).  Both precisions' chunks share one
+    pool: `workers` Python threads x 2 ATen threads per precision (64 + 64 workers on the GPU boxes' 256 hardware threads,
+    1 + 1 on a small host).  Rays are independent, so the chunking changes nothing but the shapes the host BLAS sees (fp32
+    results move by an ulp or two of their matrix products between chunkings -- far inside what the parity statistics
+    resolve, and the contract is stated against THIS evaluation's own fp32-vs-fp64 gap).  `threads`: kept for callers of the
+    round-2..5 form (ATen threads of a single evaluation); only its order of magnitude is used, as the cap on the workers."""
     import os
     from concurrent.futures import ThreadPoolExecutor
-    n = max(1, min(int(threads), (os.cpu_count() or 2) // 2))       # two evaluations share the host
+    host = os.cpu_count() or 2
+    per = 2
+    workers = max(1, min(64, 2 * int(threads), host // (2 * per)))
+    n = rays.shape[0]
+    workers = max(1, min(workers, (n + 255) // 256))                # no chunk below 256 rays: the GEMMs would be all overhead
+    sds = {dt: (oc.to_torch_sd(sd_c, dt), oc.to_torch_sd(sd_f, dt)) for dt in (torch.float32, torch.float64)}
+    jobs = [(dt, c) for c32, c64 in zip(rays.to(torch.float32).chunk(workers), rays.to(torch.float64).chunk(workers))
+            for dt, c in ((torch.float64, c64), (torch.float32, c32)) if c.shape[0]]
 
-    def run(dtype):
-        torch.set_num_threads(n)                                    # per calling thread (OpenMP ICV); MKL: the same n for both
+    def run(job):
+        dt, r = job
+        torch.set_num_threads(per)                                  # per calling thread (OpenMP ICV)
         with torch.no_grad():
-            return oc.forward_rays(oc.to_torch_sd(sd_c, dtype), oc.to_torch_sd(sd_f, dtype), rays.to(dtype), n_coarse,
-                                   n_importance, white_bkgd)
-    with ThreadPoolExecutor(2) as ex:
-        f32, f64 = ex.submit(run, torch.float32), ex.submit(run, torch.float64)
-        return f32.result(), f64.result()
+            return oc.forward_rays(sds[dt][0], sds[dt][1], r, n_coarse, n_importance, white_bkgd)
+    with ThreadPoolExecutor(max(1, len(jobs))) as ex:
+        parts = list(ex.map(run, jobs))
+    out = []
+    for dt in (torch.float32, torch.float64):
+        mine = [p for (d, _), p in zip(jobs, parts) if d == dt]
+        out.append({k: torch.cat([p[k] for p in mine], 0) for k in mine[0]})
+    return out[0], out[1]
+
+
+
+def oracle_forward_parallel(sd_c, sd_f, rays, white_bkgd, n_coarse=64, n_importance=64, dtype=torch.float32, **kw):
+    """One precision of the oracle over disjoint ray chunks side by side (see oracle_fp32_and_fp64): host threads // 2
+    ATen threads in all, 2 per worker."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, min(64, (os.cpu_count() or 2) // 4, (rays.shape[0] + 255) // 256))
+    sc, sf = oc.to_torch_sd(sd_c, dtype), oc.to_torch_sd(sd_f, dtype)
+    chunks = [c for c in rays.to(dtype).chunk(workers) if c.shape[0]]
+
+    def run(r):
+        torch.set_num_threads(2)
+        with torch.no_grad():
+            return oc.forward_rays(sc, sf, r, n_coarse, n_importance, white_bkgd, **kw)
+    with ThreadPoolExecutor(len(chunks)) as ex:
+        parts = list(ex.map(run, chunks))
+    return {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
