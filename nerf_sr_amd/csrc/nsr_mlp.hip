@@ -128,6 +128,30 @@ static float precision_weight_limit(int precision) {
   return 3.402823466e38f;
 }
 
+// both networks of a training step in ONE launch (round 6: the step's launch count; blockIdx.z = network)
+__global__ void __launch_bounds__(256) check_weights2_kernel(CheckPtrs w0, CheckPtrs w1, float limit, unsigned* tail) {
+  const CheckPtrs& w = blockIdx.z ? w1 : w0;
+  bool bad = false;
+  for (int t = blockIdx.y; t < NSR_N_STATE_TENSORS; t += gridDim.y) {
+    const float lim = (t & 1) ? 3.402823466e38f : limit;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < w.n[t]; i += gridDim.x * blockDim.x)
+      bad |= !(fabsf(w.p[t][i]) <= lim);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(tail, NSR_FLAG_WEIGHT_RANGE);
+}
+extern "C" NSR_INTERNAL int nsr_check_weights_range2(const float* const* w0, const float* const* w1, int precision, unsigned* word, void* stream) {
+  CheckPtrs a, b;
+  for (int i = 0; i < NSR_N_STATE_TENSORS; ++i) {
+    if (!w0[i] || !w1[i]) return NSR_ERR_INVALID_ARG;
+    a.p[i] = w0[i]; b.p[i] = w1[i];
+    a.n[i] = b.n[i] = kStateTensorSizes[i];
+  }
+  hipLaunchKernelGGL(check_weights2_kernel, dim3(16, NSR_N_STATE_TENSORS, 2), dim3(256), 0, nsr_stream(stream), a, b,
+                     precision_weight_limit(precision), word);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
 // the weight-range check on its own (the training step runs it on the weights it re-packs every iteration)
 extern "C" NSR_INTERNAL int nsr_check_weights_range(const float* const* w, int precision, unsigned* word, void* stream) {
   CheckPtrs cp;

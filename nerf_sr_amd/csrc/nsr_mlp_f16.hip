@@ -41,7 +41,16 @@ __device__ __forceinline__ int tensor_ld_h(int tensor) {
 
 
 // one thread per 32-bit word of the blob
-__global__ void __launch_bounds__(256) pack_f16x3_kernel(PackPtrsH w, unsigned* __restrict__ out) {
+template <bool TWO>
+__device__ __forceinline__ void pack_f16x3_body(const PackPtrsH& w, unsigned* __restrict__ out);
+__global__ void __launch_bounds__(256) pack_f16x3_kernel(PackPtrsH w, unsigned* __restrict__ out) { pack_f16x3_body<false>(w, out); }
+// both networks of a training step in one launch (round 6; blockIdx.y = network)
+__global__ void __launch_bounds__(256) pack_f16x3_2_kernel(PackPtrsH w0, unsigned* __restrict__ out0, PackPtrsH w1, unsigned* __restrict__ out1) {
+  if (blockIdx.y) pack_f16x3_body<true>(w1, out1);
+  else pack_f16x3_body<true>(w0, out0);
+}
+template <bool TWO>
+__device__ __forceinline__ void pack_f16x3_body(const PackPtrsH& w, unsigned* __restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int stream_words = kPiecesTotal * 256;
   if (idx >= stream_words + hx::kAuxFloats) return;
@@ -91,6 +100,20 @@ extern "C" NSR_INTERNAL int nsr_f16x3_pack(const float* const* w, void* packed_d
   const int total = kPiecesTotal * 256 + hx::kAuxFloats;
   hipLaunchKernelGGL(pack_f16x3_kernel, dim3((total + 255) / 256), dim3(256), 0, nsr_stream(stream), pp,
                      static_cast<unsigned*>(packed_dev));
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
+extern "C" NSR_INTERNAL int nsr_f16x3_pack2(const float* const* w0, void* packed0, const float* const* w1, void* packed1, void* stream) {
+  PackPtrsH a, b;
+  for (int i = 0; i < NSR_N_STATE_TENSORS; ++i) {
+    if (!w0[i] || !w1[i]) return NSR_ERR_INVALID_ARG;
+    a.p[i] = w0[i];
+    b.p[i] = w1[i];
+  }
+  const int total = kPiecesTotal * 256 + hx::kAuxFloats;
+  hipLaunchKernelGGL(pack_f16x3_2_kernel, dim3((total + 255) / 256, 2), dim3(256), 0, nsr_stream(stream), a,
+                     static_cast<unsigned*>(packed0), b, static_cast<unsigned*>(packed1));
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }

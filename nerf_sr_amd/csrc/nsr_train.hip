@@ -252,6 +252,9 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
                                                             float* __restrict__ d_rgb, float* __restrict__ g1,
                                                             const float* __restrict__ g_depth, float* __restrict__ bias_part) {
   const int lane = threadIdx.x & 63;
+  // COMPACT (chain path): `g1` carries the backward chain's ten gmax words, cleared here -- the kernel that runs right in front
+  // of the chain -- instead of by a memset launch of their own (round 6)
+  if (COMPACT && g1 && blockIdx.x == 0 && threadIdx.x < 10) reinterpret_cast<unsigned*>(g1)[threadIdx.x] = 0u;
   const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r >= R) return;
   const int64_t base = r * N;
@@ -510,6 +513,18 @@ __global__ void __launch_bounds__(256) finish_jobs_kernel(FinishJobs jobs) {
     if (lane == 0) q.dst[e] = (q.accumulate ? q.dst[e] : 0.0f) + (float)s;
     return;
   }
+  if (q.kind == 1 && q.splits > 64) {
+    // many slices (the head streams: 1,024, round 6): one wavefront per element, lanes stride over the slices -- a thread
+    // that walks them alone is a chain of a hundred dependent round trips
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    for (int i = e; i < q.rows; i += 4 * gridDim.x) {      // wave-uniform
+      double s = 0.0;
+      for (int z = lane; z < q.splits; z += 64) s += (double)q.partial[(int64_t)z * q.rows + i];
+      s = wave_sum_d(s);
+      if (lane == 0) q.dst[i] = (q.accumulate ? q.dst[i] : 0.0f) + (float)(s * (double)q.scale);
+    }
+    return;
+  }
   if (idx >= q.rows * q.cols) return;
   const float* src;
   int64_t stride;
@@ -525,16 +540,26 @@ __global__ void __launch_bounds__(256) finish_jobs_kernel(FinishJobs jobs) {
     stride = q.rows;
     d = q.dst + idx;
   }
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four independent chains: the loads of a round are all in flight
+  // Eight loads in flight per thread (round 6; four until then): the kernel is latency-bound -- ~21 partial tiles per
+  // product, 26 blocks per CU of which 8 are resident, every round a trip to L2 / HBM (38 us per call for 29 MB).  The
+  // association of the sum is fixed (eight chains, then a tree): bit-reproducible run to run.
+  double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   int zc = 0;
-  for (; zc + 4 <= q.splits; zc += 4) {
-    s0 += (double)src[(zc + 0) * stride];
-    s1 += (double)src[(zc + 1) * stride];
-    s2 += (double)src[(zc + 2) * stride];
-    s3 += (double)src[(zc + 3) * stride];
+  for (; zc + 8 <= q.splits; zc += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(zc + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += (double)v[u];
   }
-  for (; zc < q.splits; ++zc) s0 += (double)src[zc * stride];
-  const double sum = (s0 + s1) + (s2 + s3);
+  {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (zc + u < q.splits) ? src[(int64_t)(zc + u) * stride] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += (double)v[u];
+  }
+  const double sum = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   *d = (q.accumulate ? *d : 0.0f) + (float)(sum * (double)q.scale);
 }
 
@@ -881,12 +906,22 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, int64_t n_rays,
   auto note = [&](int job, int fin) { placed[n_placed++] = Placed{job, fin}; };
   float* part;
   int pj;
-  const int64_t per = (P / 32 + sp - 1) / sp;
+  // the two head streams: 4 slices per CU (round 6).  With one 256-thread workgroup per CU (rounds 3-5: `sp` slices) a CU had
+  // 4-16 KiB of loads in flight and the streams ran at 1.5-2.3 TB/s (28 + 21 us coarse, 44 + 31 us fine: 4 % of the step);
+  // the slot the partials go to holds sp x 256 x 256 floats, a slice writes 384 or 256
+  const int64_t n_pg = P / 32;
+  const int hs = (int)(n_pg < 1024 ? (n_pg < 1 ? 1 : n_pg) : 1024);
+  const int64_t per = (n_pg + hs - 1) / hs;
+  auto sum_rows_n = [&](float* dst, int rows, const float* partial, int n) {
+    FinishJob& q = jobs.j[jobs.n++];
+    q.kind = 1; q.dst = dst; q.rows = rows; q.cols = 1; q.partial = partial; q.splits = n; q.accumulate = acc; q.scale = 1.0f;
+    return jobs.n - 1;
+  };
   // rgb head: d_rgb_pre^T relu(zcc), a stream over the panel
   part = big_slot();
-  hipLaunchKernelGGL((panel_wsums_kernel<128, 3>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 9), P, k.d4, 4, per, part);
+  hipLaunchKernelGGL((panel_wsums_kernel<128, 3>), dim3(hs), dim3(256), 0, st, panel_of(k.zpan, P, 9), P, k.d4, 4, per, part);
   NSR_CHECK_LAUNCH();
-  sum_rows(g[kRgbW], 3 * 128, part);
+  sum_rows_n(g[kRgbW], 3 * 128, part, hs);
   auto sum_rays = [&](float* dst, int rows, const float* partial) {     // kind 2: the per-ray partials of composite_bwd_kernel
     FinishJob& q = jobs.j[jobs.n++];
     q.kind = 2; q.dst = dst; q.rows = rows; q.cols = 1; q.partial = partial; q.stride = 4; q.splits = (int)n_rays; q.accumulate = acc; q.scale = 1.0f;
@@ -903,9 +938,9 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, int64_t n_rays,
   note(pj, place(g[kFinalW], 256, 0, 256, 256, nullptr, kW, 0));
   note(pj, ~sum_rows(g[kFinalB], kW, nullptr));
   part = big_slot();
-  hipLaunchKernelGGL((panel_wsums_kernel<256, 1>), dim3(sp), dim3(256), 0, st, panel_of(k.zpan, P, 7), P, k.d4 + 3, 4, per, part);
+  hipLaunchKernelGGL((panel_wsums_kernel<256, 1>), dim3(hs), dim3(256), 0, st, panel_of(k.zpan, P, 7), P, k.d4 + 3, 4, per, part);
   NSR_CHECK_LAUNCH();
-  sum_rows(g[kSigmaW], 256, part);
+  sum_rows_n(g[kSigmaW], 256, part, hs);
   sum_rays(g[kSigmaB], 1, k.bias_part + 3);
   // trunk layers 8..1: dz_L^T (input of layer L)
   for (int L = 8; L >= 1; --L) {
@@ -973,7 +1008,7 @@ int composite_bwd(hipStream_t st, const Work& k, const float* z, int64_t R, int 
   const int K = (N + 63) / 64;
 #define NSR_LAUNCH_CB(KK)                                                                                                          \
   do {                                                                                                                             \
-    if (compact) hipLaunchKernelGGL((composite_bwd_kernel<KK, true>), grid, block, 0, st, k.rgb, k.sig, z, k.g_comp, R, N, white, k.d4, nullptr, g_depth, k.bias_part); \
+    if (compact) hipLaunchKernelGGL((composite_bwd_kernel<KK, true>), grid, block, 0, st, k.rgb, k.sig, z, k.g_comp, R, N, white, k.d4, reinterpret_cast<float*>(k.gmax), g_depth, k.bias_part); \
     else hipLaunchKernelGGL((composite_bwd_kernel<KK, false>), grid, block, 0, st, k.rgb, k.sig, z, k.g_comp, R, N, white, k.drgb, k.g1, g_depth, nullptr);   \
   } while (0)
   switch (K) {
@@ -1052,22 +1087,20 @@ int train_impl(const float* const* w_coarse, const float* const* w_fine, float* 
 
   const bool chain = chain_selected(precision);
   if (chain) {
-    for (int net = 0; net < 2; ++net) {
-      // the weights are re-packed every iteration: a run whose weights drift beyond what the split-fp16 stream carries
-      // (|w| >= 1023.75, or NaN) raises NSR_FLAG_WEIGHT_RANGE in the step's status word, like nsr_pack_weights does
-      NSR_TRY(nsr_check_weights_range(net ? w_fine : w_coarse, NSR_F16X3, k.status, stream));
-      NSR_TRY(nsr_f16x3_pack(net ? w_fine : w_coarse, k.stream_f[net], stream));
-      NSR_TRY(nsr_chain_bwd_pack(net ? w_fine : w_coarse, k.stream_b[net], stop_grad, chain_bwd_terms(precision), stream));
-    }
+    // the weights are re-packed every iteration: a run whose weights drift beyond what the split-fp16 stream carries
+    // (|w| >= 1023.75, or NaN) raises NSR_FLAG_WEIGHT_RANGE in the step's status word, like nsr_pack_weights does.
+    // Round 6: both networks per launch (6 launches -> 3), and the backward pack also clears the loss carries and writes
+    // word 1 of the status block = the colour-head option word the TRAIN instantiation of the forward kernel reads (the
+    // blob tail's layout, nsr_common.h; written every call, so a workspace that was never reset cannot switch an option on)
+    NSR_TRY(nsr_check_weights_range2(w_coarse, w_fine, NSR_F16X3, k.status, stream));
+    NSR_TRY(nsr_f16x3_pack2(w_coarse, k.stream_f[0], w_fine, k.stream_f[1], stream));
+    NSR_TRY(nsr_chain_bwd_pack2(w_coarse, k.stream_b[0], w_fine, k.stream_b[1], stop_grad, chain_bwd_terms(precision), k.carry, 8,
+                                k.status + 1, color_none ? kOptColorNone : 0u, stream));
   } else {
     NSR_TRY(prepare_weights(st, w_coarse, k.pack[0], gemm_precision(precision)));
     NSR_TRY(prepare_weights(st, w_fine, k.pack[1], gemm_precision(precision)));
+    if (hipMemsetAsync(k.carry, 0, 8 * sizeof(double), st) != hipSuccess) return NSR_ERR_LAUNCH;
   }
-  if (hipMemsetAsync(k.carry, 0, 8 * sizeof(double), st) != hipSuccess) return NSR_ERR_LAUNCH;
-  // word 1 of the status block = the colour-head option word the TRAIN instantiation of the forward kernel reads (the
-  // blob tail's layout, nsr_common.h); written every call, so a workspace that was never reset cannot switch an option on
-  if (chain && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(k.status + 1), color_none ? (int)kOptColorNone : 0, 1, st) != hipSuccess)
-    return NSR_ERR_LAUNCH;
 
   for (int64_t r0 = 0; r0 < R; r0 += ray_chunk) {
     const int64_t rc = (R - r0 < ray_chunk) ? R - r0 : ray_chunk;
@@ -1123,7 +1156,7 @@ int train_impl(const float* const* w_coarse, const float* const* w_fine, float* 
       NSR_CHECK_LAUNCH();
       NSR_TRY(composite_bwd(st, k, z, rc, N, white_bkgd, chain, depth_var ? k.g_depth : nullptr));
       if (chain) {
-        NSR_TRY(nsr_chain_bwd(k.stream_b[net], k.sgn, k.dpan, k.d4, 4, k.d4 + 3, 4, P, k.gmax, k.pscale, chain_bwd_terms(precision), stream));
+        NSR_TRY(nsr_chain_bwd(k.stream_b[net], k.sgn, k.dpan, k.d4, 4, k.d4 + 3, 4, P, k.gmax, k.pscale, chain_bwd_terms(precision), 1, stream));
         NSR_TRY(chain_weight_grads(st, k, P, rc, g, acc));
       } else {
         NSR_TRY(net_backward(st, w, k.pack[net], k, P, g, acc, stop_grad));

@@ -23,4 +23,10 @@ extern "C" NSR_INTERNAL size_t nsr_chain_bwd_packed_bytes(void);
 extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* packed_dev, int stop_grad, int terms, void* stream);
 extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const unsigned* sgn, void* dpan, const float* d_rgb, int d_rgb_stride,
                                           const float* d_sigma, int d_sigma_stride, int64_t P, unsigned* gmax,
-                                          float* pscale, int terms, void* stream);
+                                          float* pscale, int terms, int gmax_is_zero, void* stream);
+// round 6, the step's launch count: both networks per launch; the backward pack also clears `n_zero` doubles at `zero` and
+// writes `value` to `word` (the step's loss carries and its option word: two memset launches less)
+extern "C" NSR_INTERNAL int nsr_check_weights_range2(const float* const* w0, const float* const* w1, int precision, unsigned* word, void* stream);
+extern "C" NSR_INTERNAL int nsr_f16x3_pack2(const float* const* w0, void* packed0, const float* const* w1, void* packed1, void* stream);
+extern "C" NSR_INTERNAL int nsr_chain_bwd_pack2(const float* const* w0, void* packed0, const float* const* w1, void* packed1, int stop_grad,
+                                                int terms, double* zero, int n_zero, unsigned* word, unsigned value, void* stream);

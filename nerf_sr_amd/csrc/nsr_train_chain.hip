@@ -54,7 +54,23 @@ struct BwdPackPtrs {
 // are packed as zeros, so the gradient that leaves the colour branch for xyz_encoding_final is an exact 0 at every point --
 // xyz_encoding_final's weights and bias get zero gradients, the trunk sees the density head's gradient alone.
 // hi_only (round 6, the one-term chain): the stream carries the hi pieces alone -- 16 pieces per chunk, 128 per layer
+__device__ __forceinline__ void pack_bwd_body(const BwdPackPtrs& w, unsigned* __restrict__ out, int stop_grad, int hi_only);
 __global__ void __launch_bounds__(256) pack_bwd_kernel(BwdPackPtrs w, unsigned* __restrict__ out, int stop_grad, int hi_only) {
+  pack_bwd_body(w, out, stop_grad, hi_only);
+}
+// both networks of a training step in one launch (round 6; blockIdx.y = network) + the step's two start-of-step clears,
+// which used to be memset launches of their own: zero[0 .. n_zero) doubles (the loss carries) and one option word
+__global__ void __launch_bounds__(256) pack_bwd2_kernel(BwdPackPtrs w0, unsigned* __restrict__ out0, BwdPackPtrs w1, unsigned* __restrict__ out1,
+                                                        int stop_grad, int hi_only, double* __restrict__ zero, int n_zero,
+                                                        unsigned* __restrict__ word, unsigned value) {
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if ((int)threadIdx.x < n_zero) zero[threadIdx.x] = 0.0;
+    if (threadIdx.x == 64 && word) *word = value;
+  }
+  if (blockIdx.y) pack_bwd_body(w1, out1, stop_grad, hi_only);
+  else pack_bwd_body(w0, out0, stop_grad, hi_only);
+}
+__device__ __forceinline__ void pack_bwd_body(const BwdPackPtrs& w, unsigned* __restrict__ out, int stop_grad, int hi_only) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int stream_words = (hi_only ? kBwdPieces / 2 : kBwdPieces) * 256;
   if (idx >= stream_words + kBwdAuxFloats) return;
@@ -955,9 +971,25 @@ extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* pack
   return NSR_OK;
 }
 
+extern "C" NSR_INTERNAL int nsr_chain_bwd_pack2(const float* const* w0, void* packed0, const float* const* w1, void* packed1, int stop_grad,
+                                                int terms, double* zero, int n_zero, unsigned* word, unsigned value, void* stream) {
+  if (terms < 1 || terms > 3 || n_zero < 0 || n_zero > 64) return NSR_ERR_INVALID_ARG;
+  BwdPackPtrs a, b;
+  for (int i = 0; i < NSR_N_STATE_TENSORS; ++i) {
+    if (!w0[i] || !w1[i]) return NSR_ERR_INVALID_ARG;
+    a.p[i] = w0[i];
+    b.p[i] = w1[i];
+  }
+  const int total = (terms == 1 ? kBwdPieces / 2 : kBwdPieces) * 256 + kBwdAuxFloats;
+  hipLaunchKernelGGL(pack_bwd2_kernel, dim3((total + 255) / 256, 2), dim3(256), 0, nsr_stream(stream), a, static_cast<unsigned*>(packed0), b,
+                     static_cast<unsigned*>(packed1), stop_grad, terms == 1 ? 1 : 0, zero, n_zero, word, value);
+  NSR_CHECK_LAUNCH();
+  return NSR_OK;
+}
+
 extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const unsigned* sgn, void* dpan, const float* d_rgb, int d_rgb_stride,
                                           const float* d_sigma, int d_sigma_stride, int64_t P, unsigned* gmax,
-                                          float* pscale, int terms, void* stream) {
+                                          float* pscale, int terms, int gmax_is_zero, void* stream) {
   if (terms < 1 || terms > 3) return NSR_ERR_INVALID_ARG;
   if (P <= 0) return NSR_OK;
 #ifdef NSR_BWD_WAVES   // A/B builds: 4 = one wave per SIMD for the two-term chain / two 4-wave workgroups per CU for the one-term chain
@@ -965,7 +997,8 @@ extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const unsigned* sg
 #else
   const int waves = 8;
 #endif
-  if (hipMemsetAsync(gmax, 0, 10 * sizeof(unsigned), nsr_stream(stream)) != hipSuccess) return NSR_ERR_LAUNCH;
+  // gmax_is_zero: the caller's previous kernel has cleared the ten words (the training step: composite_bwd_kernel)
+  if (!gmax_is_zero && hipMemsetAsync(gmax, 0, 10 * sizeof(unsigned), nsr_stream(stream)) != hipSuccess) return NSR_ERR_LAUNCH;
   const dim3 grid((unsigned)((P + 127) / 128)), block(256);
   const dim3 grid8((unsigned)((P + 255) / 256)), block8(512);
   const float* pk = static_cast<const float*>(packed);

@@ -38,7 +38,7 @@ out = {"precision": PREC, "config": CID, "rays": N, "violations": viol, "top_ray
 
 
 def mx(a, b):
-    return float((a.double() - b.double()).abs().max())
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
 
 
 for i in (viol or order[:1]):

@@ -4,8 +4,8 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:48]
-# a step starts at the first sample_kernel launch after an adam_kernel
-starts = [i for i, r in enumerate(rows) if name(r).startswith("check_weights_kernel") and (i == 0 or not name(rows[i - 1]).startswith("check_weights") and not name(rows[i - 1]).startswith("pack_"))]
+# a step starts at its weight-range check (one launch per step since round 6; two back to back before)
+starts = [i for i, r in enumerate(rows) if name(r).startswith("check_weights") and (i == 0 or not name(rows[i - 1]).startswith(("check_weights", "pack_")))]
 i0 = starts[-2] if len(starts) > 1 else 0
 i1 = starts[-1] if len(starts) > 1 else len(rows)
 t_prev = None

@@ -52,22 +52,28 @@ def _camera(cid):
 _ORACLE_CACHE = {}
 
 
-def _oracle_block(cid, field="smooth"):
-    """fp32 and fp64 oracle outputs of the test block of config `cid` (cached: both precisions use it)."""
-    if (cid, field) in _ORACLE_CACHE:
-        return _ORACLE_CACHE[(cid, field)]
-    wh, s, ndc, white = CONFIGS[cid]
-    c2w, f, nf = _camera(cid)
-    rays = oc.subpixel_ray_grid(torch.from_numpy(c2w), wh[1], wh[0], f, s, ndc, *nf).reshape(-1, 8)
-    lo = (rays.shape[0] // 2) - (rays.shape[0] // 2) % (s * s)
-    blk = rays[lo:lo + N_RAYS].contiguous()
-    sd_c, sd_f = make_state_dict(99, field=field), make_state_dict(100, field=field)
-    from tests.util import oracle_fp32_and_fp64
-    t0 = time.time()
-    ref, ref64 = oracle_fp32_and_fp64(sd_c, sd_f, blk, white)        # both evaluations side by side, 32 threads each
-    print(f"[config #{cid} {field}] oracle fp32 + fp64 on {N_RAYS} rays: {time.time() - t0:.1f} s")
-    _ORACLE_CACHE[(cid, field)] = (lo, blk, ref, ref64)
-    return _ORACLE_CACHE[(cid, field)]
+N_RAYS_RECORD, CID_RECORD = 65536, 5      # the per-round parity record's block (scripts/parity_record.py) -- as a test on one geometry
+
+
+def _oracle_block(cid, field="smooth", n=N_RAYS):
+    """fp32 and fp64 oracle outputs of the first `n` rays of the test block of config `cid` (cached: both precisions use it;
+    the record-sized block of CID_RECORD is evaluated once and serves the 16,384-ray test as its first quarter)."""
+    n_eval = N_RAYS_RECORD if (cid == CID_RECORD and field == "smooth") else n
+    if (cid, field) not in _ORACLE_CACHE:
+        wh, s, ndc, white = CONFIGS[cid]
+        c2w, f, nf = _camera(cid)
+        rays = oc.subpixel_ray_grid(torch.from_numpy(c2w), wh[1], wh[0], f, s, ndc, *nf).reshape(-1, 8)
+        lo = (rays.shape[0] // 2) - (rays.shape[0] // 2) % (s * s)
+        blk = rays[lo:lo + n_eval].contiguous()
+        sd_c, sd_f = make_state_dict(99, field=field), make_state_dict(100, field=field)
+        from tests.util import oracle_fp32_and_fp64
+        t0 = time.time()
+        ref, ref64 = oracle_fp32_and_fp64(sd_c, sd_f, blk, white)        # both precisions, chunks side by side over the host's cores
+        print(f"[config #{cid} {field}] oracle fp32 + fp64 on {n_eval} rays: {time.time() - t0:.1f} s")
+        _ORACLE_CACHE[(cid, field)] = (lo, blk, ref, ref64)
+    lo, blk, ref, ref64 = _ORACLE_CACHE[(cid, field)]
+    assert n <= blk.shape[0]
+    return lo, blk[:n].contiguous(), {k: v[:n] for k, v in ref.items()}, {k: v[:n] for k, v in ref64.items()}
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "fp32"])
@@ -118,6 +124,44 @@ def test_frame_scale_parity(ops, cid, prec):
     far = nf[1]
     assert float((o["fine_depth"] - ref["fine_depth"]).abs()[~exempt].max()) <= 2e-4 * far
     assert float((o["fine_opacity"] - ref["fine_opacity"]).abs()[~exempt].max()) <= 2e-4
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "fp32"])
+def test_frame_scale_parity_record_block(ops, prec):
+    """The per-round parity record's protocol (scripts/parity_record.py: 65,536 consecutive rays) as a TEST, on config #5's
+    geometry -- the block on which round 5's record shows ONE ray of the `fp32` kernel at |dRGB| 1.63e-4 with an oracle
+    fp32-vs-fp64 gap of 1.6e-6 (none of the 16,384 rays of the test above).  Root cause
+    (scripts/fp32_ray_probe.py -> profiles/r6_fp32_ray_probe.json): the coarse passes agree to 4.6e-7 in the weights (the
+    oracle's own fp32 and fp64: 3.4e-7); the ray's 108th fine sample falls in a coarse bin whose pdf (1.13e-5) sits 1.3e-6
+    above the resampler's `denom < 1e-5 -> 1` snap (models/utils.py:87-88), where the inverse CDF has slope
+    bin width / denom = 5,600: the sample moves by 6.7e-4 in depth (the oracle's two evaluations: 6.6e-6 -- their rounding
+    happened to agree in that bin, which is why the GAP does not flag the ray), and the colour follows.  Everything behind
+    the coarse weights is exact: the oracle's fp32 fine pass fed with the HIP coarse weights reproduces the HIP colour to
+    1.2e-7.  So the contract per ray is as above, and a ray over it must be EXPLAINED that way
+    (tests/util.py::explained_by_resampler_conditioning: coarse weights within 2e-6, colour reproduced within 1e-5) -- at
+    most 2 such rays per 65,536, none unexplained."""
+    from tests.util import explained_by_resampler_conditioning
+    wh, s, ndc, white = CONFIGS[CID_RECORD]
+    lo, blk, ref, ref64 = _oracle_block(CID_RECORD, n=N_RAYS_RECORD)
+    sd_c, sd_f = make_state_dict(99), make_state_dict(100)
+    net_c = ops.VanillaMLP(precision=prec).load_state_dict(sd_c)
+    net_f = ops.VanillaMLP(precision=prec).load_state_dict(sd_f)
+    o = {k: v.cpu() for k, v in ops.forward_rays(net_c, net_f, blk.cuda(), 64, 64, white).items()}
+    assert float((o["coarse_comp_rgbs"] - ref["coarse_comp_rgbs"]).abs().max()) <= 1e-5
+    assert float((o["coarse_weights"] - ref["coarse_weights"]).abs().max()) <= 2e-6
+    d = (o["fine_comp_rgbs"].double() - ref["fine_comp_rgbs"].double()).abs().max(-1)[0]
+    gap = (ref["fine_comp_rgbs"].double() - ref64["fine_comp_rgbs"]).abs().max(-1)[0]
+    bound = torch.clamp_min(2.0 * gap, RGB_TOL)
+    over = torch.nonzero(d > bound).flatten()
+    explained = explained_by_resampler_conditioning(sd_f, blk, white, o, ref, over)
+    print(f"[config #{CID_RECORD} {prec}, {N_RAYS_RECORD} rays] fine max|dRGB| {float(d.max()):.2e}, p99.9 {float(torch.quantile(d, 0.999)):.2e}, "
+          f"median {float(d.median()):.1e}; rays over 1e-4: {int((d > RGB_TOL).sum())}; rays whose bound is 2 x oracle gap: "
+          f"{int((2.0 * gap > RGB_TOL).sum())}; rays over their bound: {over.tolist()} (d {[float(d[i]) for i in over]}, gap "
+          f"{[float(gap[i]) for i in over]}), explained by the resampler's conditioning: {explained.tolist()}")
+    assert bool(explained.all()), f"rays {over[~explained].tolist()} exceed max(1e-4, 2 x oracle gap) and the oracle's fine pass on the HIP coarse weights does NOT reproduce them"
+    assert over.numel() <= 2
+    assert int((2.0 * gap > RGB_TOL).sum()) <= 4 * MAX_EXEMPT
+    assert oc.psnr(o["fine_comp_rgbs"], ref["fine_comp_rgbs"]) > 100.0
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "fp32"])

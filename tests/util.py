@@ -111,3 +111,36 @@ def oracle_forward_parallel(sd_c, sd_f, rays, white_bkgd, n_coarse=64, n_importa
     with ThreadPoolExecutor(len(chunks)) as ex:
         parts = list(ex.map(run, chunks))
     return {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
+
+
+
+def explained_by_resampler_conditioning(sd_f, rays, white_bkgd, hip, ref, idx, n_coarse=64, n_importance=64,
+                                        w_tol=2e-6, rgb_tol=1e-5):
+    """Round 6 (VERDICT r5 "next" #2): which of the rays `idx` -- rays whose fine colour sits further from the fp32 oracle than
+    the per-ray contract max(1e-4, 2 x the oracle's own fp32-vs-fp64 gap) allows -- are explained by the conditioning of the
+    reference's inverse-CDF resampler ALONE?
+
+    The gap is ONE draw of rounding noise: it samples the resampler's amplification with whatever the oracle's fp32 and fp64
+    coarse weights happen to differ by in the sensitive bin, and can miss it (the ray of profiles/r5_parity_report.json,
+    geometry 5, `fp32`: gap 1.6e-6, inverse-CDF slope 5,600 in a bin whose pdf sits 1.3e-6 above the `denom < 1e-5 -> 1` snap
+    of models/utils.py:87-88; profiles/r6_fp32_ray_probe.json).  The direct test: feed the ORACLE's own fp32 fine pass
+    (resampler, fine network, compositor) with the HIP path's coarse weights.  A ray is explained iff
+      (a) the HIP coarse weights agree with the oracle's to fp32 rounding of the coarse network (<= `w_tol`; the oracle's own
+          fp32 and fp64 coarse weights differ by ~3e-7), and
+      (b) the oracle's fine pass on those weights reproduces the HIP colour (<= `rgb_tol`),
+    i.e. everything behind the coarse weights is the reference's arithmetic, and the whole difference is the reference's own
+    amplification of a rounding-level difference in front of it.  Returns a bool tensor over `idx`."""
+    if len(idx) == 0:
+        return torch.zeros(0, dtype=torch.bool)
+    sf = oc.to_torch_sd(sd_f, torch.float32)
+    r = rays[idx].float()
+    with torch.no_grad():
+        z, _ = oc.sample_coarse(r[:, 0:3], r[:, 3:6], r[:, 6:7], r[:, 7:8], n_coarse)
+        w_hip = hip["coarse_weights"][idx].float()
+        zf, xyzf = oc.resample_fine(r[:, 0:3], r[:, 3:6], z, w_hip, n_importance)
+        de = oc.posenc(r[:, 8:11] if r.shape[1] == 11 else r[:, 3:6], 4)
+        rgb, sig = oc.render_points(sf, xyzf, de)
+        comp = oc.composite(rgb, sig, zf, white_bkgd)[0]
+    a = (w_hip - ref["coarse_weights"][idx].float()).abs().max(-1)[0] <= w_tol
+    b = (comp - hip["fine_comp_rgbs"][idx].float()).abs().max(-1)[0] <= rgb_tol
+    return a & b
