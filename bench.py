@@ -319,10 +319,12 @@ def train_bench(args, rank, local, world, steps=None, warmup=None, cpu=True, sha
             # weights read and written, the gradients written and read, Adam's two moments read and written (8 x 595,844 x 4 B)
             true_bytes = R * rays.shape[1] * 4 + (R // s2) * 12 + 2 * 8 * 595844 * 4
             traffic = committed_train_traffic(R)
-            res["dtype"] = ("f32 results; forward and input gradients from split-fp16 x3 MFMA products (fp32-grade), weight "
-                            "gradients from fp16 operands (11 bits) on one MFMA per product, fp32 accumulation")
+            bwd_terms = {"f16x3": 2, "f16x3_bwd3": 3, "f16x3_bwd2": 2, "f16x3_bwd1": 1}[args.train_precision]
+            res["dtype"] = ("f32 results; forward from split-fp16 x3 MFMA products (fp32-grade), input gradients (backward chain) on "
+                            f"{bwd_terms} MFMA term(s) per product ({ {3: 'W_hi g_hi + W_hi g_lo + W_lo g_hi', 2: 'W_hi g_hi + W_lo g_hi', 1: 'W_hi g_hi'}[bwd_terms] }), "
+                            "weight gradients from fp16 operands (11 bits) on one MFMA per product, fp32 accumulation")
             res["roofline"] = {"bound": "hbm", "kernel": "whole training step, chain path (mlp_f16x3_kernel TRAIN, "
-                                                          "chain_bwd_kernel, wgrad_jobs_kernel)",
+                                                          "chain_bwd_h_kernel / chain_bwd_kernel, wgrad_jobs_kernel)",
                                "achieved": gb / (dt / steps), "peak": 8000.0, "unit": "GB/s",
                                "frac": gb / (dt / steps) / 8000.0, "traffic": traffic,
                                "gbytes_per_step": gb,
@@ -332,11 +334,11 @@ def train_bench(args, rank, local, world, steps=None, warmup=None, cpu=True, sha
                                "traffic_over_true_algorithmic_bytes": (traffic / true_bytes) if traffic else None,
                                "mfma_frac_on_true_flops": achieved / PEAK_TFLOPS["f16x3"],
                                "mfma_tflops_true": achieved,
-                               "mfma_tflops_issued": achieved * 7.0 / 3.0,
+                               "mfma_tflops_issued": achieved * (4.0 + bwd_terms) / 3.0,
                                "note": "algorithmic bytes = 21,984 B of panel + sign traffic per sample point x 192 points per ray "
                                        "(split-K partial sums, weight streams and per-ray arrays excluded; traffic = PMC-measured HBM bytes of all kernels "
                                        "of a step, " + TRAIN_TRAFFIC_FILE + ", null if the kernel sources changed since); "
-                                       "mfma_tflops_issued = 3 fp16 MFMAs per product in the forward and backward chains, 1 in the weight gradients"}
+                                       f"mfma_tflops_issued = 3 fp16 MFMAs per product in the forward chain, {bwd_terms} in the backward chain, 1 in the weight gradients"}
         if world == 1 and cpu and not args.no_cpu_baseline:
             draws = {k: (None if v is None else v.cpu()) for k, v in t.draw(R).items()}
             res["cpu_baseline"] = train_cpu_baseline(sd_c, sd_f, rays.cpu(), target.cpu(), s2, draws)
@@ -667,6 +669,12 @@ def main():
         c5 = guarded("config5", lambda: time_config(5, 2, 1))
         train_res = guarded("train", lambda: train_bench(args, rank, local, world, steps=20, warmup=5, cpu=True))
         c1_res = guarded("config1", lambda: train_bench(args, rank, local, world, steps=20, warmup=5, cpu=True, shape="vanilla"))
+    fast_res = None
+    if train_res is not None and args.train_precision == "f16x3":
+        # the stated FAST path of the training step next to the default (include/nsr_train.h: the backward chain on ONE MFMA per
+        # product -- per-tensor gradient bounds and the trajectory bound hold, the whole-gradient bound of the contract does not)
+        fa = argparse.Namespace(**{**vars(args), "train_precision": "f16x3_bwd1"})
+        fast_res = guarded("train.fast_path", lambda: train_bench(fa, rank, local, world, steps=20, warmup=5, cpu=False))
     arch_res = None
     if args.arch and not args.config and not args.no_extras and world == 1:
         arch_res = guarded("arch", lambda: arch_bench(args.arch, dev, main_r["value"]))
@@ -749,6 +757,12 @@ def main():
         keys = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline", "losses", "cpu_baseline")
         if train_res is not None:
             res["train"] = {k: train_res[k] for k in keys}
+        if fast_res is not None and "train" in res:
+            res["train"]["fast_path"] = {"train_precision": "f16x3_bwd1", "ms_per_step": fast_res["ms_per_step"], "value": fast_res["value"],
+                                         "unit": "rays/s", "losses": fast_res["losses"],
+                                         "note": "NOT the contract-grade default: backward chain on one fp16 MFMA per product (W_hi g_hi); every gradient "
+                                                 "tensor within 2e-3 of its norm of the fp64 oracle (measured 6.6e-4), 200-step Adam trajectory like any "
+                                                 "fp32-grade run, whole gradient 3.1e-4 from the fp32-gradient path (the default: 1.8e-5, bound 2e-4)"}
         if c1_res is not None:
             res["config1"] = {k: c1_res[k] for k in keys}
         if arch_res is not None:

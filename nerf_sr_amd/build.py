@@ -179,6 +179,11 @@ VARIANTS = {
                      "environment-read A/B switches of the refinement GEMMs (NSR_GEMM_TILE / _TK / _FULLN, NSR_REFINE_SEPARATE_MAX)"),
     "abl_halo": (["-DNSR_ABL_HALO_NO_PATCH", "-DNSR_ABL_HALO_NO_BDMA", "-DNSR_ABL_HALO_NO_BARRIER", "-DNSR_ABL_HALO_NO_EPILOGUE"],
                  ["nsr_gemm_f16.hip"], "ablations of conv_halo_kernel (profiles/r4_refine_halo.txt)"),
+    "halo_pairs": (["-DNSR_HALO_PAIR=0", "-DNSR_HALO_PAIR_WIDE=1", "-DNSR_HALO_GROUPED_QUARTER"], ["nsr_gemm_f16.hip"],
+                   "round 6's A/B partners of conv_halo_kernel: one workgroup per CU for the half shape; the 256-column plain layers on "
+                   "paired half tiles (measured: nothing); the grouped 128-column layer as pairs of 128 x 128 workgroups (measured: nothing)"),
+    "bwd_waves4": (["-DNSR_BWD_WAVES=4"], ["nsr_train_chain.hip"],
+                   "reduced-term backward chains on 4-wave workgroups (one wave per SIMD for two terms; round 6: 425 vs 371 us per pass)"),
     "gemm_alt": (["-DNSR_GEMM_NO_HALO", "-DNSR_GEMM_NO_XCD", "-DNSR_GEMM_NO_WROWS", "-DNSR_GEMM_K32_ONLY=1", "-DNSR_HALO_S2_MIN_CIN=256",
                   "-DNSR_ABL_RELU_FMAX"], ["nsr_gemm_f16.hip"], "staged-kernel-only build and the other GEMM A/B partners"),
 }

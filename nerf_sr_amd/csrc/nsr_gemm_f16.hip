@@ -565,8 +565,22 @@ struct HaloGeo {
   static constexpr int publish_wait(int j) { return j == ps(j) + pl(j) - 1 ? PB : PB + ppk(j == 0 ? 8 : j - 1) + ppk(j); }
 };
 
+// Workgroups per CU (round 6).  The half shape (BN x BM = 4 x 2: 256 x 128 outputs, 128 accumulator registers) of the plain
+// stride-1 kernel needs 80 KiB of LDS -- exactly half a CU's -- and fits 256 registers: TWO workgroups then share a CU, two
+// waves per SIMD, and one workgroup's prologue (cold patch + weight fetch) and un-overlapped epilogue run under the other's
+// k-steps (VERDICT r5 "next" #3a; DESIGN 9: the epilogue was 3.1 ms of the pass with nothing beside it).  The other shapes
+// use the whole register file as the accumulator, or more than 80 KiB.
+#ifndef NSR_HALO_PAIR
+#define NSR_HALO_PAIR 1
+#endif
 template <int BN, int BM, bool GROUPED, int S>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+struct HaloOcc {
+  using G = HaloGeo<BN, BM, GROUPED, S>;
+  static constexpr int kLds = G::PATCH0 + G::PATCH1 + 4 * G::SLOT;
+  static constexpr int kWaves = (NSR_HALO_PAIR && BN * BM <= 8 && S == 1 && kLds <= 81920) ? 2 : 1;
+};
+template <int BN, int BM, bool GROUPED, int S>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HaloOcc<BN, BM, GROUPED, S>::kWaves, HaloOcc<BN, BM, GROUPED, S>::kWaves)))
 conv_halo_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
   using Geo = HaloGeo<BN, BM, GROUPED, S>;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[Geo::PATCH0 + Geo::PATCH1 + 4 * Geo::SLOT];
@@ -882,7 +896,14 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
     // halo or staged is a matter of SHAPE only, never of M: the two sum K in different orders (channel-chunk-major here,
     // tap-major there), and a batch of one patch must give the bits it gives inside a batch of 256 (tests/test_gpu_refine.py);
     // the halo shapes among themselves are bit-identical (same k-steps, same order per output element)
-    const bool use_half = half_ok && (!big_ok || 0.5 * 1.05 * rounds(half_blk) < rounds(big_blk));
+    // Round 6: where the half shape runs as a PAIR of workgroups per CU (plain stride-1 layers, HaloOcc) it is always taken:
+    // a CU then holds the same 256 x 256 outputs as one big tile, with one workgroup's prologue / epilogue under the other's
+    // k-steps (same k order per output element: bit-identical; -DNSR_HALO_PAIR_WIDE=0 keeps the CU-rounds rule for A/B runs)
+#ifndef NSR_HALO_PAIR_WIDE
+#define NSR_HALO_PAIR_WIDE 0   // measured (one box, interleaved, bit-identical): 28.77 vs 28.80 ms -- nothing: the 256-column layers keep the big tile
+#endif
+    const bool paired = NSR_HALO_PAIR && NSR_HALO_PAIR_WIDE && !grouped && !s2 && half_ok;
+    const bool use_half = half_ok && (paired || !big_ok || 0.5 * 1.05 * rounds(half_blk) < rounds(big_blk));
     const bool use_big = !use_half && big_ok;
     if (use_half || use_big) {
       const int64_t n_blk = use_half ? half_blk : big_blk;
@@ -893,6 +914,17 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
     if (grouped) hipLaunchKernelGGL((conv_halo_kernel<BN_, BM_, true, S_>), hgrid, dim3(256), 0, st, a, n_ct, n_blk);       \
     else hipLaunchKernelGGL((conv_halo_kernel<BN_, BM_, false, S_>), hgrid, dim3(256), 0, st, a, n_ct, n_blk);               \
   } while (0)
+#ifdef NSR_HALO_GROUPED_QUARTER
+      // experiment (round 6): the grouped 128-column layer as PAIRS of 128 x 128 workgroups (8 images x 8 x 2 pixels each, 80 KiB)
+      // instead of one 512 x 128 workgroup per CU
+      if (grouped && !s2 && !wide && !use_half && (a.conv.Ho % 2) == 0 && (g.M % 128) == 0) {
+        const int64_t q_blk = (g.M / 128) * (g.N / 128);
+        const dim3 qgrid((unsigned)(((q_blk + 7) / 8) * 8));
+        hipLaunchKernelGGL((conv_halo_kernel<4, 1, true, 1>), qgrid, dim3(256), 0, st, a, g.N / 128, q_blk);
+        if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
+        return NSR_OK;
+      }
+#endif
       if (s2) {
         if (use_half) NSR_HALO_LAUNCH(4, 2, 2); else NSR_HALO_LAUNCH(8, 2, 2);
       } else if (use_half) {
