@@ -124,11 +124,11 @@ def cpu_baseline(sd_c, sd_f, rays_cpu: torch.Tensor, white_bkgd: bool = False):
                       f"{dt:.1f} s, {workers} workers x {threads} ATen threads = {workers * threads} of {host} host threads"}, out, n
 
 
-PMC_FILE = os.path.join("profiles", "r5_pmc.json")
+PMC_FILE = os.path.join("profiles", "r6_pmc.json")
 
 
 def committed_pmc(precision: str):
-    """Counter-derived figures of the fine-pass MLP launch from the committed PMC passes (profiles/r5_pmc.json, written by
+    """Counter-derived figures of the fine-pass MLP launch from the committed PMC passes (profiles/r6_pmc.json, written by
     scripts/pmc_collect.py from separate rocprofv3 --pmc runs): HBM bytes per launch ((2 x FETCH_SIZE + WRITE_SIZE) x
     1024, the guide's gfx950 correction), matrix-pipe busy fraction, effective clock.  They are constants of the build they
     were measured on, NOT measurements of this run: the file records the sha256 of the kernel sources
@@ -148,11 +148,11 @@ def committed_pmc(precision: str):
                                  "matches_this_build": ok}
 
 
-TRAIN_TRAFFIC_FILE = os.path.join("profiles", "r5_train_traffic.json")
+TRAIN_TRAFFIC_FILE = os.path.join("profiles", "r6_train_traffic.json")
 
 
 def committed_train_traffic(R):
-    """HBM bytes per training step from the committed PMC run (profiles/r5_train_traffic.json, measured at 2,048 rays by
+    """HBM bytes per training step from the committed PMC run (profiles/r6_train_traffic.json, measured at 2,048 rays by
     scripts/pmc_train_traffic.sh): a constant of the build it names (sha256 of the kernel sources), not a measurement of
     this run; None when the sources have changed since."""
     from nerf_sr_amd import build as nsr_build
@@ -468,17 +468,17 @@ def arch_bench(spec: str, dev, fused_rays_per_s: float, n_rays: int = 32768, rep
 
 
 def refine_pmc_busy():
-    """Time-weighted matrix-pipe busy share of the refinement pass's GEMM kernels from profiles/r5_refine_pmc.json (rocprofv3
+    """Time-weighted matrix-pipe busy share of the refinement pass's GEMM kernels from profiles/r6_refine_pmc.json (rocprofv3
     --pmc passes, scripts/pmc_refine.py), valid for the build whose source hash it carries."""
     from nerf_sr_amd import build as nsr_build
     here = nsr_build.source_hash()
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r5_refine_pmc.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r6_refine_pmc.json")
     try:
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None, {"file": None, "matches_this_build": False}
     ok = rec.get("csrc_sha256") == here
-    src = {"file": "profiles/r5_refine_pmc.json", "csrc_sha256": rec.get("csrc_sha256"), "this_build_sha256": here, "matches_this_build": ok}
+    src = {"file": "profiles/r6_refine_pmc.json", "csrc_sha256": rec.get("csrc_sha256"), "this_build_sha256": here, "matches_this_build": ok}
     ks = [v for k, v in rec.get("kernels", {}).items() if ("gemm" in k or "conv_halo" in k) and v.get("ms_under_pmc", 0) > 0]
     t = sum(v["ms_under_pmc"] for v in ks)
     return (sum(v["ms_under_pmc"] * v["mfma_busy"] for v in ks) / t if ok and t > 0 else None), src
