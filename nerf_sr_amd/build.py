@@ -179,7 +179,7 @@ VARIANTS = {
                      "environment-read A/B switches of the refinement GEMMs (NSR_GEMM_TILE / _TK / _FULLN, NSR_REFINE_SEPARATE_MAX)"),
     "abl_halo": (["-DNSR_ABL_HALO_NO_PATCH", "-DNSR_ABL_HALO_NO_BDMA", "-DNSR_ABL_HALO_NO_BARRIER", "-DNSR_ABL_HALO_NO_EPILOGUE"],
                  ["nsr_gemm_f16.hip"], "ablations of conv_halo_kernel (profiles/r4_refine_halo.txt)"),
-    "halo_pairs": (["-DNSR_HALO_PAIR=0", "-DNSR_HALO_PAIR_WIDE=1", "-DNSR_HALO_GROUPED_QUARTER"], ["nsr_gemm_f16.hip"],
+    "halo_pairs": (["-DNSR_HALO_PAIR=0", "-DNSR_HALO_PAIR_WIDE=1", "-DNSR_HALO_GROUPED_QUARTER", "-DNSR_HALO_NO_LAST"], ["nsr_gemm_f16.hip"],
                    "round 6's A/B partners of conv_halo_kernel: one workgroup per CU for the half shape; the 256-column plain layers on "
                    "paired half tiles (measured: nothing); the grouped 128-column layer as pairs of 128 x 128 workgroups (measured: nothing)"),
     "bwd_waves4": (["-DNSR_BWD_WAVES=4"], ["nsr_train_chain.hip"],

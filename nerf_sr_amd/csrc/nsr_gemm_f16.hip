@@ -800,6 +800,25 @@ conv_halo_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
   }
 #endif
   const unsigned per = (unsigned)(Ho * Wo);
+  if constexpr (BN == 2) {
+    // the network's LAST layer (128 -> 3, tanh; round 6): fp32 NHWC output, n_valid (<= 32) real columns, all of them in column
+    // block 0 -- lane (li, h) holds column li of rows 8 (r >> 2) + 4 h + (r & 3).  Same arithmetic per element as the staged
+    // kernel's gemm_epilogue (fmaf(acc, scale, bias), tanhf).
+    const float scale = g.acc_scale;
+    const bool mine = li < g.n_valid;
+    const float bias = (mine && g.bias) ? g.bias[li] : 0.0f;
+    if (mine) {
+#pragma unroll
+      for (int bi = 0; bi < BM; ++bi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = 32 * BM * wave + 32 * bi + 8 * (r >> 2) + 4 * h + (r & 3);
+          const int64_t pix = (int64_t)(oy0 + (t >> 4)) * Wo + ox0 + (t & 15);
+          g.C[((int64_t)b * per + pix) * g.ldc + li] = tanhf(fmaf(acc[bi][0][0][r], scale, bias));
+        }
+    }
+    return;
+  }
   epilogue_planes_relu<BN, BM, GROUPED>(a, [&](int bi, int bj) -> const f32x16& { return acc[bi][0][bj]; },
                                         [&](int bi, int rq, int64_t& r0, int64_t& q) {
     const int t = 32 * BM * wave + 32 * bi + 8 * rq;           // eight rows: plain 8 pixels along x; grouped one pixel's 8 images
@@ -863,6 +882,22 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   // column tiles, whole spatial blocks, 32-bit byte offsets into A (the 8 x 8 decoder layers, the stride-2 layers and the
   // 3-channel first layers stay on the staged tiles below)
 #ifndef NSR_GEMM_NO_HALO
+#ifndef NSR_HALO_NO_LAST
+  // the refinement network's last layer: stride-1 gather from pre-split planes, 64 padded columns, tanh, fp32 NHWC output
+  // (conv_halo_kernel<2, 2, false, 1>: 256 pixels x 64 columns per workgroup, 64 KiB of LDS, pairs per CU).  A matter of shape
+  // only, like the choice below.
+  if (a.Ah && !a.Ch && g.C && a.Bs && a.conv.cin > 0 && a.conv.stride == 1 && !a.conv.up && (a.conv.cin % 16) == 0 && g.N == 64 &&
+      g.n_valid <= 32 && g.act == kActTanh && !g.mask && !g.col_sums && !g.Ct && a.group <= 1 && g.acc_scale != 0.0f && g.K == 9 * a.conv.cin &&
+      (reinterpret_cast<uintptr_t>(a.Bs) & 15) == 0 && a.conv.Ho == a.conv.Hs && a.conv.Wo == a.conv.Ws && (a.conv.Ho % 16) == 0 &&
+      (a.conv.Wo % 16) == 0 && (g.M % ((int64_t)a.conv.Ho * a.conv.Wo)) == 0 &&
+      (a.a_plane + (g.M / ((int64_t)a.conv.Ho * a.conv.Wo)) * a.conv.Hs * a.conv.Ws * g.lda) * 2 < ((int64_t)1 << 32)) {
+    const int64_t n_blk = g.M / 256;
+    const dim3 hgrid((unsigned)(((n_blk + 7) / 8) * 8));
+    hipLaunchKernelGGL((conv_halo_kernel<2, 2, false, 1>), hgrid, dim3(256), 0, st, a, 1, n_blk);
+    if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
+    return NSR_OK;
+  }
+#endif
   if (a.Ah && a.Ch && a.Bs && a.conv.cin > 0 && (a.conv.stride == 1 || a.conv.stride == 2) && (a.conv.cin % 16) == 0 && (g.N % 128) == 0 &&
       g.n_valid == g.N && !g.mask && !g.col_sums && g.act == kActRelu && g.acc_scale != 0.0f && g.acc_scale != 1.0f &&
       (a.group == 8 || a.group <= 1) && g.K == 9 * a.conv.cin && (reinterpret_cast<uintptr_t>(a.Bs) & 15) == 0) {

@@ -49,11 +49,15 @@ constexpr Layer kLayersV[2][NSR_REFINE_N_LAYERS] = {{
 }};
 constexpr int pad32(int n) { return (n + 31) & ~31; }
 constexpr int kpad(int v, int l) { return pad32(9 * kLayersV[v][l].cin); }
-constexpr int npad(int v, int l) { return pad32(kLayersV[v][l].cout); }
+// the last layer (128 -> 3, tanh) is padded to 64 columns, the narrowest conv_halo_kernel shape (round 6: until then it ran on
+// the staged 128-column tile, 97 % of whose MFMAs multiplied column padding, fetching every activation nine times)
+constexpr bool last_tanh(int v, int l) { return kLayersV[v][l].act == kActTanh && kLayersV[v][l].cout <= 64 && (kLayersV[v][l].cin % 16) == 0; }
+constexpr int npad(int v, int l) { return last_tanh(v, l) ? 64 : pad32(kLayersV[v][l].cout); }
 // layers conv_halo_kernel can take (nsr_gemm_f16.hip; the shape decides at run time) carry a second, stream-ordered copy of
 // their split weights (GemmF16Args::Bs)
 constexpr bool streamed(int v, int l) {
-  return (kLayersV[v][l].cin % 16) == 0 && (kLayersV[v][l].cout % 128) == 0 && kLayersV[v][l].act == kActRelu && kpad(v, l) == 9 * kLayersV[v][l].cin;
+  return ((kLayersV[v][l].cin % 16) == 0 && (kLayersV[v][l].cout % 128) == 0 && kLayersV[v][l].act == kActRelu && kpad(v, l) == 9 * kLayersV[v][l].cin) ||
+         (last_tanh(v, l) && kpad(v, l) == 9 * kLayersV[v][l].cin);
 }
 // W' (npad x kpad) | b' (npad) | stream-ordered W' (same size; streamed layers)
 constexpr int64_t layer_floats(int v, int l) { return (int64_t)npad(v, l) * kpad(v, l) * (streamed(v, l) ? 2 : 1) + npad(v, l); }
