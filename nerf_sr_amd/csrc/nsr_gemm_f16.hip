@@ -847,7 +847,7 @@ NSR_INTERNAL int split_f16(const float* w, int64_t n, unsigned short* hi, unsign
 
 NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   const GemmArgs& g = a.g;
-  if (g.M < 0 || g.N <= 0 || g.K <= 0 || (g.K % kTK) != 0 || g.n_valid > g.N) return NSR_ERR_INVALID_ARG;
+  if (g.M < 0 || g.N <= 0 || g.K <= 0 || (g.K % 16) != 0 || g.n_valid > g.N) return NSR_ERR_INVALID_ARG;   // the staged tiles: K % 32, below
   if (!a.Bh || !a.Bl || g.Ct || g.splits > 1 || g.a_kmajor || g.b_kmajor) return NSR_ERR_INVALID_ARG;
   if ((a.ldbh % 8) || (reinterpret_cast<uintptr_t>(a.Bh) & 15) || (reinterpret_cast<uintptr_t>(a.Bl) & 15)) return NSR_ERR_INVALID_ARG;
   if (a.Ah) {   // pre-split A: 16-byte chunks of 8 halves
@@ -861,7 +861,7 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   } else if (!g.C) {
     return NSR_ERR_INVALID_ARG;
   }
-  if (a.conv.cin > 0 && ((a.conv.cin % kTK) != 0 || g.K != 9 * a.conv.cin)) return NSR_ERR_INVALID_ARG;
+  if (a.conv.cin > 0 && ((a.conv.cin % 16) != 0 || g.K != 9 * a.conv.cin)) return NSR_ERR_INVALID_ARG;    // the staged tiles: cin % 32, below
   if (a.group != 0) {   // grouped rows: conv gather, plane output, whole groups, packed column pairs of the max planes
     if (a.group != 8 || a.conv.cin <= 0 || !a.Ch || !a.Mh || (g.M % 8) || (a.ldm % 2) || (a.m_plane % 2) ||
         (reinterpret_cast<uintptr_t>(a.Mh) & 3))
@@ -937,7 +937,9 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
 #ifndef NSR_HALO_PAIR_WIDE
 #define NSR_HALO_PAIR_WIDE 0   // measured (one box, interleaved, bit-identical): 28.77 vs 28.80 ms -- nothing: the 256-column layers keep the big tile
 #endif
-    const bool paired = NSR_HALO_PAIR && NSR_HALO_PAIR_WIDE && !grouped && !s2 && half_ok;
+    // ... and always on the 128-column plain layers (round 6: layer 0, all epilogue): the alternative there is ONE 512 x 128
+    // workgroup per CU with nothing beside its epilogue
+    const bool paired = NSR_HALO_PAIR && (NSR_HALO_PAIR_WIDE || !wide) && !grouped && !s2 && half_ok;
     const bool use_half = half_ok && (paired || !big_ok || 0.5 * 1.05 * rounds(half_blk) < rounds(big_blk));
     const bool use_big = !use_half && big_ok;
     if (use_half || use_big) {
@@ -975,6 +977,7 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
     }
   }
 #endif
+  if ((g.K % kTK) != 0 || (a.conv.cin > 0 && (a.conv.cin % kTK) != 0)) return NSR_ERR_INVALID_ARG;   // staged tiles: K tiles of 32 inside a tap
   const int64_t row_tiles = (g.M + kTM - 1) / kTM;
   const bool quad_ok = g.N >= 256 && (g.N % 256) == 0 && a.Ah && a.Ch;
   bool wide = false;                                   // the 8-wave tile: NSR_GEMM_TILE=wide only

@@ -59,8 +59,16 @@ constexpr bool streamed(int v, int l) {
   return ((kLayersV[v][l].cin % 16) == 0 && (kLayersV[v][l].cout % 128) == 0 && kLayersV[v][l].act == kActRelu && kpad(v, l) == 9 * kLayersV[v][l].cin) ||
          (last_tanh(v, l) && kpad(v, l) == 9 * kLayersV[v][l].cin);
 }
-// W' (npad x kpad) | b' (npad) | stream-ordered W' (same size; streamed layers)
-constexpr int64_t layer_floats(int v, int l) { return (int64_t)npad(v, l) * kpad(v, l) * (streamed(v, l) ? 2 : 1) + npad(v, l); }
+// Layer 0 (3 -> 128 channels; round 6): in NSR_F16X3 mode the input is staged as pre-split NHWC planes of kL0Cin = 16 channels
+// (3 real) and the layer runs on conv_halo_kernel as ONE channel chunk of nine k-steps -- no im2col matrix (it was 128 B per
+// pixel written and read back, a launch of its own) and the paired half shape's overlap for a layer that is all epilogue.  Its
+// stream-ordered weights (np x 9 x 16 halves x 2 planes) sit behind the layer's bias in the blob.
+constexpr int kL0Cin = 16;
+constexpr int64_t l0_stream_floats(int v) { return (int64_t)npad(v, 0) * 9 * kL0Cin; }      // bytes / 4
+// W' (npad x kpad) | b' (npad) | stream-ordered W' (same size; streamed layers) | layer 0: its 16-channel stream
+constexpr int64_t layer_floats(int v, int l) {
+  return (int64_t)npad(v, l) * kpad(v, l) * (streamed(v, l) ? 2 : 1) + npad(v, l) + (l == 0 ? l0_stream_floats(v) : 0);
+}
 constexpr int64_t layer_offset(int v, int l) { return l == 0 ? 0 : layer_offset(v, l - 1) + layer_floats(v, l - 1); }
 constexpr int64_t pack_floats(int v) { return layer_offset(v, NSR_REFINE_N_LAYERS - 1) + layer_floats(v, NSR_REFINE_N_LAYERS - 1); }
 constexpr float kBnEps = 1e-5f;   // nn.BatchNorm2d default
@@ -106,6 +114,50 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, const float* __res
     }
     dst[idx] = v;
   }
+}
+
+// GemmF16Args::Bs of layer 0 over kL0Cin padded channels, straight from the reference's (cout, 3, 3, 3) weight (no BatchNorm on
+// that layer): [column block][tap][plane][lane][8 halves], lane (i, h) = output channel 32 nb + i, channels 8 h .. 8 h + 7
+__global__ void l0_stream_kernel(const float* __restrict__ w, int cout, int np, unsigned short* __restrict__ dst) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // ((nb * 9 + tap) * 2 + plane) * 64 + lane
+  if (idx >= (int64_t)(np / 32) * 9 * 128) return;
+  const int lane = (int)(idx & 63), plane = (int)((idx >> 6) & 1);
+  const int64_t u = idx >> 7;
+  const int nb = (int)(u / 9), tap = (int)(u % 9), n = 32 * nb + (lane & 31);
+  unsigned short out[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = 8 * (lane >> 5) + e;
+    const float x = (c < 3 && n < cout) ? kSplitScale * w[((int64_t)n * 3 + c) * 9 + tap] : 0.0f;
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)(x - (float)hi);
+    out[e] = __builtin_bit_cast(unsigned short, plane ? lo : hi);
+  }
+  *reinterpret_cast<uint4*>(dst + idx * 8) = *reinterpret_cast<const uint4*>(out);
+}
+// the reference's NCHW fp32 input (n_img, 3, H, W) as pre-split NHWC planes of kL0Cin channels (hi | lo, 13 zero channels)
+__global__ void __launch_bounds__(256) nchw3_to_planes16_kernel(const float* __restrict__ src, int64_t px_per_img, int64_t n_px,
+                                                                 unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_px) return;
+  const int64_t img = p / px_per_img, q = p - img * px_per_img;
+  unsigned short h[16], l[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) h[c] = l[c] = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float x = src[(img * 3 + c) * px_per_img + q];
+    const _Float16 xh = (_Float16)x;
+    const _Float16 xl = (_Float16)(x - (float)xh);
+    h[c] = __builtin_bit_cast(unsigned short, xh);
+    l[c] = __builtin_bit_cast(unsigned short, xl);
+  }
+  uint4* dh = reinterpret_cast<uint4*>(hi + p * 16);
+  uint4* dl = reinterpret_cast<uint4*>(lo + p * 16);
+  dh[0] = reinterpret_cast<const uint4*>(h)[0];
+  dh[1] = reinterpret_cast<const uint4*>(h)[1];
+  dl[0] = reinterpret_cast<const uint4*>(l)[0];
+  dl[1] = reinterpret_cast<const uint4*>(l)[1];
 }
 
 // GemmF16Args::Bs from the packed (hi | lo) planes: one thread per 16 B
@@ -282,6 +334,31 @@ int conv(hipStream_t st, const float* packed, int precision, int v, int l, const
   const int Ho = (Hin - 1) / L.stride + 1, Wo = (Win - 1) / L.stride + 1;   // k = 3, pad = 1
   const int kp = kpad(v, l);
   const int64_t M = (int64_t)n_img * Ho * Wo, total = M * (kp / 4);
+  // layer 0 in split-fp16 mode, whole 16 x 16 blocks, planes inside 32-bit byte offsets: the conv_halo route over 16 padded
+  // channels (above).  A matter of the patch SHAPE only (never of the batch: the entry points cut it, sets_per_pass).
+  if (l == 0 && f16 && nchw && L.cin == 3 && L.stride == 1 && !L.up && !L.bn && (Hs % 16) == 0 && (Ws % 16) == 0 &&
+      M * kL0Cin * 4 < ((int64_t)1 << 32)) {
+    unsigned short* ph = reinterpret_cast<unsigned short*>(col);
+    unsigned short* pl = ph + M * kL0Cin;
+    hipLaunchKernelGGL(nchw3_to_planes16_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, src_nchw, (int64_t)Hs * Ws, M, ph, pl);
+    NSR_CHECK_LAUNCH();
+    const float* wp0 = packed + layer_offset(v, l);
+    GemmF16Args a{};
+    a.g.M = M; a.g.N = npad(v, l); a.g.K = 9 * kL0Cin; a.g.n_valid = L.cout; a.g.act = L.act; a.g.splits = 1;
+    a.g.bias = wp0 + (int64_t)npad(v, l) * kp;
+    a.g.acc_scale = kSplitInvScale;
+    a.g.lda = kL0Cin; a.g.ldc = dst.ld;
+    a.Bh = reinterpret_cast<const unsigned short*>(wp0);       // the staged route's planes: present, unused by conv_halo_kernel
+    a.Bl = a.Bh + (int64_t)npad(v, l) * kp;
+    a.ldbh = kp;
+    a.Bs = reinterpret_cast<const unsigned short*>(wp0 + (int64_t)npad(v, l) * kp + npad(v, l));
+    a.Ah = ph;
+    a.a_plane = M * kL0Cin;
+    a.conv = ConvGather{kL0Cin, Hs, Ws, Ho, Wo, 1, 0};
+    a.Ch = hi_of(dst);
+    a.c_plane = plane_of(dst);
+    return gemm_f16x3(a, st);
+  }
   const bool implicit = f16 && !nchw && (L.cin % 32) == 0;
   if (!implicit) {
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
@@ -378,6 +455,13 @@ int pack_weights(const float* const* t, void* packed, int precision, int v, void
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nsr_stream(stream), w, b, gamma, beta,
                        mean, var, L.cin, L.cout, kpad(v, l), npad(v, l), precision == NSR_F16X3, dst + layer_offset(v, l));
     NSR_CHECK_LAUNCH();
+    if (precision == NSR_F16X3 && l == 0) {
+      if (L.bn || L.cin != 3) return NSR_ERR_UNSUPPORTED;      // the stream is made from the raw weight (cannot happen: kLayersV)
+      const int64_t n16 = (int64_t)(npad(v, 0) / 32) * 9 * 128;
+      unsigned short* s0 = reinterpret_cast<unsigned short*>(dst + layer_offset(v, 0) + (int64_t)npad(v, 0) * kpad(v, 0) + npad(v, 0));
+      hipLaunchKernelGGL(l0_stream_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, nsr_stream(stream), w, L.cout, npad(v, 0), s0);
+      NSR_CHECK_LAUNCH();
+    }
     if (precision == NSR_F16X3 && streamed(v, l)) {
       const int64_t np = npad(v, l), kp = kpad(v, l), n16 = np * kp / 4;          // 16-byte pieces of both planes
       unsigned short* hl = reinterpret_cast<unsigned short*>(dst + layer_offset(v, l));
