@@ -40,7 +40,8 @@ int nsr_refine_pack_weights(const float* const* tensors, void* packed, int preci
 
 /* H and W multiples of 8 (three stride-2 levels); 0 on invalid arguments.  The plain form is the NSR_FP32 size (the larger
  * one: that mode materialises im2col matrices); `_for` gives the size a precision actually needs (NSR_F16X3: activations
- * + a 32-column im2col matrix of the first layer only, ~21 MB per 64 x 64 patch set with 8 references). */
+ * + 128 bytes per input pixel for the first layer -- its input staged as pre-split 16-channel planes when the patch is whole
+ * 16 x 16 blocks, a 32-column im2col matrix otherwise --, ~21 MB per 64 x 64 patch set with 8 references). */
 size_t nsr_refine_workspace_bytes(int B, int R, int H, int W);
 size_t nsr_refine_workspace_bytes_for(int precision, int B, int R, int H, int W);
 /* x_synth (B, 3, H, W), x_candi (B, R, 3, H, W), out (B, 3, H, W): NCHW fp32 DEVICE (the reference's tensors) */
