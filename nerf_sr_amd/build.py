@@ -166,7 +166,7 @@ VARIANTS = {
                     "persistent + the next tile's encoding in the matrix shadow (150 pinned pieces)"),
     "timeline": (["-DNSR_ABL_TIMELINE"], ["nsr_mlp_f16.hip", "nsr_train_chain.hip"],
                  "s_memtime stamps at the phase boundaries of every tile (scripts/timeline.py)"),
-    "abl_chain": (["-DNSR_ABL_NO_AMAX", "-DNSR_ABL_NO_DENSITY_MMA", "-DNSR_ABL_FWD_NO_STORE", "-DNSR_ABL_BWD_NO_STORE"],
+    "abl_chain": (["-DNSR_ABL_NO_AMAX", "-DNSR_ABL_NO_DENSITY_MMA", "-DNSR_ABL_FWD_NO_STORE", "-DNSR_ABL_BWD_NO_STORE", "-DNSR_ABL_BWD_STORE_L2"],
                   ["nsr_mlp_f16.hip", "nsr_train_chain.hip"],
                   "what the range tracking / the density block's MFMAs / the training panel stores cost (profiles/r5_headline_experiments.json)"),
     "store_policy": (["-DNSR_PANEL_STORE_POLICY=\"\"", "-DNSR_ABL_BWD_DEFAULT_STORE"], ["nsr_mlp_f16.hip", "nsr_train_chain.hip"],

@@ -259,6 +259,9 @@ __device__ __forceinline__ void bwd_unit_store(const u32x4& v, const char* blk, 
   if (voff != 0xffffffffu) return;
 #endif
   u32x4* dst = reinterpret_cast<u32x4*>(const_cast<char*>(blk) + U * 1024 + voff);
+#ifdef NSR_ABL_BWD_STORE_L2   // ablation: the same store instructions, but every block of a wave lands on ONE 2 KiB run (L2-resident: no HBM writes)
+  dst = reinterpret_cast<u32x4*>(reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(blk) & ~(uintptr_t)0x3FFF)) + U * 1024 + voff);
+#endif
 #ifdef NSR_ABL_BWD_DEFAULT_STORE   // A/B: the default cache policy instead of non-temporal
   *dst = v;
 #else
