@@ -435,33 +435,40 @@ def arch_bench(spec: str, dev, fused_rays_per_s: float, n_rays: int = 32768, rep
     from nerf_sr_amd.weights import make_state_dict_arch
     D, W, skips = spec.split(",")
     arch = {"D": int(D), "W": int(W), "skips": tuple(int(x) for x in skips.split("+") if x != ""), "deg_pos": 10, "deg_dir": 4}
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore", RuntimeWarning)        # the slow-path warning is what this figure quantifies
-        m = NeRFDownXModel(default_options(**{**arch, "skips": list(arch["skips"])}), device=dev)
-    m.load_networks(make_state_dict_arch(99, **arch), make_state_dict_arch(100, **arch)).eval()
     frame = ops.subpixel_rays(cameras.spiral_pose(0.4), (504, 378), cameras.llff_focal(504), 2, True, device=dev).view(-1, 8)
     r0 = (frame.shape[0] - n_rays) // 2 // 4 * 4
     rays = frame[r0:r0 + n_rays].contiguous()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    ms = []
-    with torch.no_grad():
-        for i in range(reps + 1):
-            ev[0].record()
-            out = m.forward_rays(rays)
-            ev[1].record()
-            torch.cuda.synchronize()
-            if i:
-                ms.append(ev[0].elapsed_time(ev[1]))
+    secs = {}
+    for prec in ("f16x3", "fp32"):        # the route's two arithmetics: split-fp16 MFMA (three terms) and fp32 MFMA GEMMs
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)        # the slow-path warning is what this figure quantifies
+            m = NeRFDownXModel(default_options(precision=prec, **{**arch, "skips": list(arch["skips"])}), device=dev)
+        m.load_networks(make_state_dict_arch(99, **arch), make_state_dict_arch(100, **arch)).eval()
+        ms = []
+        with torch.no_grad():
+            for i in range(reps + 1):
+                ev[0].record()
+                out = m.forward_rays(rays)
+                ev[1].record()
+                torch.cuda.synchronize()
+                if i:
+                    ms.append(ev[0].elapsed_time(ev[1]))
+        secs[prec] = sum(ms) / len(ms) * 1e-3
+        if prec == "f16x3":
+            finite = bool(torch.isfinite(out["fine_comp_rgbs"]).all())
     in_xyz, in_dir, Wd = 3 + 6 * arch["deg_pos"], 3 + 6 * arch["deg_dir"], arch["W"]
     macs = sum((in_xyz if i == 0 else (Wd + in_xyz if i in arch["skips"] else Wd)) * Wd for i in range(arch["D"]))
     macs += Wd + Wd * Wd + (Wd + in_dir) * (Wd // 2) + (Wd // 2) * 3
-    t = sum(ms) / len(ms) * 1e-3
+    t = secs["f16x3"]
     rps = n_rays / t
     tf = rps * (N_COARSE + N_COARSE + N_IMPORTANCE) * 2 * macs / 1e12
-    return {"arch": arch | {"skips": list(arch["skips"])}, "route": "ops.GenericMLP: one fp32-MFMA GEMM launch per nn.Linear, stage-by-stage forward_rays",
-            "value": rps, "unit": "rays/s", "rays": n_rays, "ms": t * 1e3, "macs_per_point": macs,
-            "achieved_tflops": tf, "frac_of_fp32_mfma_peak": tf / PEAK_TFLOPS["fp32"],
-            "finite": bool(torch.isfinite(out["fine_comp_rgbs"]).all()),
+    return {"arch": arch | {"skips": list(arch["skips"])},
+            "route": "ops.GenericMLP: one GEMM launch per nn.Linear (precision f16x3: split-fp16 MFMA, three terms; fp32: fp32 MFMA), stage-by-stage forward_rays",
+            "value": rps, "unit": "rays/s", "precision": "f16x3", "rays": n_rays, "ms": t * 1e3, "macs_per_point": macs,
+            "achieved_tflops": tf, "frac_of_fp16_mfma_peak": tf / PEAK_TFLOPS["f16x3"],
+            "fp32_value": n_rays / secs["fp32"], "fp32_frac_of_fp32_mfma_peak": (n_rays / secs["fp32"]) * (N_COARSE + N_COARSE + N_IMPORTANCE) * 2 * macs / 1e12 / PEAK_TFLOPS["fp32"],
+            "finite": finite,
             "fused_default_arch_rays_per_s": fused_rays_per_s,
             "slowdown_vs_fused_default_per_ray": fused_rays_per_s / rps,
             "slowdown_vs_fused_default_per_flop": (fused_rays_per_s * 2 * 593408) / (rps * 2 * macs)}

@@ -147,6 +147,15 @@ int nsr_adam_step(float* const* w, const float* const* g, float* const* m, float
 int nsr_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* b, int act, float* y,
                int64_t ldy, float* y_t, int64_t ldyt, int64_t P, int K, int N, void* stream);
 
+/* The same nn.Linear on the split-fp16 MFMA (round 6: what a NON-default network architecture runs on layer by layer under
+ * precision f16x3, ops.GenericMLP): three v_mfma_f32_32x32x16_f16 per product, x split into (hi, lo) fp16 halves on its way
+ * to LDS, the weights pre-split ONCE by nsr_split_weights -- w_hi / w_lo (n halves each) = RNE_f16(64 w) and RNE_f16(64 w - hi);
+ * the factor is undone in the epilogue -- products exact to ~2^-21, fp32 accumulation, fp32 in and out.  Same shape rules as
+ * nsr_linear (K % 32 == 0, ldx % 4 == 0) plus ldw % 8 == 0 and 16-byte aligned w_hi / w_lo; no transposed output. */
+int nsr_split_weights(const float* w, int64_t n, void* w_hi, void* w_lo, void* stream);
+int nsr_linear_f16x3(const float* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw, const float* b, int act,
+                     float* y, int64_t ldy, int64_t P, int K, int N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,6 +104,9 @@ SIGNATURES = {
     "nsr_image_to_targets_rgba": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nsr_linear": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64,
                            c_int64, c_int, c_int, c_void_p]),
+    "nsr_split_weights": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "nsr_linear_f16x3": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int, c_int,
+                                 c_void_p]),
 }
 
 _lib = None

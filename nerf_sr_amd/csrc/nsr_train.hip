@@ -1228,6 +1228,24 @@ extern "C" int nsr_adam_step(float* const* w, const float* const* g, float* cons
   return NSR_OK;
 }
 
+extern "C" int nsr_split_weights(const float* w, int64_t n, void* w_hi, void* w_lo, void* stream) {
+  return split_f16(w, n, static_cast<unsigned short*>(w_hi), static_cast<unsigned short*>(w_lo), nsr_stream(stream));
+}
+
+extern "C" int nsr_linear_f16x3(const float* x, int64_t ldx, const void* w_hi, const void* w_lo, int64_t ldw, const float* b, int act,
+                                float* y, int64_t ldy, int64_t P, int K, int N, void* stream) {
+  if (P < 0 || K <= 0 || N <= 0 || act < 0 || act > 2 || !w_hi || !w_lo) return NSR_ERR_INVALID_ARG;
+  if (P == 0) return NSR_OK;
+  GemmF16Args a{};
+  a.g.A = x; a.g.lda = ldx; a.g.C = y; a.g.ldc = ldy; a.g.bias = b;
+  a.g.M = P; a.g.N = N; a.g.K = K; a.g.n_valid = N; a.g.act = act; a.g.splits = 1;
+  a.g.acc_scale = kSplitInvScale;
+  a.Bh = static_cast<const unsigned short*>(w_hi);
+  a.Bl = static_cast<const unsigned short*>(w_lo);
+  a.ldbh = ldw;
+  return gemm_f16x3(a, nsr_stream(stream));
+}
+
 extern "C" int nsr_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* b, int act, float* y,
                           int64_t ldy, float* y_t, int64_t ldyt, int64_t P, int K, int N, void* stream) {
   if (P < 0 || K <= 0 || N <= 0 || act < 0 || act > 2) return NSR_ERR_INVALID_ARG;

@@ -324,7 +324,7 @@ class GenericMLP:
 
     POINT_CHUNK = 262144          # rows per pass (the reference's point_chunk, options/base_options.py:70): bounds the buffers
 
-    def __init__(self, opt=None, device="cuda", **arch):
+    def __init__(self, opt=None, device="cuda", precision: str = "fp32", **arch):
         self.arch = {**arch_of(opt), **arch}
         self.spec = arch_spec(**self.arch)                  # validates
         self.color_activation = getattr(opt, "color_activation", "sigmoid") if opt is not None else "sigmoid"
@@ -340,9 +340,15 @@ class GenericMLP:
         self.in_xyz, self.in_dir = 3 + 6 * a["deg_pos"], 3 + 6 * a["deg_dir"]
         r32 = lambda n: (n + 31) // 32 * 32
         self.Kx, self.Wp, self.Hp, self.Dp, self.Rp = r32(self.in_xyz), r32(a["W"]), r32(a["W"] // 2), r32(self.in_dir), r32(a["dim_rgb"])
-        self.precision = "fp32"
+        # "fp32": every nn.Linear on the fp32 MFMA (nsr_linear); "f16x3" (round 6): on the split-fp16 MFMA, three terms per
+        # product, products exact to ~2^-21 (nsr_linear_f16x3: the weights are split once at load time) -- the arithmetic of
+        # the fused kernels' default precision, layer by layer.  The single-operand fast precisions have no layer-by-layer form.
+        if precision not in ("fp32", "f16x3"):
+            raise ValueError(f"GenericMLP precision {precision!r}: 'fp32' or 'f16x3' (the layer-by-layer route has no single-operand fast path)")
+        self.precision = precision
         self._sd = None
         self._bad = None
+        self._split = {}
 
     # -- weights ------------------------------------------------------------------------------------------------------
     def _padded(self, w, rows, col_map, cols):
@@ -382,6 +388,14 @@ class GenericMLP:
         self._rgb = (self._padded(dev["rgb.0.weight"], self.Rp, [(0, W // 2, 0)], self.Hp), self._padded_bias(dev["rgb.0.bias"], self.Rp))
         self._sd = dev
         self._bad = torch.zeros((), dtype=torch.bool, device=self.device)
+        self._split = {}
+        if self.precision == "f16x3":       # (hi, lo) fp16 halves of 64 w for every padded weight, made once
+            lib = _lib.load()
+            for w, *_ in list(self._layers) + [self._sigma, self._final, self._dir, self._rgb]:
+                hl = torch.empty(2, w.numel(), dtype=torch.int16, device=self.device)
+                _lib.check(lib.nsr_split_weights(_p(w), w.numel(), c_void_p(hl[0].data_ptr()), c_void_p(hl[1].data_ptr()), _stream()),
+                           "nsr_split_weights")
+                self._split[w.data_ptr()] = hl
         return self
 
     def state_dict(self):
@@ -403,9 +417,14 @@ class GenericMLP:
         return self
 
     # -- forward ------------------------------------------------------------------------------------------------------
-    @staticmethod
-    def _gemm(x, col0, ldx, K, w, b, act, y, ycol0, ldy, P):
+    def _gemm(self, x, col0, ldx, K, w, b, act, y, ycol0, ldy, P):
         lib, esz = _lib.load(), 4
+        hl = self._split.get(w.data_ptr())
+        if hl is not None:
+            _lib.check(lib.nsr_linear_f16x3(c_void_p(x.data_ptr() + col0 * esz), ldx, c_void_p(hl[0].data_ptr()), c_void_p(hl[1].data_ptr()),
+                                            w.shape[1], _p(b), act, c_void_p(y.data_ptr() + ycol0 * esz), ldy, P, K, w.shape[0], _stream()),
+                       "nsr_linear_f16x3")
+            return
         _lib.check(lib.nsr_linear(c_void_p(x.data_ptr() + col0 * esz), ldx, _p(w), w.shape[1], _p(b), act,
                                   c_void_p(y.data_ptr() + ycol0 * esz), ldy, c_void_p(0), 0, P, K, w.shape[0], _stream()), "nsr_linear")
 
@@ -456,7 +475,7 @@ def make_mlp(opt=None, precision: str = "fp32", device="cuda"):
     if is_default_arch(arch_of(opt)):
         return VanillaMLP(opt, precision=precision, device=device)
     warn_generic_mlp(arch_of(opt), precision)
-    return GenericMLP(opt, device=device)
+    return GenericMLP(opt, device=device, precision="f16x3" if precision == "f16x3" else "fp32")
 
 
 _GENERIC_WARNED = set()
@@ -467,15 +486,16 @@ def warn_generic_mlp(arch: dict, precision: str = "fp32") -> None:
     kernels (whose register, LDS and weight-stream layouts ARE the 8 x 256 network with a skip at layer 5) for the
     layer-by-layer fp32 GEMM route -- correct (tests/golden/arch.npz, made by the reference's own forward), but every
     activation matrix travels through HBM: `bench.py --arch D,W,skips` times it (README: ~an order of magnitude slower per
-    sample point than the fused f16x3 kernel at the default size) -- and ``precision`` is ignored there (always fp32)."""
+    sample point than the fused f16x3 kernel at the default size) -- on the fp32 MFMA, or under precision 'f16x3' on the split-fp16 MFMA (three terms per product, nsr_linear_f16x3)."""
     import warnings
     key = (arch.get("D"), arch.get("W"), tuple(arch.get("skips", ())), arch.get("deg_pos"), arch.get("deg_dir"))
     if key in _GENERIC_WARNED:
         return
     _GENERIC_WARNED.add(key)
-    note = "" if precision == "fp32" else f"; precision={precision!r} is ignored on this route (fp32 MFMA GEMMs)"
+    note = "" if precision in ("fp32", "f16x3") else f"; precision={precision!r} has no layer-by-layer form: running fp32"
+    how = "split-fp16 (three-term)" if precision == "f16x3" else "fp32"
     warnings.warn(f"NeRF-SR network D={key[0]} W={key[1]} skips={list(key[2])} deg_pos={key[3]} deg_dir={key[4]} is not the "
-                  "architecture of the fused kernels (8 x 256, skip at 4, degrees 10 / 4): running the layer-by-layer fp32 GEMM "
+                  f"architecture of the fused kernels (8 x 256, skip at 4, degrees 10 / 4): running the layer-by-layer {how} GEMM "
                   f"path (ops.GenericMLP), several times slower per sample point{note}", RuntimeWarning, stacklevel=3)
 
 

@@ -230,20 +230,23 @@ ARCH_CASES = {"small": ({"D": 4, "W": 128, "skips": (2,), "deg_pos": 6, "deg_dir
               "odd": ({"D": 6, "W": 192, "skips": (1, 3), "deg_pos": 10, "deg_dir": 4}, "blender", True)}
 
 
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
 @pytest.mark.parametrize("case", list(ARCH_CASES))
-def test_architecture_flags_run_layer_by_layer(ops, golden_dir, case):
+def test_architecture_flags_run_layer_by_layer(ops, golden_dir, case, prec):
     """--D --W --skips --deg_pos --deg_dir (models/networks.py:124-157, models/nerf_model.py:53-57): no script of the
     reference changes them and the fused kernels are laid out for the defaults, so such a network runs nn.Linear by
     nn.Linear on the fp32-MFMA GEMM (ops.GenericMLP) behind the same model interface -- against the reference's own forward
-    for two non-default networks (tests/golden/arch.npz) and the oracle."""
+    for two non-default networks (tests/golden/arch.npz) and the oracle.  Round 6: under precision 'f16x3' the same layers run
+    on the split-fp16 MFMA (nsr_linear_f16x3: three terms per product, weights split once at load time) -- same bounds."""
     from nerf_sr_amd.model import NeRFDownXModel, default_options
     from nerf_sr_amd.weights import make_state_dict_arch
     g = np.load(os.path.join(golden_dir, "arch.npz"))
     arch, tag, white = ARCH_CASES[case]
     p = np.load(os.path.join(golden_dir, f"path_{tag}.npz"))
     sd_c, sd_f = make_state_dict_arch(int(g["seed_coarse"]), **arch), make_state_dict_arch(int(g["seed_fine"]), **arch)
-    m = NeRFDownXModel(default_options(white_bkgd=white, **{**arch, "skips": list(arch["skips"])})).load_networks(sd_c, sd_f).eval()
-    assert isinstance(m.netCoarse, ops.GenericMLP) and not m.fused
+    m = NeRFDownXModel(default_options(white_bkgd=white, precision=prec, **{**arch, "skips": list(arch["skips"])})).load_networks(sd_c, sd_f).eval()
+    assert isinstance(m.netCoarse, ops.GenericMLP) and not m.fused and m.netCoarse.precision == prec
+    assert (len(m.netCoarse._split) > 0) == (prec == "f16x3")
     x = torch.from_numpy(g[f"{case}_mlp_in_256"]).cuda()
     assert float((m.netCoarse(x).cpu() - torch.from_numpy(g[f"{case}_mlp_out_256"])).abs().max()) <= 2e-5
     assert float((m.netCoarse(x[:64], sigma_only=True).cpu() - torch.from_numpy(g[f"{case}_mlp_sigma_only_64"])).abs().max()) <= 2e-5
