@@ -208,7 +208,7 @@ def train_cpu_baseline(sd_c, sd_f, rays_cpu, target_cpu, s2: int, draws):
                       f"threads over disjoint LR-aligned ray chunks = {len(jobs) * threads} of {host} host threads"}
 
 
-CHAIN_PRECISIONS = ("f16x3", "f16x3_bwd3", "f16x3_bwd2", "f16x3_bwd1")   # the chain kernels (include/nsr_train.h)
+CHAIN_PRECISIONS = ("f16x3", "f16x3_bwd3", "f16x3_bwd2", "f16x3_bwd1", "f16x3_bwdm")   # the chain kernels (include/nsr_train.h)
 
 
 def train_bench(args, rank, local, world, steps=None, warmup=None, cpu=True, shape="downx"):
@@ -319,9 +319,9 @@ def train_bench(args, rank, local, world, steps=None, warmup=None, cpu=True, sha
             # weights read and written, the gradients written and read, Adam's two moments read and written (8 x 595,844 x 4 B)
             true_bytes = R * rays.shape[1] * 4 + (R // s2) * 12 + 2 * 8 * 595844 * 4
             traffic = committed_train_traffic(R)
-            bwd_terms = {"f16x3": 2, "f16x3_bwd3": 3, "f16x3_bwd2": 2, "f16x3_bwd1": 1}[args.train_precision]
+            bwd_terms = {"f16x3": 12, "f16x3_bwd3": 3, "f16x3_bwd2": 2, "f16x3_bwd1": 1, "f16x3_bwdm": 12}[args.train_precision]
             res["dtype"] = ("f32 results; forward from split-fp16 x3 MFMA products (fp32-grade), input gradients (backward chain) on "
-                            f"{bwd_terms} MFMA term(s) per product ({ {3: 'W_hi g_hi + W_hi g_lo + W_lo g_hi', 2: 'W_hi g_hi + W_lo g_hi', 1: 'W_hi g_hi'}[bwd_terms] }), "
+                            f"{ {12: '2 / 1'}.get(bwd_terms, bwd_terms) } MFMA term(s) per product ({ {3: 'W_hi g_hi + W_hi g_lo + W_lo g_hi', 2: 'W_hi g_hi + W_lo g_hi', 1: 'W_hi g_hi', 12: 'W_hi g_hi + W_lo g_hi on the six layers nearest the output, W_hi g_hi below'}[bwd_terms] }), "
                             "weight gradients from fp16 operands (11 bits) on one MFMA per product, fp32 accumulation")
             res["roofline"] = {"bound": "hbm", "kernel": "whole training step, chain path (mlp_f16x3_kernel TRAIN, "
                                                           "chain_bwd_h_kernel / chain_bwd_kernel, wgrad_jobs_kernel)",
@@ -504,7 +504,7 @@ def main():
                     help="render (default): the headline metric; train: one optimize_parameters iteration per step "
                          "(SURVEY §8f N1: forward + backward + Adam, fp32) on a 2,048-ray batch per GPU")
     ap.add_argument("--train-rays", type=int, default=2048, help="rays per GPU per training step (multiple of 4)")
-    ap.add_argument("--train-precision", default="f16x3", choices=["f16x3", "fp32", "f16x3_gemm", "f16x3_bwd3", "f16x3_bwd2", "f16x3_bwd1"],
+    ap.add_argument("--train-precision", default="f16x3", choices=["f16x3", "fp32", "f16x3_gemm", "f16x3_bwd3", "f16x3_bwd2", "f16x3_bwd1", "f16x3_bwdm"],
                     help="training step: forward products on the split-fp16 MFMA (default, fp32-grade) or everything on the fp32 MFMA")
     ap.add_argument("--n-importance", type=int, default=64,
                     help="importance samples per ray: 64 (every script of the reference: 64 coarse + 128 fine network evaluations "

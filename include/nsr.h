@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define NSR_VERSION 130 /* 0.1.3: training precisions NSR_F16X3_BWD3 / _BWD2 / _BWD1 (nsr_train.h); NSR_F16X3 trains with the two-term backward chain; `white_bkgd` arguments renamed `render_flags` (same values) */
+#define NSR_VERSION 131 /* 0.1.3: training precisions NSR_F16X3_BWD3 / _BWD2 / _BWD1 / _BWDM (nsr_train.h); NSR_F16X3 trains with the mixed two / one-term backward chain; `white_bkgd` arguments renamed `render_flags` (same values) */
 
 typedef enum nsr_status {
   NSR_OK = 0,

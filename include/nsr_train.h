@@ -35,15 +35,20 @@ extern "C" {
  *   NSR_F16X3_BWD3: W_hi g_hi + W_hi g_lo + W_lo g_hi, three MFMAs per product, fp32-grade (rounds 2-5's arithmetic);
  *   NSR_F16X3_BWD2: W_hi g_hi + W_lo g_hi: the gradient entering a layer is its fp16 `hi` alone (11 bits, scaled per point by a
  *                   power of two), the weights keep their 22 bits;
- *   NSR_F16X3_BWD1: W_hi g_hi: one MFMA per product, both operands rounded to 11 bits.
+ *   NSR_F16X3_BWD1: W_hi g_hi: one MFMA per product, both operands rounded to 11 bits;
+ *   NSR_F16X3_BWDM: mixed -- two terms (as _BWD2) on the six layers nearest the output (dir_encoding, xyz_encoding_final,
+ *                   xyz_encoding_8 .. _5), one (as _BWD1) on the three below (xyz_encoding_4 .. _2), whose rounding passes
+ *                   through the fewest further layers.
  * NSR_F16X3 selects the cheapest of them whose gradients stay inside the bounds of tests/test_gpu_train.py (every gradient
  * tensor within 2e-3 of its norm of the fp64 oracle, 5e-4 on the heads, a 200-step Adam trajectory no further from the fp32
  * run than another fp32-grade implementation is; the whole gradient within 2e-4 of the fp32-gradient path at 393,216 sample
- * points): NSR_F16X3_BWD2 as of NSR_VERSION 130.  NSR_F16X3_BWD1 is a stated FAST path: it holds the per-tensor bounds (measured
+ * points): NSR_F16X3_BWDM as of NSR_VERSION 131 (measured 4.0e-4 / 7e-5 on the heads / whole gradient 1.0e-4; NSR_VERSION 130:
+ * NSR_F16X3_BWD2, 2.0e-4 / 7e-5 / 1.8e-5).  NSR_F16X3_BWD1 is a stated FAST path: it holds the per-tensor bounds (measured
  * 6.6e-4 / 2.2e-4 on the heads) and the trajectory bound, not the whole-gradient one (3.1e-4) -- measured: DESIGN.md 7.1. */
 #define NSR_F16X3_BWD3 19
 #define NSR_F16X3_BWD2 20
 #define NSR_F16X3_BWD1 21
+#define NSR_F16X3_BWDM 22
 
 /* Workspace for one pass over `ray_chunk` rays (activations of one network, gradient buffers, padded weight copies,
  * split-K partials; for NSR_F16X3 the activation / gradient panels, ~24 KB per sample point in all).  0 on invalid

@@ -24,9 +24,9 @@ NSR_OPT_GAMMA, NSR_OPT_COLOR_NONE = 1, 2     # include/nsr.h: colour-head option
 NSR_WHITE_BKGD, NSR_SIGMA_SOFTPLUS = 1, 2    # include/nsr.h: renderer option word (the `white_bkgd` argument)
 NSR_TRAIN_GAMMA_CORRECT, NSR_TRAIN_COLOR_NONE, NSR_TRAIN_STOP_GRAD = 4, 8, 16    # include/nsr_train.h: the training entry points' own bits of that word
 PRECISIONS = {"fp32": NSR_FP32, "bf16": NSR_BF16, "f16x3": NSR_F16X3, "f16": NSR_F16}
-NSR_F16X3_BWD3, NSR_F16X3_BWD2, NSR_F16X3_BWD1 = 19, 20, 21   # chain path, MFMAs per product of the backward chain named explicitly
+NSR_F16X3_BWD3, NSR_F16X3_BWD2, NSR_F16X3_BWD1, NSR_F16X3_BWDM = 19, 20, 21, 22   # chain path, MFMAs per product of the backward chain named explicitly
 TRAIN_PRECISIONS = {"fp32": NSR_FP32, "f16x3": NSR_F16X3, "f16x3_gemm": NSR_F16X3_GEMM,
-                    "f16x3_bwd3": NSR_F16X3_BWD3, "f16x3_bwd2": NSR_F16X3_BWD2, "f16x3_bwd1": NSR_F16X3_BWD1}
+                    "f16x3_bwd3": NSR_F16X3_BWD3, "f16x3_bwd2": NSR_F16X3_BWD2, "f16x3_bwd1": NSR_F16X3_BWD1, "f16x3_bwdm": NSR_F16X3_BWDM}
 
 # symbol -> (restype, argtypes); must list every function of include/*.h
 SIGNATURES = {

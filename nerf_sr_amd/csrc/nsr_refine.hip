@@ -124,7 +124,7 @@ __global__ void l0_stream_kernel(const float* __restrict__ w, int cout, int np, 
   const int lane = (int)(idx & 63), plane = (int)((idx >> 6) & 1);
   const int64_t u = idx >> 7;
   const int nb = (int)(u / 9), tap = (int)(u % 9), n = 32 * nb + (lane & 31);
-  unsigned short out[8];
+  __attribute__((aligned(16))) unsigned short out[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int c = 8 * (lane >> 5) + e;
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) nchw3_to_planes16_kernel(const float* __r
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_px) return;
   const int64_t img = p / px_per_img, q = p - img * px_per_img;
-  unsigned short h[16], l[16];
+  __attribute__((aligned(16))) unsigned short h[16], l[16];
 #pragma unroll
   for (int c = 0; c < 16; ++c) h[c] = l[c] = 0;
 #pragma unroll

@@ -993,12 +993,13 @@ int chain_weight_grads(hipStream_t st, const Work& k, int64_t P, int64_t n_rays,
 
 // which implementation a precision value selects (include/nsr_train.h): the chain kernels or the layer-by-layer GEMMs
 bool chain_selected(int precision) {
-  return precision == NSR_F16X3 || precision == NSR_F16X3_BWD3 || precision == NSR_F16X3_BWD2 || precision == NSR_F16X3_BWD1;
+  return precision == NSR_F16X3 || precision == NSR_F16X3_BWD3 || precision == NSR_F16X3_BWD2 || precision == NSR_F16X3_BWD1 ||
+         precision == NSR_F16X3_BWDM;
 }
 // MFMAs per product of the backward chain (include/nsr_train.h; NSR_F16X3 = the default, kDefaultBwdTerms)
-constexpr int kDefaultBwdTerms = 2;
+constexpr int kDefaultBwdTerms = 12;   // NSR_F16X3_BWDM
 int chain_bwd_terms(int precision) {
-  return precision == NSR_F16X3_BWD3 ? 3 : (precision == NSR_F16X3_BWD2 ? 2 : (precision == NSR_F16X3_BWD1 ? 1 : kDefaultBwdTerms));
+  return precision == NSR_F16X3_BWD3 ? 3 : (precision == NSR_F16X3_BWD2 ? 2 : (precision == NSR_F16X3_BWD1 ? 1 : (precision == NSR_F16X3_BWDM ? 12 : kDefaultBwdTerms)));
 }
 bool train_precision_ok(int precision) { return precision == NSR_FP32 || chain_selected(precision) || precision == NSR_F16X3_GEMM; }
 int gemm_precision(int precision) { return precision == NSR_F16X3_GEMM ? NSR_F16X3 : precision; }   // what the GEMM path's helpers expect

@@ -54,31 +54,43 @@ struct BwdPackPtrs {
 // are packed as zeros, so the gradient that leaves the colour branch for xyz_encoding_final is an exact 0 at every point --
 // xyz_encoding_final's weights and bias get zero gradients, the trunk sees the density head's gradient alone.
 // hi_only (round 6, the one-term chain): the stream carries the hi pieces alone -- 16 pieces per chunk, 128 per layer
-__device__ __forceinline__ void pack_bwd_body(const BwdPackPtrs& w, unsigned* __restrict__ out, int stop_grad, int hi_only);
-__global__ void __launch_bounds__(256) pack_bwd_kernel(BwdPackPtrs w, unsigned* __restrict__ out, int stop_grad, int hi_only) {
-  pack_bwd_body(w, out, stop_grad, hi_only);
+__device__ __forceinline__ void pack_bwd_body(const BwdPackPtrs& w, unsigned* __restrict__ out, int stop_grad, int mode);
+__global__ void __launch_bounds__(256) pack_bwd_kernel(BwdPackPtrs w, unsigned* __restrict__ out, int stop_grad, int mode) {
+  pack_bwd_body(w, out, stop_grad, mode);
 }
 // both networks of a training step in one launch (round 6; blockIdx.y = network) + the step's two start-of-step clears,
 // which used to be memset launches of their own: zero[0 .. n_zero) doubles (the loss carries) and one option word
 __global__ void __launch_bounds__(256) pack_bwd2_kernel(BwdPackPtrs w0, unsigned* __restrict__ out0, BwdPackPtrs w1, unsigned* __restrict__ out1,
-                                                        int stop_grad, int hi_only, double* __restrict__ zero, int n_zero,
+                                                        int stop_grad, int mode, double* __restrict__ zero, int n_zero,
                                                         unsigned* __restrict__ word, unsigned value) {
   if (blockIdx.x == 0 && blockIdx.y == 0) {
     if ((int)threadIdx.x < n_zero) zero[threadIdx.x] = 0.0;
     if (threadIdx.x == 64 && word) *word = value;
   }
-  if (blockIdx.y) pack_bwd_body(w1, out1, stop_grad, hi_only);
-  else pack_bwd_body(w0, out0, stop_grad, hi_only);
+  if (blockIdx.y) pack_bwd_body(w1, out1, stop_grad, mode);
+  else pack_bwd_body(w0, out0, stop_grad, mode);
 }
-__device__ __forceinline__ void pack_bwd_body(const BwdPackPtrs& w, unsigned* __restrict__ out, int stop_grad, int hi_only) {
+__device__ __forceinline__ void pack_bwd_body(const BwdPackPtrs& w, unsigned* __restrict__ out, int stop_grad, int mode) {
+  // mode: 2 / 3 = (hi, lo) pieces for every layer; 1 = hi pieces only; 12 = mixed (layers 0..5 hi + lo, 6..8 hi only)
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int stream_words = (hi_only ? kBwdPieces / 2 : kBwdPieces) * 256;
+  const int n_pieces = mode == 12 ? 1536 + 3 * 128 : (mode == 1 ? kBwdPieces / 2 : kBwdPieces);
+  const int stream_words = n_pieces * 256;
   if (idx >= stream_words + kBwdAuxFloats) return;
   unsigned v = 0u;
   if (idx < stream_words) {
     const int piece = idx >> 8, word = idx & 255;
-    const int per_layer = hi_only ? 128 : 256, per_chunk = hi_only ? kBwdChunkPieces / 2 : kBwdChunkPieces;
-    const int lam = piece / per_layer, local = piece % per_layer;
+    int lam, local;
+    bool hi_only;
+    if (mode == 12) {
+      hi_only = piece >= 1536;
+      lam = hi_only ? 6 + ((piece - 1536) >> 7) : piece >> 8;
+      local = hi_only ? (piece - 1536) & 127 : piece & 255;
+    } else {
+      hi_only = mode == 1;
+      lam = piece / (hi_only ? 128 : 256);
+      local = piece % (hi_only ? 128 : 256);
+    }
+    const int per_chunk = hi_only ? kBwdChunkPieces / 2 : kBwdChunkPieces;
     const int nb = local / per_chunk, rem = local % per_chunk;
     const int s = hi_only ? rem : rem >> 1, part = hi_only ? 0 : rem & 1;
     const int lane = word >> 2, jj = word & 3;
@@ -624,9 +636,28 @@ __device__ __forceinline__ ChunkRef make_ref_w(int piece0, int pieces, int wave)
   c.count = ((wave + 1) * pieces) / W - c.first;
   return c;
 }
-template <int NT, int W>
+// MODE = MFMA terms per product over the nine layers of the chain: 1 or 2 = that many everywhere; 12 = MIXED (round 6): two
+// terms on the six layers nearest the output (dir_encoding, xyz_encoding_final, trunk 8 .. 5), one on the three below (trunk
+// 4 .. 2).  A weight-rounding error injected near the output reaches every tensor below it, one injected near the input reaches
+// few: profiles/r6_bwd_terms_study.txt section 3 -- 6 + 3 is the first mix that keeps the whole gradient inside 2e-4 with
+// margin.  Per layer the stream, the ring geometry and the k-steps are that layer's NT's; a layer's last two blocks fetch, and
+// its last block prefetches, chunks of the NEXT layer's geometry.
+template <int MODE>
+__device__ __host__ constexpr int nt_of(int lam) { return MODE == 12 ? (lam < 6 ? 2 : 1) : MODE; }
+template <int MODE>
+__device__ __host__ constexpr int max_nt() { return MODE == 12 ? 2 : MODE; }
+template <int MODE>
+__device__ __host__ constexpr int layer_piece0(int lam) {      // first 1 KiB piece of layer lam in the stream
+  return MODE == 12 ? (lam < 6 ? 256 * lam : 1536 + 128 * (lam - 6)) : (MODE == 1 ? 128 : 256) * lam;
+}
+template <int MODE>
+__device__ __host__ constexpr int stream_pieces() { return layer_piece0<MODE>(kBwdLayers); }
+template <int MODE, int W>
 __device__ __forceinline__ ChunkRef hseq(int q, int wave) {   // chunk q = 8 lam + nb; past the end chunk 0 again (idle slot)
-  return make_ref_w<W>((q < 8 * kBwdLayers ? q : 0) * HCfg<NT, W>::kChunkPieces, HCfg<NT, W>::kChunkPieces, wave);
+  const int qq = q < 8 * kBwdLayers ? q : 0;
+  const int lam = qq >> 3, nb = qq & 7;
+  const int pieces = (MODE == 12 ? (lam < 6 ? 2 : 1) : MODE) == 1 ? 16 : 32;
+  return make_ref_w<W>(layer_piece0<MODE>(lam) + nb * pieces, pieces, wave);
 }
 struct PreH {
   u32x4 ah[kPF], al[kPF];   // al: NT = 2 only
@@ -743,7 +774,7 @@ __device__ __forceinline__ void hsplit_gap(int s, int g, Acc& p, unsigned mz, Sc
 }
 
 // bwd_layer without the lo operand set (see there for the flags)
-template <int NT, int W, bool PREV_MASK, bool MASK, bool ADD, bool LAST, bool NEXT_MASK, bool FIRST = false>
+template <int MODE, int NT, int NTN, int W, bool PREV_MASK, bool MASK, bool ADD, bool LAST, bool NEXT_MASK, bool FIRST = false>
 __device__ __forceinline__ void bwd_layer_h(int lam, int prev_panel, int panel, int next_panel, u32x4 (&bh)[16], u32x4 (&oh)[16],
                                             const float* wsig_h, float d_sigma, Loader& ld, unsigned ring0, Acc& pend, PreH& pre,
                                             unsigned (&mz)[2], Scale& prev, const BwdCtx& cx) {
@@ -757,11 +788,12 @@ __device__ __forceinline__ void bwd_layer_h(int lam, int prev_panel, int panel, 
   for (int nb = 0; nb < 8; ++nb) {
     const int q = 8 * lam + nb;
     constexpr int D = HCfg<NT, W>::kDepth;
-    const ChunkRef c2 = hseq<NT, W>(q + D - 1, ld.wave);     // the chunk fetched during this block
+    constexpr unsigned kSlot = (unsigned)HCfg<max_nt<MODE>(), W>::kSlotB;      // slots are sized for the chain's widest chunk
+    const ChunkRef c2 = hseq<MODE, W>(q + D - 1, ld.wave);     // the chunk fetched during this block
     // slots of chunks q, q + 1 and of the chunk fetched now (= the slot chunk q - 1 has left)
-    ld.slot_cur = ring0 + ((unsigned)q % D) * (unsigned)HCfg<NT, W>::kSlotB;
-    ld.slot_next = ring0 + ((unsigned)(q + 1) % D) * (unsigned)HCfg<NT, W>::kSlotB;
-    ld.slot_free = ring0 + ((unsigned)(q + D - 1) % D) * (unsigned)HCfg<NT, W>::kSlotB;
+    ld.slot_cur = ring0 + ((unsigned)q % D) * kSlot;
+    ld.slot_next = ring0 + ((unsigned)(q + 1) % D) * kSlot;
+    ld.slot_free = ring0 + ((unsigned)(q + D - 1) % D) * kSlot;
     Acc acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc.m[r] = 0.0f;
@@ -779,8 +811,10 @@ __device__ __forceinline__ void bwd_layer_h(int lam, int prev_panel, int panel, 
                              : sign_block(const_cast<unsigned*>(cx.sgn), cx.dp.group, next_panel, 0));
     const int pb = (nb == 0) ? 7 : nb - 1;
     const unsigned mz_pend = mz[(pb >> 1) & 1];
-    auto mma = [&](auto young) {
-      block_mma_h<NT, HCfg<NT, W>::kMine, kBar, decltype(young)::value>(
+    // the chunk fetched during this block (q + 2) and the one whose first fragments are prefetched at its end (q + 1) belong to
+    // the next layer from blocks 6 / 7 on
+    auto mma = [&](auto young, auto fetch_nt, auto pre_nt) {
+      block_mma_h<NT, HCfg<decltype(fetch_nt)::value, W>::kMine, kBar, decltype(young)::value>(
           acc, pre, a_addr, ld, c2, [&](int s) -> u32x4 { return bh[s]; },
           [&](int s, int g) {
             if (nb == 0) {
@@ -794,17 +828,22 @@ __device__ __forceinline__ void bwd_layer_h(int lam, int prev_panel, int panel, 
             if (load_next && g == LG && s == 6) mask_dma(next_blk, cx.lane4, cx.lmask);
             if (MASK && !(nb & 1) && g == LG && s == 14) mz[(nb >> 1) & 1] = mask_read(cx.lmask + cx.lane4);
           },
-          [&](int k) { prefetch_frag_h<NT>(nxt, k, ld.slot_next + ld.lane_off); });
+          [&](int k) { prefetch_frag_h<decltype(pre_nt)::value>(nxt, k, ld.slot_next + ld.lane_off); });
+    };
+    auto mma_nb = [&](auto young) {
+      if (nb < 6) mma(young, std::integral_constant<int, NT>{}, std::integral_constant<int, NT>{});
+      else if (nb == 6) mma(young, std::integral_constant<int, NTN>{}, std::integral_constant<int, NT>{});
+      else mma(young, std::integral_constant<int, NTN>{}, std::integral_constant<int, NTN>{});
     };
     if (FIRST) {
       switch (nb) {   // nb is a constant after unrolling
-#define NSR_YF(B) case B: mma(std::integral_constant<int, hyoung_first<NT, W>(B)>{}); break;
+#define NSR_YF(B) case B: mma_nb(std::integral_constant<int, hyoung_first<NT, W>(B)>{}); break;
         NSR_YF(0) NSR_YF(1) NSR_YF(2) NSR_YF(3) NSR_YF(4) NSR_YF(5) NSR_YF(6) NSR_YF(7)
 #undef NSR_YF
         default: break;
       }
     } else {
-      mma(std::integral_constant<int, HCfg<NT, W>::kYoungSteady>{});
+      mma_nb(std::integral_constant<int, HCfg<NT, W>::kYoungSteady>{});
     }
     if (ADD) {
 #pragma unroll
@@ -816,11 +855,13 @@ __device__ __forceinline__ void bwd_layer_h(int lam, int prev_panel, int panel, 
   prev = cur;
 }
 
-template <int NT, int W>
-__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(HOcc<NT, W>::kWavesPerEu, HOcc<NT, W>::kWavesPerEu)))
+template <int MODE, int W>
+__global__ void __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(HOcc<max_nt<MODE>(), W>::kWavesPerEu, HOcc<max_nt<MODE>(), W>::kWavesPerEu)))
 chain_bwd_h_kernel(const float* __restrict__ packed, const unsigned* __restrict__ sgn, char* __restrict__ dpan,
                    const float* __restrict__ d_rgb, int d_rgb_stride, const float* __restrict__ d_sigma, int d_sigma_stride,
                    int64_t P, unsigned* __restrict__ gmax, float* __restrict__ pscale) {
+  constexpr int NT = max_nt<MODE>();         // ring geometry: the widest chunk
+  constexpr int NT0 = nt_of<MODE>(0);
   using C = HCfg<NT, W>;
   constexpr int kAux0 = C::kDepth * C::kSlotB / 4;
   __shared__ __attribute__((aligned(16))) float ring[kAux0 + kBwdAuxFloats + 16 + W * 64];
@@ -829,7 +870,7 @@ chain_bwd_h_kernel(const float* __restrict__ packed, const unsigned* __restrict_
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m = lane & 31, h = lane >> 5;
-  for (int i = threadIdx.x; i < kBwdAuxFloats; i += 64 * W) ring[kAux0 + i] = packed[C::kPieces * 256 + i];
+  for (int i = threadIdx.x; i < kBwdAuxFloats; i += 64 * W) ring[kAux0 + i] = packed[stream_pieces<MODE>() * 256 + i];
 
   Loader ld;
   ld.stream = packed;
@@ -842,9 +883,9 @@ chain_bwd_h_kernel(const float* __restrict__ packed, const unsigned* __restrict_
   // chunks 0 .. kDepth - 2 stream in behind the prologue
 #pragma unroll
   for (int c = 0; c < C::kDepth - 1; ++c) {
-    loader_prepare_dma(ld, hseq<NT, W>(c, wave), ring0 + (unsigned)c * (unsigned)C::kSlotB);
+    loader_prepare_dma(ld, hseq<MODE, W>(c, wave), ring0 + (unsigned)c * (unsigned)C::kSlotB);
 #pragma unroll
-    for (int i = 0; i < C::kMine; ++i) loader_issue(ld, i);
+    for (int i = 0; i < HCfg<NT0, W>::kMine; ++i) loader_issue(ld, i);       // chunks 0, 1: layer 0's geometry
   }
 
   // panels are laid out in point groups of 32 (one wave), four per 128-point tile of the FORWARD kernel: n_groups follows
@@ -925,23 +966,40 @@ chain_bwd_h_kernel(const float* __restrict__ packed, const unsigned* __restrict_
   __syncthreads();
   PreH pre;
 #pragma unroll
-  for (int k = 0; k < kPF; ++k) prefetch_frag_h<NT>(pre, k, ld.slot_cur + ld.lane_off);
-  loader_prepare_dma(ld, hseq<NT, W>(C::kDepth - 1, wave), ld.slot_free);   // replaced at the first publish point; keeps the descriptor defined
+  for (int k = 0; k < kPF; ++k) prefetch_frag_h<NT0>(pre, k, ld.slot_cur + ld.lane_off);
+  loader_prepare_dma(ld, hseq<MODE, W>(C::kDepth - 1, wave), ld.slot_free);   // replaced at the first publish point; keeps the descriptor defined
 
   Acc pend;
 #pragma unroll
   for (int r = 0; r < 16; ++r) pend.m[r] = 0.0f;
   unsigned mz[2] = {0u, 0u};
 
-  bwd_layer_h<NT, W, false, false, false, false, true, true>(0, -1, 8, 7, bh, oh, wsig_h, gs, ld, ring0, pend, pre, mz, prev, cx);
-  bwd_layer_h<NT, W, false, true, true, false, true>(1, 8, 7, 6, oh, bh, wsig_h, gs, ld, ring0, pend, pre, mz, prev, cx);
+  if constexpr (MODE == 12) {
+    // nine layers written out: each with its own and its successor's geometry (the register sets swap roles layer by layer)
+#define NSR_L(LAM, PM, M, ADDF, LASTF, NM, FIRSTF, PP, P_, NP, IN, OUT)                                                                   \
+    bwd_layer_h<MODE, nt_of<MODE>(LAM), nt_of<MODE>(LAM < 8 ? LAM + 1 : 0), W, PM, M, ADDF, LASTF, NM, FIRSTF>(LAM, PP, P_, NP, IN, OUT, wsig_h, \
+                                                                                                               gs, ld, ring0, pend, pre, mz, prev, cx)
+    NSR_L(0, false, false, false, false, true, true, -1, 8, 7, bh, oh);
+    NSR_L(1, false, true, true, false, true, false, 8, 7, 6, oh, bh);
+    NSR_L(2, true, true, false, false, true, false, 7, 6, 5, bh, oh);
+    NSR_L(3, true, true, false, false, true, false, 6, 5, 4, oh, bh);
+    NSR_L(4, true, true, false, false, true, false, 5, 4, 3, bh, oh);
+    NSR_L(5, true, true, false, false, true, false, 4, 3, 2, oh, bh);
+    NSR_L(6, true, true, false, false, true, false, 3, 2, 1, bh, oh);
+    NSR_L(7, true, true, false, false, true, false, 2, 1, 0, oh, bh);
+    NSR_L(8, true, true, false, true, false, false, 1, 0, -1, bh, oh);
+#undef NSR_L
+  } else {
+  bwd_layer_h<MODE, NT, NT, W, false, false, false, false, true, true>(0, -1, 8, 7, bh, oh, wsig_h, gs, ld, ring0, pend, pre, mz, prev, cx);
+  bwd_layer_h<MODE, NT, NT, W, false, true, true, false, true>(1, 8, 7, 6, oh, bh, wsig_h, gs, ld, ring0, pend, pre, mz, prev, cx);
 #pragma unroll 1
   for (int pair = 0; pair < 3; ++pair) {
     const int lam = 2 + 2 * pair;
-    bwd_layer_h<NT, W, true, true, false, false, true>(lam, 9 - lam, 8 - lam, 7 - lam, bh, oh, wsig_h, gs, ld, ring0, pend, pre, mz, prev, cx);
-    bwd_layer_h<NT, W, true, true, false, false, true>(lam + 1, 8 - lam, 7 - lam, 6 - lam, oh, bh, wsig_h, gs, ld, ring0, pend, pre, mz, prev, cx);
+    bwd_layer_h<MODE, NT, NT, W, true, true, false, false, true>(lam, 9 - lam, 8 - lam, 7 - lam, bh, oh, wsig_h, gs, ld, ring0, pend, pre, mz, prev, cx);
+    bwd_layer_h<MODE, NT, NT, W, true, true, false, false, true>(lam + 1, 8 - lam, 7 - lam, 6 - lam, oh, bh, wsig_h, gs, ld, ring0, pend, pre, mz, prev, cx);
   }
-  bwd_layer_h<NT, W, true, true, false, true, false>(8, 1, 0, -1, bh, oh, wsig_h, gs, ld, ring0, pend, pre, mz, prev, cx);
+  bwd_layer_h<MODE, NT, NT, W, true, true, false, true, false>(8, 1, 0, -1, bh, oh, wsig_h, gs, ld, ring0, pend, pre, mz, prev, cx);
+  }
   {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA write-back before inline asm reads the accumulators
 #pragma unroll
@@ -958,34 +1016,38 @@ chain_bwd_h_kernel(const float* __restrict__ packed, const unsigned* __restrict_
 
 }  // namespace
 
+// terms: 1, 2, 3 MFMA terms per product on every layer, or 12 = mixed (two on layers 0..5, one on 6..8)
+static bool bwd_terms_ok(int terms) { return terms == 1 || terms == 2 || terms == 3 || terms == 12; }
+static int bwd_stream_pieces(int terms) { return terms == 12 ? 1536 + 3 * 128 : (terms == 1 ? kBwdPieces / 2 : kBwdPieces); }
+
 extern "C" NSR_INTERNAL size_t nsr_chain_bwd_packed_bytes(void) { return 4 * (size_t)(kBwdPieces * 256 + kBwdAuxFloats); }
 
 extern "C" NSR_INTERNAL int nsr_chain_bwd_pack(const float* const* w, void* packed_dev, int stop_grad, int terms, void* stream) {
-  if (terms < 1 || terms > 3) return NSR_ERR_INVALID_ARG;
+  if (!bwd_terms_ok(terms)) return NSR_ERR_INVALID_ARG;
   BwdPackPtrs pp;
   for (int i = 0; i < NSR_N_STATE_TENSORS; ++i) {
     if (!w[i]) return NSR_ERR_INVALID_ARG;
     pp.p[i] = w[i];
   }
-  const int total = (terms == 1 ? kBwdPieces / 2 : kBwdPieces) * 256 + kBwdAuxFloats;
+  const int total = bwd_stream_pieces(terms) * 256 + kBwdAuxFloats;
   hipLaunchKernelGGL(pack_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, nsr_stream(stream), pp,
-                     static_cast<unsigned*>(packed_dev), stop_grad, terms == 1 ? 1 : 0);
+                     static_cast<unsigned*>(packed_dev), stop_grad, terms);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
 
 extern "C" NSR_INTERNAL int nsr_chain_bwd_pack2(const float* const* w0, void* packed0, const float* const* w1, void* packed1, int stop_grad,
                                                 int terms, double* zero, int n_zero, unsigned* word, unsigned value, void* stream) {
-  if (terms < 1 || terms > 3 || n_zero < 0 || n_zero > 64) return NSR_ERR_INVALID_ARG;
+  if (!bwd_terms_ok(terms) || n_zero < 0 || n_zero > 64) return NSR_ERR_INVALID_ARG;
   BwdPackPtrs a, b;
   for (int i = 0; i < NSR_N_STATE_TENSORS; ++i) {
     if (!w0[i] || !w1[i]) return NSR_ERR_INVALID_ARG;
     a.p[i] = w0[i];
     b.p[i] = w1[i];
   }
-  const int total = (terms == 1 ? kBwdPieces / 2 : kBwdPieces) * 256 + kBwdAuxFloats;
+  const int total = bwd_stream_pieces(terms) * 256 + kBwdAuxFloats;
   hipLaunchKernelGGL(pack_bwd2_kernel, dim3((total + 255) / 256, 2), dim3(256), 0, nsr_stream(stream), a, static_cast<unsigned*>(packed0), b,
-                     static_cast<unsigned*>(packed1), stop_grad, terms == 1 ? 1 : 0, zero, n_zero, word, value);
+                     static_cast<unsigned*>(packed1), stop_grad, terms, zero, n_zero, word, value);
   NSR_CHECK_LAUNCH();
   return NSR_OK;
 }
@@ -993,7 +1055,7 @@ extern "C" NSR_INTERNAL int nsr_chain_bwd_pack2(const float* const* w0, void* pa
 extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const unsigned* sgn, void* dpan, const float* d_rgb, int d_rgb_stride,
                                           const float* d_sigma, int d_sigma_stride, int64_t P, unsigned* gmax,
                                           float* pscale, int terms, int gmax_is_zero, void* stream) {
-  if (terms < 1 || terms > 3) return NSR_ERR_INVALID_ARG;
+  if (!bwd_terms_ok(terms)) return NSR_ERR_INVALID_ARG;
   if (P <= 0) return NSR_OK;
 #ifdef NSR_BWD_WAVES   // A/B builds: 4 = one wave per SIMD for the two-term chain / two 4-wave workgroups per CU for the one-term chain
   const int waves = NSR_BWD_WAVES;
@@ -1007,7 +1069,9 @@ extern "C" NSR_INTERNAL int nsr_chain_bwd(const void* packed, const unsigned* sg
   const float* pk = static_cast<const float*>(packed);
   char* dp = static_cast<char*>(dpan);
   hipStream_t st = nsr_stream(stream);
-  if (terms == 3)
+  if (terms == 12)
+    hipLaunchKernelGGL((chain_bwd_h_kernel<12, 8>), grid8, block8, 0, st, pk, sgn, dp, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, P, gmax, pscale);
+  else if (terms == 3)
     hipLaunchKernelGGL(chain_bwd_kernel, grid, block, 0, st, pk, sgn, dp, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, P, gmax, pscale);
   else if (terms == 2 && waves == 8)
     hipLaunchKernelGGL((chain_bwd_h_kernel<2, 8>), grid8, block8, 0, st, pk, sgn, dp, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, P, gmax, pscale);

@@ -92,8 +92,8 @@ class Trainer:
         if precision not in _lib.TRAIN_PRECISIONS:
             raise ValueError("precision must be 'fp32' (every product on the fp32 MFMA, layer by layer), 'f16x3' (the chain "
                              "kernels: forward on the split-fp16 MFMA, weight gradients on one fp16 MFMA per product, input "
-                             "gradients on the default number of MFMA terms), 'f16x3_bwd3' / 'f16x3_bwd2' / 'f16x3_bwd1' (the "
-                             "chain kernels with three / two / one MFMA per product of the input gradients, include/nsr_train.h) "
+                             "gradients on the default number of MFMA terms), 'f16x3_bwd3' / 'f16x3_bwd2' / 'f16x3_bwd1' / 'f16x3_bwdm' (the "
+                             "chain kernels with three / two / one / mixed two-one MFMAs per product of the input gradients, include/nsr_train.h) "
                              "or 'f16x3_gemm' (layer by layer, forward products split-fp16, gradients fp32)")
         self.precision, self._prec = precision, _lib.TRAIN_PRECISIONS[precision]
         self.device = torch.device(device)

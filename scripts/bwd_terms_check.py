@@ -17,7 +17,7 @@ from oracle import train_oracle as to          # checker only (this script is ev
 from tests.util import train_draws
 from tests.trained_field import adam_trajectory, trajectory_drift
 
-VARIANTS = ("f16x3_bwd3", "f16x3_bwd2", "f16x3_bwd1")
+VARIANTS = ("f16x3_bwd3", "f16x3_bwd2", "f16x3_bwdm", "f16x3_bwd1")
 HEAD = ("rgb.0.weight", "rgb.0.bias", "dir_encoding.0.weight", "dir_encoding.0.bias", "xyz_encoding_final.weight",
         "xyz_encoding_final.bias", "sigma.weight", "sigma.bias")
 out = {"csrc_sha256": build.source_hash(), "fixtures": {}, "bench_scale": {}, "trajectory": {}}

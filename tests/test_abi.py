@@ -37,7 +37,7 @@ def test_header_symbols_exported_and_bound(lib):
 
 
 def test_version_and_status_strings(lib):
-    assert lib.nsr_version() == 130
+    assert lib.nsr_version() == 131
     assert lib.nsr_status_string(0) == b"ok"
     for code in (-1, -2, -3, -4, -5, -99):
         assert len(lib.nsr_status_string(code)) > 0

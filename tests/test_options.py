@@ -106,7 +106,7 @@ def test_training_option_word():
 
 def test_training_precision_values_match_the_header_and_size_the_chain_workspace():
     """Round 6 (include/nsr_train.h): the backward chain's arithmetic is a precision value of the training entry points --
-    NSR_F16X3_BWD3 / _BWD2 / _BWD1 -- and the Python mirror's names map onto exactly those numbers.  All four chain values
+    NSR_F16X3_BWD3 / _BWD2 / _BWD1 / _BWDM -- and the Python mirror's names map onto exactly those numbers.  All five chain values
     (NSR_F16X3 is the default among them) take the chain path's workspace, NSR_F16X3_GEMM / NSR_FP32 the GEMM path's; an
     unknown value sizes nothing.  No compute: the library answers from its arguments (CPU box)."""
     import os
@@ -114,14 +114,14 @@ def test_training_precision_values_match_the_header_and_size_the_chain_workspace
     from nerf_sr_amd import _lib
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "nsr_train.h")).read()
     for name, key in (("NSR_F16X3_GEMM", "f16x3_gemm"), ("NSR_F16X3_BWD3", "f16x3_bwd3"), ("NSR_F16X3_BWD2", "f16x3_bwd2"),
-                      ("NSR_F16X3_BWD1", "f16x3_bwd1")):
+                      ("NSR_F16X3_BWD1", "f16x3_bwd1"), ("NSR_F16X3_BWDM", "f16x3_bwdm")):
         assert int(re.search(rf"#define {name} (\d+)", hdr).group(1)) == _lib.TRAIN_PRECISIONS[key]
     assert len(set(_lib.TRAIN_PRECISIONS.values())) == len(_lib.TRAIN_PRECISIONS)
     lib = _lib.load()
     chain = lib.nsr_train_workspace_bytes_for(_lib.NSR_F16X3, 2048, 64, 64)
     assert chain > 0
-    for key in ("f16x3_bwd3", "f16x3_bwd2", "f16x3_bwd1"):
+    for key in ("f16x3_bwd3", "f16x3_bwd2", "f16x3_bwd1", "f16x3_bwdm"):
         assert lib.nsr_train_workspace_bytes_for(_lib.TRAIN_PRECISIONS[key], 2048, 64, 64) == chain
     gemm = lib.nsr_train_workspace_bytes_for(_lib.NSR_F16X3_GEMM, 2048, 64, 64)
     assert gemm == lib.nsr_train_workspace_bytes_for(_lib.NSR_FP32, 2048, 64, 64) and gemm != chain
-    assert lib.nsr_train_workspace_bytes_for(22, 2048, 64, 64) == 0
+    assert lib.nsr_train_workspace_bytes_for(23, 2048, 64, 64) == 0
