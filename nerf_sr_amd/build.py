@@ -169,6 +169,8 @@ VARIANTS = {
     "abl_chain": (["-DNSR_ABL_NO_AMAX", "-DNSR_ABL_NO_DENSITY_MMA", "-DNSR_ABL_FWD_NO_STORE", "-DNSR_ABL_BWD_NO_STORE", "-DNSR_ABL_BWD_STORE_L2"],
                   ["nsr_mlp_f16.hip", "nsr_train_chain.hip"],
                   "what the range tracking / the density block's MFMAs / the training panel stores cost (profiles/r5_headline_experiments.json)"),
+    "halo_no_multi": (["-DNSR_HALO_NO_MULTI"], ["nsr_gemm_f16.hip"],
+                      "refinement pass with the 8 x 8-pixel plain layers on the staged tiles (round 6 A/B; other K order: not bit-identical)"),
     "store_policy": (["-DNSR_PANEL_STORE_POLICY=\"\"", "-DNSR_ABL_BWD_DEFAULT_STORE"], ["nsr_mlp_f16.hip", "nsr_train_chain.hip"],
                      "training panel stores with the default cache policy instead of non-temporal (A/B)"),
     "abl_ring": (["-DNSR_ABL_NO_DMA", "-DNSR_ABL_NO_BARRIER", "-DNSR_ABL_NO_DRAIN", "-DNSR_ABL_NO_CONVERT"], ["nsr_mlp_f16.hip"],

@@ -160,8 +160,11 @@ __device__ __forceinline__ float lane_xor1(float v) {       // the neighbouring 
 // rows(bi, rq, r0, q): first output row of the eight rows (bi, rq) of this wave (GROUPED: member 0's row) and, GROUPED, the
 // row of the max planes; false = past the end of M.
 // acc(bi, bj): the accumulator block.
-template <int BN, int BM, bool GROUPED, class Acc, class Rows>
-__device__ __forceinline__ void epilogue_planes_relu(const GemmF16Args& a, Acc acc, Rows rows, int n0, int li, int h) {
+// MULTI (with GROUPED's row order and addressing): the eight rows of a pixel are eight PLAIN images -- no max planes, and only
+// the first `members` of them exist (the last block of a batch that is not a multiple of eight).
+template <int BN, int BM, bool GROUPED, bool MULTI = false, class Acc, class Rows>
+__device__ __forceinline__ void epilogue_planes_relu(const GemmF16Args& a, Acc acc, Rows rows, int n0, int li, int h, int members = 8) {
+  static_assert(!MULTI || GROUPED, "MULTI uses the grouped row order");
   const GemmArgs& g = a.g;
   const bool odd = li & 1;
   const unsigned per = GROUPED ? (unsigned)(a.conv.Ho * a.conv.Wo) : 1u;
@@ -180,7 +183,7 @@ __device__ __forceinline__ void epilogue_planes_relu(const GemmF16Args& a, Acc a
       if (!rows(bi, rq, r0, q)) continue;
       char* const ph = reinterpret_cast<char*>(a.Ch + r0 * g.ldc + n0);
       char* const pl = ph + a.c_plane * 2;
-      char* const mh = GROUPED ? reinterpret_cast<char*>(a.Mh + q * a.ldm + n0) : nullptr;
+      char* const mh = (GROUPED && !MULTI) ? reinterpret_cast<char*>(a.Mh + q * a.ldm + n0) : nullptr;
 #pragma unroll
       for (int bj = 0; bj < BN; ++bj) {
         float x[4];
@@ -190,9 +193,10 @@ __device__ __forceinline__ void epilogue_planes_relu(const GemmF16Args& a, Acc a
         for (int pr = 0; pr < 2; ++pr) {
           const float xa = x[2 * pr], xb = x[2 * pr + 1];
           const float got = lane_xor1(odd ? xa : xb);
-          store_split_pair(ph, pl, lane_off + (unsigned)pr * pr_off + 64u * bj, odd ? got : xa, odd ? xb : got);
+          if (!MULTI || 4 * h + 2 * pr + (odd ? 1 : 0) < members)
+            store_split_pair(ph, pl, lane_off + (unsigned)pr * pr_off + 64u * bj, odd ? got : xa, odd ? xb : got);
         }
-        if (GROUPED) {
+        if (GROUPED && !MULTI) {
           float mx = nsr_max_relu(nsr_max_relu(x[0], x[1]), nsr_max_relu(x[2], x[3]));      // NaN-propagating, like torch.max
           {
             // v_permlane32_swap: lanes 32-63 of the first register <-> lanes 0-31 of the second: r0 = the lower half's value in
@@ -579,9 +583,14 @@ struct HaloOcc {
   static constexpr int kLds = G::PATCH0 + G::PATCH1 + 4 * G::SLOT;
   static constexpr int kWaves = (NSR_HALO_PAIR && BN * BM <= 8 && S == 1 && kLds <= 81920) ? 2 : 1;
 };
-template <int BN, int BM, bool GROUPED, int S>
+// MULTI (round 6; with GROUPED's geometry): the eight images of a block are eight consecutive PLAIN images -- the 8 x 8-pixel
+// layers of the decoder and of the encoder over the synthesised patches, whose images are smaller than a plain block (16 x 16).
+// No max planes; a batch that is not a multiple of eight ends in a block whose missing images are gathered clamped (the last
+// image again) and never stored.
+template <int BN, int BM, bool GROUPED, int S, bool MULTI = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HaloOcc<BN, BM, GROUPED, S>::kWaves, HaloOcc<BN, BM, GROUPED, S>::kWaves)))
 conv_halo_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
+  static_assert(!MULTI || GROUPED, "MULTI uses the grouped geometry");
   using Geo = HaloGeo<BN, BM, GROUPED, S>;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[Geo::PATCH0 + Geo::PATCH1 + 4 * Geo::SLOT];
   const GemmArgs& g = a.g;
@@ -596,6 +605,7 @@ conv_halo_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
   const int b = (int)(st / tpi), ti = (int)(st % tpi);            // image (group of 8 images) and block within it
   const int oy0 = (ti / tiles_x) * Geo::TH, ox0 = (ti % tiles_x) * Geo::TW;
   const int cin = a.conv.cin, ncc = cin / 16;
+  const int n_img = MULTI ? (int)(g.M / ((int64_t)Ho * Wo)) : 0;
   const unsigned lds0 = (unsigned)(size_t)((const __attribute__((address_space(3))) unsigned char*)lds);
   const unsigned ring0 = lds0 + (unsigned)(Geo::PATCH0 + Geo::PATCH1);
   const unsigned lane16 = (unsigned)lane * 16u;
@@ -651,7 +661,8 @@ conv_halo_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
     iy = iy < 0 ? 0 : (iy >= Hin ? Hin - 1 : iy);
     ix = ix < 0 ? 0 : (ix >= Win ? Win - 1 : ix);
     const int sy = a.conv.up ? iy >> 1 : iy, sx = a.conv.up ? ix >> 1 : ix;
-    const int img = GROUPED ? 8 * b + r : b;
+    int img = GROUPED ? 8 * b + r : b;
+    if (MULTI) img = img < n_img ? img : n_img - 1;
     const int64_t off = (((int64_t)img * a.conv.Hs + sy) * a.conv.Ws + sx) * g.lda + ((p >> 1) ? a.a_plane : 0) + 8 * (p & 1);
     return (unsigned)(off * 2);                     // < 2^32: the launch checks
   };
@@ -819,7 +830,7 @@ conv_halo_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
     }
     return;
   }
-  epilogue_planes_relu<BN, BM, GROUPED>(a, [&](int bi, int bj) -> const f32x16& { return acc[bi][0][bj]; },
+  epilogue_planes_relu<BN, BM, GROUPED, MULTI>(a, [&](int bi, int bj) -> const f32x16& { return acc[bi][0][bj]; },
                                         [&](int bi, int rq, int64_t& r0, int64_t& q) {
     const int t = 32 * BM * wave + 32 * bi + 8 * rq;           // eight rows: plain 8 pixels along x; grouped one pixel's 8 images
     const int dy = GROUPED ? t >> 6 : t >> 4, dx = GROUPED ? (t >> 3) & 7 : t & 15;
@@ -827,7 +838,7 @@ conv_halo_kernel(GemmF16Args a, int n_col_tiles, int64_t n_blocks) {
     q = (int64_t)b * per + pix;
     r0 = GROUPED ? (int64_t)b * 8 * per + pix : q;
     return true;
-  }, n0, li, h);
+  }, n0, li, h, MULTI ? (n_img - 8 * b < 8 ? n_img - 8 * b : 8) : 8);
 }
 
 // (Round 2's LDS-DMA fed variant of this kernel -- pre-split operands streamed global -> LDS into a double-buffered,
@@ -879,8 +890,8 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
   // compiler's order does not (the inference kernel gets there with a hand-pinned schedule and an LDS-DMA ring).
   // Numbers and the kernel's description: profiles/r3_refine_tiles.txt.
   // conv_halo_kernel first: stride-1 3 x 3 gathers from pre-split planes into plane outputs with ReLU, whole 128 / 256
-  // column tiles, whole spatial blocks, 32-bit byte offsets into A (the 8 x 8 decoder layers, the stride-2 layers and the
-  // 3-channel first layers stay on the staged tiles below)
+  // column tiles, whole spatial blocks, 32-bit byte offsets into A (round 6: the stride-2 layers, the 8 x 8-pixel layers and
+  // the 3-channel first layer run here too; patch shapes that are not whole blocks stay on the staged tiles below)
 #ifndef NSR_GEMM_NO_HALO
 #ifndef NSR_HALO_NO_LAST
   // the refinement network's last layer: stride-1 gather from pre-split planes, 64 padded columns, tanh, fp32 NHWC output
@@ -939,6 +950,21 @@ NSR_INTERNAL int gemm_f16x3(const GemmF16Args& a, hipStream_t st) {
 #endif
     // ... and always on the 128-column plain layers (round 6: layer 0, all epilogue): the alternative there is ONE 512 x 128
     // workgroup per CU with nothing beside its epilogue
+#ifndef NSR_HALO_NO_MULTI
+    // Round 6: plain layers over 8 x 8-pixel images (smaller than a plain block): eight images per block on the grouped
+    // geometry, 8 x 4 pixels x 8 images x 128 columns per workgroup (MULTI above).  Until then they ran on the staged tile at a
+    // third of the matrix pipe (340 workgroups of 144 K tiles: 1.33 CU-rounds, nine-fold re-reads of the activations).  A
+    // matter of the image SHAPE only: any number of images (the last block is masked).
+    if (!grouped && common && a.conv.Wo == 8 && (a.conv.Ho % 4) == 0 && 16 * per_img * g.ldc < ((int64_t)1 << 32)) {
+      const int64_t n_img = g.M / per_img;
+      const int64_t m_blk = ((n_img + 7) / 8) * (a.conv.Ho / 4) * (g.N / 128);
+      const dim3 mgrid((unsigned)(((m_blk + 7) / 8) * 8));
+      if (s2) hipLaunchKernelGGL((conv_halo_kernel<4, 2, true, 2, true>), mgrid, dim3(256), 0, st, a, g.N / 128, m_blk);
+      else hipLaunchKernelGGL((conv_halo_kernel<4, 2, true, 1, true>), mgrid, dim3(256), 0, st, a, g.N / 128, m_blk);
+      if (hipGetLastError() != hipSuccess) return NSR_ERR_LAUNCH;
+      return NSR_OK;
+    }
+#endif
     const bool paired = NSR_HALO_PAIR && (NSR_HALO_PAIR_WIDE || !wide) && !grouped && !s2 && half_ok;
     const bool use_half = half_ok && (paired || !big_ok || 0.5 * 1.05 * rounds(half_blk) < rounds(big_blk));
     const bool use_big = !use_half && big_ok;

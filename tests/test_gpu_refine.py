@@ -64,6 +64,23 @@ def test_refine_nan_travels_like_torch(net):
     assert float((y.double() - want)[ok].abs().max()) <= TOL
 
 
+def test_refine_batches_around_the_eight_image_blocks(net):
+    """Round 6: the 8 x 8-pixel plain layers (decoder conv1 / conv2, the last encoder layer over the synthesised patches) run
+    eight IMAGES per workgroup block (conv_halo_kernel MULTI, csrc/nsr_gemm_f16.hip); a batch that is not a multiple of eight
+    ends in a block whose missing images are gathered clamped and never stored.  Batches of 7, 8 and 9 patch sets: every set
+    gives the bits it gives alone, and the set behind the block boundary agrees with the oracle."""
+    gen = torch.Generator().manual_seed(33)
+    x = torch.rand(9, 3, 64, 64, generator=gen) * 2 - 1
+    c = torch.rand(9, 8, 3, 64, 64, generator=gen) * 2 - 1
+    alone = [net(x[i:i + 1].cuda(), c[i:i + 1].cuda()) for i in range(9)]
+    for n in (7, 8, 9):
+        y = net(x[:n].cuda(), c[:n].cuda())
+        for i in range(n):
+            assert torch.equal(y[i:i + 1], alone[i]), (n, i)
+    want = ro.forward(make_refine_state_dict(7), x[8:9], c[8:9], dtype=torch.float64)
+    assert float((alone[8].cpu().double() - want).abs().max()) <= TOL
+
+
 @pytest.mark.parametrize("hw", [(128, 64), (64, 96), (48, 80)])
 def test_refine_other_patch_shapes_vs_oracle(net, hw):
     """Patches that are not the reference's 64 x 64 square: several spatial blocks per image in x and in y (the LDS-patch
