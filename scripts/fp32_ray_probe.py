@@ -5,7 +5,8 @@ Finds the ray again (same block of 65,536 rays of config #5's frame, same field)
 path (the stage-by-stage C-ABI route: nsr_sample_along_rays -> nsr_render_rays -> nsr_composite -> nsr_resample_along_rays -> ...)
 next to the oracle in fp32 and fp64, and CROSS-FEEDS the stages (the oracle's fine pass on the HIP path's fine depths and
 vice versa) so that the stage whose output diverges is named, not guessed.
-usage (GPU box): python scripts/fp32_ray_probe.py [precision=fp32] [config=5] [N=65536] > gpurun_out/fp32_ray_probe.json"""
+usage (GPU box): python scripts/fp32_ray_probe.py [precision=fp32] [config=5] [N=65536] > gpurun_out/fp32_ray_probe.json
+       `config` = llff | blender: the TRAINED field of tests/test_gpu_trained.py (4,000 steps, then the test's block of N rays)."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -15,19 +16,28 @@ from oracle import nerf_oracle as oc       # checker (evidence tooling, not the 
 from tests.util import oracle_fp32_and_fp64
 
 PREC = sys.argv[1] if len(sys.argv) > 1 else "fp32"
-CID = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+TRAINED = len(sys.argv) > 2 and sys.argv[2] in ("llff", "blender")
+CID = sys.argv[2] if TRAINED else (int(sys.argv[2]) if len(sys.argv) > 2 else 5)
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 CONFIGS = {2: ((504, 378), 2, True, False), 3: ((400, 400), 2, False, True), 4: ((1008, 756), 4, True, False), 5: ((800, 800), 4, False, True)}
-wh, s, ndc, white = CONFIGS[CID]
-if ndc:
-    c2w, f, nf = cameras.spiral_pose(0.4), cameras.llff_focal(wh[0]), (0.0, 1.0)
+if TRAINED:
+    from tests import trained_field as tf
+    res = tf.train_field(CID, steps=4000)
+    sd_c, sd_f = res["sd_coarse"], res["sd_fine"]
+    blk, ref, ref64 = tf.oracle_block(CID, sd_c, sd_f, N)
+    blk = blk.cuda().contiguous()
+    white = tf.FAMILIES[CID][3]
 else:
-    c2w, f, nf = cameras.spheric_pose(40.0, -30.0, 4.0), cameras.blender_focal(wh[0]), (2.0, 6.0)
-rays = ops.subpixel_rays(c2w, wh, f, s, ndc, *nf).view(-1, 8)
-lo = (rays.shape[0] // 2) - (rays.shape[0] // 2) % (s * s)
-blk = rays[lo:lo + N].contiguous()
-sd_c, sd_f = make_state_dict(99), make_state_dict(100)
-ref, ref64 = oracle_fp32_and_fp64(sd_c, sd_f, blk.cpu(), white)
+    wh, s, ndc, white = CONFIGS[CID]
+    if ndc:
+        c2w, f, nf = cameras.spiral_pose(0.4), cameras.llff_focal(wh[0]), (0.0, 1.0)
+    else:
+        c2w, f, nf = cameras.spheric_pose(40.0, -30.0, 4.0), cameras.blender_focal(wh[0]), (2.0, 6.0)
+    rays = ops.subpixel_rays(c2w, wh, f, s, ndc, *nf).view(-1, 8)
+    lo = (rays.shape[0] // 2) - (rays.shape[0] // 2) % (s * s)
+    blk = rays[lo:lo + N].contiguous()
+    sd_c, sd_f = make_state_dict(99), make_state_dict(100)
+    ref, ref64 = oracle_fp32_and_fp64(sd_c, sd_f, blk.cpu(), white)
 nc, nfn = ops.VanillaMLP(precision=PREC).load_state_dict(sd_c), ops.VanillaMLP(precision=PREC).load_state_dict(sd_f)
 hip = ops.forward_rays(nc, nfn, blk, 64, 64, white)
 d = (hip["fine_comp_rgbs"].cpu().double() - ref["fine_comp_rgbs"].double()).abs().max(-1)[0]
@@ -60,7 +70,7 @@ for i in (viol or order[:1]):
         rr = rc.to(dt)
         with torch.no_grad():
             z, xyz = oc.sample_coarse(rr[:, 0:3], rr[:, 3:6], rr[:, 6:7], rr[:, 7:8], 64)
-            de = oc.posenc(rr[:, 3:6], 4)
+            de = oc.posenc(rr[:, 8:11] if rr.shape[1] == 11 else rr[:, 3:6], 4)
             rgb, sig = oc.render_points(sc, xyz, de)
             comp = oc.composite(rgb, sig, z, white)
             zf, xyzf = oc.resample_fine(rr[:, 0:3], rr[:, 3:6], z, comp[3], 64)

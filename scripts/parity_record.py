@@ -70,9 +70,12 @@ def block_stats(sd_c, sd_f, blk, white):
         from tests.util import explained_by_resampler_conditioning
         over_idx = torch.nonzero(d > torch.clamp_min(2.0 * gap, 1e-4)).flatten()
         hip_cpu = {k: v.cpu() for k, v in hip.items()}
-        expl = explained_by_resampler_conditioning(sd_f, blk.cpu(), white, hip_cpu, ref, over_idx)
+        expl = explained_by_resampler_conditioning(sd_f, blk.cpu(), white, hip_cpu, ref, over_idx, ref64=ref64)
+        own_w = (ref["coarse_weights"].double() - ref64["coarse_weights"]).abs().max(-1)[0]
+        hip_w = (hip_cpu["coarse_weights"].double() - ref["coarse_weights"].double()).abs().max(-1)[0]
         entry[prec] = {
-            "rays_over_bound": [{"i": int(i), "d": float(d[i]), "oracle_gap": float(gap[i]), "explained_by_resampler_conditioning": bool(e)}
+            "rays_over_bound": [{"i": int(i), "d": float(d[i]), "oracle_gap": float(gap[i]), "explained_by_resampler_conditioning": bool(e),
+                                 "coarse_weights_hip_vs_oracle32": float(hip_w[i]), "coarse_weights_oracle32_vs_oracle64": float(own_w[i])}
                                 for i, e in zip(over_idx.tolist(), expl.tolist())],
             "violations_unexplained": int((~expl).sum()),
             "max": st["hip_vs_oracle32"]["max"], "p999": st["hip_vs_oracle32"]["p999"], "median": st["hip_vs_oracle32"]["median"],

@@ -41,3 +41,20 @@ def test_cross_feed_rule_accepts_rounding_level_coarse_differences_and_rejects_e
     bad_w = {"coarse_weights": w3, "fine_comp_rgbs": fine3}
     assert not bool(explained_by_resampler_conditioning(sd_f, rays, True, bad_w, ref, idx).any())
     assert explained_by_resampler_conditioning(sd_f, rays, True, impl, ref, torch.zeros(0, dtype=torch.long)).numel() == 0
+    # the coarse-weight yardstick with the oracle's fp64 evaluation at hand: twice the oracle's OWN fp32-vs-fp64 distance on
+    # the ray (never below w_tol).  Weights 5e-6 away are rejected on this smooth field (own distance ~3e-7) ...
+    ref64 = oracle_forward_parallel(sd_c, sd_f, rays, True, dtype=torch.float64)
+    own = (ref["coarse_weights"].double() - ref64["coarse_weights"]).abs().max(-1)[0]
+    assert float(own.max()) < 1e-6
+    w4 = ref["coarse_weights"] + 5e-6
+    with torch.no_grad():
+        zf4, xyzf4 = oc.resample_fine(rays[:, 0:3], rays[:, 3:6], z, w4, 64)
+        rgb4, sig4 = oc.render_points(sf, xyzf4, oc.posenc(rays[:, 3:6], 4))
+        fine4 = oc.composite(rgb4, sig4, zf4, True)[0]
+    off = {"coarse_weights": w4, "fine_comp_rgbs": fine4}
+    assert not bool(explained_by_resampler_conditioning(sd_f, rays, True, off, ref, idx, ref64=ref64).any())
+    # ... and accepted where the oracle's own two precisions sit further apart than that (a stand-in fp64 record 4e-6 away)
+    far64 = {k: v.clone() for k, v in ref64.items()}
+    far64["coarse_weights"] = ref["coarse_weights"].double() + 4e-6
+    assert bool(explained_by_resampler_conditioning(sd_f, rays, True, off, ref, idx, ref64=far64).all())
+    assert bool(explained_by_resampler_conditioning(sd_f, rays, True, impl, ref, idx, ref64=ref64).all())

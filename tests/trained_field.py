@@ -236,7 +236,8 @@ def parity_stats(hip: Dict[str, torch.Tensor], ref, ref64, cross_feed=None) -> D
     if cross_feed is not None and over.numel():
         from tests.util import explained_by_resampler_conditioning
         sd_f, rays, white = cross_feed
-        explained = explained_by_resampler_conditioning(sd_f, rays.cpu(), white, {k: v.cpu() for k, v in hip.items()}, ref, over)
+        explained = explained_by_resampler_conditioning(sd_f, rays.cpu(), white, {k: v.cpu() for k, v in hip.items()}, ref, over,
+                                                        ref64=ref64)
     return {
         "rays_over_bound": [{"i": int(i), "d": float(d[i]), "oracle_gap": float(gap[i]), "marginal": bool(m), "explained_by_resampler_conditioning": bool(e)}
                             for i, m, e in zip(over.tolist(), marginal.tolist(), explained.tolist())],
