@@ -22,7 +22,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
 // operands: (nthreads, 4 sets, 8 halves) for A and B
-template <int NACC, int WAVES_PER_SIMD>
+// ORDER: which operand registers consecutive MFMAs name (round 6: does operand REUSE between neighbours change what the power
+// limit lets through?)  0: A changes every MFMA, B every second (the default);  1: both change every MFMA;  2: A held for four
+// MFMAs, B changes;  3: A held for the whole trip, B changes;  4: both held (one A, one B)
+template <int ORDER>
+__device__ __forceinline__ int a_set(int k) { return ORDER == 2 ? (k >> 2) & 3 : (ORDER >= 3 ? 0 : k & 3); }
+template <int ORDER>
+__device__ __forceinline__ int b_set(int k) { return ORDER == 0 ? (k >> 1) & 3 : (ORDER == 1 ? (k + (k >> 2)) & 3 : (ORDER == 4 ? 0 : k & 3)); }
+template <int NACC, int WAVES_PER_SIMD, int ORDER = 0>
 __global__ void __launch_bounds__(256 * WAVES_PER_SIMD) __attribute__((amdgpu_waves_per_eu(WAVES_PER_SIMD, WAVES_PER_SIMD)))
 mfma_loop(const h8* __restrict__ a_in, const h8* __restrict__ b_in, int iters, float* __restrict__ sink,
           unsigned long long* __restrict__ clocks) {
@@ -46,7 +53,7 @@ mfma_loop(const h8* __restrict__ a_in, const h8* __restrict__ b_in, int iters, f
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int k = 0; k < 24; ++k)   // 24 MFMAs per trip, operand sets and accumulators round-robin
-      acc[k % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k & 3], b[(k >> 1) & 3], acc[k % NACC], 0, 0, 0);
+      acc[k % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[a_set<ORDER>(k)], b[b_set<ORDER>(k)], acc[k % NACC], 0, 0, 0);
   }
   if (threadIdx.x == 0) {
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -67,7 +74,7 @@ static float gauss() {
   return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);
 }
 
-template <int NACC, int WPS>
+template <int NACC, int WPS, int ORDER = 0>
 static void run(const char* data_name, int data, int n_cu) {
   const int threads = 256 * WPS, blocks = n_cu, n = threads * blocks;
   std::vector<_Float16> ha((size_t)n * 32), hb((size_t)n * 32);
@@ -102,7 +109,7 @@ static void run(const char* data_name, int data, int n_cu) {
   double clock_ghz = 0.0;
   for (int rep = 0; rep < 3; ++rep) {
     CHECK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL((mfma_loop<NACC, WPS>), dim3(blocks), dim3(threads), 0, 0, da, db, iters, sink, clk);
+    hipLaunchKernelGGL((mfma_loop<NACC, WPS, ORDER>), dim3(blocks), dim3(threads), 0, 0, da, db, iters, sink, clk);
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipEventSynchronize(e1));
     float ms;
@@ -117,6 +124,7 @@ static void run(const char* data_name, int data, int n_cu) {
     }
   }
   const double flops = (double)blocks * 4 * WPS * iters * 24.0 * 2.0 * 32 * 32 * 16;
+  if (ORDER) printf("order %d ", ORDER);
   printf("%-22s acc=%d waves/SIMD=%d : %7.2f ms  %6.3f PFLOP/s issued  clock %.2f GHz  (%.1f cyc/MFMA/SIMD)\n", data_name, NACC, WPS,
          best, flops / (best * 1e-3) / 1e15, clock_ghz, clock_ghz * 1e9 * best * 1e-3 / ((double)iters * 24.0 * WPS));
   CHECK(hipFree(da)); CHECK(hipFree(db)); CHECK(hipFree(sink)); CHECK(hipFree(clk));
@@ -166,6 +174,18 @@ int main(int argc, char** argv) {
   CHECK(hipGetDeviceProperties(&p, 0));
   const int n_cu = p.multiProcessorCount;
   printf("%s, %d CUs, clockRate %.0f MHz\n", p.name, n_cu, p.clockRate / 1e3);
+  if (argc >= 2 && std::string(argv[1]) == "reuse") {     // operand reuse between neighbouring MFMAs, on realistic data
+    for (int rep = 0; rep < 2; ++rep)
+      for (int d = 1; d < 3; ++d) {
+        const char* nm = d == 1 ? "random hi x hi" : "split-fp16 (hi, lo) mix";
+        run<4, 1, 0>(nm, d, n_cu);
+        run<4, 1, 1>(nm, d, n_cu);
+        run<4, 1, 2>(nm, d, n_cu);
+        run<4, 1, 3>(nm, d, n_cu);
+        run<4, 1, 4>(nm, d, n_cu);
+      }
+    return 0;
+  }
   const char* names[3] = {"zeros", "random hi x hi", "split-fp16 (hi, lo) mix"};
   for (int d = 0; d < 3; ++d) {
     run<1, 1>(names[d], d, n_cu);
