@@ -49,10 +49,10 @@ timeout 300 python bench.py --mode train --train-precision f16x3_gemm --steps 20
 timeout 300 python bench.py --mode train --train-precision fp32 --steps 20 --warmup 5 --no-cpu-baseline > $O/train_bench_fp32.json 2>> $O/bench.err
 bash scripts/gpu_refine_stats.sh new > $O/refine_stats.log 2>&1; cp gpurun_out/refstats/new_kernel_stats.csv $O/refine_kernel_stats.csv; tail -3 $O/refine_stats.log | cut -c1-120
 timeout 600 python scripts/train_drift.py 200 > $O/r6_train_drift.json 2>> $O/bench.err
-# round 6: the backward chain on 3 / 2 / 1 MFMA terms -- gradients vs the fp64 oracle, bench scale vs the fp32-gradient path, trajectory;
+# round 6: the backward chain on 3 / 2 / mixed (the default) / 1 MFMA terms -- gradients vs the fp64 oracle, bench scale vs the fp32-gradient path, trajectory;
 # the step time of each (interleaved); the multi-seed drift record
 timeout 900 python scripts/bwd_terms_check.py > $O/r6_bwd_terms_gpu.json 2>> $O/bench.err
-for r in 1 2 3; do for v in f16x3_bwd3 f16x3_bwd2 f16x3_bwd1; do
+for r in 1 2 3; do for v in f16x3_bwd3 f16x3_bwd2 f16x3_bwdm f16x3_bwd1; do
   timeout 300 python bench.py --mode train --train-precision $v --steps 40 --warmup 8 --no-cpu-baseline 2>> $O/bench.err | python -c "import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('round $r $v  ms_per_step %.3f' % d['ms_per_step'])"
 done; done | tee $O/r6_train_terms_ab.txt
 timeout 300 python bench.py --mode train --train-precision f16x3_bwd1 --steps 50 --warmup 10 --no-cpu-baseline > $O/train_bench_bwd1.json 2>> $O/bench.err
